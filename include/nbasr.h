@@ -1,0 +1,116 @@
+/*
+ * nbasr.h -- C ABI of libnbasr_hip.so: the MI355X (gfx950) kernels behind the NAS-Bench-ASR
+ * acoustic-model forward pass.
+ *
+ * Every entry point replaces one piece of the reference's PyTorch forward (files under
+ * /root/reference/nasbench_asr/model/torch/ -- cited per function as file:line).  The reference
+ * has no FFI of its own for this path (it calls torch ATen), so this ABI is the boundary a
+ * `hip` backend package binds with ctypes; see INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - plain pointers and ints only; all pointers are DEVICE pointers owned by the caller
+ *     (torch tensors' data_ptr()); no allocation, no ownership transfer, no host sync;
+ *   - kernels are enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - activations use the reference's (batch, channels, frames) order with frames contiguous and
+ *     a row pitch `ld` (elements) that must be a multiple of 4; columns frames..ld-1 of every
+ *     activation buffer are kept at ZERO by every kernel (and must be zero on input);
+ *   - weights are in the layouts torch stores them in (state_dict tensors, contiguous);
+ *   - return value: 0 on success, a negative NBASR_E* code for argument errors, or a positive
+ *     hipError_t; nbasr_last_error() gives a thread-local message for the last failure;
+ *   - re-entrant and thread-safe (no global mutable state except the thread-local message).
+ */
+#ifndef NBASR_H
+#define NBASR_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBASR_ABI_VERSION 1
+
+#define NBASR_OK 0
+#define NBASR_EINVAL (-1)   /* bad size / unsupported shape */
+#define NBASR_EALIGN (-2)   /* pointer or pitch alignment   */
+#define NBASR_ENULL (-3)    /* required pointer is NULL     */
+
+typedef void* nbasr_stream_t;
+
+/* ABI version of the loaded library (== NBASR_ABI_VERSION it was built with). */
+int nbasr_version(void);
+
+/* Message for the most recent failing call on this thread ("" if none). */
+const char* nbasr_last_error(void);
+
+/* Zero-padding rule of PadConvRelu (reference ops.py:12-17, look-ahead context = 4 frames).
+ * Pure host arithmetic; usable without a GPU. */
+int nbasr_pad_amounts(int kernel, int dilation, int stride, int* left, int* right);
+
+/* Number of output frames of the model for `frames` input frames (two stride-2 downsample
+ * convs, reference model.py:76): ceil(ceil(T/2)/2).  Host arithmetic. */
+int nbasr_output_frames(int frames);
+
+/* Node operation, grouped-convolution flavour, fused with the node's skip-sum
+ * (reference ops.py:24-30 with groups=100 from the table ops.py:73-76, Node.forward model.py:13-22):
+ *     y = min(relu(conv1d(zero_pad(x), w, bias, dilation, groups)), 20) + skip0 + skip1 + skip2
+ * x, y, skip*: (batch, channels, ld); w: (channels, channels/groups, kernel); bias: (channels).
+ * NULL skips are absent (a Zero branch).  Supported: kernel in {5,7}, dilation in {1,2},
+ * channels/groups in {6,8,10,12}.  Skips are added left to right (python `sum` order). */
+int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias,
+                               const float* skip0, const float* skip1, const float* skip2,
+                               float* y, int batch, int channels, int frames, int ld,
+                               int groups, int kernel, int dilation, nbasr_stream_t stream);
+
+/* Node whose main op is `zero` (reference ops.py:67-68): y = 0 + skip0 + skip1 + skip2. */
+int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, float* y,
+                   int batch, int channels, int frames, int ld, nbasr_stream_t stream);
+
+/* LayerNorm over the channel dimension of (batch, channels, ld), biased variance
+ * (reference model.py:92 + 125-128 and model.py:46-47 + 55-58; eps = 1e-3 there).
+ * In-place (y == x) is allowed. */
+int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y,
+                             int batch, int channels, int frames, int ld, float eps,
+                             nbasr_stream_t stream);
+
+/* Dense PadConvRelu (groups = 1) on the fp32 matrix cores, fused bias + relu + clamp (+ skips):
+ *   kernel == 8: the four downsample convs (reference model.py:82-89, ops.py:24-30), stride 1|2;
+ *   kernel == 1: the `linear` node op (reference ops.py:42-50), stride must be 1.
+ * x: (batch, c_in, ld_in) with frames_in valid frames (ld_in need not be a multiple of 4 here:
+ * the model input has whatever length the caller gives); y: (batch, c_out, ld_out) with
+ * ceil(frames_in/stride) valid frames; w: (c_out, c_in, kernel); skips as above (c_out, ld_out). */
+int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
+                             const float* skip0, const float* skip1, const float* skip2,
+                             float* y, int batch, int c_in, int frames_in, int ld_in,
+                             int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
+
+/* nn.LSTM(input_size=c_in, hidden_size=hidden, batch_first) forward with zero initial state
+ * (reference model.py:100 and 118-121): gates i,f,g,o; biases b_ih + b_hh.
+ * x: (batch, c_in, ld) encoder layout (the reference's permute is folded into the loader);
+ * w_ih: (4*hidden, c_in); w_hh: (4*hidden, hidden); h_out: (batch, frames, hidden).
+ * Workspaces (caller-owned): gates_ws (batch*frames*4*hidden floats), cell_ws (batch*hidden). */
+int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh,
+                       const float* b_ih, const float* b_hh, float* gates_ws, float* cell_ws,
+                       float* h_out, int batch, int c_in, int frames, int ld, int hidden,
+                       nbasr_stream_t stream);
+
+/* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
+ * logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias. */
+int nbasr_linear_head(const float* h, const float* w, const float* bias, float* logits,
+                      int rows, int features, int classes, nbasr_stream_t stream);
+
+/* Head for the use_rnn=False model (reference model.py:103): input is the encoder output
+ * x (batch, features, ld); logits (batch, frames, classes). */
+int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits,
+                          int batch, int features, int frames, int ld, int classes,
+                          nbasr_stream_t stream);
+
+/* Copy (batch, channels, frames) with pitch ld_src into pitch ld_dst, zero-filling columns
+ * frames..ld_dst-1 (used to bring caller tensors into the pitched internal layout). */
+int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,
+                  nbasr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBASR_H */

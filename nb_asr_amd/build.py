@@ -1,0 +1,78 @@
+"""Build libnbasr_hip.so (the C-ABI HIP library, include/nbasr.h) in-tree with hipcc for gfx950.
+
+``python -m nb_asr_amd.build`` or ``nb_asr_amd.build.build_library()``.  hipcc cross-compiles
+without a GPU present.  Objects go to ``nb_asr_amd/csrc/build/`` and the library to
+``nb_asr_amd/lib/libnbasr_hip.so`` (both git-ignored; the .so travels with gpurun snapshots).
+"""
+import concurrent.futures
+import os
+import pathlib
+import shutil
+import subprocess
+import sys
+
+PKG_DIR = pathlib.Path(__file__).resolve().parent
+REPO_DIR = PKG_DIR.parent
+CSRC_DIR = PKG_DIR / 'csrc'
+OBJ_DIR = CSRC_DIR / 'build'
+LIB_PATH = PKG_DIR / 'lib' / 'libnbasr_hip.so'
+INCLUDE_DIR = REPO_DIR / 'include'
+ARCH = 'gfx950'
+
+SOURCES = ['api.cpp', 'grouped_conv.hip', 'layernorm.hip', 'gemm_conv.hip', 'lstm.hip']
+CXXFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: the HIP extension cannot be built on this machine')
+    return exe
+
+
+def _newer(target, deps):
+    if not target.exists():
+        return True
+    t = target.stat().st_mtime
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def _compile(src, obj, headers, verbose):
+    if not _newer(obj, [src] + headers):
+        return False
+    cmd = [_hipcc(), *CXXFLAGS, f'-I{INCLUDE_DIR}', f'-I{CSRC_DIR}', '-x', 'hip', '-c', str(src), '-o', str(obj)]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f'hipcc failed on {src.name}:\n{res.stdout}\n{res.stderr}')
+    if verbose and res.stderr.strip():
+        print(res.stderr, file=sys.stderr)
+    return True
+
+
+def build_library(force=False, verbose=False, jobs=4):
+    """Compile every source for gfx950 and link the shared library.  Returns its path."""
+    OBJ_DIR.mkdir(parents=True, exist_ok=True)
+    LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
+    headers = sorted(CSRC_DIR.glob('*.h')) + sorted(INCLUDE_DIR.glob('*.h'))
+    pairs = [(CSRC_DIR / s, OBJ_DIR / (s.rsplit('.', 1)[0] + '.o')) for s in SOURCES]
+    if force:
+        for _, obj in pairs:
+            obj.unlink(missing_ok=True)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
+        rebuilt = list(pool.map(lambda p: _compile(p[0], p[1], headers, verbose), pairs))
+    objs = [obj for _, obj in pairs]
+    if any(rebuilt) or _newer(LIB_PATH, objs):
+        cmd = [_hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(LIB_PATH)] + [str(o) for o in objs]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f'link failed:\n{res.stdout}\n{res.stderr}')
+    return LIB_PATH
+
+
+if __name__ == '__main__':
+    path = build_library(force='--force' in sys.argv, verbose=True)
+    print(f'built {path}')

@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels of libnbasr_hip.so (internal; the public ABI is include/nbasr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "nbasr.h"
+
+namespace nbasr {
+
+// thread-local error text behind nbasr_last_error()
+void set_error(const char* fmt, ...);
+void clear_error();
+
+inline hipStream_t as_stream(nbasr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return static_cast<int>(e);
+    }
+    return NBASR_OK;
+}
+
+// host + device copy of the PadConvRelu padding rule (reference ops.py:12-17, context = 4)
+__host__ __device__ constexpr int pad_left(int kernel, int dilation, int stride) {
+    return (4 / stride >= kernel * dilation - stride) ? 0 : (kernel - 1) * dilation - 4 / stride;
+}
+__host__ __device__ constexpr int pad_right(int kernel, int dilation, int stride) {
+    return (4 / stride >= kernel * dilation - stride) ? kernel * dilation - stride : 4 / stride;
+}
+
+constexpr float kClamp = 20.0f;   // reference ops.py:28
+
+__device__ __forceinline__ float relu_clamp(float v) { return fminf(fmaxf(v, 0.0f), kClamp); }
+
+#define NBASR_REQUIRE(cond, code, ...)          \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::nbasr::set_error(__VA_ARGS__);    \
+            return (code);                      \
+        }                                       \
+    } while (0)
+
+}  // namespace nbasr

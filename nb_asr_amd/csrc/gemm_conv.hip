@@ -1,0 +1,273 @@
+// Dense (groups = 1) convolution as an implicit GEMM on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact f32 fma chains, so results are f32-for-f32 comparable with the
+// reference's oneDNN path), with the PadConvRelu epilogue fused:
+//   KW = 8 : the four downsample convs, stride 1 | 2   (reference model.py:82-89, ops.py:24-30)
+//   KW = 1 : the `linear` node op                       (reference ops.py:42-50)
+//   KW = 1, transposed store: the LSTM input projection x W_ih^T + b_ih + b_hh for all frames at
+//            once                                        (reference model.py:100, 118-121)
+//
+//   D[co][t] = sum_{ci, tap} W[co][ci][tap] * xpad[ci][t * stride + tap - lpad]
+//
+// GEMM view per utterance: M = c_out, N = output frames, K = c_in * KW.  A workgroup (4 waves, 2x2)
+// owns a 128 x 128 tile; a wave owns 64 x 64 as 2 x 2 MFMA 32x32 blocks (64 accumulator VGPRs).
+// Per K-step of 64: the weight tile (128 x 64, K-contiguous rows in HBM) is staged k-major in LDS;
+// the input is staged as KC = 64/KW channel ROWS of (127*stride + KW) frames -- the sliding window
+// is resolved when fragments are read from LDS, so every input element is fetched from global
+// memory once per tile and reused KW times from LDS (no im2col, no padded copy).  Zero padding is
+// applied by predicate while staging.  Global loads for step s+1 are issued before the MFMAs of
+// step s (register staging), so HBM/L2 latency hides under the 8192-cycle MFMA block.
+//
+// Workgroup -> tile order is m-major and XCD-aware: the 8 XCDs each walk a contiguous range of
+// tiles, so the 32 CUs of an XCD share one 128-row weight slab in their 4 MiB L2.
+// MFMA-bound: 2 * c_out * c_in * KW * frames_out * batch flops per launch.
+#include "common.h"
+
+#include <type_traits>
+
+namespace nbasr {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDA = BM;   // lanes run along m for both the staging writes and the fragment reads: conflict-free unpadded
+
+struct GemmConvArgs {
+    const float* x; const float* w; const float* bias; const float* bias2;
+    const float* s0; const float* s1; const float* s2;
+    float* y;
+    int c_in, frames_in, ld_in, c_out, frames_out, ld_out, lpad, ktot;
+    int n_cover;                 // output columns the tiles must cover (ld_out: pitch columns get zeros)
+    int n_mt, n_nt, batch;
+};
+
+template <int KW, int STRIDE>
+struct Geo {
+    static constexpr int KC = BK / KW;                       // input channels per K-step
+    static constexpr int XW = (BN - 1) * STRIDE + KW;        // staged frames per channel row
+    static constexpr int LDX = XW;                           // lanes run along frames: conflict-free unpadded
+    static constexpr int XELEMS = KC * XW;
+    static constexpr int XREGS = (XELEMS + 255) / 256;
+    static constexpr int LDS_FLOATS = BK * LDA + KC * LDX;
+};
+
+template <int KW, int STRIDE, bool SWAP, bool RELU>
+__global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
+{
+    using G = Geo<KW, STRIDE>;
+    __shared__ float lds[G::LDS_FLOATS];
+    float* As = lds;                    // [BK][LDA]  k-major weight tile
+    float* Xs = lds + BK * LDA;         // [KC][LDX]  input channel rows
+
+    // ---- XCD-aware, m-major tile order (bijective remap, cdna guide T1) ------------------------
+    const int nwg = gridDim.x;
+    const int id = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    const int per_m = a.n_nt * a.batch;
+    const int mt_i = L / per_m;
+    const int rem = L - mt_i * per_m;
+    const int b = rem / a.n_nt;
+    const int nt_i = rem - b * a.n_nt;
+    const int m0 = mt_i * BM, n0 = nt_i * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
+    const int tin0 = n0 * STRIDE - a.lpad;
+
+    // wave-uniform validity of the 32x32 blocks (skip MFMAs on fully out-of-range blocks)
+    bool mval[2], nval[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mval[i] = (m0 + wm * 64 + i * 32) < a.c_out;
+        nval[i] = (n0 + wn * 64 + i * 32) < a.n_cover;
+    }
+
+    const bool full = mval[0] && mval[1] && nval[0] && nval[1];
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- register staging ----------------------------------------------------------------------
+    float4 areg[8];
+    float xreg[G::XREGS];
+    const int a_row = tid & 127, a_kh = tid >> 7;   // lane -> weight row; 16-byte k-chunks kh, kh+2, ...
+
+    auto prefetch = [&](int ks) {
+        const int k0 = ks * BK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + a_row;
+            const int k = k0 + (a_kh + 2 * i) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < a.c_out && k < a.ktot)
+                v = *reinterpret_cast<const float4*>(a.w + static_cast<size_t>(row) * a.ktot + k);
+            areg[i] = v;
+        }
+        const int ci0 = ks * G::KC;
+#pragma unroll
+        for (int i = 0; i < G::XREGS; ++i) {
+            const int e = tid + 256 * i;
+            const int ci = e / G::XW;
+            const int p = e - ci * G::XW;
+            const int t = tin0 + p;
+            float v = 0.f;
+            if (e < G::XELEMS && (ci0 + ci) < a.c_in && t >= 0 && t < a.frames_in)
+                v = xb[static_cast<size_t>(ci0 + ci) * a.ld_in + t];
+            xreg[i] = v;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float* dst = As + ((a_kh + 2 * i) * 4) * LDA + a_row;
+            dst[0 * LDA] = areg[i].x; dst[1 * LDA] = areg[i].y; dst[2 * LDA] = areg[i].z; dst[3 * LDA] = areg[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < G::XREGS; ++i) {
+            const int e = tid + 256 * i;
+            const int ci = e / G::XW;
+            const int p = e - ci * G::XW;
+            if (e < G::XELEMS) Xs[ci * G::LDX + p] = xreg[i];
+        }
+    };
+
+    const int nks = (a.ktot + BK - 1) / BK;
+    const float* a_base = As + half * LDA + wm * 64 + l31;
+    const float* x_base = (KW == 1) ? Xs + half * G::LDX + (wn * 64 + l31)
+                                    : Xs + (wn * 64 + l31) * STRIDE + half;
+
+    prefetch(0);
+    for (int ks = 0; ks < nks; ++ks) {
+        __syncthreads();                 // previous step's fragment reads are done
+        commit();
+        __syncthreads();
+        if (ks + 1 < nks) prefetch(ks + 1);
+
+        auto mma_step = [&](auto all_valid) {
+#pragma unroll
+            for (int kk = 0; kk < BK / 2; ++kk) {
+                const int xo = (KW == 1) ? 2 * kk * G::LDX : (kk / (KW / 2 > 0 ? KW / 2 : 1)) * G::LDX + 2 * (kk % (KW / 2 > 0 ? KW / 2 : 1));
+                float av[2], bv[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) av[i] = a_base[2 * kk * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bv[j] = x_base[xo + j * 32 * STRIDE];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        if (decltype(all_valid)::value || (mval[i] && nval[j]))
+                            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0)
+                                             : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        };
+        if (full) mma_step(std::true_type{}); else mma_step(std::false_type{});
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------
+    // C/D layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!(mval[i] && nval[j])) continue;
+            const int mb = m0 + wm * 64 + i * 32;     // c_out block base
+            const int nb = n0 + wn * 64 + j * 32;     // frame block base
+            if (!SWAP) {
+                const int n = nb + l31;
+                if (n >= a.ld_out) continue;
+                const bool live = n < a.frames_out;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (m >= a.c_out) continue;
+                    float v = acc[i][j][r] + a.bias[m];
+                    if (RELU) v = relu_clamp(v);
+                    const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
+                    if (a.s0) v += a.s0[off];
+                    if (a.s1) v += a.s1[off];
+                    if (a.s2) v += a.s2[off];
+                    a.y[off] = live ? v : 0.f;
+                }
+            } else {
+                // transposed store: y[(b * frames_out + t) * c_out + m], lanes along m
+                const int m = mb + l31;
+                if (m >= a.c_out) continue;
+                float bsum = a.bias[m];
+                if (a.bias2) bsum += a.bias2[m];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int t = nb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (t >= a.frames_out) continue;
+                    float v = acc[i][j][r] + bsum;
+                    if (RELU) v = relu_clamp(v);
+                    a.y[(static_cast<size_t>(b) * a.frames_out + t) * a.c_out + m] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int KW, int STRIDE, bool SWAP, bool RELU>
+static int launch_gemm_conv(GemmConvArgs a, hipStream_t stream, const char* what)
+{
+    a.n_mt = (a.c_out + BM - 1) / BM;
+    a.n_cover = SWAP ? a.frames_out : a.ld_out;
+    a.n_nt = (a.n_cover + BN - 1) / BN;
+    const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
+    if (nwg == 0) return NBASR_OK;
+    NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", what, nwg);
+    hipLaunchKernelGGL((gemm_conv_kernel<KW, STRIDE, SWAP, RELU>), dim3(static_cast<unsigned>(nwg)), dim3(256), 0, stream, a);
+    return launch_status(what);
+}
+
+// internal entry used by lstm.hip: gates(b, t, 4H) = x(b, :, t) . w_ih^T + b_ih + b_hh
+int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* gates,
+                          int batch, int c_in, int frames, int ld, int rows4h, hipStream_t stream)
+{
+    GemmConvArgs a{};
+    a.x = x; a.w = w_ih; a.bias = b_ih; a.bias2 = b_hh; a.y = gates;
+    a.c_in = c_in; a.frames_in = frames; a.ld_in = ld; a.c_out = rows4h; a.frames_out = frames; a.ld_out = rows4h;
+    a.lpad = 0; a.ktot = c_in; a.batch = batch;
+    return launch_gemm_conv<1, 1, true, false>(a, stream, "nbasr_lstm_forward(input projection)");
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
+                                        const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                                        int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                                        nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused: x, w, bias, y must be non-NULL");
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused: bad sizes");
+    NBASR_REQUIRE((kernel == 8 && (stride == 1 || stride == 2)) || (kernel == 1 && stride == 1), NBASR_EINVAL,
+                  "nbasr_dense_conv1d_fused: (kernel=%d, stride=%d) unsupported; model uses k=8 s in {1,2} and k=1 s=1", kernel, stride);
+    const int frames_out = (frames_in + stride - 1) / stride;
+    NBASR_REQUIRE(ld_in >= frames_in, NBASR_EINVAL, "nbasr_dense_conv1d_fused: ld_in=%d < frames_in=%d", ld_in, frames_in);
+    NBASR_REQUIRE(ld_out >= frames_out && ld_out % 4 == 0, NBASR_EALIGN,
+                  "nbasr_dense_conv1d_fused: ld_out=%d must be >= %d output frames and a multiple of 4", ld_out, frames_out);
+    NBASR_REQUIRE((c_in * kernel) % 4 == 0 && aligned16(w), NBASR_EALIGN,
+                  "nbasr_dense_conv1d_fused: c_in*kernel=%d must be a multiple of 4 and w 16-byte aligned", c_in * kernel);
+    if (batch == 0 || frames_out == 0) return NBASR_OK;
+    GemmConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.bias2 = nullptr; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
+    a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
+    a.lpad = pad_left(kernel, 1, stride); a.ktot = c_in * kernel; a.batch = batch;
+    hipStream_t s = as_stream(stream);
+    if (kernel == 8 && stride == 1) return launch_gemm_conv<8, 1, false, true>(a, s, "nbasr_dense_conv1d_fused");
+    if (kernel == 8 && stride == 2) return launch_gemm_conv<8, 2, false, true>(a, s, "nbasr_dense_conv1d_fused");
+    return launch_gemm_conv<1, 1, false, true>(a, s, "nbasr_dense_conv1d_fused");
+}

@@ -1,0 +1,126 @@
+// LayerNorm over the CHANNEL dimension of a (batch, channels, frames) tensor, frames contiguous
+// (reference model.py:92 + 125-128 after each downsample conv, model.py:46-47 + 55-58 at the end of
+// each cell; eps = 1e-3, biased variance, affine).  The reference permutes to (B,T,C), normalises and
+// permutes back, leaving a strided view; here the reduction dimension is simply the SLOW dimension,
+// so no lane ever needs a cross-lane reduction for the statistics of its own frames.
+//
+// Mapping: a 256-thread workgroup owns 64 consecutive frames of one utterance as 16 lanes x 16-byte
+// chunks (256-byte contiguous row segments) times 16 channel rows in flight; channels are strided
+// over the 16 row slots.  Pass 1 accumulates shifted sums per lane (shift = first sample, so the
+// single pass is cancellation-safe), the 16 row partials are merged with Chan's parallel-variance
+// formula through LDS, pass 2 re-reads the tile (L2 / Infinity-Cache warm) and writes the result.
+// HBM-bound: 2 reads + 1 write of the tensor (algorithmic minimum 1 read + 1 write).
+#include "common.h"
+
+namespace nbasr {
+
+constexpr int LN_ROWS = 16;   // channel rows in flight per workgroup
+constexpr int LN_QS = 16;     // 16-byte chunks (4 frames each) per row segment
+
+__global__ __launch_bounds__(256) void layernorm_channels_kernel(
+    const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* y, int channels, int frames, int ld, float eps)   // x may alias y (in-place)
+{
+    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
+    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
+    __shared__ float s_cnt[LN_ROWS];
+    __shared__ float s_mu[LN_QS * 4];
+    __shared__ float s_rstd[LN_QS * 4];
+
+    const int ql = threadIdx.x & (LN_QS - 1);
+    const int row = threadIdx.x / LN_QS;
+    const int nq = ld >> 2;
+    const int q = blockIdx.x * LN_QS + ql;
+    const int b = blockIdx.y;
+    const bool active = q < nq;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+
+    // ---- pass 1: per-lane shifted sums over this lane's channel subset -------------------------
+    float shift[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    int n = 0;
+    if (active) {
+        for (int c = row; c < channels; c += LN_ROWS) {
+            const float4 v = *reinterpret_cast<const float4*>(x + base + static_cast<size_t>(c) * ld);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+            if (n == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) shift[r] = e[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = e[r] - shift[r];
+                s1[r] += d;
+                s2[r] = __builtin_fmaf(d, d, s2[r]);
+            }
+            ++n;
+        }
+    }
+    const float fn = static_cast<float>(n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float dm = n ? s1[r] / fn : 0.f;
+        s_mean[row][ql * 4 + r] = shift[r] + dm;
+        s_m2[row][ql * 4 + r] = n ? fmaxf(s2[r] - dm * s1[r], 0.f) : 0.f;
+    }
+    if (ql == 0) s_cnt[row] = fn;
+    __syncthreads();
+
+    // ---- merge the 16 row partials (one thread per frame column) -------------------------------
+    if (threadIdx.x < LN_QS * 4) {
+        const int col = threadIdx.x;
+        float cnt = 0.f, mean = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_ROWS; ++k) {
+            const float nb = s_cnt[k];
+            if (nb > 0.f) {
+                const float tot = cnt + nb;
+                const float delta = s_mean[k][col] - mean;
+                mean += delta * (nb / tot);
+                m2 += s_m2[k][col] + delta * delta * (cnt * nb / tot);
+                cnt = tot;
+            }
+        }
+        s_mu[col] = mean;
+        s_rstd[col] = 1.0f / sqrtf(m2 / fmaxf(cnt, 1.f) + eps);
+    }
+    __syncthreads();
+
+    // ---- pass 2: normalise, scale, shift; keep the pitch columns at zero -----------------------
+    if (!active) return;
+    float mu[4], rs[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mu[r] = s_mu[ql * 4 + r]; rs[r] = s_rstd[ql * 4 + r]; }
+    const int t0 = q * 4;
+    for (int c = row; c < channels; c += LN_ROWS) {
+        const size_t off = base + static_cast<size_t>(c) * ld;
+        const float4 v = *reinterpret_cast<const float4*>(x + off);
+        const float g = gamma[c], bt = beta[c];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            o[r] = (o[r] - mu[r]) * rs[r] * g + bt;
+            if (t0 + r >= frames) o[r] = 0.f;
+        }
+        *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y, int batch,
+                                        int channels, int frames, int ld, float eps, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(x && gamma && beta && y, NBASR_ENULL, "nbasr_layernorm_channels: NULL pointer");
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_layernorm_channels: bad sizes");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_layernorm_channels: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    NBASR_REQUIRE(aligned16(x) && aligned16(y), NBASR_EALIGN, "nbasr_layernorm_channels: x, y must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_layernorm_channels: batch %d > 65535", batch);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    const int nq = ld / 4;
+    hipLaunchKernelGGL(layernorm_channels_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
+                       x, gamma, beta, y, channels, frames, ld, eps);
+    return launch_status("nbasr_layernorm_channels");
+}

@@ -1,0 +1,214 @@
+// nn.LSTM(1200 -> 500, batch_first, one layer, zero initial state) and the CTC head nn.Linear
+// (reference model.py:100-103, forward model.py:118-124), gate order i, f, g, o, bias b_ih + b_hh.
+//
+//  1. input projection for ALL frames at once: one fp32-MFMA GEMM (gemm_conv.hip, transposed store)
+//     gates[b][t][4H] = x[b][:, t] . W_ih^T + b_ih + b_hh      -- the reference's permute(0,2,1) is
+//     folded into the operand loader, nothing is transposed in memory;
+//  2. the recurrence: one launch per frame.  A workgroup owns 16 hidden units x 16 utterances and
+//     all four gates; its 4 waves split K = hidden four ways (v_mfma_f32_16x16x4_f32, 16-byte
+//     operand loads: the 4 components of a lane's float4 feed 4 consecutive MFMAs, which is a
+//     k-permutation applied identically to W_hh and h and therefore leaves the sums unchanged),
+//     partial tiles are reduced through LDS and the gate nonlinearities, cell update and h store are
+//     fused behind the reduction.  h_{t-1} is read straight from the (batch, frames, hidden) output.
+//  3. head: logits = h . W^T + b on 16x16x4 MFMA tiles (classes padded to 64 in registers only).
+//
+// The recurrence is latency-bound (frames dependent steps); steps are plain stream-ordered launches.
+#include "common.h"
+
+namespace nbasr {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* gates,
+                          int batch, int c_in, int frames, int ld, int rows4h, hipStream_t stream);
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// grid: (ceil(hidden/16), ceil(batch/16)); block 256 = 4 waves (K quarters)
+__global__ __launch_bounds__(256) void lstm_step_kernel(
+    const float* __restrict__ gates_in,   // (batch, frames, 4*hidden): input projection incl. biases
+    const float* __restrict__ w_hh,       // (4*hidden, hidden)
+    float* __restrict__ cell,             // (batch, hidden) running cell state
+    float* h_out,                         // (batch, frames, hidden); row t-1 is read, row t written
+    int batch, int frames, int hidden, int t)
+{
+    __shared__ float red[4][4][4][64];    // [wave][gate][reg][lane]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+
+    floatx4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    if (t > 0) {
+        const int kchunks = (hidden + 15) / 16;              // 16 k per chunk
+        const int per_wave = (kchunks + 3) / 4;
+        const int c_begin = wave * per_wave;
+        const int c_end = min(kchunks, c_begin + per_wave);
+        const bool row_ok = (j0 + i16) < hidden;
+        const bool col_ok = (b0 + i16) < batch;
+        const float* hrow = h_out + (static_cast<size_t>(b0 + i16) * frames + (t - 1)) * hidden;
+        for (int c = c_begin; c < c_end; ++c) {
+            const int k = c * 16 + kq * 4;
+            const bool kok = k < hidden;                      // hidden % 4 == 0: whole float4 in or out
+            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col_ok && kok) hv = *reinterpret_cast<const float4*>(hrow + k);
+            float4 wv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                wv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row_ok && kok)
+                    wv[g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].x, hv.x, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].y, hv.y, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].z, hv.z, acc[g], 0, 0, 0);
+                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].w, hv.w, acc[g], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][g][r][lane] = acc[g][r];
+    __syncthreads();
+
+    // one thread per (hidden unit, utterance): C/D layout col = lane & 15 (utterance),
+    // row = (lane >> 4) * 4 + reg (hidden unit)
+    const int pl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+    const int j = j0 + (pl >> 4) * 4 + pr;
+    const int b = b0 + (pl & 15);
+    if (j >= hidden || b >= batch) return;
+    float pre[4];
+    const float* gin = gates_in + (static_cast<size_t>(b) * frames + t) * (4 * hidden);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s = red[0][g][pr][pl];
+        s += red[1][g][pr][pl];
+        s += red[2][g][pr][pl];
+        s += red[3][g][pr][pl];
+        pre[g] = gin[g * hidden + j] + s;
+    }
+    const size_t ci = static_cast<size_t>(b) * hidden + j;
+    const float c_prev = (t > 0) ? cell[ci] : 0.f;
+    const float c_new = sigmoidf_(pre[1]) * c_prev + sigmoidf_(pre[0]) * tanhf(pre[2]);
+    const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
+    cell[ci] = c_new;
+    h_out[(static_cast<size_t>(b) * frames + t) * hidden + j] = h_new;
+}
+
+// logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias; classes <= 64.
+// BCT = true: h is the encoder output (batch, features, ld) and row = (b, t)  (use_rnn=False model).
+template <bool BCT>
+__global__ __launch_bounds__(256) void head_kernel(
+    const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int rows, int features, int classes, int frames, int ld)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int r0 = (blockIdx.x * 4 + wave) * 16;
+    if (r0 >= rows) return;
+
+    floatx4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int row = r0 + i16;
+    const bool row_ok = row < rows;
+    const int kchunks = (features + 15) / 16;
+    for (int c = 0; c < kchunks; ++c) {
+        const int k = c * 16 + kq * 4;
+        const bool kok = k < features;                        // features % 4 == 0
+        float av[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok && kok) {
+            if (!BCT) {
+                const float4 v = *reinterpret_cast<const float4*>(h + static_cast<size_t>(row) * features + k);
+                av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+            } else {
+                const int bb = row / frames, tt = row - bb * frames;
+                const float* p = h + (static_cast<size_t>(bb) * features + k) * ld + tt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[e] = p[static_cast<size_t>(e) * ld];
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int cls = n * 16 + i16;
+            float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cls < classes && kok) wv = *reinterpret_cast<const float4*>(w + static_cast<size_t>(cls) * features + k);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wv.x, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wv.y, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wv.z, acc[n], 0, 0, 0);
+            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wv.w, acc[n], 0, 0, 0);
+        }
+    }
+    // D[m = row][n = class]: col = lane & 15 (class), row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int cls = n * 16 + i16;
+        if (cls >= classes) continue;
+        const float bv = bias[cls];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = r0 + kq * 4 + r;
+            if (rr < rows) out[static_cast<size_t>(rr) * classes + cls] = acc[n][r] + bv;
+        }
+    }
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                                  const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
+                                  int c_in, int frames, int ld, int hidden, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && gates_ws && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_forward: NULL pointer");
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames >= 0 && hidden > 0 && ld >= frames, NBASR_EINVAL, "nbasr_lstm_forward: bad sizes");
+    NBASR_REQUIRE(hidden % 4 == 0 && c_in % 4 == 0, NBASR_EALIGN, "nbasr_lstm_forward: hidden=%d and c_in=%d must be multiples of 4", hidden, c_in);
+    NBASR_REQUIRE(aligned16(w_ih) && aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_forward: w_ih, w_hh, h_out must be 16-byte aligned");
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    hipStream_t s = as_stream(stream);
+    int rc = lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, s);
+    if (rc != NBASR_OK) return rc;
+    const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
+    for (int t = 0; t < frames; ++t)
+        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
+    return launch_status("nbasr_lstm_forward");
+}
+
+extern "C" int nbasr_linear_head(const float* h, const float* w, const float* bias, float* logits, int rows,
+                                 int features, int classes, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(h && w && bias && logits, NBASR_ENULL, "nbasr_linear_head: NULL pointer");
+    NBASR_REQUIRE(rows >= 0 && features > 0 && classes > 0 && classes <= 64, NBASR_EINVAL,
+                  "nbasr_linear_head: rows=%d features=%d classes=%d (classes must be <= 64)", rows, features, classes);
+    NBASR_REQUIRE(features % 4 == 0 && aligned16(h) && aligned16(w), NBASR_EALIGN,
+                  "nbasr_linear_head: features must be a multiple of 4 and h, w 16-byte aligned");
+    if (rows == 0) return NBASR_OK;
+    hipLaunchKernelGGL(head_kernel<false>, dim3((rows + 63) / 64), dim3(256), 0, as_stream(stream),
+                       h, w, bias, logits, rows, features, classes, 0, 0);
+    return launch_status("nbasr_linear_head");
+}
+
+extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits, int batch,
+                                     int features, int frames, int ld, int classes, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(x && w && bias && logits, NBASR_ENULL, "nbasr_linear_head_bct: NULL pointer");
+    NBASR_REQUIRE(batch >= 0 && features > 0 && frames >= 0 && ld >= frames && classes > 0 && classes <= 64, NBASR_EINVAL,
+                  "nbasr_linear_head_bct: bad sizes (classes must be <= 64)");
+    NBASR_REQUIRE(features % 4 == 0 && aligned16(w), NBASR_EALIGN, "nbasr_linear_head_bct: features must be a multiple of 4, w 16-byte aligned");
+    const long long rows = static_cast<long long>(batch) * frames;
+    if (rows == 0) return NBASR_OK;
+    hipLaunchKernelGGL(head_kernel<true>, dim3(static_cast<unsigned>((rows + 63) / 64)), dim3(256), 0, as_stream(stream),
+                       x, w, bias, logits, static_cast<int>(rows), features, classes, frames, ld);
+    return launch_status("nbasr_linear_head_bct");
+}

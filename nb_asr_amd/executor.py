@@ -1,0 +1,119 @@
+"""Host-side executor: walks the model's layer list and enqueues the HIP kernels.
+
+Replaces the isinstance-dispatch loop of the reference's ``ASRModel.forward`` (model.py:116-131),
+``SearchCell.forward`` (model.py:49-59) and ``Node.forward`` (model.py:13-22):
+
+* activations stay in (batch, channels, frames) order in pitched workspace buffers (row pitch =
+  frames rounded up to 4, pitch columns kept at zero), so none of the reference's permutes, padded
+  copies, ``zeros_like`` branches or ``0 + x`` adds exist here;
+* a node is ONE launch: main op + bias + ReLU + clamp + the sum of its flagged skip inputs;
+* LayerNorm runs on the channel (slow) dimension in place.
+
+Four workspace buffers sized for the widest block are rotated; nothing is allocated per call
+except the returned logits.
+"""
+import weakref
+
+import torch
+
+from . import hip
+
+
+def node_into(node, inputs, frames, out):
+    """Enqueue one cell node: ``out = op(inputs[-1]) + sum(flagged inputs)`` (left-to-right)."""
+    from .ops import PadConvRelu, Linear, Zero, Identity
+    if len(inputs) != len(node.branch_ops):
+        raise AssertionError('Branch op and input list have different lenghts')
+    skips = [src for branch, src in zip(node.branch_ops, inputs) if isinstance(branch, Identity)]
+    op, last = node.op, inputs[-1]
+    if isinstance(op, PadConvRelu):
+        hip.grouped_conv1d_fused(last, op.conv.weight.detach(), op.conv.bias.detach(), skips, out, frames,
+                                 op.groups, op.kernel_size, op.dilation)
+    elif isinstance(op, Linear):
+        hip.dense_conv1d_fused(last, frames, op.linear.weight.detach().unsqueeze(-1), op.linear.bias.detach(),
+                               skips, out, 1)
+    elif isinstance(op, Zero):
+        hip.skip_sum(skips, out, frames)
+    else:
+        raise TypeError(f'unsupported node operation {type(op).__name__}')
+    return out
+
+
+class ForwardPlan:
+    """Workspace + launch sequence of one model for one (batch, frames, device)."""
+
+    def __init__(self, model, batch, frames, device):
+        from .model import FILTERS, DOWN_STRIDES, LSTM_HIDDEN
+        self._model = weakref.ref(model)
+        self.batch, self.frames, self.device = batch, frames, device
+        t, self.block_frames = frames, []
+        for s in DOWN_STRIDES:
+            t = (t + s - 1) // s
+            self.block_frames.append(t)
+        self.out_frames = self.block_frames[-1]
+        elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
+        self.pool = [torch.empty(max(elems, 4), device=device, dtype=torch.float32) for _ in range(4)]
+        if model.use_rnn:
+            self.gates_ws = torch.empty(batch * self.out_frames * 4 * LSTM_HIDDEN, device=device, dtype=torch.float32)
+            self.cell_ws = torch.empty(batch * LSTM_HIDDEN, device=device, dtype=torch.float32)
+            self.h_out = torch.empty(batch, self.out_frames, LSTM_HIDDEN, device=device, dtype=torch.float32)
+
+    def _view(self, idx, channels, frames):
+        ld = hip.round_up4(frames)
+        return self.pool[idx][: self.batch * channels * ld].view(self.batch, channels, ld)
+
+    def run(self, x):
+        from .model import SearchCell
+        from .ops import PadConvRelu
+        import torch.nn as nn
+
+        model = self._model()
+        if model is None:
+            raise RuntimeError('the model this plan belongs to no longer exists')
+        if x.dtype != torch.float32:
+            raise hip.HipError(f'input must be float32 (got {x.dtype})')
+        x = x.detach().contiguous()
+        act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
+        blk = -1
+        logits = None
+        for layer in model.model:
+            if isinstance(layer, PadConvRelu):
+                blk += 1
+                dst = 0 if cur != 0 else 1
+                t_out = self.block_frames[blk]
+                out = self._view(dst, layer.conv.out_channels, t_out)
+                hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(), (), out,
+                                       layer.strides)
+                act, act_frames, cur = out, t_out, dst
+            elif isinstance(layer, nn.LayerNorm):
+                if act.dim() != 3:
+                    raise RuntimeError('LayerNorm in an unexpected position of the layer list')
+                hip.layernorm_channels(act, layer.weight.detach(), layer.bias.detach(), act, act_frames, layer.eps)
+            elif isinstance(layer, SearchCell):
+                free = [i for i in range(4) if i != cur]
+                if len(layer.nodes) > len(free):
+                    raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
+                outs = [act]
+                for node, dst in zip(layer.nodes, free):
+                    outs.append(node_into(node, outs, act_frames, self._view(dst, layer.filters, act_frames)))
+                act, cur = outs[-1], free[len(layer.nodes) - 1]
+                if layer.use_norm:
+                    hip.layernorm_channels(act, layer.norm_layer.weight.detach(), layer.norm_layer.bias.detach(), act,
+                                           act_frames, layer.norm_layer.eps)
+            elif isinstance(layer, nn.Dropout):
+                continue                                     # identity: eval mode or p == 0 (checked by the model)
+            elif isinstance(layer, nn.LSTM):
+                hip.lstm_forward(act, act_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
+                                 layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach(), self.gates_ws, self.cell_ws,
+                                 self.h_out)
+                act = self.h_out                             # (batch, frames, hidden)
+            elif isinstance(layer, nn.Linear):
+                logits = torch.empty(self.batch, act_frames, layer.out_features, device=self.device, dtype=torch.float32)
+                if act.dim() == 3 and act is self.__dict__.get('h_out'):
+                    hip.linear_head(act, layer.weight.detach(), layer.bias.detach(), logits)
+                else:
+                    hip.linear_head_bct(act, act_frames, layer.weight.detach(), layer.bias.detach(), logits)
+                act = logits
+            else:
+                raise TypeError(f'unsupported layer {type(layer).__name__} in the model list')
+        return logits

@@ -1,0 +1,186 @@
+"""ctypes binding of libnbasr_hip.so (C ABI declared in include/nbasr.h).
+
+PyTorch is used here only as plumbing: device memory (``tensor.data_ptr()``) and the current HIP
+stream.  Every wrapper validates device / dtype / contiguity on the host, passes raw pointers
+and sizes, and raises ``HipError`` with the library's message on a non-zero return code.
+
+There is NO fallback: if the library is missing or the tensors are not on a HIP device the
+call fails loudly (build with ``python -m nb_asr_amd.build``).
+"""
+import ctypes
+import pathlib
+
+import torch
+
+LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libnbasr_hip.so'
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
+_c_int = ctypes.c_int
+_c_stream = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol declared in include/nbasr.h
+SIGNATURES = {
+    'nbasr_version': (_c_int, []),
+    'nbasr_last_error': (ctypes.c_char_p, []),
+    'nbasr_pad_amounts': (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
+    'nbasr_output_frames': (_c_int, [_c_int]),
+    'nbasr_grouped_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_stream]),
+    'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load (once) and type the shared library.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = pathlib.Path(path) if path is not None else LIB_PATH
+    if not p.exists():
+        raise HipError(f'{p} not found: the HIP extension has not been built '
+                       f'(run `python -m nb_asr_amd.build`); there is no CPU fallback')
+    lib = ctypes.CDLL(str(p))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)        # AttributeError if a declared symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    got = lib.nbasr_version()
+    if got != ABI_VERSION:
+        raise HipError(f'{p}: ABI version {got}, binding expects {ABI_VERSION}; rebuild the library')
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().nbasr_last_error().decode('utf-8', 'replace')
+        raise HipError(f'{what} failed with code {rc}: {msg}')
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipError(f'{name} must be a tensor on a HIP device (got {getattr(t, "device", type(t))}); '
+                       f'this package has no CPU path')
+    if t.dtype != torch.float32:
+        raise HipError(f'{name} must be float32 (got {t.dtype})')
+    if not t.is_contiguous():
+        raise HipError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+def _opt(t, name):
+    return None if t is None else _dev(t, name)
+
+
+# ---------------------------------------------------------------------------------------------
+# host-only helpers (usable without a GPU)
+# ---------------------------------------------------------------------------------------------
+def pad_amounts(kernel, dilation, stride):
+    left, right = _c_int(), _c_int()
+    _check(load_library().nbasr_pad_amounts(kernel, dilation, stride, ctypes.byref(left), ctypes.byref(right)),
+           'nbasr_pad_amounts')
+    return left.value, right.value
+
+
+def output_frames(frames):
+    return load_library().nbasr_output_frames(frames)
+
+
+def round_up4(n):
+    return (n + 3) & ~3
+
+
+# ---------------------------------------------------------------------------------------------
+# device entry points; activations are (batch, channels, ld) float32 tensors whose last dimension
+# is the row pitch ld (a multiple of 4) and `frames` <= ld the number of valid frames
+# ---------------------------------------------------------------------------------------------
+def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dilation):
+    b, c, ld = x.shape
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_grouped_conv1d_fused(
+        _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
+        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c, frames, ld, groups, kernel, dilation, _stream(x)),
+        'nbasr_grouped_conv1d_fused')
+    return y
+
+
+def skip_sum(skips, y, frames):
+    b, c, ld = y.shape
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_skip_sum(_opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
+                                         _dev(y, 'y'), b, c, frames, ld, _stream(y)), 'nbasr_skip_sum')
+    return y
+
+
+def layernorm_channels(x, gamma, beta, y, frames, eps):
+    b, c, ld = x.shape
+    _check(load_library().nbasr_layernorm_channels(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
+                                                   _dev(y, 'y'), b, c, frames, ld, float(eps), _stream(x)),
+           'nbasr_layernorm_channels')
+    return y
+
+
+def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride):
+    b, c_in, ld_in = x.shape
+    c_out, _, kernel = weight.shape if weight.dim() == 3 else (weight.shape[0], weight.shape[1], 1)
+    ld_out = y.shape[2]
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_dense_conv1d_fused(
+        _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
+        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)),
+        'nbasr_dense_conv1d_fused')
+    return y
+
+
+def lstm_forward(x, frames, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out):
+    b, c_in, ld = x.shape
+    hidden = w_hh.shape[1]
+    _check(load_library().nbasr_lstm_forward(
+        _dev(x, 'x'), _dev(w_ih, 'w_ih'), _dev(w_hh, 'w_hh'), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'),
+        _dev(gates_ws, 'gates_ws'), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
+        b, c_in, frames, ld, hidden, _stream(x)), 'nbasr_lstm_forward')
+    return h_out
+
+
+def linear_head(h, weight, bias, logits):
+    classes, features = weight.shape
+    rows = h.numel() // features
+    _check(load_library().nbasr_linear_head(_dev(h, 'h'), _dev(weight, 'weight'), _dev(bias, 'bias'),
+                                            _dev(logits, 'logits'), rows, features, classes, _stream(h)),
+           'nbasr_linear_head')
+    return logits
+
+
+def linear_head_bct(x, frames, weight, bias, logits):
+    b, features, ld = x.shape
+    classes = weight.shape[0]
+    _check(load_library().nbasr_linear_head_bct(_dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'),
+                                                _dev(logits, 'logits'), b, features, frames, ld, classes,
+                                                _stream(x)), 'nbasr_linear_head_bct')
+    return logits
+
+
+def repitch(src, dst, frames):
+    """src (..., ld_src) -> dst (..., ld_dst): copy `frames` columns, zero the rest of dst's pitch."""
+    rows = src.numel() // src.shape[-1]
+    _check(load_library().nbasr_repitch(_dev(src, 'src'), _dev(dst, 'dst'), rows, frames, src.shape[-1],
+                                        dst.shape[-1], _stream(src)), 'nbasr_repitch')
+    return dst

@@ -1,0 +1,147 @@
+"""The NAS-Bench-ASR acoustic model with a HIP forward.
+
+Interface mirror of the reference's ``nasbench_asr/model/torch/model.py``: ``Node`` (7-22),
+``SearchCell`` (25-59), ``ASRModel`` (62-135) with the same constructor arguments, attributes
+(``arch_desc, num_classes, use_rnn, use_norm, dropout_rate``), module tree and hence the same
+``state_dict`` keys, so reference checkpoints load unchanged:
+
+    model.{i}.conv.weight|bias             downsample PadConvRelu (k=8), i = 0, 5, 11, 18
+    model.{i}.weight|bias                  block LayerNorm, i = 1, 6, 12, 19
+    model.{i}.nodes.{j}.op.conv.*          grouped-conv node op      (cells)
+    model.{i}.nodes.{j}.op.linear.*        linear node op
+    model.{i}.norm_layer.weight|bias       cell LayerNorm
+    model.27.weight_ih_l0 ...              nn.LSTM;  model.28.weight|bias the CTC head
+
+``forward((B, 80, T)) -> (B, ceil(ceil(T/2)/2), 49)`` runs entirely on HIP kernels through
+``executor.ForwardPlan``; the nested torch modules are parameter containers.  Inputs must live on
+a HIP device -- there is no CPU path in this package.
+"""
+import torch
+import torch.nn as nn
+
+from . import hip
+from .executor import ForwardPlan, node_into
+from .ops import PadConvRelu, _ops, _branch_ops, _check_dropout, _pitched
+
+FILTERS = (600, 800, 1000, 1200)
+CELLS_PER_BLOCK = (3, 4, 5, 6)
+DOWN_KERNELS = (8, 8, 8, 8)
+DOWN_STRIDES = (1, 1, 2, 2)
+FEATURES = 80
+LSTM_HIDDEN = 500
+LN_EPS = 0.001
+
+
+class Node(nn.Module):
+    """Main op applied to the newest input plus the sum of the flagged earlier inputs."""
+
+    def __init__(self, filters, op_ctor, branch_op_ctors, dropout_rate=0.0):
+        super().__init__()
+        self.op = op_ctor(filters, filters, dropout_rate=dropout_rate)
+        self.branch_ops = [make() for make in branch_op_ctors]     # plain list: no parameters, no keys
+
+    def forward(self, input_list):
+        pitched = [_pitched(t) for t in input_list]
+        frames = pitched[-1][1]
+        out = torch.empty_like(pitched[-1][0])
+        node_into(self, [p for p, _ in pitched], frames, out)       # one fused launch
+        return out[:, :, :frames]
+
+
+class SearchCell(nn.Module):
+    """``len(node_configs)`` nodes in sequence, the last node's output LayerNorm-ed over channels."""
+
+    def __init__(self, filters, node_configs, dropout_rate=0.0, use_norm=True):
+        super().__init__()
+        self.filters = filters
+        self.node_configs = [list(cfg) for cfg in node_configs]
+        self.nodes = nn.ModuleList()
+        for op_name, *flags in node_configs:
+            if op_name not in _ops:
+                raise ValueError(f'Operation "{op_name}" is not implemented')
+            if any(f not in _branch_ops for f in flags):
+                raise ValueError(f'Invalid branch operations: {flags}, expected is a vector of 0 (no skip-con.) '
+                                 f'and 1 (skip-con. present)')
+            self.nodes.append(Node(filters, _ops[op_name], [_branch_ops[f] for f in flags], dropout_rate))
+        self.use_norm = use_norm
+        if use_norm:
+            self.norm_layer = nn.LayerNorm(filters, eps=LN_EPS)
+
+    def forward(self, input):
+        outs = [input]
+        for node in self.nodes:
+            outs.append(node(outs))
+        y = outs[-1]
+        if self.use_norm:
+            yp, frames = _pitched(y)
+            hip.layernorm_channels(yp, self.norm_layer.weight.detach(), self.norm_layer.bias.detach(), yp, frames,
+                                   self.norm_layer.eps)
+            y = yp[:, :, :frames]
+        return y
+
+
+class ASRModel(nn.Module):
+    def __init__(self, arch_desc, num_classes=48, use_rnn=False, use_norm=True, dropout_rate=0.0, **kwargs):
+        super().__init__()
+        self.arch_desc = arch_desc
+        self.num_classes = num_classes
+        self.use_rnn = use_rnn
+        self.use_norm = use_norm
+        self.dropout_rate = dropout_rate
+
+        layers = nn.ModuleList()
+        width_in = FEATURES
+        for blk, width in enumerate(FILTERS):
+            layers.append(PadConvRelu(width_in, width, DOWN_KERNELS[blk], dilation=1, strides=DOWN_STRIDES[blk],
+                                      groups=1, name=f'conv_{blk}'))
+            layers.append(nn.LayerNorm(width, eps=LN_EPS))
+            for _ in range(CELLS_PER_BLOCK[blk]):
+                layers.append(SearchCell(width, arch_desc, dropout_rate=dropout_rate, use_norm=use_norm))
+            width_in = width
+        if use_rnn:
+            layers.append(nn.Dropout(dropout_rate))
+            layers.append(nn.LSTM(input_size=FILTERS[-1], hidden_size=LSTM_HIDDEN, batch_first=True, dropout=0.0))
+            layers.append(nn.Linear(LSTM_HIDDEN, num_classes + 1))
+        else:
+            layers.append(nn.Linear(FILTERS[-1], num_classes + 1))
+        self.model = layers
+        self._plans = {}
+
+    # ------------------------------------------------------------------------------------------
+    def get_prunable_copy(self, bn=False, masks=None):
+        """Clone with ``use_norm=bn`` (cell LayerNorms dropped when False); weights copied non-strictly."""
+        clone = ASRModel(arch_desc=self.arch_desc, num_classes=self.num_classes, use_rnn=self.use_rnn, use_norm=bn,
+                         dropout_rate=self.dropout_rate)
+        clone.load_state_dict(self.state_dict(), strict=False)
+        ref = next(self.parameters())
+        clone.to(ref.device)
+        clone.train()
+        return clone
+
+    def forward(self, input):
+        """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1)."""
+        _check_dropout(self)
+        if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES:
+            raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor, got {tuple(getattr(input, "shape", ()))}')
+        if not input.is_cuda:
+            raise hip.HipError('ASRModel.forward needs its input on a HIP device; this package has no CPU path')
+        key = (input.shape[0], input.shape[2], input.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) >= 4:          # bounded cache: workspaces are hundreds of MB
+                self._plans.clear()
+            plan = self._plans[key] = ForwardPlan(self, input.shape[0], input.shape[2], input.device)
+        return plan.run(input)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state['_plans'] = {}                  # never pickle / deepcopy workspaces
+        return state
+
+    def _apply(self, fn, *args, **kwargs):
+        self._plans = {}                      # parameters may move: drop cached workspaces
+        return super()._apply(fn, *args, **kwargs)
+
+    @property
+    def backend(self):
+        return 'hip'

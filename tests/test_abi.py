@@ -1,0 +1,55 @@
+"""The C-ABI library loads and exports exactly what include/nbasr.h declares (no GPU needed)."""
+import ctypes
+import pathlib
+import re
+
+import pytest
+
+from nb_asr_amd import hip
+
+HEADER = pathlib.Path(__file__).resolve().parent.parent / 'include' / 'nbasr.h'
+
+
+def declared_symbols():
+    text = re.sub(r'/\*.*?\*/', '', HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r'\b(nbasr_[a-z0-9_]+)\s*\(', text)))
+
+
+def test_header_and_binding_agree():
+    names = declared_symbols()
+    assert len(names) >= 12
+    assert sorted(hip.SIGNATURES) == names
+
+
+def test_library_exports_every_declared_symbol(built_library):
+    lib = ctypes.CDLL(str(built_library))
+    for name in declared_symbols():
+        assert hasattr(lib, name), name
+    assert hip.load_library().nbasr_version() == hip.ABI_VERSION == 1
+
+
+def test_signatures_have_no_torch_types():
+    code = re.sub(r'/\*.*?\*/', '', HEADER.read_text(), flags=re.S)          # declarations only, comments stripped
+    assert 'extern "C"' in code
+    for forbidden in ('torch', 'Tensor', 'at::', 'c10::', 'std::'):
+        assert forbidden not in code
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    lib = hip.load_library()
+    # NULL pointers / bad sizes are rejected on the host before anything touches a device
+    rc = lib.nbasr_grouped_conv1d_fused(None, None, None, None, None, None, None, 1, 600, 16, 16, 100, 5, 1, None)
+    assert rc == -3 and b'non-NULL' in lib.nbasr_last_error()
+    rc = lib.nbasr_layernorm_channels(16, 16, 16, 16, 1, 600, 10, 10, 1e-3, None)      # ld not a multiple of 4
+    assert rc == -2 and b'multiple of 4' in lib.nbasr_last_error()
+    rc = lib.nbasr_grouped_conv1d_fused(16, 16, 16, None, None, None, 16, 1, 700, 16, 16, 100, 5, 1, None)
+    assert rc == -1 and b'channels/groups=7' in lib.nbasr_last_error()
+    rc = lib.nbasr_dense_conv1d_fused(16, 16, 16, None, None, None, 16, 1, 80, 16, 16, 600, 16, 3, 1, None)
+    assert rc == -1 and b'unsupported' in lib.nbasr_last_error()
+    rc = lib.nbasr_linear_head(16, 16, 16, 16, 10, 500, 65, None)
+    assert rc == -1
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(hip.HipError, match='no CPU fallback'):
+        hip.load_library(tmp_path / 'libnbasr_hip.so')

@@ -1,0 +1,113 @@
+"""Host-side model surface: construction, state_dict compatibility, error behaviour (no GPU needed)."""
+import hashlib
+import io
+import json
+
+import pytest
+import torch
+
+import cases
+import nb_asr_amd as nb
+from nb_asr_amd import hip, model as nb_model, ops as nb_ops
+from oracle import asr_oracle as oracle
+
+
+def _sha(text):
+    return hashlib.sha256(text.encode('utf-8')).hexdigest()
+
+
+@pytest.mark.parametrize('arch', [cases.ARCH_A, cases.ARCH_D, cases.ARCH_M])
+@pytest.mark.parametrize('use_rnn', [True, False])
+def test_state_dict_matches_reference(known, arch, use_rnn):
+    m = nb.get_model(arch, use_rnn=use_rnn, dropout_rate=0.0)
+    tag = f'{json.dumps(arch)}|rnn={use_rnn}'
+    assert sum(p.numel() for p in m.parameters()) == known['param_counts'][tag]
+    layout = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    assert _sha(json.dumps(layout)) == known['state_dict_digests'][tag]        # same keys, order and shapes
+    assert {k: tuple(s) for k, s in layout} == oracle.parameter_shapes(arch, use_rnn=use_rnn)
+    assert m.training == known['returned_in_training_mode'][tag] is True
+    assert m.backend == 'hip'
+    assert (m.arch_desc, m.num_classes, m.use_rnn, m.use_norm, m.dropout_rate) == (nb.arch_vec_to_names(arch), 48, use_rnn, True, 0.0)
+
+
+def test_known_param_counts(known):
+    assert known['param_counts'][f'{json.dumps(cases.ARCH_A)}|rnn=True'] == 26341349
+    assert known['param_counts'][f'{json.dumps(cases.ARCH_A)}|rnn=False'] == 22971649
+    assert known['param_counts'][f'{json.dumps(cases.ARCH_D)}|rnn=True'] == 27032549
+
+
+def test_reference_init_distribution():
+    torch.manual_seed(0)
+    m = nb.get_model(cases.ARCH_M, use_rnn=True, dropout_rate=0.0)
+    for key, p in m.state_dict().items():
+        if p.dim() >= 2:
+            recept = p[0][0].numel() if p.dim() > 2 else 1
+            bound = (6.0 / ((p.shape[0] + p.shape[1]) * recept)) ** 0.5        # Xavier-uniform
+            assert float(p.abs().max()) <= bound * (1 + 1e-6), key
+            assert float(p.abs().max()) > 0.9 * bound, key
+        elif 'bias' in key:
+            assert float(p.abs().max()) == 0.0, key
+        else:
+            assert torch.all(p == 1.0), key                                      # LayerNorm gamma untouched
+
+
+def test_module_tree_is_what_the_trainer_relies_on():
+    m = nb.get_model(cases.ARCH_M, use_rnn=True, dropout_rate=0.1)
+    convs = [l for l in m.modules() if isinstance(l, nb_ops.PadConvRelu)]        # trainer.py:221 regularises these
+    assert len(convs) == 4 + 18 and all(hasattr(l.conv, 'weight') for l in convs)
+    assert len(m.model) == 29 and isinstance(m.model[27], torch.nn.LSTM) and isinstance(m.model[28], torch.nn.Linear)
+    cell = m.model[2]
+    assert isinstance(cell, nb_model.SearchCell) and len(cell.nodes) == 3
+    assert [type(b).__name__ for b in cell.nodes[2].branch_ops] == ['Zero', 'Identity', 'Identity']
+    assert isinstance(cell.nodes[0].op, nb_ops.Linear) and isinstance(cell.nodes[1].op, nb_ops.Zero)
+    assert (cell.nodes[2].op.lpad, cell.nodes[2].op.rpad) == (4, 4)
+    assert (m.model[0].lpad, m.model[0].rpad, m.model[11].lpad, m.model[11].rpad) == (3, 4, 5, 2)
+
+
+def test_invalid_descriptions_raise():
+    with pytest.raises(ValueError, match='not implemented'):
+        nb_model.SearchCell(600, [['conv9', 0]])
+    with pytest.raises(ValueError, match='Invalid branch operations'):
+        nb_model.SearchCell(600, [['conv5', 2]])
+    with pytest.raises(ValueError, match='Unknown backend'):
+        nb.get_model(cases.ARCH_A, True, 0.0, backend='tf')
+    with pytest.raises(TypeError):
+        nb.get_model(cases.ARCH_A)                         # use_rnn / dropout_rate have no defaults
+    assert nb.make_model is nb.get_model
+
+
+def test_checkpoint_round_trip_and_prunable_copy():
+    m = nb.get_model(cases.ARCH_D, use_rnn=True, dropout_rate=0.0)
+    buf = io.BytesIO()
+    torch.save({'model': m.state_dict()}, buf)             # trainer.py:249-253 format
+    buf.seek(0)
+    m2 = nb.get_model(cases.ARCH_D, use_rnn=True, dropout_rate=0.0)
+    m2.load_state_dict(torch.load(buf)['model'])
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
+    pruned = m.get_prunable_copy()
+    assert pruned.use_norm is False and pruned.training
+    keys = set(pruned.state_dict())
+    assert not any('norm_layer' in k for k in keys) and 'model.1.weight' in keys         # block LayerNorms stay
+    assert torch.equal(pruned.state_dict()['model.2.nodes.0.op.conv.weight'], m.state_dict()['model.2.nodes.0.op.conv.weight'])
+    assert m.get_prunable_copy(bn=True).use_norm is True
+
+
+def test_no_cpu_path_and_no_silent_dropout():
+    m = nb.get_model(cases.ARCH_A, use_rnn=True, dropout_rate=0.2)
+    with pytest.raises(NotImplementedError, match='dropout'):
+        m(torch.zeros(1, 80, 16))
+    m.eval()
+    with pytest.raises(hip.HipError, match='no CPU path'):
+        m(torch.zeros(1, 80, 16))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 40, 16))
+    with pytest.raises(hip.HipError):
+        nb_ops.PadConvRelu(24, 24, 5, 1, 1, groups=4).eval()(torch.zeros(1, 24, 16))
+
+
+def test_print_model_summary(capsys):
+    m = nb.get_model(cases.ARCH_A, use_rnn=False, dropout_rate=0.0)
+    nb.print_model_summary(m)
+    out = capsys.readouterr().out
+    assert 'Trainable parameters: 22,971,649' in out and 'SearchCell' in out

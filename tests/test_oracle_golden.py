@@ -1,0 +1,159 @@
+"""Pin the CPU oracle (oracle/asr_oracle.py) against the golden outputs of the reference.
+
+The expected arrays were produced by running the reference's own modules (tests/golden/make_golden.py);
+here the oracle is evaluated on the same keyed inputs.  The oracle issues the same ATen primitives as
+the reference for convolutions (bit-exact on the generating box) and restates LayerNorm / LSTM, so the
+tolerances are one or two fp32 ulps scaled by the data.  No GPU needed.
+"""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from nb_asr_amd.weights import keyed_fill_, keyed_input
+from oracle import asr_oracle as oracle
+
+
+def close(got, want, rtol=2e-5, atol=2e-6):
+    assert tuple(got.shape) == tuple(want.shape)
+    r = cases.worst_ratio(got, want, rtol, atol)
+    assert r <= 1.0, f'worst err/tol = {r:.3f}'
+
+
+@pytest.mark.parametrize('cg,k,d', cases.GCONV_CASES)
+def test_grouped_conv(op_fx, cg, k, d):
+    c, tag = cg * 4, f'gconv/cg{cg}_k{k}_d{d}'
+    p = cases.keyed_params({'conv.weight': (c, cg, k), 'conv.bias': (c,)}, tag)
+    x = cases.keyed_x(tag, (2, c, 37), 2.0)
+    close(oracle.pad_conv_relu(x, p['conv.weight'], p['conv.bias'], d, 1, 4), op_fx[tag])
+
+
+@pytest.mark.parametrize('name,c,k,d', cases.GCONV100_CASES)
+def test_grouped_conv_production_width(op_fx, name, c, k, d):
+    tag = f'gconv100/{name}_c{c}'
+    p = cases.keyed_params({'conv.weight': (c, c // 100, k), 'conv.bias': (c,)}, tag)
+    x = cases.keyed_x(tag, (1, c, 22), 2.0)
+    close(oracle.pad_conv_relu(x, p['conv.weight'], p['conv.bias'], d, 1, 100), op_fx[tag])
+
+
+def test_clamp_is_reached(op_fx):
+    tag = 'gconv/clamp'
+    p = cases.keyed_params({'conv.weight': (24, 6, 5), 'conv.bias': (24,)}, tag)
+    y = oracle.pad_conv_relu(cases.keyed_x(tag, (1, 24, 16), 40.0), p['conv.weight'], p['conv.bias'], 1, 1, 4)
+    assert float(y.max()) == 20.0 and float(y.min()) == 0.0
+    close(y, op_fx[tag])
+
+
+@pytest.mark.parametrize('cin,cout,t,s,b', cases.DENSE_CASES)
+def test_dense_conv(op_fx, cin, cout, t, s, b):
+    tag = f'dense/cin{cin}_cout{cout}_t{t}_s{s}'
+    p = cases.keyed_params({'conv.weight': (cout, cin, 8), 'conv.bias': (cout,)}, tag)
+    y = oracle.pad_conv_relu(cases.keyed_x(tag, (b, cin, t)), p['conv.weight'], p['conv.bias'], 1, s, 1)
+    assert y.shape[2] == oracle.out_length(t, s)
+    close(y, op_fx[tag])
+
+
+@pytest.mark.parametrize('c,t,b', cases.LINEAR_CASES)
+def test_linear_op(op_fx, c, t, b):
+    tag = f'linear/c{c}_t{t}'
+    p = cases.keyed_params({'linear.weight': (c, c), 'linear.bias': (c,)}, tag)
+    close(oracle.linear_relu(cases.keyed_x(tag, (b, c, t)), p['linear.weight'], p['linear.bias']), op_fx[tag])
+
+
+def test_zero_branch_does_not_propagate_nan(op_fx):
+    assert np.array_equal(op_fx['zero/nan'], np.zeros((1, 1, 4), dtype=np.float32))
+    x = torch.tensor([[[float('nan'), float('inf'), 1.0, -2.0]]])
+    y = oracle.node_forward([x], 'zero', [0], {}, '')
+    assert torch.equal(y, torch.zeros_like(x))
+
+
+@pytest.mark.parametrize('op_name', cases.NODE_OPS)
+def test_node_all_skip_patterns(op_fx, op_name):
+    c, t = 600, 12
+    ins = [torch.from_numpy(cases.keyed_normal(f'node/in{i}', 3, (1, c, t))) for i in range(3)]
+    p = cases.keyed_params(cases.node_shapes(op_name, c), f'node/{op_name}')
+    for pattern in range(8):
+        flags = [(pattern >> i) & 1 for i in range(3)]
+        want = op_fx[f'node/{op_name}_s{flags[0]}{flags[1]}{flags[2]}']
+        close(oracle.node_forward(ins, op_name, flags, p, ''), want)
+
+
+@pytest.mark.parametrize('arch_tag', ['A', 'D', 'M'])
+@pytest.mark.parametrize('use_norm', [True, False])
+def test_cell(op_fx, arch_tag, use_norm):
+    arch = cases.ARCHS[arch_tag]
+    p = cases.keyed_params(cases.cell_shapes(arch, 600, use_norm), f'cell/{arch_tag}')
+    x = cases.keyed_x(f'cell/{arch_tag}', (1, 600, 18))
+    close(oracle.cell_forward(x, oracle.arch_names(arch), p, '', use_norm), op_fx[f'cell/{arch_tag}_norm{int(use_norm)}'],
+          rtol=2e-5, atol=4e-6)
+
+
+@pytest.mark.parametrize('c,t', cases.LAYERNORM_CASES)
+def test_layernorm(op_fx, c, t):
+    tag = f'layernorm/c{c}_t{t}'
+    p = cases.keyed_params({'weight': (c,), 'bias': (c,)}, tag)
+    x = cases.keyed_x(tag, (2, c, t))
+    x[0, :, 0] *= 1e-4
+    x[1, :, 1] += 50.0
+    close(oracle.layer_norm_channels(x, p['weight'], p['bias']), op_fx[tag], rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('inp,hid,t,b', cases.LSTM_CASES)
+def test_lstm(op_fx, inp, hid, t, b):
+    tag = f'lstm/i{inp}_h{hid}_t{t}'
+    p = cases.keyed_params({'weight_ih_l0': (4 * hid, inp), 'weight_hh_l0': (4 * hid, hid), 'bias_ih_l0': (4 * hid,),
+                            'bias_hh_l0': (4 * hid,)}, tag, bias_scale=0.5)
+    x = cases.keyed_x(tag, (b, t, inp))
+    close(oracle.lstm_forward(x, p['weight_ih_l0'], p['weight_hh_l0'], p['bias_ih_l0'], p['bias_hh_l0']), op_fx[tag])
+
+
+class _Holder(torch.nn.Module):
+    """state_dict-shaped parameter bag so keyed_fill_ can fill oracle parameters without any model class."""
+
+    def __init__(self, shapes):
+        super().__init__()
+        self._keys = list(shapes)
+        for i, (k, shp) in enumerate(shapes.items()):
+            self.register_buffer(f'p{i}', torch.zeros(shp))
+
+    def state_dict(self, *a, **kw):
+        return {k: getattr(self, f'p{i}') for i, k in enumerate(self._keys)}
+
+
+def oracle_params(arch, use_rnn, mode, seed=1235):
+    holder = _Holder(oracle.parameter_shapes(arch, use_rnn=use_rnn))
+    keyed_fill_(holder, seed=seed, mode=mode)
+    return holder.state_dict()
+
+
+@pytest.mark.parametrize('tag,arch,use_rnn,mode,b,t', cases.MODEL_CASES)
+def test_full_model(model_fx, tag, arch, use_rnn, mode, b, t):
+    params = oracle_params(arch, use_rnn, mode)
+    x = keyed_input(b, t, seed=0)
+    taps = {}
+    logits = oracle.asr_forward(params, arch, x, use_rnn=use_rnn, taps=taps)
+    want = torch.from_numpy(model_fx[f'{tag}/logits'])
+    assert tuple(logits.shape) == tuple(want.shape) == (b, oracle.out_length(oracle.out_length(t, 2), 2), 49)
+    # north-star tolerance; cases whose fp32 noise floor (reference vs an fp64 evaluation, stored with the
+    # fixture) is itself close to the tolerance get proportional slack
+    slack = max(1.0, 2.5 * float(model_fx[f'{tag}/ref_noise_ratio']))
+    assert cases.worst_ratio(logits, want, 1e-4, 1e-5) <= slack
+    # per-layer: sampled values and statistics, relative to each layer's own scale
+    stats, samples = model_fx[f'{tag}/layer_stats'], model_fx[f'{tag}/layer_samples']
+    for idx, out in taps.items():
+        flat = out.contiguous().flatten()
+        got = flat[torch.from_numpy(cases.sample_indices(tag, idx, flat.numel()))]
+        scale = stats[idx, 2] + 1e-30
+        assert float((got.double() - torch.from_numpy(samples[idx]).double()).abs().max()) <= 1e-4 * scale, f'layer {idx}'
+        assert abs(float(out.double().abs().max()) - stats[idx, 2]) <= 1e-4 * scale, f'layer {idx} absmax'
+        assert abs(float(out.double().mean()) - stats[idx, 0]) <= 1e-4 * scale, f'layer {idx} mean'
+    # fp64 evaluation of the oracle reproduces the stored fp64 truth
+    truth = oracle.asr_forward(params, arch, x, use_rnn=use_rnn, dtype=torch.float64)
+    assert float((truth - torch.from_numpy(model_fx[f'{tag}/logits_f64'])).abs().max()) <= 1e-9 * (1 + float(truth.abs().max()))
+
+
+def test_flop_model_matches_survey():
+    f = oracle.flops_per_forward(cases.ARCH_A, 64, 1000)
+    assert abs(f['total'] / 1e9 - 1526.4) < 0.5             # 1 526.4 GFLOP
+    assert abs(f['dense'] / 1e9 - 1257.5) < 0.5 and abs(f['grouped'] / 1e9 - 159.4) < 0.2
+    assert abs(oracle.flops_per_forward(cases.ARCH_D, 64, 1000)['total'] / 1e9 - 1568.9) < 0.5
