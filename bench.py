@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Headline benchmark: utterances/s and p50 forward latency of the HIP forward pass.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]/[2], the configuration the metric is quoted on): arch_vec
+[[1,0],[1,0,0],[1,0,0,0]], use_rnn=True, fp32, synthetic filterbank batch x ~ N(0,1) of shape (64, 80, 1000) PER GPU,
+random-init weights from the keyed generator ('lively': He-uniform so activations are O(1) at every depth -- the
+reference's Xavier init makes this no-skip architecture's activations decay to 1e-25).
+A step = one forward over one batch, inputs resident in HBM; with N > 1 every rank forwards its own 64 utterances
+(batch-sharded, weak scaling) and the step ends with one RCCL all-gather of the logits.
+
+One JSON line on stdout (rank 0).  Besides the driver's contract fields it carries
+  roofline      fused grouped Conv1d kernel (the graded, HBM-bound kernel of SURVEY.md 8(d)): algorithmic bytes of
+                its 54 launches / their HIP-event time, vs 8 TB/s
+  roofline_mfma the dense downsample convs on the fp32 matrix cores vs 157.3 TFLOP/s
+  cpu_baseline  the CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample, host cores
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ARCH = [[1, 0], [1, 0, 0], [1, 0, 0, 0]]
+BATCH, FRAMES, FEATURES = 64, 1000, 80
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_MFMA_PEAK_TFLOPS = 157.3    # ibid.: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def grouped_conv_bytes(batch, channels, frames, kernel, n_skips, groups=100):
+    """Algorithmic HBM bytes of one fused grouped-conv launch: read x, write y, read each
+    fused skip input, read weights + bias once."""
+    return 4.0 * (batch * channels * frames * (2 + n_skips) + channels * (channels // groups) * kernel + channels)
+
+
+def dense_conv_flops(batch, c_in, c_out, kernel, frames_out):
+    return 2.0 * batch * frames_out * c_out * c_in * kernel
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=BATCH, help='utterances per GPU')
+    ap.add_argument('--frames', type=int, default=FRAMES)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs a torch.distributed.run launch with --nproc-per-node {args.gpus}')
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs a HIP device (no CPU path in nb_asr_amd)')
+
+    import nb_asr_amd as nb
+    from nb_asr_amd.weights import keyed_fill_, keyed_input
+    from nb_asr_amd.parallel import ShardedForward
+
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+    runner = ShardedForward(world_size=world, rank=rank, device=device)      # RCCL process group when world > 1
+
+    model = nb.get_model(ARCH, use_rnn=True, dropout_rate=0.0)
+    keyed_fill_(model, seed=1235, mode='lively')
+    model = model.to(device).eval()
+    x = keyed_input(args.batch, args.frames, seed=rank).to(device)           # resident in HBM before timing
+
+    def step():
+        with torch.no_grad():
+            return runner.forward(model, x)                                   # forward + all-gather of logits (N > 1)
+
+    for _ in range(args.warmup):
+        out = step()
+    runner.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    runner.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = runner.max_over_ranks(elapsed)
+    assert out.shape == (args.batch * world, (((args.frames + 1) // 2) + 1) // 2, 49) and bool(torch.isfinite(out).all())
+
+    # p50 forward latency: each forward bracketed by HIP events on the launch stream
+    lat = []
+    for _ in range(max(args.steps, 5)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        step()
+        e1.record()
+        e1.synchronize()
+        lat.append(e0.elapsed_time(e1))
+    p50 = statistics.median(lat)
+
+    result = {
+        'metric': 'utterances_per_sec',
+        'value': args.batch * world * args.steps / elapsed,
+        'unit': 'utterances/s',
+        'n_gpus': world,
+        'steps': args.steps,
+        'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps,
+        'p50_forward_ms': p50,
+        'higher_is_better': True,
+        'scaling': 'weak',
+        'vs_baseline': None,
+        'dtype': 'f32',
+        'data': 'synthetic N(0,1) filterbanks (B,80,T) from a keyed generator; random-init He-uniform weights (keyed)',
+        'config': {'workload': 'BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True fp32, HIP conv + HIP LSTM',
+                   'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames, 'features': FEATURES,
+                   'parallelism': f'batch-sharded x{world}, one RCCL all-gather of logits' if world > 1 else 'single GPU'},
+    }
+
+    if rank == 0 and not args.no_roofline:
+        result.update(roofline_leg(model, x, args))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline_leg(model, args)
+    runner.barrier()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    runner.close()
+
+
+def roofline_leg(model, x, args):
+    """Re-run `steps` forwards with HIP events around every launch of the graded kernels (same stream)."""
+    plan = next(iter(model._plans.values()))
+    plan.timer = []
+    with torch.no_grad():
+        for _ in range(args.steps):
+            model(x)
+    torch.cuda.synchronize()
+    records, plan.timer = plan.timer, None
+    agg = {}
+    for kind, meta, e0, e1 in records:
+        a = agg.setdefault((kind, meta), [0.0, 0])
+        a[0] += e0.elapsed_time(e1)
+        a[1] += 1
+    out = {}
+    # fused grouped Conv1d (HBM-bound)
+    tot_bytes = tot_ms = 0.0
+    per_block, launches = {}, 0
+    for (kind, meta), (ms, n) in agg.items():
+        if kind != 'grouped_conv':
+            continue
+        blk, c, _, k, frames, n_skips = meta
+        b = grouped_conv_bytes(args.batch, c, frames, k, n_skips)
+        tot_bytes += b * n
+        tot_ms += ms
+        launches += n
+        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}', {'bytes_per_launch': b, 'ms': 0.0, 'n': 0})
+        e['ms'] += ms
+        e['n'] += n
+    if launches:
+        achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+        out['roofline'] = {
+            'kernel': 'grouped_conv_kernel<CG,K,D> (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum)',
+            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None,
+            'bytes_per_launch_avg': tot_bytes / launches, 'us_per_launch_avg': 1e3 * tot_ms / launches,
+            'launches_per_forward': launches // args.steps,
+            'per_block': {k: {'GBps': v['bytes_per_launch'] * v['n'] / (v['ms'] * 1e-3) / 1e9, 'us_per_launch': 1e3 * v['ms'] / v['n'],
+                              'bytes_per_launch': v['bytes_per_launch']} for k, v in sorted(per_block.items())},
+        }
+    # dense downsample convs (MFMA-bound)
+    tot_flops = tot_ms = 0.0
+    per_layer = {}
+    for (kind, meta), (ms, n) in agg.items():
+        if kind != 'dense_conv':
+            continue
+        blk, c_in, c_out, k, frames_out, _ = meta
+        f = dense_conv_flops(args.batch, c_in, c_out, k, frames_out)
+        tot_flops += f * n
+        tot_ms += ms
+        per_layer[f'conv_{blk}_{c_in}x{c_out}_T{frames_out}'] = {'TFLOPs': f * n / (ms * 1e-3) / 1e12, 'us_per_launch': 1e3 * ms / n}
+    if tot_ms:
+        achieved = tot_flops / (tot_ms * 1e-3) / 1e12
+        out['roofline_mfma'] = {'kernel': 'gemm_conv_kernel<8,S> (dense k=8 conv, v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
+                                'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None, 'per_layer': per_layer}
+    # where the forward's time goes (event-bracketed launches, ms per forward)
+    split = {}
+    for (kind, _meta), (ms, _n) in agg.items():
+        split[kind] = split.get(kind, 0.0) + ms / args.steps
+    out['ms_per_forward_by_kernel'] = split
+    return out
+
+
+def cpu_baseline_leg(model, args):
+    """The CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample of the same workload."""
+    from oracle import asr_oracle as oracle
+    from nb_asr_amd.weights import keyed_input
+    sample_b = min(8, args.batch)
+    params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    xs = keyed_input(sample_b, args.frames, seed=0)
+    with torch.no_grad():
+        oracle.asr_forward(params, ARCH, xs, use_rnn=True)                  # warm-up
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            oracle.asr_forward(params, ARCH, xs, use_rnn=True)
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return {'value': sample_b / med, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'B={sample_b}, T={args.frames}, median of 3 forwards of oracle/asr_oracle.py (torch CPU ops), '
+                      f'os.cpu_count()={os.cpu_count()}', 'seconds_per_forward': med}
+
+
+if __name__ == '__main__':
+    main()

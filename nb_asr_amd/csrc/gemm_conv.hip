@@ -152,6 +152,15 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
         __syncthreads();
         if (ks + 1 < nks) prefetch(ks + 1);
 
+        // blocked summation: every 64-deep K-step accumulates into a fresh tile that is then added to the
+        // running total, so rounding error grows like sqrt(64) + sqrt(K/64) instead of sqrt(K)
+        floatx16 part[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
         auto mma_step = [&](auto all_valid) {
 #pragma unroll
             for (int kk = 0; kk < BK / 2; ++kk) {
@@ -166,11 +175,15 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         if (decltype(all_valid)::value || (mval[i] && nval[j]))
-                            acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], acc[i][j], 0, 0, 0)
-                                             : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                            part[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[j], av[i], part[i][j], 0, 0, 0)
+                                              : __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], part[i][j], 0, 0, 0);
             }
         };
         if (full) mma_step(std::true_type{}); else mma_step(std::false_type{});
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] += part[i][j];
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
@@ -251,7 +264,6 @@ extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const fl
                                         nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused: x, w, bias, y must be non-NULL");
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused: bad sizes");
     NBASR_REQUIRE((kernel == 8 && (stride == 1 || stride == 2)) || (kernel == 1 && stride == 1), NBASR_EINVAL,
                   "nbasr_dense_conv1d_fused: (kernel=%d, stride=%d) unsupported; model uses k=8 s in {1,2} and k=1 s=1", kernel, stride);
@@ -262,6 +274,7 @@ extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const fl
     NBASR_REQUIRE((c_in * kernel) % 4 == 0 && aligned16(w), NBASR_EALIGN,
                   "nbasr_dense_conv1d_fused: c_in*kernel=%d must be a multiple of 4 and w 16-byte aligned", c_in * kernel);
     if (batch == 0 || frames_out == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused: x, w, bias, y must be non-NULL");
     GemmConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.bias2 = nullptr; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
     a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;

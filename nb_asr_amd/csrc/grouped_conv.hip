@@ -151,14 +151,14 @@ extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const 
                                           nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_grouped_conv1d_fused: x, w, bias, y must be non-NULL");
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "nbasr_grouped_conv1d_fused: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
+    if (batch == 0 || ld == 0) return NBASR_OK;      // empty batch: nothing to do (empty tensors have NULL storage)
+    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_grouped_conv1d_fused: x, w, bias, y must be non-NULL");
     NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_grouped_conv1d_fused: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
     NBASR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
                   "nbasr_grouped_conv1d_fused: activation pointers must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_grouped_conv1d_fused: batch %d > 65535", batch);
-    if (batch == 0 || ld == 0) return NBASR_OK;
     hipStream_t s = as_stream(stream);
     switch (channels / groups) {
         case 6:  return dispatch_kd<6>(kernel, dilation, x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, s);
@@ -175,8 +175,9 @@ extern "C" int nbasr_skip_sum(const float* skip0, const float* skip1, const floa
                               int channels, int frames, int ld, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(y, NBASR_ENULL, "nbasr_skip_sum: y must be non-NULL");
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_skip_sum: bad sizes");
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(y, NBASR_ENULL, "nbasr_skip_sum: y must be non-NULL");
     NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_skip_sum: ld=%d must be >= frames and a multiple of 4", ld);
     NBASR_REQUIRE(aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
                   "nbasr_skip_sum: pointers must be 16-byte aligned");
@@ -191,8 +192,9 @@ extern "C" int nbasr_repitch(const float* src, float* dst, int rows, int frames,
                              nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(src && dst, NBASR_ENULL, "nbasr_repitch: NULL pointer");
     NBASR_REQUIRE(rows >= 0 && frames >= 0 && ld_src >= frames && ld_dst >= frames, NBASR_EINVAL, "nbasr_repitch: bad sizes");
+    if (rows == 0 || ld_dst == 0) return NBASR_OK;
+    NBASR_REQUIRE(src && dst, NBASR_ENULL, "nbasr_repitch: NULL pointer");
     if (rows == 0 || ld_dst == 0) return NBASR_OK;
     hipLaunchKernelGGL(repitch_kernel, dim3((ld_dst + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, as_stream(stream),
                        src, dst, rows, frames, ld_src, ld_dst);

@@ -113,9 +113,10 @@ extern "C" int nbasr_layernorm_channels(const float* x, const float* gamma, cons
                                         int channels, int frames, int ld, float eps, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(x && gamma && beta && y, NBASR_ENULL, "nbasr_layernorm_channels: NULL pointer");
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_layernorm_channels: bad sizes");
     NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_layernorm_channels: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && gamma && beta && y, NBASR_ENULL, "nbasr_layernorm_channels: NULL pointer");
     NBASR_REQUIRE(aligned16(x) && aligned16(y), NBASR_EALIGN, "nbasr_layernorm_channels: x, y must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_layernorm_channels: batch %d > 65535", batch);
     if (batch == 0 || ld == 0) return NBASR_OK;

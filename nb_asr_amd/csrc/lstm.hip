@@ -169,11 +169,11 @@ extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float
                                   int c_in, int frames, int ld, int hidden, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && gates_ws && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_forward: NULL pointer");
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames >= 0 && hidden > 0 && ld >= frames, NBASR_EINVAL, "nbasr_lstm_forward: bad sizes");
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && gates_ws && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_forward: NULL pointer");
     NBASR_REQUIRE(hidden % 4 == 0 && c_in % 4 == 0, NBASR_EALIGN, "nbasr_lstm_forward: hidden=%d and c_in=%d must be multiples of 4", hidden, c_in);
     NBASR_REQUIRE(aligned16(w_ih) && aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_forward: w_ih, w_hh, h_out must be 16-byte aligned");
-    if (batch == 0 || frames == 0) return NBASR_OK;
     hipStream_t s = as_stream(stream);
     int rc = lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, s);
     if (rc != NBASR_OK) return rc;
@@ -187,9 +187,10 @@ extern "C" int nbasr_linear_head(const float* h, const float* w, const float* bi
                                  int features, int classes, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(h && w && bias && logits, NBASR_ENULL, "nbasr_linear_head: NULL pointer");
     NBASR_REQUIRE(rows >= 0 && features > 0 && classes > 0 && classes <= 64, NBASR_EINVAL,
                   "nbasr_linear_head: rows=%d features=%d classes=%d (classes must be <= 64)", rows, features, classes);
+    if (rows == 0) return NBASR_OK;
+    NBASR_REQUIRE(h && w && bias && logits, NBASR_ENULL, "nbasr_linear_head: NULL pointer");
     NBASR_REQUIRE(features % 4 == 0 && aligned16(h) && aligned16(w), NBASR_EALIGN,
                   "nbasr_linear_head: features must be a multiple of 4 and h, w 16-byte aligned");
     if (rows == 0) return NBASR_OK;
@@ -202,9 +203,10 @@ extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float
                                      int features, int frames, int ld, int classes, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(x && w && bias && logits, NBASR_ENULL, "nbasr_linear_head_bct: NULL pointer");
     NBASR_REQUIRE(batch >= 0 && features > 0 && frames >= 0 && ld >= frames && classes > 0 && classes <= 64, NBASR_EINVAL,
                   "nbasr_linear_head_bct: bad sizes (classes must be <= 64)");
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && w && bias && logits, NBASR_ENULL, "nbasr_linear_head_bct: NULL pointer");
     NBASR_REQUIRE(features % 4 == 0 && aligned16(w), NBASR_EALIGN, "nbasr_linear_head_bct: features must be a multiple of 4, w 16-byte aligned");
     const long long rows = static_cast<long long>(batch) * frames;
     if (rows == 0) return NBASR_OK;

@@ -51,6 +51,7 @@ class ForwardPlan:
             t = (t + s - 1) // s
             self.block_frames.append(t)
         self.out_frames = self.block_frames[-1]
+        self.timer = None
         elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
         self.pool = [torch.empty(max(elems, 4), device=device, dtype=torch.float32) for _ in range(4)]
         if model.use_rnn:
@@ -58,11 +59,25 @@ class ForwardPlan:
             self.cell_ws = torch.empty(batch * LSTM_HIDDEN, device=device, dtype=torch.float32)
             self.h_out = torch.empty(batch, self.out_frames, LSTM_HIDDEN, device=device, dtype=torch.float32)
 
+    def _timed(self, kind, meta, launch):
+        """Run ``launch()``; when ``self.timer`` is a list, bracket it with HIP events on the current stream
+        (bench.py's per-kernel roofline leg) and append (kind, meta, start, stop)."""
+        if self.timer is None:
+            return launch()
+        start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        out = launch()
+        stop.record()
+        self.timer.append((kind, meta, start, stop))
+        return out
+
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)
         return self.pool[idx][: self.batch * channels * ld].view(self.batch, channels, ld)
 
-    def run(self, x):
+    def run(self, x, taps=None):
+        """Enqueue one forward.  ``taps`` (a dict) receives a copy of every layer's output, keyed by the
+        layer's index in ``model.model``, in the oracle's layouts ((B,C,T) for encoder layers and the LSTM)."""
         from .model import SearchCell
         from .ops import PadConvRelu
         import torch.nn as nn
@@ -76,36 +91,46 @@ class ForwardPlan:
         act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
         blk = -1
         logits = None
-        for layer in model.model:
+        for idx, layer in enumerate(model.model):
+            if taps is not None and idx > 0:
+                taps[idx - 1] = self._tap(act, act_frames)
             if isinstance(layer, PadConvRelu):
                 blk += 1
                 dst = 0 if cur != 0 else 1
                 t_out = self.block_frames[blk]
                 out = self._view(dst, layer.conv.out_channels, t_out)
-                hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(), (), out,
-                                       layer.strides)
+                self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
+                            lambda: hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(),
+                                                           (), out, layer.strides))
                 act, act_frames, cur = out, t_out, dst
             elif isinstance(layer, nn.LayerNorm):
                 if act.dim() != 3:
                     raise RuntimeError('LayerNorm in an unexpected position of the layer list')
-                hip.layernorm_channels(act, layer.weight.detach(), layer.bias.detach(), act, act_frames, layer.eps)
+                self._timed('layernorm', (blk, act.shape[1], act.shape[1], 0, act_frames, 0),
+                            lambda: hip.layernorm_channels(act, layer.weight.detach(), layer.bias.detach(), act, act_frames, layer.eps))
             elif isinstance(layer, SearchCell):
                 free = [i for i in range(4) if i != cur]
                 if len(layer.nodes) > len(free):
                     raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
                 outs = [act]
                 for node, dst in zip(layer.nodes, free):
-                    outs.append(node_into(node, outs, act_frames, self._view(dst, layer.filters, act_frames)))
+                    n_skips = sum(type(br).__name__ == 'Identity' for br in node.branch_ops)
+                    kind = {'PadConvRelu': 'grouped_conv', 'Linear': 'linear_op', 'Zero': 'skip_sum'}[type(node.op).__name__]
+                    meta = (blk, layer.filters, layer.filters, getattr(node.op, 'kernel_size', 1), act_frames, n_skips)
+                    view = self._view(dst, layer.filters, act_frames)
+                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view)))
                 act, cur = outs[-1], free[len(layer.nodes) - 1]
                 if layer.use_norm:
-                    hip.layernorm_channels(act, layer.norm_layer.weight.detach(), layer.norm_layer.bias.detach(), act,
-                                           act_frames, layer.norm_layer.eps)
+                    self._timed('layernorm', (blk, layer.filters, layer.filters, 0, act_frames, 0),
+                                lambda: hip.layernorm_channels(act, layer.norm_layer.weight.detach(), layer.norm_layer.bias.detach(),
+                                                               act, act_frames, layer.norm_layer.eps))
             elif isinstance(layer, nn.Dropout):
-                continue                                     # identity: eval mode or p == 0 (checked by the model)
+                pass                                         # identity: eval mode or p == 0 (checked by the model)
             elif isinstance(layer, nn.LSTM):
-                hip.lstm_forward(act, act_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
-                                 layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach(), self.gates_ws, self.cell_ws,
-                                 self.h_out)
+                self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                            lambda: hip.lstm_forward(act, act_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
+                                                     layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach(), self.gates_ws,
+                                                     self.cell_ws, self.h_out))
                 act = self.h_out                             # (batch, frames, hidden)
             elif isinstance(layer, nn.Linear):
                 logits = torch.empty(self.batch, act_frames, layer.out_features, device=self.device, dtype=torch.float32)
@@ -116,4 +141,11 @@ class ForwardPlan:
                 act = logits
             else:
                 raise TypeError(f'unsupported layer {type(layer).__name__} in the model list')
+        if taps is not None:
+            taps[len(model.model) - 1] = logits.clone()
         return logits
+
+    def _tap(self, act, frames):
+        if act is self.__dict__.get('h_out'):
+            return act.permute(0, 2, 1).clone()              # (B, H, T) like the oracle's LSTM tap
+        return act[:, :, :frames].clone()

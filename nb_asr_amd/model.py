@@ -118,7 +118,12 @@ class ASRModel(nn.Module):
         clone.train()
         return clone
 
-    def forward(self, input):
+    def forward_with_taps(self, input):
+        """``forward`` that also returns {layer index: copy of that layer's output} (parity debugging)."""
+        taps = {}
+        return self.forward(input, _taps=taps), taps
+
+    def forward(self, input, _taps=None):
         """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1)."""
         _check_dropout(self)
         if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES:
@@ -131,7 +136,7 @@ class ASRModel(nn.Module):
             if len(self._plans) >= 4:          # bounded cache: workspaces are hundreds of MB
                 self._plans.clear()
             plan = self._plans[key] = ForwardPlan(self, input.shape[0], input.shape[2], input.device)
-        return plan.run(input)
+        return plan.run(input, _taps)
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -1,0 +1,89 @@
+"""Multi-GPU execution of the forward pass: batch-sharded replicas, one process per GPU.
+
+Utterances are independent (no BatchNorm, LayerNorm is per frame), so the path shards along the batch with
+NO collective inside the forward; every rank holds a full weight replica (105 MB fp32).  The only exchange is
+ONE all-gather of the logits shard (batch/G, T', 49) at the end -- RCCL over xGMI when the backend is "nccl"
+(RCCL on ROCm), gloo on CPU for tests.  The reference's own multi-GPU code is torch.nn.DataParallel in the
+trainer (training/torch/trainer.py:91-92: single process, scatter/replicate/gather); this replaces that pattern
+with process-per-GPU replicas.  The shard is sub-megabyte, so the op is latency-bound: a single all-gather
+(no bucketing, no overlap) is the right shape for the point-to-point xGMI mesh.
+"""
+import datetime
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous, balanced [begin, end) of rank's shard (first n_items % world_size ranks get one extra)."""
+    base, extra = divmod(n_items, world_size)
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+class ShardedForward:
+    """Owns the process group (if any) and runs ``model`` on this rank's shard."""
+
+    def __init__(self, world_size=None, rank=None, device=None, backend=None):
+        self.world_size = int(os.environ.get('WORLD_SIZE', '1')) if world_size is None else world_size
+        self.rank = int(os.environ.get('RANK', '0')) if rank is None else rank
+        self.device = device
+        self._own_group = False
+        if self.world_size > 1 and not dist.is_initialized():
+            if backend is None:
+                backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            kwargs = {}
+            if backend == 'nccl':
+                kwargs['device_id'] = torch.device(device)
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world_size,
+                                    timeout=datetime.timedelta(seconds=600), **kwargs)
+            self._own_group = True
+
+    # -- collectives -------------------------------------------------------------------------------------------
+    def gather_logits(self, local):
+        """All-gather equally sized (b, T', classes) shards into (world*b, T', classes), rank order."""
+        if self.world_size == 1:
+            return local
+        local = local.contiguous()
+        out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local)
+        return out
+
+    def gather_ragged(self, local, n_items):
+        """All-gather shards of a global batch of ``n_items`` split by ``shard_bounds`` (sizes may differ by one)."""
+        if self.world_size == 1:
+            return local
+        sizes = [e - b for b, e in (shard_bounds(n_items, self.world_size, r) for r in range(self.world_size))]
+        pad = max(sizes)
+        buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
+        buf[: local.shape[0]] = local
+        full = self.gather_logits(buf)
+        return torch.cat([full[r * pad: r * pad + sizes[r]] for r in range(self.world_size)], dim=0)
+
+    def forward(self, model, local_x):
+        """This rank's utterances through the model, then the one all-gather."""
+        return self.gather_logits(model(local_x))
+
+    def forward_global(self, model, global_x):
+        """Shard a replicated global batch, forward this rank's slice, gather all logits in original order."""
+        begin, end = shard_bounds(global_x.shape[0], self.world_size, self.rank)
+        return self.gather_ragged(model(global_x[begin:end]), global_x.shape[0])
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, value):
+        if self.world_size == 1:
+            return value
+        dev = self.device if (self.device is not None and dist.get_backend() == 'nccl') else 'cpu'
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def close(self):
+        if self._own_group and dist.is_initialized():
+            dist.destroy_process_group()

@@ -1,0 +1,140 @@
+"""End-to-end parity of the HIP forward (get_model(...).forward) with the reference's golden logits,
+per-layer statistics, and the CPU oracle; plus size-independent properties at BASELINE's full size.
+
+North-star tolerance for logits: rtol 1e-4 / atol 1e-5 against the reference's CPU forward.  Fixtures whose
+fp32 noise floor (reference vs an fp64 evaluation of the same weights, stored as `ref_noise_ratio`) is itself
+close to that bound get proportional slack, exactly like the oracle's own pinning test.
+"""
+import pytest
+import torch
+
+import cases
+import nb_asr_amd as nb
+from nb_asr_amd.weights import keyed_fill_, keyed_input
+from oracle import asr_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def build(arch, use_rnn, mode, seed=1235):
+    m = nb.get_model(arch, use_rnn=use_rnn, dropout_rate=0.0)
+    keyed_fill_(m, seed=seed, mode=mode)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize('tag,arch,use_rnn,mode,b,t', cases.MODEL_CASES)
+def test_model_golden(model_fx, tag, arch, use_rnn, mode, b, t):
+    m = build(arch, use_rnn, mode)
+    x = keyed_input(b, t, seed=0).to(DEV)
+    with torch.no_grad():
+        logits, taps = m.forward_with_taps(x)
+    want = torch.from_numpy(model_fx[f'{tag}/logits'])
+    assert tuple(logits.shape) == tuple(want.shape)
+    assert torch.isfinite(logits).all()
+    noise = float(model_fx[f'{tag}/ref_noise_ratio'])
+    ratio = cases.worst_ratio(logits, want, 1e-4, 1e-5)
+    assert ratio <= max(1.0, 2.5 * noise), f'{tag}: worst err/tol {ratio:.3f} (reference noise floor {noise:.3f})'
+    # not further from an fp64 evaluation than fp32 arithmetic explains
+    truth = torch.from_numpy(model_fx[f'{tag}/logits_f64'])
+    assert cases.worst_ratio(logits, truth, 1e-4, 1e-5) <= max(1.0, 2.5 * noise)
+    # per-layer parity relative to each layer's own scale (vanishing-activation regime)
+    stats, samples = model_fx[f'{tag}/layer_stats'], model_fx[f'{tag}/layer_samples']
+    assert sorted(taps) == list(range(len(m.model)))
+    for idx in sorted(taps):
+        out = taps[idx].cpu().contiguous()
+        flat = out.flatten()
+        got = flat[torch.from_numpy(cases.sample_indices(tag, idx, flat.numel()))]
+        scale = stats[idx, 2] + 1e-30
+        err = float((got.double() - torch.from_numpy(samples[idx]).double()).abs().max())
+        assert err <= 2e-4 * scale, f'{tag} layer {idx}: sample err {err:.3e} vs scale {scale:.3e}'
+        assert abs(float(out.double().abs().max()) - stats[idx, 2]) <= 2e-4 * scale, f'{tag} layer {idx} absmax'
+        assert abs(float(out.double().mean()) - stats[idx, 0]) <= 2e-4 * scale, f'{tag} layer {idx} mean'
+        assert abs(float(out.double().std(unbiased=False)) - stats[idx, 1]) <= 2e-4 * scale, f'{tag} layer {idx} std'
+
+
+@pytest.mark.parametrize('arch,use_rnn,b,t', [(cases.ARCH_D, True, 3, 131), (cases.ARCH_M, False, 2, 258), ([[2, 1], [3, 0, 1], [4, 1, 0, 1]], True, 2, 64),
+                                              (cases.ARCH_A, True, 1, 3), (cases.ARCH_D, True, 2, 1)])
+def test_model_vs_oracle(arch, use_rnn, b, t):
+    m = build(arch, use_rnn, 'lively', seed=77)
+    x = keyed_input(b, t, seed=5)
+    want = oracle.asr_forward({k: v.cpu() for k, v in m.state_dict().items()}, arch, x, use_rnn=use_rnn)
+    truth = oracle.asr_forward({k: v.cpu() for k, v in m.state_dict().items()}, arch, x, use_rnn=use_rnn, dtype=torch.float64)
+    with torch.no_grad():
+        got = m(x.to(DEV))
+    noise = cases.worst_ratio(want, truth, 1e-4, 1e-5)
+    assert cases.worst_ratio(got, want, 1e-4, 1e-5) <= max(1.0, 2.5 * noise)
+
+
+def test_prunable_copy_without_cell_norms():
+    m = build(cases.ARCH_D, True, 'xavier')          # reference init: without cell norms He-init activations blow up
+    pruned = m.get_prunable_copy().eval()
+    x = keyed_input(2, 40, seed=1)
+    want = oracle.asr_forward({k: v.cpu() for k, v in pruned.state_dict().items()}, cases.ARCH_D, x, use_rnn=True, use_norm=False)
+    truth = oracle.asr_forward({k: v.cpu() for k, v in pruned.state_dict().items()}, cases.ARCH_D, x, use_rnn=True, use_norm=False,
+                               dtype=torch.float64)
+    with torch.no_grad():
+        got = pruned(x.to(DEV))
+    noise = cases.worst_ratio(want, truth, 1e-4, 1e-5)
+    ratio = cases.worst_ratio(got, want, 1e-4, 1e-5)
+    print(f'prunable copy: worst err/tol {ratio:.3f}, cpu fp32 noise floor {noise:.3f}')
+    assert ratio <= max(1.0, 2.5 * noise)
+
+
+def test_reference_style_usage():
+    """The README flow of the reference: get_model(arch, use_rnn, dropout_rate, gpu) then model(input)."""
+    torch.manual_seed(0)
+    m = nb.get_model(cases.ARCH_D, use_rnn=True, dropout_rate=0.0, gpu=0)
+    assert next(m.parameters()).is_cuda and m.training
+    y = m(torch.randn(2, 80, 100, device=DEV))            # training mode with p = 0 is allowed
+    assert tuple(y.shape) == (2, 25, 49) and torch.isfinite(y).all()
+    want = oracle.asr_forward({k: v.cpu() for k, v in m.state_dict().items()}, cases.ARCH_D, torch.zeros(1, 80, 8), use_rnn=True)
+    assert tuple(want.shape) == (1, 2, 49)
+
+
+class TestFullSize:
+    """BASELINE config 2/3: B=64, T=1000, arch conv5 x3.  The oracle is too slow for the whole batch, so the
+    checks are size-independent properties plus the oracle on two of the 64 utterances."""
+
+    @pytest.fixture(scope='class')
+    def run(self):
+        m = build(cases.ARCH_A, True, 'lively')
+        x = keyed_input(64, 1000, seed=0)
+        with torch.no_grad():
+            y = m(x.to(DEV))
+            y2 = m(x.to(DEV))
+        torch.cuda.synchronize()
+        return m, x, y, y2
+
+    def test_shape_finite_deterministic(self, run):
+        _, _, y, y2 = run
+        assert tuple(y.shape) == (64, 250, 49) and torch.isfinite(y).all()
+        assert torch.equal(y, y2)                                           # no atomics, fixed reduction order
+
+    def test_utterances_are_independent(self, run):
+        m, x, y, _ = run
+        with torch.no_grad():
+            part = m(x[5:9].to(DEV))
+        assert torch.equal(part, y[5:9])                                    # batch sharding is exact
+
+    def test_sampled_utterances_match_oracle(self, run):
+        m, x, y, _ = run
+        params = {k: v.cpu() for k, v in m.state_dict().items()}
+        sel = [0, 63]
+        want = oracle.asr_forward(params, cases.ARCH_A, x[sel], use_rnn=True)
+        truth = oracle.asr_forward(params, cases.ARCH_A, x[sel], use_rnn=True, dtype=torch.float64)
+        noise = cases.worst_ratio(want, truth, 1e-4, 1e-5)
+        assert cases.worst_ratio(y[sel], want, 1e-4, 1e-5) <= max(1.0, 2.5 * noise)
+
+    def test_bounded_look_ahead(self, run):
+        """Every conv looks at most `context` = 4 of ITS frames ahead (ops.py:8; 2 for the stride-2 downsample
+        convs), LayerNorm is per frame and the LSTM is causal.  In input frames the encoder's total look-ahead
+        is 10*4 + 13*4 + (2 + 15*4*2) + (2*2 + 18*4*4) = 506, so zeroing the input from frame 800 on cannot
+        change logits before output frame (800 - 506) / 4 = 73 -- and must change later ones."""
+        m, x, y, _ = run
+        x2 = x[:2].clone()
+        x2[:, :, 800:] = 0.0
+        with torch.no_grad():
+            y2 = m(x2.to(DEV))
+        assert torch.equal(y2[:, :73], y[:2, :73])
+        assert not torch.equal(y2[:, 200:], y[:2, 200:])

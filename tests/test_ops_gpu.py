@@ -1,0 +1,242 @@
+"""Parity of every HIP kernel (called through the C ABI) with the golden vectors and the CPU oracle.
+
+Sizes are small enough for the oracle to finish in seconds.  Tolerances: the kernels sum in a different
+order than oneDNN, so outputs agree to a few fp32 ulps of the accumulated magnitude: rtol 2e-5 / atol 5e-6
+on O(1) data (the north-star end-to-end bound is rtol 1e-4 / atol 1e-5).  Skip-sums are bit-exact.
+"""
+import pytest
+import torch
+
+import cases
+from nb_asr_amd import hip, model as nb_model, ops as nb_ops
+from oracle import asr_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+RTOL, ATOL = 2e-5, 5e-6
+
+
+def close(got, want, rtol=RTOL, atol=ATOL):
+    got = got.detach().cpu() if isinstance(got, torch.Tensor) else torch.as_tensor(got)
+    want = torch.as_tensor(want)
+    assert tuple(got.shape) == tuple(want.shape), (got.shape, want.shape)
+    assert torch.isfinite(got).all()
+    r = cases.worst_ratio(got, want, rtol, atol)
+    assert r <= 1.0, f'worst err/tol = {r:.3f}'
+
+
+def pitched(x):
+    """(B,C,T) cpu tensor -> zero-pitched device tensor (B,C,ld), T."""
+    b, c, t = x.shape
+    buf = torch.zeros(b, c, hip.round_up4(t), device=DEV)
+    buf[:, :, :t] = x.to(DEV)
+    return buf, t
+
+
+def grouped(x, w, bias, k, d, groups, skips=()):
+    xp, t = pitched(x)
+    sk = [pitched(s)[0] for s in skips]
+    y = torch.full_like(xp, float('nan'))
+    hip.grouped_conv1d_fused(xp, w.to(DEV), bias.to(DEV), sk, y, t, groups, k, d)
+    assert torch.all(y[:, :, t:] == 0)                       # pitch columns are kept at zero
+    return y[:, :, :t]
+
+
+@pytest.mark.parametrize('cg,k,d', cases.GCONV_CASES)
+def test_grouped_conv_golden(op_fx, cg, k, d):
+    c, tag = cg * 4, f'gconv/cg{cg}_k{k}_d{d}'
+    p = cases.keyed_params({'conv.weight': (c, cg, k), 'conv.bias': (c,)}, tag)
+    close(grouped(cases.keyed_x(tag, (2, c, 37), 2.0), p['conv.weight'], p['conv.bias'], k, d, 4), op_fx[tag])
+
+
+@pytest.mark.parametrize('name,c,k,d', cases.GCONV100_CASES)
+def test_grouped_conv_production_width_golden(op_fx, name, c, k, d):
+    tag = f'gconv100/{name}_c{c}'
+    p = cases.keyed_params({'conv.weight': (c, c // 100, k), 'conv.bias': (c,)}, tag)
+    close(grouped(cases.keyed_x(tag, (1, c, 22), 2.0), p['conv.weight'], p['conv.bias'], k, d, 100), op_fx[tag])
+
+
+def test_grouped_conv_clamp_golden(op_fx):
+    tag = 'gconv/clamp'
+    p = cases.keyed_params({'conv.weight': (24, 6, 5), 'conv.bias': (24,)}, tag)
+    y = grouped(cases.keyed_x(tag, (1, 24, 16), 40.0), p['conv.weight'], p['conv.bias'], 5, 1, 4)
+    assert float(y.max()) == 20.0 and float(y.min()) == 0.0
+    close(y, op_fx[tag], rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize('t', [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 1000, 1027])
+@pytest.mark.parametrize('k,d', [(5, 1), (7, 2)])
+def test_grouped_conv_ragged_lengths_vs_oracle(t, k, d):
+    torch.manual_seed(t * 10 + k)
+    c, groups, b = 40, 4, 3
+    x = torch.randn(b, c, t)
+    w = torch.randn(c, c // groups, k) * 0.3
+    bias = torch.randn(c) * 0.2
+    skips = [torch.randn(b, c, t), torch.randn(b, c, t)]
+    want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + skips[0] + skips[1]
+    close(grouped(x, w, bias, k, d, groups, skips), want)
+
+
+def test_grouped_conv_empty_and_errors():
+    y = torch.empty(0, 24, 16, device=DEV)
+    hip.grouped_conv1d_fused(torch.empty(0, 24, 16, device=DEV), torch.zeros(24, 6, 5, device=DEV), torch.zeros(24, device=DEV), (), y, 16, 4, 5, 1)
+    x = torch.zeros(1, 24, 16, device=DEV)
+    with pytest.raises(hip.HipError, match='unsupported'):
+        hip.grouped_conv1d_fused(x, torch.zeros(24, 6, 3, device=DEV), torch.zeros(24, device=DEV), (), torch.empty_like(x), 16, 4, 3, 1)
+    with pytest.raises(hip.HipError, match='multiple of 4'):
+        hip.grouped_conv1d_fused(torch.zeros(1, 24, 18, device=DEV), torch.zeros(24, 6, 5, device=DEV), torch.zeros(24, device=DEV), (), torch.zeros(1, 24, 18, device=DEV), 18, 4, 5, 1)
+    with pytest.raises(hip.HipError, match='HIP device'):
+        hip.grouped_conv1d_fused(torch.zeros(1, 24, 16), torch.zeros(24, 6, 5, device=DEV), torch.zeros(24, device=DEV), (), torch.empty_like(x), 16, 4, 5, 1)
+
+
+def dense(x, w, bias, stride, skips=()):
+    b, cin, t = x.shape
+    t_out = (t + stride - 1) // stride
+    y = torch.full((b, w.shape[0], hip.round_up4(t_out)), float('nan'), device=DEV)
+    sk = [pitched(s)[0] for s in skips]
+    hip.dense_conv1d_fused(x.to(DEV).contiguous(), t, w.to(DEV), bias.to(DEV), sk, y, stride)
+    assert torch.all(y[:, :, t_out:] == 0)
+    return y[:, :, :t_out]
+
+
+@pytest.mark.parametrize('cin,cout,t,s,b', cases.DENSE_CASES)
+def test_dense_conv_golden(op_fx, cin, cout, t, s, b):
+    tag = f'dense/cin{cin}_cout{cout}_t{t}_s{s}'
+    p = cases.keyed_params({'conv.weight': (cout, cin, 8), 'conv.bias': (cout,)}, tag)
+    close(dense(cases.keyed_x(tag, (b, cin, t)), p['conv.weight'], p['conv.bias'], s), op_fx[tag])
+
+
+@pytest.mark.parametrize('cin,cout,t,s', [(8, 8, 1, 1), (8, 8, 1, 2), (12, 130, 129, 1), (12, 130, 257, 2), (80, 600, 300, 1),
+                                          (600, 136, 140, 2), (20, 33, 7, 2)])
+def test_dense_conv_shapes_vs_oracle(cin, cout, t, s):
+    torch.manual_seed(cin + cout + t)
+    x, w, bias = torch.randn(2, cin, t), torch.randn(cout, cin, 8) * (1.0 / (cin * 8) ** 0.5), torch.randn(cout) * 0.1
+    close(dense(x, w, bias, s), oracle.pad_conv_relu(x, w, bias, 1, s, 1))
+
+
+@pytest.mark.parametrize('c,t,b', cases.LINEAR_CASES)
+def test_linear_op_golden(op_fx, c, t, b):
+    tag = f'linear/c{c}_t{t}'
+    p = cases.keyed_params({'linear.weight': (c, c), 'linear.bias': (c,)}, tag)
+    y = dense(cases.keyed_x(tag, (b, c, t)), p['linear.weight'].unsqueeze(-1).contiguous(), p['linear.bias'], 1)
+    close(y, op_fx[tag])
+
+
+def test_zero_and_skip_sum(op_fx):
+    xp, t = pitched(torch.tensor([[[float('nan'), float('inf'), 1.0, -2.0]]]))
+    y = torch.full_like(xp, 7.0)
+    hip.skip_sum((), y, t)
+    assert torch.equal(y.cpu(), torch.from_numpy(op_fx['zero/nan']))        # exact zeros, NaN/Inf not propagated
+    a, b_, c = (torch.randn(2, 24, 37) for _ in range(3))
+    out = torch.empty_like(pitched(a)[0])
+    hip.skip_sum([pitched(a)[0], pitched(b_)[0], pitched(c)[0]], out, 37)
+    assert torch.equal(out[:, :, :37].cpu(), ((0 + a) + b_) + c)            # bit-exact, python-sum order
+
+
+@pytest.mark.parametrize('op_name', cases.NODE_OPS)
+def test_node_all_skip_patterns_golden(op_fx, op_name):
+    c, t = 600, 12
+    ins = [torch.from_numpy(cases.keyed_normal(f'node/in{i}', 3, (1, c, t))) for i in range(3)]
+    p = cases.keyed_params(cases.node_shapes(op_name, c), f'node/{op_name}')
+    for pattern in range(8):
+        flags = [(pattern >> i) & 1 for i in range(3)]
+        node = nb_model.Node(c, nb_ops._ops[op_name], [nb_ops._branch_ops[f] for f in flags]).to(DEV).eval()
+        node.load_state_dict(p)
+        y = node([i.to(DEV) for i in ins])
+        close(y, op_fx[f'node/{op_name}_s{flags[0]}{flags[1]}{flags[2]}'])
+
+
+@pytest.mark.parametrize('arch_tag', ['A', 'D', 'M'])
+@pytest.mark.parametrize('use_norm', [True, False])
+def test_cell_golden(op_fx, arch_tag, use_norm):
+    arch = cases.ARCHS[arch_tag]
+    cell = nb_model.SearchCell(600, oracle.arch_names(arch), use_norm=use_norm).to(DEV).eval()
+    cell.load_state_dict(cases.keyed_params(cases.cell_shapes(arch, 600, use_norm), f'cell/{arch_tag}'))
+    y = cell(cases.keyed_x(f'cell/{arch_tag}', (1, 600, 18)).to(DEV))
+    close(y, op_fx[f'cell/{arch_tag}_norm{int(use_norm)}'], rtol=5e-5, atol=1e-5)
+
+
+def layernorm(x, g, b, eps=1e-3):
+    xp, t = pitched(x)
+    y = torch.full_like(xp, float('nan'))
+    hip.layernorm_channels(xp, g.to(DEV), b.to(DEV), y, t, eps)
+    assert torch.all(y[:, :, t:] == 0)
+    hip.layernorm_channels(xp, g.to(DEV), b.to(DEV), xp, t, eps)            # in place gives the same bits
+    assert torch.equal(xp, y)
+    return y[:, :, :t]
+
+
+@pytest.mark.parametrize('c,t', cases.LAYERNORM_CASES)
+def test_layernorm_golden(op_fx, c, t):
+    tag = f'layernorm/c{c}_t{t}'
+    p = cases.keyed_params({'weight': (c,), 'bias': (c,)}, tag)
+    x = cases.keyed_x(tag, (2, c, t))
+    x[0, :, 0] *= 1e-4
+    x[1, :, 1] += 50.0
+    close(layernorm(x, p['weight'], p['bias']), op_fx[tag], rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('c,t', [(600, 1000), (1200, 251), (800, 1), (40, 66)])
+def test_layernorm_vs_fp64_oracle(c, t):
+    torch.manual_seed(c + t)
+    x, g, b = torch.randn(2, c, t) * 3 + 1.5, torch.rand(c) + 0.5, torch.randn(c) * 0.1
+    want = oracle.layer_norm_channels(x.double(), g.double(), b.double())
+    close(layernorm(x, g, b), want, rtol=1e-5, atol=5e-6)
+
+
+def lstm(x, p):
+    b, t, inp = x.shape
+    hid = p['weight_hh_l0'].shape[1]
+    xp, _ = pitched(x.permute(0, 2, 1).contiguous())                        # encoder layout (B, C, T)
+    gates = torch.empty(b * t * 4 * hid, device=DEV)
+    cell = torch.empty(b * hid, device=DEV)
+    h = torch.full((b, t, hid), float('nan'), device=DEV)
+    hip.lstm_forward(xp, t, p['weight_ih_l0'].to(DEV), p['weight_hh_l0'].to(DEV), p['bias_ih_l0'].to(DEV),
+                     p['bias_hh_l0'].to(DEV), gates, cell, h)
+    return h
+
+
+@pytest.mark.parametrize('inp,hid,t,b', cases.LSTM_CASES)
+def test_lstm_golden(op_fx, inp, hid, t, b):
+    tag = f'lstm/i{inp}_h{hid}_t{t}'
+    p = cases.keyed_params({'weight_ih_l0': (4 * hid, inp), 'weight_hh_l0': (4 * hid, hid), 'bias_ih_l0': (4 * hid,),
+                            'bias_hh_l0': (4 * hid,)}, tag, bias_scale=0.5)
+    close(lstm(cases.keyed_x(tag, (b, t, inp)), p), op_fx[tag])
+
+
+def test_lstm_model_width_vs_oracle():
+    torch.manual_seed(5)
+    b, t, inp, hid = 5, 30, 1200, 500
+    p = {'weight_ih_l0': torch.randn(4 * hid, inp) * 0.03, 'weight_hh_l0': torch.randn(4 * hid, hid) * 0.05,
+         'bias_ih_l0': torch.randn(4 * hid) * 0.1, 'bias_hh_l0': torch.randn(4 * hid) * 0.1}
+    x = torch.randn(b, t, inp)
+    want = oracle.lstm_forward(x, p['weight_ih_l0'], p['weight_hh_l0'], p['bias_ih_l0'], p['bias_hh_l0'])
+    close(lstm(x, p), want, rtol=2e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('rows,features,classes', [(1, 500, 49), (250, 500, 49), (67, 20, 49), (130, 1200, 49), (5, 8, 3)])
+def test_linear_head_vs_oracle(rows, features, classes):
+    torch.manual_seed(rows)
+    h, w, b = torch.randn(rows, features), torch.randn(classes, features) * 0.05, torch.randn(classes)
+    out = torch.full((rows, classes), float('nan'), device=DEV)
+    hip.linear_head(h.to(DEV), w.to(DEV), b.to(DEV), out)
+    close(out, h @ w.t() + b)
+    # encoder-layout variant (use_rnn=False): x (B, features, T)
+    bsz, t = 3, max(rows // 3, 1)
+    x = torch.randn(bsz, features, t)
+    xp, _ = pitched(x)
+    out2 = torch.full((bsz, t, classes), float('nan'), device=DEV)
+    hip.linear_head_bct(xp, t, w.to(DEV), b.to(DEV), out2)
+    close(out2, x.permute(0, 2, 1) @ w.t() + b)
+
+
+def test_standalone_op_modules_accept_unpitched_inputs():
+    torch.manual_seed(1)
+    m = nb_ops.PadConvRelu(24, 24, 7, 2, 1, groups=4).to(DEV).eval()
+    x = torch.randn(2, 24, 37)
+    want = oracle.pad_conv_relu(x, m.conv.weight.cpu(), m.conv.bias.cpu(), 2, 1, 4)
+    close(m(x.to(DEV)), want.detach())
+    lin = nb_ops.Linear(24, 24).to(DEV).eval()
+    close(lin(x.to(DEV)), oracle.linear_relu(x, lin.linear.weight.cpu(), lin.linear.bias.cpu()).detach())
+    down = nb_ops.PadConvRelu(24, 40, 8, 1, 2).to(DEV).eval()
+    close(down(x.to(DEV)), oracle.pad_conv_relu(x, down.conv.weight.cpu(), down.conv.bias.cpu(), 1, 2, 1).detach())
