@@ -134,6 +134,24 @@ def main():
     runner.close()
 
 
+def pmc_traffic_per_launch(kernel_prefix):
+    """HBM bytes per launch of a kernel family from the newest committed PMC summary (profiles/rNN_pmc_hbm_traffic.csv:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied by tools/summarize_pmc.py).
+    Launch-weighted mean over the family's template instances; None when no summary is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_hbm_traffic.csv')))
+    if not files:
+        return None, None
+    tot = n = 0.0
+    with open(files[-1], newline='') as f:
+        for row in csv.DictReader(f):
+            if row['kernel'].startswith(kernel_prefix):
+                tot += float(row['hbm_total_MB']) * 1e6 * int(row['launches'])
+                n += int(row['launches'])
+    return (tot / n if n else None), os.path.basename(files[-1])
+
+
 def roofline_leg(model, x, args):
     """Re-run `steps` forwards with HIP events around every launch of the graded kernels (same stream)."""
     plan = next(iter(model._plans.values()))
@@ -164,11 +182,14 @@ def roofline_leg(model, x, args):
         e['ms'] += ms
         e['n'] += n
     if launches:
+        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_conv_kernel')
+        if args.batch != BATCH or args.frames != FRAMES:
+            traffic, traffic_src = None, None          # the committed counters are for the default workload only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
         out['roofline'] = {
             'kernel': 'grouped_conv_kernel<CG,K,D> (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum)',
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,
+            'traffic': traffic, 'traffic_source': traffic_src,
             'bytes_per_launch_avg': tot_bytes / launches, 'us_per_launch_avg': 1e3 * tot_ms / launches,
             'launches_per_forward': launches // args.steps,
             'per_block': {k: {'GBps': v['bytes_per_launch'] * v['n'] / (v['ms'] * 1e-3) / 1e9, 'us_per_launch': 1e3 * v['ms'] / v['n'],

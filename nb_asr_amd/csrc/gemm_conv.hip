@@ -28,7 +28,7 @@ namespace nbasr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int LDA = BM;   // lanes run along m for both the staging writes and the fragment reads: conflict-free unpadded
 
 struct GemmConvArgs {
@@ -37,12 +37,15 @@ struct GemmConvArgs {
     float* y;
     int c_in, frames_in, ld_in, c_out, frames_out, ld_out, lpad, ktot;
     int n_cover;                 // output columns the tiles must cover (ld_out: pitch columns get zeros)
+    int row_stride_t, row_stride_b;   // transposed store: output row of (b, t) = t * row_stride_t + b * row_stride_b
     int n_mt, n_nt, batch;
 };
 
 template <int KW, int STRIDE>
 struct Geo {
+    static constexpr int BK = (KW == 1) ? 32 : 64;           // K-step (KW = 1 stages 4x more input rows per k: keep registers < 256)
     static constexpr int KC = BK / KW;                       // input channels per K-step
+    static constexpr int AREGS = BM * BK / 4 / 256;          // float4 weight chunks per thread per K-step
     static constexpr int XW = (BN - 1) * STRIDE + KW;        // staged frames per channel row
     static constexpr int LDX = XW;                           // lanes run along frames: conflict-free unpadded
     static constexpr int XELEMS = KC * XW;
@@ -51,12 +54,13 @@ struct Geo {
 };
 
 template <int KW, int STRIDE, bool SWAP, bool RELU>
-__global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
+__global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
 {
     using G = Geo<KW, STRIDE>;
     __shared__ float lds[G::LDS_FLOATS];
+    constexpr int BK = G::BK;
     float* As = lds;                    // [BK][LDA]  k-major weight tile
-    float* Xs = lds + BK * LDA;         // [KC][LDX]  input channel rows
+    float* Xs = lds + G::BK * LDA;         // [KC][LDX]  input channel rows
 
     // ---- XCD-aware, m-major tile order (bijective remap, cdna guide T1) ------------------------
     const int nwg = gridDim.x;
@@ -97,14 +101,14 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // ---- register staging ----------------------------------------------------------------------
-    float4 areg[8];
+    float4 areg[G::AREGS];
     float xreg[G::XREGS];
     const int a_row = tid & 127, a_kh = tid >> 7;   // lane -> weight row; 16-byte k-chunks kh, kh+2, ...
 
     auto prefetch = [&](int ks) {
         const int k0 = ks * BK;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < G::AREGS; ++i) {
             const int row = m0 + a_row;
             const int k = k0 + (a_kh + 2 * i) * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
     };
     auto commit = [&]() {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < G::AREGS; ++i) {
             float* dst = As + ((a_kh + 2 * i) * 4) * LDA + a_row;
             dst[0 * LDA] = areg[i].x; dst[1 * LDA] = areg[i].y; dst[2 * LDA] = areg[i].z; dst[3 * LDA] = areg[i].w;
         }
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
                     a.y[off] = live ? v : 0.f;
                 }
             } else {
-                // transposed store: y[(b * frames_out + t) * c_out + m], lanes along m
+                // transposed store: y[row(b, t) * c_out + m], lanes along m
                 const int m = mb + l31;
                 if (m >= a.c_out) continue;
                 float bsum = a.bias[m];
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(const GemmConvArgs a)
                     if (t >= a.frames_out) continue;
                     float v = acc[i][j][r] + bsum;
                     if (RELU) v = relu_clamp(v);
-                    a.y[(static_cast<size_t>(b) * a.frames_out + t) * a.c_out + m] = v;
+                    a.y[(static_cast<size_t>(t) * a.row_stride_t + static_cast<size_t>(b) * a.row_stride_b) * a.c_out + m] = v;
                 }
             }
         }
@@ -243,7 +247,8 @@ static int launch_gemm_conv(GemmConvArgs a, hipStream_t stream, const char* what
     return launch_status(what);
 }
 
-// internal entry used by lstm.hip: gates(b, t, 4H) = x(b, :, t) . w_ih^T + b_ih + b_hh
+// internal entry used by lstm.hip: gates(t, b, 4H) = x(b, :, t) . w_ih^T + b_ih + b_hh  (TIME-major, so that the
+// recurrence reads one contiguous batch x 4H slab per step)
 int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* gates,
                           int batch, int c_in, int frames, int ld, int rows4h, hipStream_t stream)
 {
@@ -251,6 +256,7 @@ int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, 
     a.x = x; a.w = w_ih; a.bias = b_ih; a.bias2 = b_hh; a.y = gates;
     a.c_in = c_in; a.frames_in = frames; a.ld_in = ld; a.c_out = rows4h; a.frames_out = frames; a.ld_out = rows4h;
     a.lpad = 0; a.ktot = c_in; a.batch = batch;
+    a.row_stride_t = batch; a.row_stride_b = 1;
     return launch_gemm_conv<1, 1, true, false>(a, stream, "nbasr_lstm_forward(input projection)");
 }
 

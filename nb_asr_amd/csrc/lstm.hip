@@ -2,10 +2,10 @@
 // (reference model.py:100-103, forward model.py:118-124), gate order i, f, g, o, bias b_ih + b_hh.
 //
 //  1. input projection for ALL frames at once: one fp32-MFMA GEMM (gemm_conv.hip, transposed store)
-//     gates[b][t][4H] = x[b][:, t] . W_ih^T + b_ih + b_hh      -- the reference's permute(0,2,1) is
+//     gates[t][b][4H] = x[b][:, t] . W_ih^T + b_ih + b_hh      -- the reference's permute(0,2,1) is
 //     folded into the operand loader, nothing is transposed in memory;
 //  2. the recurrence: one launch per frame.  A workgroup owns 16 hidden units x 16 utterances and
-//     all four gates; its 4 waves split K = hidden four ways (v_mfma_f32_16x16x4_f32, 16-byte
+//     all four gates; its 8 waves split K = hidden eight ways (v_mfma_f32_16x16x4_f32, 16-byte
 //     operand loads: the 4 components of a lane's float4 feed 4 consecutive MFMAs, which is a
 //     k-permutation applied identically to W_hh and h and therefore leaves the sums unchanged),
 //     partial tiles are reduced through LDS and the gate nonlinearities, cell update and h store are
@@ -24,19 +24,37 @@ int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, 
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// grid: (ceil(hidden/16), ceil(batch/16)); block 256 = 4 waves (K quarters)
-__global__ __launch_bounds__(256) void lstm_step_kernel(
-    const float* __restrict__ gates_in,   // (batch, frames, 4*hidden): input projection incl. biases
+// grid: (ceil(hidden/16), ceil(batch/16)); block 512 = 8 waves, each owning one eighth of K per round
+constexpr int LSTM_WAVES = 8;
+constexpr int LSTM_CHUNKS = 4;      // 16-deep k chunks per wave per round (8 waves x 4 x 16 = 512 >= hidden 500)
+
+__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
+    const float* __restrict__ gates_in,   // (frames, batch, 4*hidden): input projection incl. biases, time-major
     const float* __restrict__ w_hh,       // (4*hidden, hidden)
     float* __restrict__ cell,             // (batch, hidden) running cell state
     float* h_out,                         // (batch, frames, hidden); row t-1 is read, row t written
     int batch, int frames, int hidden, int t)
 {
-    __shared__ float red[4][4][4][64];    // [wave][gate][reg][lane]
+    __shared__ float red[LSTM_WAVES][4][4][64];    // [wave][gate][reg][lane]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
     const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+
+    // epilogue role of threads 0..255: one (hidden unit, utterance) each, lanes along the HIDDEN index so the gate
+    // reads, the cell state and the h store are 64-byte contiguous per 16 lanes.  Their gate pre-activations come
+    // from HBM (written once by the input GEMM): issue those loads FIRST so their latency hides under the matmul.
+    const int jj = threadIdx.x & 15, bb = (threadIdx.x >> 4) & 15;
+    const int ej = j0 + jj, eb = b0 + bb;
+    const bool e_ok = threadIdx.x < 256 && ej < hidden && eb < batch;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_prev = 0.f;
+    if (e_ok) {
+        const float* gin = gates_in + (static_cast<size_t>(t) * batch + eb) * (4 * hidden);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = gin[g * hidden + ej];
+        if (t > 0) c_prev = cell[static_cast<size_t>(eb) * hidden + ej];
+    }
 
     floatx4 acc[4];
 #pragma unroll
@@ -44,30 +62,37 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(
 
     if (t > 0) {
         const int kchunks = (hidden + 15) / 16;              // 16 k per chunk
-        const int per_wave = (kchunks + 3) / 4;
-        const int c_begin = wave * per_wave;
-        const int c_end = min(kchunks, c_begin + per_wave);
         const bool row_ok = (j0 + i16) < hidden;
         const bool col_ok = (b0 + i16) < batch;
         const float* hrow = h_out + (static_cast<size_t>(b0 + i16) * frames + (t - 1)) * hidden;
-        for (int c = c_begin; c < c_end; ++c) {
-            const int k = c * 16 + kq * 4;
-            const bool kok = k < hidden;                      // hidden % 4 == 0: whole float4 in or out
-            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (col_ok && kok) hv = *reinterpret_cast<const float4*>(hrow + k);
-            float4 wv[4];
+        // wave w owns chunks [4w + 32r, 4w + 32r + 4) of round r; all 20 16-byte loads of a round are issued before
+        // the first MFMA so their L2 latencies overlap (one round covers hidden <= 512)
+        for (int base = wave * LSTM_CHUNKS; base < kchunks; base += LSTM_WAVES * LSTM_CHUNKS) {
+            float4 hv[LSTM_CHUNKS], wv[LSTM_CHUNKS][4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                wv[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row_ok && kok)
-                    wv[g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+                const int k = (base + c) * 16 + kq * 4;
+                const bool kok = k < hidden;                  // hidden % 4 == 0: whole float4 in or out
+                hv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_ok && kok) hv[c] = *reinterpret_cast<const float4*>(hrow + k);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    wv[c][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row_ok && kok)
+                        wv[c][g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
+                }
             }
+            // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].x, hv.x, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].y, hv.y, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].z, hv.z, acc[g], 0, 0, 0);
-                acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[g].w, hv.w, acc[g], 0, 0, 0);
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].x, hv[c].x, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].y, hv[c].y, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].z, hv[c].z, acc[g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].w, hv[c].w, acc[g], 0, 0, 0);
             }
         }
     }
@@ -77,28 +102,21 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(
         for (int r = 0; r < 4; ++r) red[wave][g][r][lane] = acc[g][r];
     __syncthreads();
 
-    // one thread per (hidden unit, utterance): C/D layout col = lane & 15 (utterance),
-    // row = (lane >> 4) * 4 + reg (hidden unit)
-    const int pl = threadIdx.x & 63, pr = threadIdx.x >> 6;
-    const int j = j0 + (pl >> 4) * 4 + pr;
-    const int b = b0 + (pl & 15);
-    if (j >= hidden || b >= batch) return;
-    float pre[4];
-    const float* gin = gates_in + (static_cast<size_t>(b) * frames + t) * (4 * hidden);
+    // C/D layout of the tiles: col = lane & 15 (utterance), row = (lane >> 4) * 4 + reg (hidden unit)
+    //   =>  element (jj, bb) sits at reg = jj & 3, lane = (jj >> 2) * 16 + bb
+    if (!e_ok) return;
+    const int pr = jj & 3, pl = (jj >> 2) * 16 + bb;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float s = red[0][g][pr][pl];
-        s += red[1][g][pr][pl];
-        s += red[2][g][pr][pl];
-        s += red[3][g][pr][pl];
-        pre[g] = gin[g * hidden + j] + s;
+#pragma unroll
+        for (int w = 1; w < LSTM_WAVES; ++w) s += red[w][g][pr][pl];
+        pre[g] += s;
     }
-    const size_t ci = static_cast<size_t>(b) * hidden + j;
-    const float c_prev = (t > 0) ? cell[ci] : 0.f;
     const float c_new = sigmoidf_(pre[1]) * c_prev + sigmoidf_(pre[0]) * tanhf(pre[2]);
     const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
-    cell[ci] = c_new;
-    h_out[(static_cast<size_t>(b) * frames + t) * hidden + j] = h_new;
+    cell[static_cast<size_t>(eb) * hidden + ej] = c_new;
+    h_out[(static_cast<size_t>(eb) * frames + t) * hidden + ej] = h_new;
 }
 
 // logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias; classes <= 64.
@@ -179,7 +197,7 @@ extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float
     if (rc != NBASR_OK) return rc;
     const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
     for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(256), 0, s, gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
+        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, s, gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
     return launch_status("nbasr_lstm_forward");
 }
 

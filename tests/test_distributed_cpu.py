@@ -1,0 +1,85 @@
+"""world_size-2 gloo tests of the batch-sharded runner (nb_asr_amd/parallel.py) on CPU.
+
+The HIP forward itself needs a GPU, so a stand-in per-utterance "model" is used here: what is under test is
+the sharding arithmetic, the single all-gather (equal and ragged shards), rank ordering, and the barrier /
+max-over-ranks timing helpers bench.py relies on.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from nb_asr_amd.parallel import ShardedForward, shard_bounds
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _fake_model(x):
+    """Per-utterance function with the model's output geometry: (b, 80, T) -> (b, ceil(ceil(T/2)/2), 49)."""
+    t_out = ((x.shape[2] + 1) // 2 + 1) // 2
+    feat = x.mean(dim=1)[:, : t_out * 4: 4]
+    return feat.unsqueeze(-1) * torch.arange(1, 50, dtype=x.dtype).view(1, 1, 49) + x.sum(dim=(1, 2)).view(-1, 1, 1)
+
+
+def _worker(rank, world, port, n_items, out_queue):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    runner = ShardedForward(world_size=world, rank=rank, device='cpu', backend='gloo')
+    torch.manual_seed(0)                                   # same "global batch" on every rank
+    global_x = torch.randn(n_items, 80, 37)
+    want = _fake_model(global_x)
+    got = runner.forward_global(_fake_model, global_x)     # ragged when n_items % world != 0
+    ok_global = torch.equal(got, want)
+    # bench.py's path: every rank forwards its own equally sized shard, then one all-gather
+    local = torch.full((3, 80, 16), float(rank + 1))
+    gathered = runner.forward(_fake_model, local)
+    ok_local = gathered.shape[0] == 3 * world and all(
+        torch.equal(gathered[3 * r: 3 * r + 3], _fake_model(torch.full((3, 80, 16), float(r + 1)))) for r in range(world))
+    runner.barrier()
+    slowest = runner.max_over_ranks(10.0 + rank)
+    runner.close()
+    out_queue.put((rank, ok_global, ok_local, slowest))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('n_items', [8, 5])
+def test_two_rank_gloo_sharded_forward(n_items):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_global, ok_local, slowest in results:
+        assert ok_global, f'rank {rank}: gathered logits differ from the unsharded result'
+        assert ok_local, f'rank {rank}: equal-shard all-gather is wrong'
+        assert slowest == 10.0 + (world - 1)
+
+
+def test_single_process_is_a_no_op():
+    runner = ShardedForward(world_size=1, rank=0, device='cpu')
+    x = torch.randn(4, 80, 20)
+    assert torch.equal(runner.forward(_fake_model, x), _fake_model(x))
+    assert torch.equal(runner.forward_global(_fake_model, x), _fake_model(x))
+    assert runner.max_over_ranks(1.5) == 1.5
+    runner.barrier()
+    runner.close()
