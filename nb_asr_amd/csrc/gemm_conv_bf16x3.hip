@@ -1,0 +1,344 @@
+// Dense k=8 PadConvRelu (reference model.py:82-89, ops.py:24-30) as an fp32-ACCURATE implicit GEMM on the bf16
+// matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16, 16x the rate of the fp32 MFMA).
+//
+// Every fp32 operand is split EXACTLY into three bf16 terms  v = hi + mid + lo  (hi = rne(v), mid = rne(v - hi),
+// lo = rne(v - hi - mid): 3 x 8 significand bits cover fp32's 24) and the product is evaluated as the six terms
+//     a*b ~= ah*bh + (ah*bm + am*bh) + (ah*bl + al*bh + am*bm)
+// The dropped terms (am*bl, al*bm, al*bl) are <= 2^-24 |a*b|, i.e. below the rounding error of an fp32 multiply;
+// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so the result carries fp32-level error
+// (checked against an fp64 oracle in tests/).  6 MFMAs at 16x the rate = 2.67x the fp32 matrix peak.
+//
+// GEMM view per utterance: M = c_out, N = output frames, K = (c_in, tap).  Since an MFMA sums 16 consecutive k that
+// must sit in one lane's registers, k runs over 16 input CHANNELS for a fixed tap:
+//     D[co][t] += sum_{ci<16} W[co][g*16+ci][tap] * x[g*16+ci][t*stride + tap - lpad]      for every (group g, tap)
+//  * weights are split and re-laid-out ONCE (nbasr_pack_dense_weights) into the exact LDS image of each
+//    (row tile, channel group, tap quad): [split][tap][128 rows][16 ci] bf16 = 48 KiB, so a K-step's weights are a
+//    straight 48 KiB copy done by LDS-DMA (global_load_lds_dwordx4, no VGPRs), double-buffered;
+//  * the input tile of a channel group is converted/split on the fly and stored TRANSPOSED [frame][16 ci] so a
+//    B fragment (8 consecutive channels of one frame) is one aligned ds_read_b128; it is staged once per group and
+//    reused by all 8 taps (sliding window resolved by the row index; stride-2 rows are de-interleaved by parity so
+//    the 32 lanes of a fragment read hit consecutive rows);
+//  * one 512-thread workgroup per CU: 128 x 256 tile / 8 waves (2 x 4, 64 x 64 each), K-step = 16 channels x 4 taps =
+//    96 MFMAs per wave, one barrier per step; the hi*hi products accumulate in their own register set, so the large
+//    running sum is rounded once per 16 k (the chain length of a 16-way blocked fp32 summation).
+#include "common.h"
+
+#include <type_traits>
+
+namespace nbasr {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8, PB_TP = 4;   // tile, channels per group, taps per step
+constexpr int PB_THREADS = 512;                                              // 8 waves: 2 (rows) x 4 (frames), 64 x 64 each
+constexpr int PB_QSTEPS = PB_TAPS / PB_TP;                                   // K-steps per channel group
+constexpr int PB_A_STEP_BYTES = 3 * PB_TP * PB_M * PB_CI * 2;                // 49152: one step's weight image
+
+template <int S>
+struct GeoP {
+    static constexpr int XR = (PB_N - 1) * S + PB_TAPS;          // input frames needed per channel
+    static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
+    static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
+    static constexpr int X_BYTES = 3 * ROWS * PB_CI * 2;
+    static constexpr int XITEMS = XR * (PB_CI / 2);              // (frame, channel pair) items per group
+    static constexpr int XI = (XITEMS + PB_THREADS - 1) / PB_THREADS;
+    static constexpr int LDS_BYTES = 2 * PB_A_STEP_BYTES + X_BYTES;
+    __device__ static constexpr int rowmap(int row) { return (S == 1) ? row : (row & 1) * XRH + (row >> 1); }
+};
+
+struct PackedConvArgs {
+    const float* x; const unsigned char* wp; const float* bias;
+    const float* s0; const float* s1; const float* s2;
+    float* y;
+    int c_in, frames_in, ld_in, c_out, frames_out, ld_out, lpad;
+    int n_groups, n_mt, n_nt, batch;
+};
+
+__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
+    hi = static_cast<__bf16>(v);
+    const float r1 = v - static_cast<float>(hi);
+    mid = static_cast<__bf16>(r1);
+    const float r2 = r1 - static_cast<float>(mid);
+    lo = static_cast<__bf16>(r2);
+}
+
+__device__ __forceinline__ unsigned pack2(__bf16 a, __bf16 b) {
+    return static_cast<unsigned>(__builtin_bit_cast(unsigned short, a)) |
+           (static_cast<unsigned>(__builtin_bit_cast(unsigned short, b)) << 16);
+}
+
+// ---- one-time weight split + re-layout -------------------------------------------------------------------------
+// packed element (mt, g, q, split, tp, co_l, ci_l) <- W[mt*128 + co_l][g*16 + ci_l][q*2 + tp]   (zero outside)
+__global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
+                                                                 int c_out, int c_in, int n_mt, int n_groups)
+{
+    const long long total = static_cast<long long>(n_mt) * n_groups * PB_QSTEPS * PB_TP * PB_M * PB_CI;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<long long>(gridDim.x) * blockDim.x) {
+        long long e = i;
+        const int ci_l = e % PB_CI; e /= PB_CI;
+        const int co_l = e % PB_M; e /= PB_M;
+        const int tp = e % PB_TP; e /= PB_TP;
+        const int q = e % PB_QSTEPS; e /= PB_QSTEPS;
+        const int g = e % n_groups; e /= n_groups;
+        const int mt = static_cast<int>(e);
+        const int co = mt * PB_M + co_l, ci = g * PB_CI + ci_l, tap = q * PB_TP + tp;
+        const float v = (co < c_out && ci < c_in) ? w[(static_cast<size_t>(co) * c_in + ci) * PB_TAPS + tap] : 0.f;
+        __bf16 s[3];
+        split3(v, s[0], s[1], s[2]);
+        const size_t step = (static_cast<size_t>(mt) * n_groups + g) * PB_QSTEPS + q;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            wp[(((step * 3 + k) * PB_TP + tp) * PB_M + co_l) * PB_CI + ci_l] = s[k];
+    }
+}
+
+// ---- the GEMM -----------------------------------------------------------------------------------------------------
+template <int S>
+__global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const PackedConvArgs a)
+{
+    using G = GeoP<S>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Abuf = smem;                               // [2][PB_A_STEP_BYTES]
+    unsigned char* const Xbuf = smem + 2 * PB_A_STEP_BYTES;         // [3 splits][ROWS][16 ci] bf16
+
+    // XCD-aware, m-major tile order (as gemm_conv.hip)
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    const int per_m = a.n_nt * a.batch;
+    const int mt_i = L / per_m;
+    const int rem = L - mt_i * per_m;
+    const int b = rem / a.n_nt;
+    const int nt_i = rem - b * a.n_nt;
+    const int m0 = mt_i * PB_M, n0 = nt_i * PB_N;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
+    const int tin0 = n0 * S - a.lpad;
+    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_QSTEPS * PB_A_STEP_BYTES;
+
+    bool mval[2], nval[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mval[i] = (m0 + wm * 64 + i * 32) < a.c_out;
+        nval[i] = (n0 + wn * 64 + i * 32) < a.ld_out;
+    }
+    const bool wave_active = mval[0] && nval[0];      // a wave whose whole 64 x 64 tile is out of range issues no MFMAs
+
+    // two accumulator sets: `big` only ever receives hi*hi (ONE rounding of the large running sum per 16 k, the
+    // accumulation-chain length of a 16-way blocked fp32 sum); the five small cross terms go to `small`
+    floatx16 big[2][2], small[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { big[i][j][r] = 0.f; small[i][j][r] = 0.f; }
+
+    // ---- staging helpers ---------------------------------------------------------------------------------------
+    // weights of K-step `step` (global index within this row tile) -> Abuf[buf] by LDS-DMA: 24 x 1 KiB wave copies
+    auto dma_weights = [&](int step, int buf) {
+        const unsigned char* src = wtile + static_cast<size_t>(step) * PB_A_STEP_BYTES;
+#pragma unroll
+        for (int j = 0; j < PB_A_STEP_BYTES / 1024 / 8; ++j) {
+            const int chunk = wave * (PB_A_STEP_BYTES / 1024 / 8) + j;
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(src + chunk * 1024 + lane * 16),
+                (__attribute__((address_space(3))) void*)(Abuf + buf * PB_A_STEP_BYTES + chunk * 1024),
+                16, 0, 0);
+        }
+    };
+    float xreg[G::XI][2];
+    auto load_x = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < G::XI; ++i) {
+            const int e = tid + PB_THREADS * i;
+            const int p = e & 7, row = e >> 3;
+            const int t = tin0 + row;
+            const int ci = g * PB_CI + 2 * p;
+            const bool ok = e < G::XITEMS && t >= 0 && t < a.frames_in;
+            xreg[i][0] = (ok && ci < a.c_in) ? xb[static_cast<size_t>(ci) * a.ld_in + t] : 0.f;
+            xreg[i][1] = (ok && ci + 1 < a.c_in) ? xb[static_cast<size_t>(ci + 1) * a.ld_in + t] : 0.f;
+        }
+    };
+    auto commit_x = [&]() {
+#pragma unroll
+        for (int i = 0; i < G::XI; ++i) {
+            const int e = tid + PB_THREADS * i;
+            const int p = e & 7, row = e >> 3;
+            if (e < G::XITEMS) {
+                __bf16 s0[3], s1[3];
+                split3(xreg[i][0], s0[0], s0[1], s0[2]);
+                split3(xreg[i][1], s1[0], s1[1], s1[2]);
+                unsigned* dst = reinterpret_cast<unsigned*>(Xbuf) + G::rowmap(row) * (PB_CI / 2) + p;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dst[k * G::ROWS * (PB_CI / 2)] = pack2(s0[k], s1[k]);
+            }
+        }
+    };
+
+    // per-lane fragment bases (bytes)
+    const int a_lane = (wm * 64 + l31) * (PB_CI * 2) + half * 16;
+    const int x_lane = half * 16;
+
+    auto mma_step = [&](auto qc, int buf) {
+        constexpr int q = decltype(qc)::value;
+        const unsigned char* A = Abuf + buf * PB_A_STEP_BYTES + a_lane;
+        // NOT unrolled: hoisting the fragment reads of all four taps above the first MFMA costs 192 VGPRs (spills);
+        // per tap 12 x ds_read_b128 are issued, then 24 MFMAs start as their operands arrive (counted lgkmcnt)
+#pragma unroll 1
+        for (int tp = 0; tp < PB_TP; ++tp) {
+            const int tap = q * PB_TP + tp;
+            bf16x8 af[2][3], bfr[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    af[i][k] = *reinterpret_cast<const bf16x8*>(A + ((k * PB_TP + tp) * PB_M + i * 32) * (PB_CI * 2));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = G::rowmap((wn * 64 + j * 32 + l31) * S + tap);
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    bfr[j][k] = *reinterpret_cast<const bf16x8*>(Xbuf + (k * G::ROWS + row) * (PB_CI * 2) + x_lane);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    {
+                        floatx16 c = small[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], c, 0, 0, 0);   // lo * hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], c, 0, 0, 0);   // hi * lo
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], c, 0, 0, 0);   // mid * mid
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], c, 0, 0, 0);   // mid * hi
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], c, 0, 0, 0);   // hi * mid
+                        small[i][j] = c;
+                        big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], big[i][j], 0, 0, 0);   // hi * hi
+                    }
+        }
+    };
+
+    // ---- main loop: groups of 16 channels x 4 K-steps of 2 taps ----------------------------------------------
+    const int ng = a.n_groups;
+    load_x(0);
+    dma_weights(0, 0);
+    commit_x();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int g = 0; g < ng; ++g) {
+        const bool more = g + 1 < ng;
+        auto step = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            if (q == 0 && more) load_x(g + 1);                                    // registers, consumed after q = last
+            if (q + 1 < PB_QSTEPS || more) dma_weights(g * PB_QSTEPS + q + 1, (q + 1) & 1);
+            if (wave_active) mma_step(qc, q & 1);     // single code path: two variants double the accumulator live ranges
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's weight DMA (and any x prefetch) has landed
+            __syncthreads();               // ... in every wave, and all fragment reads of this step are done
+            if (q == PB_QSTEPS - 1 && more) {
+                commit_x();
+                __syncthreads();
+            }
+        };
+        static_assert(PB_QSTEPS == 2, "the group loop is written for two K-steps per channel group");
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+    }
+
+    // ---- epilogue: bias + ReLU + min(20) (+ skips), rows of 32 frames per store ------------------------------
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (!(mval[i] && nval[j])) continue;
+            const int mb = m0 + wm * 64 + i * 32;
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            if (n >= a.ld_out) continue;
+            const bool live = n < a.frames_out;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (m >= a.c_out) continue;
+                float v = relu_clamp((big[i][j][r] + small[i][j][r]) + a.bias[m]);
+                const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
+                if (a.s0) v += a.s0[off];
+                if (a.s1) v += a.s1[off];
+                if (a.s2) v += a.s2[off];
+                a.y[off] = live ? v : 0.f;
+            }
+        }
+    }
+}
+
+template <int S>
+static int launch_packed(PackedConvArgs a, hipStream_t stream)
+{
+    using G = GeoP<S>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_bf16x3_kernel<S>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (attr != hipSuccess) {
+        set_error("nbasr_dense_conv1d_fused_packed: cannot reserve %d bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(attr));
+        return static_cast<int>(attr);
+    }
+    a.n_mt = (a.c_out + PB_M - 1) / PB_M;
+    a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
+    const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
+    NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: too many tiles (%lld)", nwg);
+    hipLaunchKernelGGL((gemm_conv_bf16x3_kernel<S>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+    return launch_status("nbasr_dense_conv1d_fused_packed");
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel)
+{
+    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS) return 0;
+    const size_t n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
+    return n_mt * n_groups * PB_QSTEPS * PB_A_STEP_BYTES;
+}
+
+extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
+    NBASR_REQUIRE(kernel == PB_TAPS, NBASR_EINVAL, "nbasr_pack_dense_weights: kernel=%d unsupported (the downsample convs have k=8)", kernel);
+    NBASR_REQUIRE(w && packed, NBASR_ENULL, "nbasr_pack_dense_weights: NULL pointer");
+    NBASR_REQUIRE(aligned16(packed), NBASR_EALIGN, "nbasr_pack_dense_weights: packed buffer must be 16-byte aligned");
+    const int n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
+    hipLaunchKernelGGL(pack_dense_weights_kernel, dim3(2048), dim3(256), 0, as_stream(stream), w,
+                       static_cast<__bf16*>(packed), c_out, c_in, n_mt, n_groups);
+    return launch_status("nbasr_pack_dense_weights");
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias, const float* skip0,
+                                               const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                                               int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                                               nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: bad sizes");
+    NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
+                  "nbasr_dense_conv1d_fused_packed: (kernel=%d, stride=%d) unsupported; packed path covers k=8, s in {1,2}", kernel, stride);
+    const int frames_out = (frames_in + stride - 1) / stride;
+    NBASR_REQUIRE(ld_in >= frames_in, NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: ld_in=%d < frames_in=%d", ld_in, frames_in);
+    NBASR_REQUIRE(ld_out >= frames_out && ld_out % 4 == 0, NBASR_EALIGN,
+                  "nbasr_dense_conv1d_fused_packed: ld_out=%d must be >= %d output frames and a multiple of 4", ld_out, frames_out);
+    if (batch == 0 || frames_out == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && packed_w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed: x, packed_w, bias, y must be non-NULL");
+    NBASR_REQUIRE(aligned16(packed_w), NBASR_EALIGN, "nbasr_dense_conv1d_fused_packed: packed weights must be 16-byte aligned");
+    PackedConvArgs a{};
+    a.x = x; a.wp = static_cast<const unsigned char*>(packed_w); a.bias = bias; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
+    a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
+    a.lpad = pad_left(kernel, 1, stride); a.n_groups = (c_in + PB_CI - 1) / PB_CI; a.batch = batch;
+    return stride == 1 ? launch_packed<1>(a, as_stream(stream)) : launch_packed<2>(a, as_stream(stream));
+}

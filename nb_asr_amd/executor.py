@@ -12,6 +12,7 @@ Replaces the isinstance-dispatch loop of the reference's ``ASRModel.forward`` (m
 Four workspace buffers sized for the widest block are rotated; nothing is allocated per call
 except the returned logits.
 """
+import os
 import weakref
 
 import torch
@@ -52,6 +53,12 @@ class ForwardPlan:
             self.block_frames.append(t)
         self.out_frames = self.block_frames[-1]
         self.timer = None
+        # dense k=8 convs: 'bf16x3' = fp32-accurate 3-way bf16 split on the bf16 matrix cores (default),
+        # 'f32' = the exact-fp32 MFMA kernel
+        self.dense_mode = os.environ.get('NBASR_DENSE_MODE', 'bf16x3')
+        if self.dense_mode not in ('bf16x3', 'f32'):
+            raise ValueError(f'NBASR_DENSE_MODE must be bf16x3 or f32, got {self.dense_mode!r}')
+        self._packed = {}            # id(layer) -> (weight data_ptr, weight version, packed tensor)
         elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
         self.pool = [torch.empty(max(elems, 4), device=device, dtype=torch.float32) for _ in range(4)]
         if model.use_rnn:
@@ -70,6 +77,23 @@ class ForwardPlan:
         stop.record()
         self.timer.append((kind, meta, start, stop))
         return out
+
+    def _packed_weights(self, layer):
+        """Split/re-laid-out copy of a downsample conv's weights, rebuilt whenever the parameter changes."""
+        w = layer.conv.weight
+        key = (w.data_ptr(), w._version)
+        hit = self._packed.get(id(layer))
+        if hit is None or hit[0] != key:
+            hit = (key, hip.pack_dense_weights(w.detach()))
+            self._packed[id(layer)] = hit
+        return hit[1]
+
+    def _dense(self, layer, act, act_frames, out):
+        if self.dense_mode == 'bf16x3' and layer.kernel_size == 8:
+            return hip.dense_conv1d_fused_packed(act, act_frames, self._packed_weights(layer), layer.conv.out_channels,
+                                                 layer.kernel_size, layer.conv.bias.detach(), (), out, layer.strides)
+        return hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(), (), out,
+                                      layer.strides)
 
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)
@@ -100,8 +124,7 @@ class ForwardPlan:
                 t_out = self.block_frames[blk]
                 out = self._view(dst, layer.conv.out_channels, t_out)
                 self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
-                            lambda: hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(),
-                                                           (), out, layer.strides))
+                            lambda: self._dense(layer, act, act_frames, out))
                 act, act_frames, cur = out, t_out, dst
             elif isinstance(layer, nn.LayerNorm):
                 if act.dim() != 3:

@@ -29,6 +29,9 @@ SIGNATURES = {
     'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_stream]),
     'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_pack_dense_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_dense_conv1d_fused_packed': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
@@ -147,6 +150,33 @@ def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride):
         _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
         _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)),
         'nbasr_dense_conv1d_fused')
+    return y
+
+
+def pack_dense_weights(weight):
+    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its 3 x bf16 split in the kernel's LDS layout."""
+    c_out, c_in, kernel = weight.shape
+    nbytes = load_library().nbasr_packed_dense_weights_bytes(c_out, c_in, kernel)
+    if nbytes == 0:
+        raise HipError(f'packed dense path does not cover weight shape {tuple(weight.shape)}')
+    if not weight.is_cuda:
+        raise HipError('weight must be on a HIP device')
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _check(load_library().nbasr_pack_dense_weights(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel,
+                                                   _stream(weight)), 'nbasr_pack_dense_weights')
+    return packed
+
+
+def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride):
+    b, c_in, ld_in = x.shape
+    ld_out = y.shape[2]
+    s = list(skips) + [None] * (3 - len(skips))
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise HipError('packed weights must be the uint8 device tensor returned by pack_dense_weights')
+    _check(load_library().nbasr_dense_conv1d_fused_packed(
+        _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
+        _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)),
+        'nbasr_dense_conv1d_fused_packed')
     return y
 
 

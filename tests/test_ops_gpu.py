@@ -114,6 +114,50 @@ def test_dense_conv_shapes_vs_oracle(cin, cout, t, s):
     close(dense(x, w, bias, s), oracle.pad_conv_relu(x, w, bias, 1, s, 1))
 
 
+def dense_packed(x, w, bias, stride):
+    b, cin, t = x.shape
+    t_out = (t + stride - 1) // stride
+    y = torch.full((b, w.shape[0], hip.round_up4(t_out)), float('nan'), device=DEV)
+    packed = hip.pack_dense_weights(w.to(DEV))
+    hip.dense_conv1d_fused_packed(x.to(DEV).contiguous(), t, packed, w.shape[0], 8, bias.to(DEV), (), y, stride)
+    assert torch.all(y[:, :, t_out:] == 0)
+    return y[:, :, :t_out]
+
+
+@pytest.mark.parametrize('cin,cout,t,s,b', cases.DENSE_CASES)
+def test_dense_conv_split_bf16_golden(op_fx, cin, cout, t, s, b):
+    """The 3-way bf16 split path (default for the downsample convs) meets the same tolerance as the fp32 MFMA path."""
+    tag = f'dense/cin{cin}_cout{cout}_t{t}_s{s}'
+    p = cases.keyed_params({'conv.weight': (cout, cin, 8), 'conv.bias': (cout,)}, tag)
+    close(dense_packed(cases.keyed_x(tag, (b, cin, t)), p['conv.weight'], p['conv.bias'], s), op_fx[tag])
+
+
+@pytest.mark.parametrize('cin,cout,t,s', [(8, 8, 1, 1), (8, 8, 1, 2), (12, 130, 129, 1), (12, 130, 257, 2), (80, 600, 300, 1),
+                                          (600, 136, 140, 2), (20, 33, 7, 2), (17, 260, 515, 1), (1000, 1200, 260, 2)])
+def test_dense_conv_split_bf16_vs_fp64(cin, cout, t, s):
+    """fp32-level accuracy claim: error against an fp64 evaluation is at most 2.5x that of the exact-fp32 MFMA kernel
+    (both measured relative to the output scale), and absolutely below 2e-6 of the scale."""
+    torch.manual_seed(cin + cout + t)
+    x, w, bias = torch.randn(2, cin, t), torch.randn(cout, cin, 8) * (2.0 / (cin * 8)) ** 0.5, torch.randn(cout) * 0.1
+    want = oracle.pad_conv_relu(x.double(), w.double(), bias.double(), 1, s, 1)
+    scale = float(want.abs().max())
+    e16 = float((dense_packed(x, w, bias, s).cpu().double() - want).pow(2).mean().sqrt()) / scale
+    e32 = float((dense(x, w, bias, s).cpu().double() - want).pow(2).mean().sqrt()) / scale
+    assert e16 <= max(2.5 * e32, 3e-8) and e16 < 2e-6, (e16, e32)
+
+
+def test_packed_weights_extreme_values_split_exactly():
+    """hi + mid + lo reproduces fp32 values of any magnitude (incl. tiny ones from the vanishing-activation regime)."""
+    torch.manual_seed(0)
+    cin, cout, t = 16, 128, 40
+    w = torch.randn(cout, cin, 8) * torch.logspace(-20, 3, cout).view(-1, 1, 1)
+    x = torch.zeros(1, cin, t)
+    x[0, 3, 20] = 1.0                                     # impulse: output = bias-free copy of single weights
+    y = dense_packed(x, w, torch.zeros(cout), 1)
+    want = oracle.pad_conv_relu(x, w, torch.zeros(cout), 1, 1, 1)
+    assert torch.equal(y.cpu(), want)                      # exact: one non-zero product per output, split is lossless
+
+
 @pytest.mark.parametrize('c,t,b', cases.LINEAR_CASES)
 def test_linear_op_golden(op_fx, c, t, b):
     tag = f'linear/c{c}_t{t}'
