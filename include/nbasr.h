@@ -117,6 +117,50 @@ int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, flo
                           int batch, int features, int frames, int ld, int classes,
                           nbasr_stream_t stream);
 
+/* ---- deferred LayerNorm ("normalise on load") ---------------------------------------------------------------
+ * Instead of materialising LayerNorm(x) (2 reads + 1 write of the tensor), nbasr_channel_stats makes ONE read pass
+ * and stores per-frame statistics; every consumer of the normalised tensor then applies
+ *     xn[b][c][t] = (x[b][c][t] - mean[b][t]) * rstd[b][t] * gamma[c] + beta[c]
+ * while loading (zero padding and pitch columns stay exactly zero).  Same arithmetic as nbasr_layernorm_channels
+ * (reference model.py:92 + 125-128, model.py:46-47 + 55-58).
+ * stats: (batch, 2, ld) floats -- row 0 = mean, row 1 = rstd = 1/sqrt(var + eps); both 0 in columns >= frames. */
+typedef struct nbasr_deferred_ln {
+    const float* stats;
+    const float* gamma;   /* (channels) */
+    const float* beta;    /* (channels) */
+} nbasr_deferred_ln;
+
+int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
+                        nbasr_stream_t stream);
+
+/* The `_ln` variants take the same arguments as their plain counterparts plus `ln` (may be NULL = plain behaviour) and
+ * flags saying which operand carries the pending LayerNorm: the main input x and/or skip0 (inside a cell only the
+ * cell input is a LayerNorm output, and it is always skip0 when it is a skip). */
+int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias,
+                                  const float* skip0, const float* skip1, const float* skip2,
+                                  float* y, int batch, int channels, int frames, int ld,
+                                  int groups, int kernel, int dilation,
+                                  const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
+int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y,
+                      int batch, int channels, int frames, int ld,
+                      const nbasr_deferred_ln* ln, int ln_on_skip0, nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_ln(const float* x, const float* w, const float* bias,
+                                const float* skip0, const float* skip1, const float* skip2,
+                                float* y, int batch, int c_in, int frames_in, int ld_in,
+                                int c_out, int ld_out, int kernel, int stride,
+                                const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_ln(const float* x, const void* packed_w, const float* bias,
+                                       float* y, int batch, int c_in, int frames_in, int ld_in,
+                                       int c_out, int ld_out, int kernel, int stride,
+                                       const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh,
+                          const float* b_ih, const float* b_hh, float* gates_ws, float* cell_ws,
+                          float* h_out, int batch, int c_in, int frames, int ld, int hidden,
+                          const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+int nbasr_linear_head_bct_ln(const float* x, const float* w, const float* bias, float* logits,
+                             int batch, int features, int frames, int ld, int classes,
+                             const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+
 /* Copy (batch, channels, frames) with pitch ld_src into pitch ld_dst, zero-filling columns
  * frames..ld_dst-1 (used to bring caller tensors into the pitched internal layout). */
 int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,

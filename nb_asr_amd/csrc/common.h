@@ -36,6 +36,18 @@ __host__ __device__ constexpr int pad_right(int kernel, int dilation, int stride
 
 constexpr float kClamp = 20.0f;   // reference ops.py:28
 
+// device-side view of nbasr_deferred_ln (stats == nullptr: no pending LayerNorm)
+struct LnRef {
+    const float* stats; const float* gamma; const float* beta;
+};
+inline LnRef ln_ref(const nbasr_deferred_ln* ln, bool wanted) {
+    return (ln && wanted) ? LnRef{ln->stats, ln->gamma, ln->beta} : LnRef{nullptr, nullptr, nullptr};
+}
+// xn = (x - mean) * rstd * gamma + beta, exactly 0 where rstd == 0 (pitch columns / frames outside the utterance)
+__device__ __forceinline__ float ln_apply(float x, float mean, float rstd, float gamma, float beta) {
+    return rstd != 0.f ? __builtin_fmaf((x - mean) * rstd, gamma, beta) : 0.f;
+}
+
 __device__ __forceinline__ float relu_clamp(float v) { return fminf(fmaxf(v, 0.0f), kClamp); }
 
 #define NBASR_REQUIRE(cond, code, ...)          \

@@ -41,6 +41,7 @@ struct GemmConvArgs {
     int n_cover;                 // output columns the tiles must cover (ld_out: pitch columns get zeros)
     int row_stride_t, row_stride_b;   // transposed store: output row of (b, t) = t * row_stride_t + b * row_stride_b
     int n_mt, n_nt, batch;
+    LnRef ln_x, ln_s0;           // pending LayerNorm of the input / of skip0 (deferred normalisation, nbasr.h)
 };
 
 template <int KW, int STRIDE>
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
 
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * STRIDE - a.lpad;
+    const float* __restrict__ xstats = a.ln_x.stats ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
 
     // wave-uniform validity of the 32x32 blocks (skip MFMAs on fully out-of-range blocks)
     bool mval[2], nval[2];
@@ -126,8 +128,11 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
             const int p = e - ci * G::XW;
             const int t = tin0 + p;
             float v = 0.f;
-            if (e < G::XELEMS && (ci0 + ci) < a.c_in && t >= 0 && t < a.frames_in)
+            if (e < G::XELEMS && (ci0 + ci) < a.c_in && t >= 0 && t < a.frames_in) {
                 v = xb[static_cast<size_t>(ci0 + ci) * a.ld_in + t];
+                if (a.ln_x.stats)
+                    v = ln_apply(v, xstats[t], xstats[a.ld_in + t], a.ln_x.gamma[ci0 + ci], a.ln_x.beta[ci0 + ci]);
+            }
             xreg[i] = v;
         }
     };
@@ -213,6 +218,11 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
                 const int n = nb + l31;
                 if (n >= a.ld_out) continue;
                 const bool live = n < a.frames_out;
+                float s0m = 0.f, s0r = 0.f;
+                if (a.s0 && a.ln_s0.stats) {
+                    const float* st = a.ln_s0.stats + static_cast<size_t>(b) * 2 * a.ld_out;
+                    s0m = st[n]; s0r = st[a.ld_out + n];
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -220,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
                     float v = acc[i][j][r] + a.bias[m];
                     if (RELU) v = relu_clamp(v);
                     const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
-                    if (a.s0) v += a.s0[off];
+                    if (a.s0) v += a.ln_s0.stats ? ln_apply(a.s0[off], s0m, s0r, a.ln_s0.gamma[m], a.ln_s0.beta[m]) : a.s0[off];
                     if (a.s1) v += a.s1[off];
                     if (a.s2) v += a.s2[off];
                     a.y[off] = live ? v : 0.f;
@@ -260,13 +270,14 @@ static int launch_gemm_conv(GemmConvArgs a, hipStream_t stream, const char* what
 // internal entry used by lstm.hip: gates(t, b, 4H) = x(b, :, t) . w_ih^T + b_ih + b_hh  (TIME-major, so that the
 // recurrence reads one contiguous batch x 4H slab per step)
 int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* gates,
-                          int batch, int c_in, int frames, int ld, int rows4h, hipStream_t stream)
+                          int batch, int c_in, int frames, int ld, int rows4h, LnRef ln, hipStream_t stream)
 {
     GemmConvArgs a{};
     a.x = x; a.w = w_ih; a.bias = b_ih; a.bias2 = b_hh; a.y = gates;
     a.c_in = c_in; a.frames_in = frames; a.ld_in = ld; a.c_out = rows4h; a.frames_out = frames; a.ld_out = rows4h;
     a.lpad = 0; a.ktot = c_in; a.batch = batch;
     a.row_stride_t = batch; a.row_stride_b = 1;
+    a.ln_x = ln;
     return launch_gemm_conv<1, 1, true, false>(a, stream, "nbasr_lstm_forward(input projection)");
 }
 
@@ -274,10 +285,10 @@ int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, 
 
 using namespace nbasr;
 
-extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
-                                        const float* skip1, const float* skip2, float* y, int batch, int c_in,
-                                        int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                                        nbasr_stream_t stream)
+extern "C" int nbasr_dense_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
+                                           const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                                           int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                                           const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused: bad sizes");
@@ -291,12 +302,27 @@ extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const fl
                   "nbasr_dense_conv1d_fused: c_in*kernel=%d must be a multiple of 4 and w 16-byte aligned", c_in * kernel);
     if (batch == 0 || frames_out == 0) return NBASR_OK;
     NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused: x, w, bias, y must be non-NULL");
+    const bool any_ln = ln && (ln_on_x || (ln_on_skip0 && skip0));
+    NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL,
+                  "nbasr_dense_conv1d_fused_ln: deferred LayerNorm needs stats, gamma and beta");
+    NBASR_REQUIRE(!(ln && ln_on_x && ln_on_skip0 && skip0) || (c_in == c_out && ld_in == ld_out), NBASR_EINVAL,
+                  "nbasr_dense_conv1d_fused_ln: one descriptor for x and skip0 needs equal shapes");
     GemmConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.bias2 = nullptr; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
     a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
     a.lpad = pad_left(kernel, 1, stride); a.ktot = c_in * kernel; a.batch = batch;
+    a.ln_x = ln_ref(ln, ln_on_x != 0); a.ln_s0 = ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr);
     hipStream_t s = as_stream(stream);
     if (kernel == 8 && stride == 1) return launch_gemm_conv<8, 1, false, true>(a, s, "nbasr_dense_conv1d_fused");
     if (kernel == 8 && stride == 2) return launch_gemm_conv<8, 2, false, true>(a, s, "nbasr_dense_conv1d_fused");
     return launch_gemm_conv<1, 1, false, true>(a, s, "nbasr_dense_conv1d_fused");
+}
+
+extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
+                                        const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                                        int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                                        nbasr_stream_t stream)
+{
+    return nbasr_dense_conv1d_fused_ln(x, w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                       kernel, stride, nullptr, 0, 0, stream);
 }

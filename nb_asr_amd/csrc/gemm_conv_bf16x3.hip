@@ -53,6 +53,7 @@ struct PackedConvArgs {
     float* y;
     int c_in, frames_in, ld_in, c_out, frames_out, ld_out, lpad;
     int n_groups, n_mt, n_nt, batch;
+    LnRef ln_x;                  // pending LayerNorm of the input (deferred normalisation, nbasr.h)
 };
 
 __device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
 
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * S - a.lpad;
+    const float* __restrict__ xstats = a.ln_x.stats ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
     const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_QSTEPS * PB_A_STEP_BYTES;
 
     bool mval[2], nval[2];
@@ -164,8 +166,15 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             const int t = tin0 + row;
             const int ci = g * PB_CI + 2 * p;
             const bool ok = e < G::XITEMS && t >= 0 && t < a.frames_in;
-            xreg[i][0] = (ok && ci < a.c_in) ? xb[static_cast<size_t>(ci) * a.ld_in + t] : 0.f;
-            xreg[i][1] = (ok && ci + 1 < a.c_in) ? xb[static_cast<size_t>(ci + 1) * a.ld_in + t] : 0.f;
+            float v0 = (ok && ci < a.c_in) ? xb[static_cast<size_t>(ci) * a.ld_in + t] : 0.f;
+            float v1 = (ok && ci + 1 < a.c_in) ? xb[static_cast<size_t>(ci + 1) * a.ld_in + t] : 0.f;
+            if (a.ln_x.stats && ok) {
+                const float mean = xstats[t], rstd = xstats[a.ld_in + t];
+                if (ci < a.c_in) v0 = ln_apply(v0, mean, rstd, a.ln_x.gamma[ci], a.ln_x.beta[ci]);
+                if (ci + 1 < a.c_in) v1 = ln_apply(v1, mean, rstd, a.ln_x.gamma[ci + 1], a.ln_x.beta[ci + 1]);
+            }
+            xreg[i][0] = v0;
+            xreg[i][1] = v1;
         }
     };
     auto commit_x = [&]() {
@@ -320,10 +329,10 @@ extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out,
     return launch_status("nbasr_pack_dense_weights");
 }
 
-extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias, const float* skip0,
-                                               const float* skip1, const float* skip2, float* y, int batch, int c_in,
-                                               int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                                               nbasr_stream_t stream)
+static int dense_packed_impl(const float* x, const void* packed_w, const float* bias, const float* skip0,
+                             const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                             int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                             const nbasr_deferred_ln* ln, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: bad sizes");
@@ -340,5 +349,24 @@ extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packe
     a.x = x; a.wp = static_cast<const unsigned char*>(packed_w); a.bias = bias; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
     a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
     a.lpad = pad_left(kernel, 1, stride); a.n_groups = (c_in + PB_CI - 1) / PB_CI; a.batch = batch;
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_ln: deferred LayerNorm needs stats, gamma and beta");
+    a.ln_x = ln_ref(ln, true);
     return stride == 1 ? launch_packed<1>(a, as_stream(stream)) : launch_packed<2>(a, as_stream(stream));
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias, const float* skip0,
+                                               const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                                               int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                                               nbasr_stream_t stream)
+{
+    return dense_packed_impl(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel,
+                             stride, nullptr, stream);
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed_ln(const float* x, const void* packed_w, const float* bias, float* y, int batch,
+                                                  int c_in, int frames_in, int ld_in, int c_out, int ld_out, int kernel,
+                                                  int stride, const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+{
+    return dense_packed_impl(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                             kernel, stride, ln, stream);
 }

@@ -16,11 +16,13 @@
 
 namespace nbasr {
 
-template <int CG, int K, int D>
+// LNX: the main input carries a pending LayerNorm (deferred normalisation, nbasr.h) applied while loading;
+// ln_s0.stats != nullptr: skip0 carries one (inside a cell both are the cell input, with the same statistics).
+template <int CG, int K, int D, bool LNX>
 __global__ __launch_bounds__(256) void grouped_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
-    float* __restrict__ y, int channels, int frames, int ld, int groups)
+    float* __restrict__ y, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0)
 {
     constexpr int LPAD = pad_left(K, D, 1);
     constexpr int SPAN = (K - 1) * D;            // taps reach frames [t - LPAD, t - LPAD + SPAN]
@@ -51,6 +53,23 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         for (int r = 0; r < 4; ++r) acc[co][r] = bv;
     }
 
+    // per-frame LayerNorm statistics of the window (shared by all input channels)
+    float mw[LNX ? NCH * 4 : 1], rw[LNX ? NCH * 4 : 1];
+    if (LNX) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_x.stats + static_cast<size_t>(b) * 2 * ld);
+        const float4* __restrict__ rrow = mrow + nq;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int qq = q - QL + c;
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = m;
+            if (active && qq >= 0 && qq < nq) { m = mrow[qq]; r = rrow[qq]; }
+            mw[(4 * c + 0) % (LNX ? NCH * 4 : 1)] = m.x; mw[(4 * c + 1) % (LNX ? NCH * 4 : 1)] = m.y;
+            mw[(4 * c + 2) % (LNX ? NCH * 4 : 1)] = m.z; mw[(4 * c + 3) % (LNX ? NCH * 4 : 1)] = m.w;
+            rw[(4 * c + 0) % (LNX ? NCH * 4 : 1)] = r.x; rw[(4 * c + 1) % (LNX ? NCH * 4 : 1)] = r.y;
+            rw[(4 * c + 2) % (LNX ? NCH * 4 : 1)] = r.z; rw[(4 * c + 3) % (LNX ? NCH * 4 : 1)] = r.w;
+        }
+    }
+
 #pragma unroll 2
     for (int ci = 0; ci < CG; ++ci) {
         const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + row0 + static_cast<size_t>(ci) * ld);
@@ -61,6 +80,12 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (active && qq >= 0 && qq < nq) v = xrow[qq];
             xw[4 * c + 0] = v.x; xw[4 * c + 1] = v.y; xw[4 * c + 2] = v.z; xw[4 * c + 3] = v.w;
+        }
+        if (LNX) {
+            const float gam = ln_x.gamma[g * CG + ci], bet = ln_x.beta[g * CG + ci];     // wave-uniform: scalar loads
+#pragma unroll
+            for (int e = 0; e < NCH * 4; ++e)
+                xw[e] = ln_apply(xw[e], mw[e % (LNX ? NCH * 4 : 1)], rw[e % (LNX ? NCH * 4 : 1)], gam, bet);
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -76,13 +101,27 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
 
     if (!active) return;
     const int t0 = q * 4;
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;          // statistics of this lane's own 4 frames (skip0)
+    if (s0 && ln_s0.stats) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_s0.stats + static_cast<size_t>(b) * 2 * ld);
+        sm = mrow[q];
+        sr = mrow[nq + q];
+    }
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
         const size_t off = row0 + static_cast<size_t>(co) * ld + t0;
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-        if (s0) { const float4 v = *reinterpret_cast<const float4*>(s0 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        if (s0) {
+            float4 v = *reinterpret_cast<const float4*>(s0 + off);
+            if (ln_s0.stats) {
+                const float gam = ln_s0.gamma[g * CG + co], bet = ln_s0.beta[g * CG + co];
+                v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
+                v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
+            }
+            o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+        }
         if (s1) { const float4 v = *reinterpret_cast<const float4*>(s1 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         if (s2) { const float4 v = *reinterpret_cast<const float4*>(s2 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         // keep the pitch columns frames..ld-1 at zero (layout invariant, nbasr.h)
@@ -92,15 +131,30 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
     }
 }
 
-// y = 0 + skip0 + skip1 + skip2 for a node whose main op is `zero` (reference ops.py:67-68)
+// y = 0 + skip0 + skip1 + skip2 for a node whose main op is `zero` (reference ops.py:67-68); skip0 may carry a pending
+// LayerNorm, in which case the materialised (normalised) value is what gets summed and stored
 __global__ __launch_bounds__(256) void skip_sum_kernel(
     const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
-    float* __restrict__ y, size_t n4)
+    float* __restrict__ y, size_t n4, int channels, int nq, const LnRef ln_s0)
 {
     const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (s0) { const float4 v = reinterpret_cast<const float4*>(s0)[i]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        if (s0) {
+            float4 v = reinterpret_cast<const float4*>(s0)[i];
+            if (ln_s0.stats) {
+                const size_t row = i / nq;
+                const int q = static_cast<int>(i - row * nq);
+                const int c = static_cast<int>(row % channels);
+                const size_t b = row / channels;
+                const float4* mrow = reinterpret_cast<const float4*>(ln_s0.stats + b * 2 * (static_cast<size_t>(nq) * 4));
+                const float4 m = mrow[q], r = mrow[nq + q];
+                const float gam = ln_s0.gamma[c], bet = ln_s0.beta[c];
+                v.x = ln_apply(v.x, m.x, r.x, gam, bet); v.y = ln_apply(v.y, m.y, r.y, gam, bet);
+                v.z = ln_apply(v.z, m.z, r.z, gam, bet); v.w = ln_apply(v.w, m.w, r.w, gam, bet);
+            }
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        }
         if (s1) { const float4 v = reinterpret_cast<const float4*>(s1)[i]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
         if (s2) { const float4 v = reinterpret_cast<const float4*>(s2)[i]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
         reinterpret_cast<float4*>(y)[i] = o;
@@ -116,27 +170,33 @@ __global__ __launch_bounds__(256) void repitch_kernel(
         dst[static_cast<size_t>(r) * ld_dst + t] = (t < frames) ? src[static_cast<size_t>(r) * ld_src + t] : 0.f;
 }
 
+struct GroupedArgs {
+    const float* x; const float* w; const float* bias; const float* s0; const float* s1; const float* s2; float* y;
+    int batch, channels, frames, ld, groups;
+    LnRef ln_x, ln_s0;
+};
+
 template <int CG, int K, int D>
-static int launch_grouped(const float* x, const float* w, const float* bias, const float* s0, const float* s1,
-                          const float* s2, float* y, int batch, int channels, int frames, int ld, int groups,
-                          hipStream_t stream)
+static int launch_grouped(const GroupedArgs& a, hipStream_t stream)
 {
-    const int nq = ld / 4;
-    dim3 grid((nq + 63) / 64, (groups + 3) / 4, batch);
-    hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D>), grid, dim3(256), 0, stream,
-                       x, w, bias, s0, s1, s2, y, channels, frames, ld, groups);
+    const int nq = a.ld / 4;
+    dim3 grid((nq + 63) / 64, (a.groups + 3) / 4, a.batch);
+    if (a.ln_x.stats)
+        hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D, true>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1,
+                           a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0);
+    else
+        hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D, false>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1,
+                           a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0);
     return launch_status("nbasr_grouped_conv1d_fused");
 }
 
 template <int CG>
-static int dispatch_kd(int kernel, int dilation, const float* x, const float* w, const float* bias, const float* s0,
-                       const float* s1, const float* s2, float* y, int batch, int channels, int frames, int ld,
-                       int groups, hipStream_t stream)
+static int dispatch_kd(int kernel, int dilation, const GroupedArgs& a, hipStream_t stream)
 {
-    if (kernel == 5 && dilation == 1) return launch_grouped<CG, 5, 1>(x, w, bias, s0, s1, s2, y, batch, channels, frames, ld, groups, stream);
-    if (kernel == 5 && dilation == 2) return launch_grouped<CG, 5, 2>(x, w, bias, s0, s1, s2, y, batch, channels, frames, ld, groups, stream);
-    if (kernel == 7 && dilation == 1) return launch_grouped<CG, 7, 1>(x, w, bias, s0, s1, s2, y, batch, channels, frames, ld, groups, stream);
-    if (kernel == 7 && dilation == 2) return launch_grouped<CG, 7, 2>(x, w, bias, s0, s1, s2, y, batch, channels, frames, ld, groups, stream);
+    if (kernel == 5 && dilation == 1) return launch_grouped<CG, 5, 1>(a, stream);
+    if (kernel == 5 && dilation == 2) return launch_grouped<CG, 5, 2>(a, stream);
+    if (kernel == 7 && dilation == 1) return launch_grouped<CG, 7, 1>(a, stream);
+    if (kernel == 7 && dilation == 2) return launch_grouped<CG, 7, 2>(a, stream);
     set_error("nbasr_grouped_conv1d_fused: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
     return NBASR_EINVAL;
 }
@@ -145,10 +205,10 @@ static int dispatch_kd(int kernel, int dilation, const float* x, const float* w,
 
 using namespace nbasr;
 
-extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
-                                          const float* skip1, const float* skip2, float* y, int batch, int channels,
-                                          int frames, int ld, int groups, int kernel, int dilation,
-                                          nbasr_stream_t stream)
+extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
+                                             const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                             int frames, int ld, int groups, int kernel, int dilation,
+                                             const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
@@ -159,20 +219,35 @@ extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const 
     NBASR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
                   "nbasr_grouped_conv1d_fused: activation pointers must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_grouped_conv1d_fused: batch %d > 65535", batch);
+    const bool any_ln = ln && (ln_on_x || (ln_on_skip0 && skip0));
+    NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
+                  "nbasr_grouped_conv1d_fused_ln: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
+    GroupedArgs a{x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups,
+                  ln_ref(ln, ln_on_x != 0), ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr)};
     hipStream_t s = as_stream(stream);
     switch (channels / groups) {
-        case 6:  return dispatch_kd<6>(kernel, dilation, x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, s);
-        case 8:  return dispatch_kd<8>(kernel, dilation, x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, s);
-        case 10: return dispatch_kd<10>(kernel, dilation, x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, s);
-        case 12: return dispatch_kd<12>(kernel, dilation, x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, s);
+        case 6:  return dispatch_kd<6>(kernel, dilation, a, s);
+        case 8:  return dispatch_kd<8>(kernel, dilation, a, s);
+        case 10: return dispatch_kd<10>(kernel, dilation, a, s);
+        case 12: return dispatch_kd<12>(kernel, dilation, a, s);
         default:
             set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", channels / groups);
             return NBASR_EINVAL;
     }
 }
 
-extern "C" int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
-                              int channels, int frames, int ld, nbasr_stream_t stream)
+extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
+                                          const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                          int frames, int ld, int groups, int kernel, int dilation,
+                                          nbasr_stream_t stream)
+{
+    return nbasr_grouped_conv1d_fused_ln(x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, kernel,
+                                         dilation, nullptr, 0, 0, stream);
+}
+
+extern "C" int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
+                                 int channels, int frames, int ld, const nbasr_deferred_ln* ln, int ln_on_skip0,
+                                 nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_skip_sum: bad sizes");
@@ -181,11 +256,20 @@ extern "C" int nbasr_skip_sum(const float* skip0, const float* skip1, const floa
     NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_skip_sum: ld=%d must be >= frames and a multiple of 4", ld);
     NBASR_REQUIRE(aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
                   "nbasr_skip_sum: pointers must be 16-byte aligned");
+    const bool use_ln = ln && ln_on_skip0 && skip0;
+    NBASR_REQUIRE(!use_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
+                  "nbasr_skip_sum_ln: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
     const size_t n4 = static_cast<size_t>(batch) * channels * ld / 4;
-    if (n4 == 0) return NBASR_OK;
     const unsigned blocks = static_cast<unsigned>(n4 / 256 + 1 < 4096 ? n4 / 256 + 1 : 4096);
-    hipLaunchKernelGGL(skip_sum_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), skip0, skip1, skip2, y, n4);
+    hipLaunchKernelGGL(skip_sum_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), skip0, skip1, skip2, y, n4, channels,
+                       ld / 4, ln_ref(ln, use_ln));
     return launch_status("nbasr_skip_sum");
+}
+
+extern "C" int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
+                              int channels, int frames, int ld, nbasr_stream_t stream)
+{
+    return nbasr_skip_sum_ln(skip0, skip1, skip2, y, batch, channels, frames, ld, nullptr, 0, stream);
 }
 
 extern "C" int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,

@@ -17,25 +17,12 @@ namespace nbasr {
 constexpr int LN_ROWS = 16;   // channel rows in flight per workgroup
 constexpr int LN_QS = 16;     // 16-byte chunks (4 frames each) per row segment
 
-__global__ __launch_bounds__(256) void layernorm_channels_kernel(
-    const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* y, int channels, int frames, int ld, float eps)   // x may alias y (in-place)
+// Statistics of one 64-frame tile: fills s_mu / s_rstd (LDS) for the tile's frame columns.  Called by all 256 threads.
+__device__ __forceinline__ void tile_statistics(const float* x, int channels, int ld, float eps, size_t base, bool active,
+                                                int row, int ql, float (*s_mean)[LN_QS * 4], float (*s_m2)[LN_QS * 4],
+                                                float* s_cnt, float* s_mu, float* s_rstd)
 {
-    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
-    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
-    __shared__ float s_cnt[LN_ROWS];
-    __shared__ float s_mu[LN_QS * 4];
-    __shared__ float s_rstd[LN_QS * 4];
-
-    const int ql = threadIdx.x & (LN_QS - 1);
-    const int row = threadIdx.x / LN_QS;
-    const int nq = ld >> 2;
-    const int q = blockIdx.x * LN_QS + ql;
-    const int b = blockIdx.y;
-    const bool active = q < nq;
-    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
-
-    // ---- pass 1: per-lane shifted sums over this lane's channel subset -------------------------
+    // per-lane shifted sums over this lane's channel subset
     float shift[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     int n = 0;
     if (active) {
@@ -65,7 +52,7 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
     if (ql == 0) s_cnt[row] = fn;
     __syncthreads();
 
-    // ---- merge the 16 row partials (one thread per frame column) -------------------------------
+    // merge the 16 row partials (Chan's parallel-variance formula), one thread per frame column
     if (threadIdx.x < LN_QS * 4) {
         const int col = threadIdx.x;
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
@@ -84,8 +71,29 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
         s_rstd[col] = 1.0f / sqrtf(m2 / fmaxf(cnt, 1.f) + eps);
     }
     __syncthreads();
+}
 
-    // ---- pass 2: normalise, scale, shift; keep the pitch columns at zero -----------------------
+__global__ __launch_bounds__(256) void layernorm_channels_kernel(
+    const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* y, int channels, int frames, int ld, float eps)   // x may alias y (in-place)
+{
+    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
+    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
+    __shared__ float s_cnt[LN_ROWS];
+    __shared__ float s_mu[LN_QS * 4];
+    __shared__ float s_rstd[LN_QS * 4];
+
+    const int ql = threadIdx.x & (LN_QS - 1);
+    const int row = threadIdx.x / LN_QS;
+    const int nq = ld >> 2;
+    const int q = blockIdx.x * LN_QS + ql;
+    const int b = blockIdx.y;
+    const bool active = q < nq;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+
+    tile_statistics(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
+
+    // pass 2: normalise, scale, shift; keep the pitch columns at zero
     if (!active) return;
     float mu[4], rs[4];
 #pragma unroll
@@ -102,6 +110,37 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
             if (t0 + r >= frames) o[r] = 0.f;
         }
         *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// deferred LayerNorm: ONE read pass, per-frame (mean, rstd) only; consumers normalise while loading
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+                                                            int channels, int frames, int ld, float eps)
+{
+    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
+    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
+    __shared__ float s_cnt[LN_ROWS];
+    __shared__ float s_mu[LN_QS * 4];
+    __shared__ float s_rstd[LN_QS * 4];
+
+    const int ql = threadIdx.x & (LN_QS - 1);
+    const int row = threadIdx.x / LN_QS;
+    const int nq = ld >> 2;
+    const int q = blockIdx.x * LN_QS + ql;
+    const int b = blockIdx.y;
+    const bool active = q < nq;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+
+    tile_statistics(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
+
+    if (threadIdx.x < LN_QS * 4) {
+        const int t = blockIdx.x * (LN_QS * 4) + threadIdx.x;
+        if (t < ld) {
+            const bool live = t < frames;
+            float* srow = stats + static_cast<size_t>(b) * 2 * ld;
+            srow[t] = live ? s_mu[threadIdx.x] : 0.f;
+            srow[ld + t] = live ? s_rstd[threadIdx.x] : 0.f;
+        }
     }
 }
 
@@ -124,4 +163,20 @@ extern "C" int nbasr_layernorm_channels(const float* x, const float* gamma, cons
     hipLaunchKernelGGL(layernorm_channels_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
                        x, gamma, beta, y, channels, frames, ld, eps);
     return launch_status("nbasr_layernorm_channels");
+}
+
+extern "C" int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
+                                   nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_channel_stats: bad sizes");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_channel_stats: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && stats, NBASR_ENULL, "nbasr_channel_stats: NULL pointer");
+    NBASR_REQUIRE(aligned16(x) && aligned16(stats), NBASR_EALIGN, "nbasr_channel_stats: x, stats must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_channel_stats: batch %d > 65535", batch);
+    const int nq = ld / 4;
+    hipLaunchKernelGGL(channel_stats_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
+                       x, stats, channels, frames, ld, eps);
+    return launch_status("nbasr_channel_stats");
 }

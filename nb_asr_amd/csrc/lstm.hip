@@ -20,7 +20,7 @@ namespace nbasr {
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh, float* gates,
-                          int batch, int c_in, int frames, int ld, int rows4h, hipStream_t stream);
+                          int batch, int c_in, int frames, int ld, int rows4h, LnRef ln, hipStream_t stream);
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
 template <bool BCT>
 __global__ __launch_bounds__(256) void head_kernel(
     const float* __restrict__ h, const float* __restrict__ w, const float* __restrict__ bias,
-    float* __restrict__ out, int rows, int features, int classes, int frames, int ld)
+    float* __restrict__ out, int rows, int features, int classes, int frames, int ld, const LnRef ln)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -151,6 +151,12 @@ __global__ __launch_bounds__(256) void head_kernel(
                 const float* p = h + (static_cast<size_t>(bb) * features + k) * ld + tt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) av[e] = p[static_cast<size_t>(e) * ld];
+                if (ln.stats) {
+                    const float* st = ln.stats + static_cast<size_t>(bb) * 2 * ld;
+                    const float mean = st[tt], rstd = st[ld + tt];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = ln_apply(av[e], mean, rstd, ln.gamma[k + e], ln.beta[k + e]);
+                }
             }
         }
 #pragma unroll
@@ -182,9 +188,10 @@ __global__ __launch_bounds__(256) void head_kernel(
 
 using namespace nbasr;
 
-extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
-                                  const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
-                                  int c_in, int frames, int ld, int hidden, nbasr_stream_t stream)
+extern "C" int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                                     const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
+                                     int c_in, int frames, int ld, int hidden, const nbasr_deferred_ln* ln,
+                                     nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames >= 0 && hidden > 0 && ld >= frames, NBASR_EINVAL, "nbasr_lstm_forward: bad sizes");
@@ -193,12 +200,20 @@ extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float
     NBASR_REQUIRE(hidden % 4 == 0 && c_in % 4 == 0, NBASR_EALIGN, "nbasr_lstm_forward: hidden=%d and c_in=%d must be multiples of 4", hidden, c_in);
     NBASR_REQUIRE(aligned16(w_ih) && aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_forward: w_ih, w_hh, h_out must be 16-byte aligned");
     hipStream_t s = as_stream(stream);
-    int rc = lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, s);
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_lstm_forward_ln: deferred LayerNorm needs stats, gamma and beta");
+    int rc = lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, ln_ref(ln, true), s);
     if (rc != NBASR_OK) return rc;
     const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
     for (int t = 0; t < frames; ++t)
         hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, s, gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
     return launch_status("nbasr_lstm_forward");
+}
+
+extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                                  const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
+                                  int c_in, int frames, int ld, int hidden, nbasr_stream_t stream)
+{
+    return nbasr_lstm_forward_ln(x, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out, batch, c_in, frames, ld, hidden, nullptr, stream);
 }
 
 extern "C" int nbasr_linear_head(const float* h, const float* w, const float* bias, float* logits, int rows,
@@ -213,12 +228,13 @@ extern "C" int nbasr_linear_head(const float* h, const float* w, const float* bi
                   "nbasr_linear_head: features must be a multiple of 4 and h, w 16-byte aligned");
     if (rows == 0) return NBASR_OK;
     hipLaunchKernelGGL(head_kernel<false>, dim3((rows + 63) / 64), dim3(256), 0, as_stream(stream),
-                       h, w, bias, logits, rows, features, classes, 0, 0);
+                       h, w, bias, logits, rows, features, classes, 0, 0, LnRef{nullptr, nullptr, nullptr});
     return launch_status("nbasr_linear_head");
 }
 
-extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits, int batch,
-                                     int features, int frames, int ld, int classes, nbasr_stream_t stream)
+extern "C" int nbasr_linear_head_bct_ln(const float* x, const float* w, const float* bias, float* logits, int batch,
+                                        int features, int frames, int ld, int classes, const nbasr_deferred_ln* ln,
+                                        nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && features > 0 && frames >= 0 && ld >= frames && classes > 0 && classes <= 64, NBASR_EINVAL,
@@ -226,9 +242,16 @@ extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float
     if (batch == 0 || frames == 0) return NBASR_OK;
     NBASR_REQUIRE(x && w && bias && logits, NBASR_ENULL, "nbasr_linear_head_bct: NULL pointer");
     NBASR_REQUIRE(features % 4 == 0 && aligned16(w), NBASR_EALIGN, "nbasr_linear_head_bct: features must be a multiple of 4, w 16-byte aligned");
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_linear_head_bct_ln: deferred LayerNorm needs stats, gamma and beta");
     const long long rows = static_cast<long long>(batch) * frames;
     if (rows == 0) return NBASR_OK;
     hipLaunchKernelGGL(head_kernel<true>, dim3(static_cast<unsigned>((rows + 63) / 64)), dim3(256), 0, as_stream(stream),
-                       x, w, bias, logits, static_cast<int>(rows), features, classes, frames, ld);
+                       x, w, bias, logits, static_cast<int>(rows), features, classes, frames, ld, ln_ref(ln, true));
     return launch_status("nbasr_linear_head_bct");
+}
+
+extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits, int batch,
+                                     int features, int frames, int ld, int classes, nbasr_stream_t stream)
+{
+    return nbasr_linear_head_bct_ln(x, w, bias, logits, batch, features, frames, ld, classes, nullptr, stream);
 }

@@ -20,21 +20,27 @@ import torch
 from . import hip
 
 
-def node_into(node, inputs, frames, out):
-    """Enqueue one cell node: ``out = op(inputs[-1]) + sum(flagged inputs)`` (left-to-right)."""
+def node_into(node, inputs, frames, out, ln0=None):
+    """Enqueue one cell node: ``out = op(inputs[-1]) + sum(flagged inputs)`` (left-to-right).
+
+    ``ln0`` = (stats, gamma, beta): ``inputs[0]`` (the cell input) is stored un-normalised with a pending LayerNorm that
+    the kernel applies while loading -- as the main input when the node is the cell's first, as skip0 when flagged."""
     from .ops import PadConvRelu, Linear, Zero, Identity
     if len(inputs) != len(node.branch_ops):
         raise AssertionError('Branch op and input list have different lenghts')
     skips = [src for branch, src in zip(node.branch_ops, inputs) if isinstance(branch, Identity)]
     op, last = node.op, inputs[-1]
+    on_x = ln0 is not None and len(inputs) == 1
+    on_s0 = ln0 is not None and isinstance(node.branch_ops[0], Identity)       # the cell input, if flagged, is skips[0]
+    ln = ln0 if (on_x or on_s0) else None
     if isinstance(op, PadConvRelu):
         hip.grouped_conv1d_fused(last, op.conv.weight.detach(), op.conv.bias.detach(), skips, out, frames,
-                                 op.groups, op.kernel_size, op.dilation)
+                                 op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0)
     elif isinstance(op, Linear):
         hip.dense_conv1d_fused(last, frames, op.linear.weight.detach().unsqueeze(-1), op.linear.bias.detach(),
-                               skips, out, 1)
+                               skips, out, 1, ln, on_x, on_s0)
     elif isinstance(op, Zero):
-        hip.skip_sum(skips, out, frames)
+        hip.skip_sum(skips, out, frames, ln if on_s0 else None, on_s0)
     else:
         raise TypeError(f'unsupported node operation {type(op).__name__}')
     return out
@@ -59,6 +65,13 @@ class ForwardPlan:
         if self.dense_mode not in ('bf16x3', 'f32'):
             raise ValueError(f'NBASR_DENSE_MODE must be bf16x3 or f32, got {self.dense_mode!r}')
         self._packed = {}            # id(layer) -> (weight data_ptr, weight version, packed tensor)
+        # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
+        # 'materialize' = the stand-alone LayerNorm kernel writes the normalised tensor
+        self.ln_mode = os.environ.get('NBASR_LN_MODE', 'deferred')
+        if self.ln_mode not in ('deferred', 'materialize'):
+            raise ValueError(f'NBASR_LN_MODE must be deferred or materialize, got {self.ln_mode!r}')
+        stat_elems = max(batch * 2 * hip.round_up4(t) for t in self.block_frames)
+        self.stats = [torch.empty(max(stat_elems, 4), device=device, dtype=torch.float32) for _ in range(2)]
         elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
         self.pool = [torch.empty(max(elems, 4), device=device, dtype=torch.float32) for _ in range(4)]
         if model.use_rnn:
@@ -88,12 +101,38 @@ class ForwardPlan:
             self._packed[id(layer)] = hit
         return hit[1]
 
-    def _dense(self, layer, act, act_frames, out):
+    def _dense(self, layer, act, act_frames, out, ln):
         if self.dense_mode == 'bf16x3' and layer.kernel_size == 8:
             return hip.dense_conv1d_fused_packed(act, act_frames, self._packed_weights(layer), layer.conv.out_channels,
-                                                 layer.kernel_size, layer.conv.bias.detach(), (), out, layer.strides)
+                                                 layer.kernel_size, layer.conv.bias.detach(), (), out, layer.strides, ln)
         return hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(), (), out,
-                                      layer.strides)
+                                      layer.strides, ln, ln is not None, False)
+
+    @staticmethod
+    def _cheap_consumer(nxt):
+        """Deferral pays only where normalising on load is nearly free: a following cell whose first node is a grouped
+        convolution (or `zero`).  GEMM consumers (the next block's dense conv, a `linear` first node, the LSTM, the head)
+        stage their input through a register pipeline where the extra per-element work costs more than the LayerNorm
+        pass it saves (measured: +2 ms on the dense convs, +1.2 ms on the LSTM projection)."""
+        from .model import SearchCell
+        from .ops import Linear
+        return isinstance(nxt, SearchCell) and not isinstance(nxt.nodes[0].op, Linear)
+
+    def _norm(self, norm, act, act_frames, kind_meta, taps, tap_idx, nxt):
+        """LayerNorm of ``act``: returns the pending descriptor (deferred) or None after normalising in place."""
+        if self.ln_mode == 'materialize' or not self._cheap_consumer(nxt):
+            self._timed('layernorm', kind_meta, lambda: hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(),
+                                                                               act, act_frames, norm.eps))
+            return None
+        self._stat_turn ^= 1
+        b, _, ld = act.shape
+        stats = self.stats[self._stat_turn][: b * 2 * ld].view(b, 2, ld)
+        self._timed('channel_stats', kind_meta, lambda: hip.channel_stats(act, stats, act_frames, norm.eps))
+        if taps is not None:                         # parity debugging: materialise a copy, the flow stays deferred
+            copy = torch.empty_like(act)
+            hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(), copy, act_frames, norm.eps)
+            taps[tap_idx] = copy[:, :, :act_frames].clone()
+        return (stats, norm.weight.detach(), norm.bias.detach())
 
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)
@@ -113,24 +152,30 @@ class ForwardPlan:
             raise hip.HipError(f'input must be float32 (got {x.dtype})')
         x = x.detach().contiguous()
         act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
+        pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
+        self._stat_turn = 0
         blk = -1
         logits = None
+        n_layers = len(model.model)
         for idx, layer in enumerate(model.model):
-            if taps is not None and idx > 0:
-                taps[idx - 1] = self._tap(act, act_frames)
             if isinstance(layer, PadConvRelu):
                 blk += 1
                 dst = 0 if cur != 0 else 1
                 t_out = self.block_frames[blk]
                 out = self._view(dst, layer.conv.out_channels, t_out)
+                ln, src, src_frames = pending, act, act_frames
                 self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
-                            lambda: self._dense(layer, act, act_frames, out))
-                act, act_frames, cur = out, t_out, dst
+                            lambda: self._dense(layer, src, src_frames, out, ln))
+                act, act_frames, cur, pending = out, t_out, dst, None
+                if taps is not None:
+                    taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.LayerNorm):
-                if act.dim() != 3:
+                if act.dim() != 3 or pending is not None:
                     raise RuntimeError('LayerNorm in an unexpected position of the layer list')
-                self._timed('layernorm', (blk, act.shape[1], act.shape[1], 0, act_frames, 0),
-                            lambda: hip.layernorm_channels(act, layer.weight.detach(), layer.bias.detach(), act, act_frames, layer.eps))
+                pending = self._norm(layer, act, act_frames, (blk, act.shape[1], act.shape[1], 0, act_frames, 0), taps, idx,
+                                     model.model[idx + 1] if idx + 1 < n_layers else None)
+                if taps is not None and pending is None:
+                    taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, SearchCell):
                 free = [i for i in range(4) if i != cur]
                 if len(layer.nodes) > len(free):
@@ -141,29 +186,37 @@ class ForwardPlan:
                     kind = {'PadConvRelu': 'grouped_conv', 'Linear': 'linear_op', 'Zero': 'skip_sum'}[type(node.op).__name__]
                     meta = (blk, layer.filters, layer.filters, getattr(node.op, 'kernel_size', 1), act_frames, n_skips)
                     view = self._view(dst, layer.filters, act_frames)
-                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view)))
-                act, cur = outs[-1], free[len(layer.nodes) - 1]
+                    ln0 = pending
+                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0)))
+                act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 if layer.use_norm:
-                    self._timed('layernorm', (blk, layer.filters, layer.filters, 0, act_frames, 0),
-                                lambda: hip.layernorm_channels(act, layer.norm_layer.weight.detach(), layer.norm_layer.bias.detach(),
-                                                               act, act_frames, layer.norm_layer.eps))
+                    pending = self._norm(layer.norm_layer, act, act_frames, (blk, layer.filters, layer.filters, 0, act_frames, 0),
+                                         taps, idx, model.model[idx + 1] if idx + 1 < n_layers else None)
+                if taps is not None and pending is None:
+                    taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.Dropout):
-                pass                                         # identity: eval mode or p == 0 (checked by the model)
+                if taps is not None:                      # identity: eval mode or p == 0 (checked by the model)
+                    taps[idx] = taps[idx - 1]
             elif isinstance(layer, nn.LSTM):
+                ln, src, src_frames = pending, act, act_frames
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_forward(act, act_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
+                            lambda: hip.lstm_forward(src, src_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
                                                      layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach(), self.gates_ws,
-                                                     self.cell_ws, self.h_out))
-                act = self.h_out                             # (batch, frames, hidden)
+                                                     self.cell_ws, self.h_out, ln))
+                act, pending = self.h_out, None            # (batch, frames, hidden)
+                if taps is not None:
+                    taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.Linear):
                 logits = torch.empty(self.batch, act_frames, layer.out_features, device=self.device, dtype=torch.float32)
                 if act.dim() == 3 and act is self.__dict__.get('h_out'):
                     hip.linear_head(act, layer.weight.detach(), layer.bias.detach(), logits)
                 else:
-                    hip.linear_head_bct(act, act_frames, layer.weight.detach(), layer.bias.detach(), logits)
-                act = logits
+                    hip.linear_head_bct(act, act_frames, layer.weight.detach(), layer.bias.detach(), logits, pending)
+                act, pending = logits, None
             else:
                 raise TypeError(f'unsupported layer {type(layer).__name__} in the model list')
+        if idx != n_layers - 1 or logits is None:
+            raise RuntimeError('the model list does not end in the CTC head')
         if taps is not None:
             taps[len(model.model) - 1] = logits.clone()
         return logits

@@ -19,6 +19,13 @@ _c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
 _c_int = ctypes.c_int
 _c_stream = ctypes.c_void_p
 
+class DeferredLN(ctypes.Structure):
+    """struct nbasr_deferred_ln: per-frame statistics + affine parameters of a pending LayerNorm."""
+    _fields_ = [('stats', ctypes.c_void_p), ('gamma', ctypes.c_void_p), ('beta', ctypes.c_void_p)]
+
+
+_c_ln_p = ctypes.POINTER(DeferredLN)
+
 # name -> (restype, argtypes); must list every symbol declared in include/nbasr.h
 SIGNATURES = {
     'nbasr_version': (_c_int, []),
@@ -35,12 +42,21 @@ SIGNATURES = {
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    'nbasr_grouped_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_skip_sum_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_stream]),
+    'nbasr_dense_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_dense_conv1d_fused_packed_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_ln_p, _c_stream]),
+    'nbasr_lstm_forward_ln': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    'nbasr_linear_head_bct_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
 }
 
 
 class HipError(RuntimeError):
     pass
+
+
 
 
 _lib = None
@@ -93,6 +109,14 @@ def _opt(t, name):
     return None if t is None else _dev(t, name)
 
 
+def _ln(ln):
+    """(stats, gamma, beta) tensors of a pending LayerNorm -> pointer to a nbasr_deferred_ln (or NULL)."""
+    if ln is None:
+        return None
+    stats, gamma, beta = ln
+    return ctypes.byref(DeferredLN(_dev(stats, 'ln.stats'), _dev(gamma, 'ln.gamma'), _dev(beta, 'ln.beta')))
+
+
 # ---------------------------------------------------------------------------------------------
 # host-only helpers (usable without a GPU)
 # ---------------------------------------------------------------------------------------------
@@ -115,22 +139,33 @@ def round_up4(n):
 # device entry points; activations are (batch, channels, ld) float32 tensors whose last dimension
 # is the row pitch ld (a multiple of 4) and `frames` <= ld the number of valid frames
 # ---------------------------------------------------------------------------------------------
-def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dilation):
+def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dilation, ln=None, ln_on_x=False,
+                         ln_on_skip0=False):
+    """`ln` = (stats, gamma, beta) of a pending LayerNorm carried by x (ln_on_x) and/or skips[0] (ln_on_skip0)."""
     b, c, ld = x.shape
     s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_grouped_conv1d_fused(
+    _check(load_library().nbasr_grouped_conv1d_fused_ln(
         _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
-        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c, frames, ld, groups, kernel, dilation, _stream(x)),
-        'nbasr_grouped_conv1d_fused')
+        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
+        int(ln_on_skip0), _stream(x)), 'nbasr_grouped_conv1d_fused')
     return y
 
 
-def skip_sum(skips, y, frames):
+def skip_sum(skips, y, frames, ln=None, ln_on_skip0=False):
     b, c, ld = y.shape
     s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_skip_sum(_opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
-                                         _dev(y, 'y'), b, c, frames, ld, _stream(y)), 'nbasr_skip_sum')
+    _check(load_library().nbasr_skip_sum_ln(_opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
+                                            _dev(y, 'y'), b, c, frames, ld, _ln(ln), int(ln_on_skip0), _stream(y)),
+           'nbasr_skip_sum')
     return y
+
+
+def channel_stats(x, stats, frames, eps):
+    """One read pass over x (B, C, ld): stats (B, 2, ld) <- per-frame (mean, 1/sqrt(var + eps)) over channels."""
+    b, c, ld = x.shape
+    _check(load_library().nbasr_channel_stats(_dev(x, 'x'), _dev(stats, 'stats'), b, c, frames, ld, float(eps), _stream(x)),
+           'nbasr_channel_stats')
+    return stats
 
 
 def layernorm_channels(x, gamma, beta, y, frames, eps):
@@ -141,15 +176,15 @@ def layernorm_channels(x, gamma, beta, y, frames, eps):
     return y
 
 
-def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride):
+def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln_on_x=False, ln_on_skip0=False):
     b, c_in, ld_in = x.shape
     c_out, _, kernel = weight.shape if weight.dim() == 3 else (weight.shape[0], weight.shape[1], 1)
     ld_out = y.shape[2]
     s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_dense_conv1d_fused(
+    _check(load_library().nbasr_dense_conv1d_fused_ln(
         _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
-        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)),
-        'nbasr_dense_conv1d_fused')
+        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _ln(ln), int(ln_on_x),
+        int(ln_on_skip0), _stream(x)), 'nbasr_dense_conv1d_fused')
     return y
 
 
@@ -167,12 +202,19 @@ def pack_dense_weights(weight):
     return packed
 
 
-def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride):
+def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride, ln=None):
     b, c_in, ld_in = x.shape
     ld_out = y.shape[2]
     s = list(skips) + [None] * (3 - len(skips))
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise HipError('packed weights must be the uint8 device tensor returned by pack_dense_weights')
+    if ln is not None:
+        if any(t is not None for t in s):
+            raise HipError('the packed path takes a deferred LayerNorm only without skip inputs')
+        _check(load_library().nbasr_dense_conv1d_fused_packed_ln(
+            _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out,
+            kernel, stride, _ln(ln), _stream(x)), 'nbasr_dense_conv1d_fused_packed')
+        return y
     _check(load_library().nbasr_dense_conv1d_fused_packed(
         _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
         _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)),
@@ -180,13 +222,13 @@ def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, 
     return y
 
 
-def lstm_forward(x, frames, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out):
+def lstm_forward(x, frames, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out, ln=None):
     b, c_in, ld = x.shape
     hidden = w_hh.shape[1]
-    _check(load_library().nbasr_lstm_forward(
+    _check(load_library().nbasr_lstm_forward_ln(
         _dev(x, 'x'), _dev(w_ih, 'w_ih'), _dev(w_hh, 'w_hh'), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'),
         _dev(gates_ws, 'gates_ws'), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
-        b, c_in, frames, ld, hidden, _stream(x)), 'nbasr_lstm_forward')
+        b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_forward')
     return h_out
 
 
@@ -199,12 +241,12 @@ def linear_head(h, weight, bias, logits):
     return logits
 
 
-def linear_head_bct(x, frames, weight, bias, logits):
+def linear_head_bct(x, frames, weight, bias, logits, ln=None):
     b, features, ld = x.shape
     classes = weight.shape[0]
-    _check(load_library().nbasr_linear_head_bct(_dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'),
-                                                _dev(logits, 'logits'), b, features, frames, ld, classes,
-                                                _stream(x)), 'nbasr_linear_head_bct')
+    _check(load_library().nbasr_linear_head_bct_ln(_dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'),
+                                                   _dev(logits, 'logits'), b, features, frames, ld, classes, _ln(ln),
+                                                   _stream(x)), 'nbasr_linear_head_bct')
     return logits
 
 

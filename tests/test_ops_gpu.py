@@ -284,3 +284,74 @@ def test_standalone_op_modules_accept_unpitched_inputs():
     close(lin(x.to(DEV)), oracle.linear_relu(x, lin.linear.weight.cpu(), lin.linear.bias.cpu()).detach())
     down = nb_ops.PadConvRelu(24, 40, 8, 1, 2).to(DEV).eval()
     close(down(x.to(DEV)), oracle.pad_conv_relu(x, down.conv.weight.cpu(), down.conv.bias.cpu(), 1, 2, 1).detach())
+
+
+# ---- deferred LayerNorm: one statistics pass + normalise-on-load in every consumer -----------------------------------
+def _ln_setup(c, t, b=2, seed=0):
+    torch.manual_seed(seed)
+    x = torch.randn(b, c, t) * 2.0 + 0.7
+    g, be = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+    xp, _ = pitched(x)
+    stats = torch.full((b, 2, xp.shape[2]), float('nan'), device=DEV)
+    hip.channel_stats(xp, stats, t, 1e-3)
+    normed = torch.empty_like(xp)
+    hip.layernorm_channels(xp, g.to(DEV), be.to(DEV), normed, t, 1e-3)          # materialised reference
+    return x, xp, (stats, g.to(DEV), be.to(DEV)), normed
+
+
+@pytest.mark.parametrize('c,t', [(600, 37), (24, 1000), (1200, 5)])
+def test_channel_stats_vs_fp64(c, t):
+    x, xp, (stats, _, _), _ = _ln_setup(c, t)
+    mean = x.double().mean(dim=1)
+    rstd = 1.0 / torch.sqrt(x.double().var(dim=1, unbiased=False) + 1e-3)
+    close(stats[:, 0, :t], mean, rtol=1e-5, atol=1e-6)
+    close(stats[:, 1, :t], rstd, rtol=1e-5, atol=1e-6)
+    assert torch.all(stats[:, :, t:] == 0)
+
+
+@pytest.mark.parametrize('k,d', [(5, 1), (5, 2), (7, 1), (7, 2)])
+@pytest.mark.parametrize('on_x,on_s0', [(True, False), (False, True), (True, True)])
+def test_grouped_conv_deferred_ln_matches_materialised(k, d, on_x, on_s0):
+    c, groups, t = 40, 4, 133
+    x, xp, ln, normed = _ln_setup(c, t, seed=k + d)
+    w, bias = torch.randn(c, c // groups, k, device=DEV) * 0.3, torch.randn(c, device=DEV) * 0.2
+    other = torch.randn_like(xp)
+    other[:, :, t:] = 0
+    # main input: the LayerNorm-ed tensor (on_x) or an unrelated plain one; skip0: LayerNorm-ed (on_s0) or absent
+    main_raw, main_ref = (xp, normed) if on_x else (other, other)
+    want, got = torch.empty_like(xp), torch.full_like(xp, float('nan'))
+    hip.grouped_conv1d_fused(main_ref, w, bias, [normed, other] if on_s0 else [], want, t, groups, k, d)
+    hip.grouped_conv1d_fused(main_raw, w, bias, [xp, other] if on_s0 else [], got, t, groups, k, d, ln, on_x, on_s0)
+    assert torch.all(got[:, :, t:] == 0)
+    close(got, want.cpu(), rtol=1e-5, atol=2e-6)
+
+
+def test_skip_sum_and_linear_op_deferred_ln():
+    c, t = 24, 70
+    x, xp, ln, normed = _ln_setup(c, t, seed=3)
+    other = torch.randn_like(xp)
+    other[:, :, t:] = 0
+    want, got = torch.empty_like(xp), torch.full_like(xp, float('nan'))
+    hip.skip_sum([normed, other], want, t)
+    hip.skip_sum([xp, other], got, t, ln, True)
+    close(got, want.cpu(), rtol=1e-6, atol=1e-6)
+    w, bias = torch.randn(c, c, 1, device=DEV) * 0.2, torch.randn(c, device=DEV) * 0.1
+    hip.dense_conv1d_fused(normed, t, w, bias, [normed], want, 1)
+    hip.dense_conv1d_fused(xp, t, w, bias, [xp], got, 1, ln, True, True)
+    assert torch.all(got[:, :, t:] == 0)
+    close(got, want.cpu(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_dense_conv_deferred_ln_both_paths(stride):
+    c, cout, t = 40, 72, 150
+    x, xp, ln, normed = _ln_setup(c, t, seed=stride)
+    w, bias = torch.randn(cout, c, 8, device=DEV) * 0.1, torch.randn(cout, device=DEV) * 0.1
+    t_out = (t + stride - 1) // stride
+    want = torch.empty(2, cout, hip.round_up4(t_out), device=DEV)
+    got32, got16 = torch.full_like(want, float('nan')), torch.full_like(want, float('nan'))
+    hip.dense_conv1d_fused(normed, t, w, bias, [], want, stride)
+    hip.dense_conv1d_fused(xp, t, w, bias, [], got32, stride, ln, True, False)
+    hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w), cout, 8, bias, [], got16, stride, ln)
+    close(got32, want.cpu(), rtol=1e-5, atol=2e-6)
+    close(got16, want.cpu(), rtol=1e-5, atol=2e-6)
