@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""BASELINE config 5: latency of every unique architecture (B=32, T=1000), one architecture per GPU at a time.
+
+    python tools/latency_sweep.py --out DIR [--limit N] [--batch 32] [--frames 1000]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/latency_sweep.py --out DIR
+
+Embarrassingly parallel: rank r takes architectures r, r+G, ... of the 8 242 unique ones; no collective on the data path;
+rows are gathered once at the end (all_gather_object) and rank 0 writes DIR/nb-asr-bench-{device}.pickle in the format
+the reference's BenchmarkingDataset / from_folder load.
+"""
+import argparse
+import os
+import pathlib
+import sys
+
+import torch
+
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+from nb_asr_amd import bench_dataset
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', required=True)
+    ap.add_argument('--device-name', default='mi355x-fp32')
+    ap.add_argument('--limit', type=int, default=None)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--frames', type=int, default=1000)
+    ap.add_argument('--iters', type=int, default=5)
+    a = ap.parse_args()
+    world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
+    device = torch.device('cuda', local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+    work = bench_dataset.sweep_work_list(a.limit, rank, world)
+    rows = bench_dataset.latency_sweep(work, device, a.batch, a.frames, iters=a.iters, progress=50 if rank == 0 else None)
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rows)
+        rows = [r for part in gathered for r in part]
+        dist.destroy_process_group()
+    if rank == 0:
+        out = pathlib.Path(a.out)
+        out.mkdir(parents=True, exist_ok=True)
+        path = out / bench_dataset.file_name(a.device_name)
+        bench_dataset.write_benchmarking_dataset(path, a.device_name, sorted(rows), extra_header={
+            'batch_size': a.batch, 'frames': a.frames, 'dtype': 'fp32', 'n_gpus': world})
+        lat = sorted(r[1] for r in rows)
+        print(f'wrote {path}: {len(rows)} architectures, latency min {lat[0] * 1e3:.2f} ms  median {lat[len(lat) // 2] * 1e3:.2f} ms  '
+              f'max {lat[-1] * 1e3:.2f} ms')
+
+
+if __name__ == '__main__':
+    main()
