@@ -10,7 +10,10 @@ Workload (BASELINE.json configs[1]/[2], the configuration the metric is quoted o
 random-init weights from the keyed generator ('lively': He-uniform so activations are O(1) at every depth -- the
 reference's Xavier init makes this no-skip architecture's activations decay to 1e-25).
 A step = one forward over one batch, inputs resident in HBM; with N > 1 every rank forwards its own 64 utterances
-(batch-sharded, weak scaling) and the step ends with one RCCL all-gather of the logits.
+(batch-sharded, weak scaling) and the step ends with one RCCL all-gather of the logits.  `value` is the throughput of K
+back-to-back steps issued through model.forward_async (the latency-bound LSTM tail of step i overlaps the encoder of step
+i+1 on a second HIP stream; every step is a complete forward, all K complete inside the timed region);
+`value_sequential` / `p50_forward_ms` are the same K steps as plain model(x) calls (no overlap).
 
 One JSON line on stdout (rank 0).  Besides the driver's contract fields it carries
   roofline      fused grouped Conv1d kernel (the graded, HBM-bound kernel of SURVEY.md 8(d)): algorithmic bytes of
@@ -52,6 +55,7 @@ def main():
     ap.add_argument('--frames', type=int, default=FRAMES)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--no-pipeline', action='store_true', help='time plain back-to-back model(x) calls only')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -81,18 +85,44 @@ def main():
         with torch.no_grad():
             return runner.forward(model, x)                                   # forward + all-gather of logits (N > 1)
 
+    def timed(run_steps):
+        runner.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = run_steps()
+        torch.cuda.synchronize()
+        runner.barrier()
+        return runner.max_over_ranks(time.perf_counter() - t0), out
+
+    def sequential():
+        out = None
+        for _ in range(args.steps):
+            out = step()
+        return out
+
+    def pipelined():
+        # back-to-back batches: the LSTM + head of step i run on a side stream while the main stream already runs the
+        # encoder of step i+1 (model.forward_async); every step is a complete forward and all K finish before the
+        # closing synchronize
+        with torch.no_grad():
+            handles = [model.forward_async(x) for _ in range(args.steps)]
+            out = None
+            for h in handles:
+                out = runner.gather_logits(h.result())
+        return out
+
     for _ in range(args.warmup):
         out = step()
-    runner.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    runner.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = runner.max_over_ranks(elapsed)
+    with torch.no_grad():
+        for _ in range(2):
+            model.forward_async(x).result()
+    elapsed_seq, out = timed(sequential)
     assert out.shape == (args.batch * world, (((args.frames + 1) // 2) + 1) // 2, 49) and bool(torch.isfinite(out).all())
+    if args.no_pipeline:
+        elapsed = elapsed_seq
+    else:
+        elapsed, out2 = timed(pipelined)
+        assert torch.equal(out2, out)
 
     # p50 forward latency: each forward bracketed by HIP events on the launch stream
     lat = []
@@ -114,6 +144,8 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps,
         'p50_forward_ms': p50,
+        'value_sequential': args.batch * world * args.steps / elapsed_seq,
+        'ms_per_step_sequential': 1e3 * elapsed_seq / args.steps,
         'higher_is_better': True,
         'scaling': 'weak',
         'vs_baseline': None,
@@ -121,7 +153,8 @@ def main():
         'data': 'synthetic N(0,1) filterbanks (B,80,T) from a keyed generator; random-init He-uniform weights (keyed)',
         'config': {'workload': 'BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True fp32, HIP conv + HIP LSTM',
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames, 'features': FEATURES,
-                   'parallelism': f'batch-sharded x{world}, one RCCL all-gather of logits' if world > 1 else 'single GPU'},
+                   'parallelism': f'batch-sharded x{world}, one RCCL all-gather of logits' if world > 1 else 'single GPU',
+                   'pipelined': not args.no_pipeline},
     }
 
     if rank == 0 and not args.no_roofline:

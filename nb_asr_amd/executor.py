@@ -46,6 +46,22 @@ def node_into(node, inputs, frames, out, ln0=None):
     return out
 
 
+class PendingLogits:
+    """Logits produced on the plan's side stream (pipelined forward).  ``result()`` makes the caller's current stream
+    wait for them -- until then the next batch's encoder may already be running on the main stream."""
+
+    def __init__(self, logits, event):
+        self._logits, self._event = logits, event
+
+    def result(self):
+        if self._event is not None:
+            cur = torch.cuda.current_stream(self._logits.device)
+            cur.wait_event(self._event)
+            self._logits.record_stream(cur)
+            self._event = None
+        return self._logits
+
+
 class ForwardPlan:
     """Workspace + launch sequence of one model for one (batch, frames, device)."""
 
@@ -78,6 +94,12 @@ class ForwardPlan:
             self.gates_ws = torch.empty(batch * self.out_frames * 4 * LSTM_HIDDEN, device=device, dtype=torch.float32)
             self.cell_ws = torch.empty(batch * LSTM_HIDDEN, device=device, dtype=torch.float32)
             self.h_out = torch.empty(batch, self.out_frames, LSTM_HIDDEN, device=device, dtype=torch.float32)
+        # pipelined mode (forward_async): the latency-bound LSTM + head of batch i run on a side stream while the main
+        # stream already runs the encoder of batch i+1; the encoder output is double-buffered for that
+        self.side_stream = None
+        self.enc_out = None
+        self.tail_done = [None, None]
+        self._turn = 0
 
     def _timed(self, kind, meta, launch):
         """Run ``launch()``; when ``self.timer`` is a list, bracket it with HIP events on the current stream
@@ -118,11 +140,13 @@ class ForwardPlan:
         from .ops import Linear
         return isinstance(nxt, SearchCell) and not isinstance(nxt.nodes[0].op, Linear)
 
-    def _norm(self, norm, act, act_frames, kind_meta, taps, tap_idx, nxt):
-        """LayerNorm of ``act``: returns the pending descriptor (deferred) or None after normalising in place."""
-        if self.ln_mode == 'materialize' or not self._cheap_consumer(nxt):
+    def _norm(self, norm, act, act_frames, kind_meta, taps, tap_idx, nxt, out=None):
+        """LayerNorm of ``act``: returns the pending descriptor (deferred) or None after normalising in place (or into
+        ``out``)."""
+        if self.ln_mode == 'materialize' or not self._cheap_consumer(nxt) or out is not None:
+            dst = act if out is None else out
             self._timed('layernorm', kind_meta, lambda: hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(),
-                                                                               act, act_frames, norm.eps))
+                                                                               dst, act_frames, norm.eps))
             return None
         self._stat_turn ^= 1
         b, _, ld = act.shape
@@ -138,9 +162,21 @@ class ForwardPlan:
         ld = hip.round_up4(frames)
         return self.pool[idx][: self.batch * channels * ld].view(self.batch, channels, ld)
 
-    def run(self, x, taps=None):
+    def _pipeline_buffers(self, channels, frames):
+        if self.side_stream is None:
+            self.side_stream = torch.cuda.Stream(device=self.device)
+            ld = hip.round_up4(frames)
+            self.enc_out = [torch.empty(self.batch, channels, ld, device=self.device, dtype=torch.float32) for _ in range(2)]
+        self._turn ^= 1
+        k = self._turn
+        if self.tail_done[k] is not None:            # the LSTM that read this buffer two forwards ago
+            torch.cuda.current_stream(self.device).wait_event(self.tail_done[k])
+        return k, self.enc_out[k]
+
+    def run(self, x, taps=None, pipelined=False):
         """Enqueue one forward.  ``taps`` (a dict) receives a copy of every layer's output, keyed by the
-        layer's index in ``model.model``, in the oracle's layouts ((B,C,T) for encoder layers and the LSTM)."""
+        layer's index in ``model.model``, in the oracle's layouts ((B,C,T) for encoder layers and the LSTM).
+        ``pipelined``: LSTM + head go to the side stream and a ``PendingLogits`` is returned."""
         from .model import SearchCell
         from .ops import PadConvRelu
         import torch.nn as nn
@@ -153,6 +189,8 @@ class ForwardPlan:
         x = x.detach().contiguous()
         act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
         pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
+        pipe = bool(pipelined) and model.use_rnn and taps is None
+        pipe_k, tail_ctx = None, None
         self._stat_turn = 0
         blk = -1
         logits = None
@@ -189,15 +227,30 @@ class ForwardPlan:
                     ln0 = pending
                     outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0)))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
+                nxt = model.model[idx + 1] if idx + 1 < n_layers else None
+                feeds_tail = pipe and isinstance(nxt, (nn.Dropout, nn.LSTM))
+                if feeds_tail:
+                    pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)
                 if layer.use_norm:
                     pending = self._norm(layer.norm_layer, act, act_frames, (blk, layer.filters, layer.filters, 0, act_frames, 0),
-                                         taps, idx, model.model[idx + 1] if idx + 1 < n_layers else None)
+                                         taps, idx, nxt, enc if feeds_tail else None)
+                    if feeds_tail:
+                        act, cur = enc, None
+                elif feeds_tail:
+                    hip.repitch(act, enc, act_frames)
+                    act, cur = enc, None
                 if taps is not None and pending is None:
                     taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.Dropout):
                 if taps is not None:                      # identity: eval mode or p == 0 (checked by the model)
                     taps[idx] = taps[idx - 1]
             elif isinstance(layer, nn.LSTM):
+                if pipe:                                   # everything from here on runs on the side stream
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream(self.device))
+                    self.side_stream.wait_event(ready)
+                    tail_ctx = torch.cuda.stream(self.side_stream)
+                    tail_ctx.__enter__()
                 ln, src, src_frames = pending, act, act_frames
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
                             lambda: hip.lstm_forward(src, src_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
@@ -215,8 +268,15 @@ class ForwardPlan:
                 act, pending = logits, None
             else:
                 raise TypeError(f'unsupported layer {type(layer).__name__} in the model list')
+        if tail_ctx is not None:
+            done = torch.cuda.Event()
+            done.record(self.side_stream)
+            tail_ctx.__exit__(None, None, None)
+            self.tail_done[pipe_k] = done
         if idx != n_layers - 1 or logits is None:
             raise RuntimeError('the model list does not end in the CTC head')
+        if pipelined:
+            return PendingLogits(logits, self.tail_done[pipe_k] if tail_ctx is not None else None)
         if taps is not None:
             taps[len(model.model) - 1] = logits.clone()
         return logits

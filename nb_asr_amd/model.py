@@ -123,7 +123,13 @@ class ASRModel(nn.Module):
         taps = {}
         return self.forward(input, _taps=taps), taps
 
-    def forward(self, input, _taps=None):
+    def forward_async(self, input):
+        """Pipelined forward for back-to-back batches: the encoder runs on the current stream, the latency-bound
+        LSTM + head on the plan's side stream, so the NEXT call's encoder overlaps with this call's LSTM.  Returns a
+        handle; ``handle.result()`` makes the current stream wait for the logits and returns them."""
+        return self.forward(input, _pipelined=True)
+
+    def forward(self, input, _taps=None, _pipelined=False):
         """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1)."""
         _check_dropout(self)
         if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES:
@@ -136,7 +142,7 @@ class ASRModel(nn.Module):
             if len(self._plans) >= 4:          # bounded cache: workspaces are hundreds of MB
                 self._plans.clear()
             plan = self._plans[key] = ForwardPlan(self, input.shape[0], input.shape[2], input.device)
-        return plan.run(input, _taps)
+        return plan.run(input, _taps, _pipelined)
 
     def __getstate__(self):
         state = self.__dict__.copy()

@@ -138,3 +138,22 @@ class TestFullSize:
             y2 = m(x2.to(DEV))
         assert torch.equal(y2[:, :73], y[:2, :73])
         assert not torch.equal(y2[:, 200:], y[:2, 200:])
+
+
+def test_pipelined_forward_matches_and_overlaps_safely():
+    """forward_async (LSTM + head on a side stream, double-buffered encoder output) gives bit-identical logits for
+    a stream of different batches, in order, including when handles are resolved late."""
+    m = build(cases.ARCH_D, True, 'lively')
+    xs = [keyed_input(3, 120, seed=s).to(DEV) for s in range(5)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+        handles = [m.forward_async(x) for x in xs]          # five forwards in flight, nothing resolved yet
+        got = [h.result() for h in handles]
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+        again = m(xs[2])                                     # the synchronous path still works after pipelined use
+        assert torch.equal(again, want[2])
+        norn = build(cases.ARCH_M, False, 'lively')
+        x = keyed_input(2, 40, seed=1).to(DEV)
+        assert torch.equal(norn.forward_async(x).result(), norn(x))
