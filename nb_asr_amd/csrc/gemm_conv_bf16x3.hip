@@ -12,10 +12,10 @@
 // must sit in one lane's registers, k runs over 16 input CHANNELS for a fixed tap:
 //     D[co][t] += sum_{ci<16} W[co][g*16+ci][tap] * x[g*16+ci][t*stride + tap - lpad]      for every (group g, tap)
 //  * weights are split and re-laid-out ONCE (nbasr_pack_dense_weights) into the exact LDS image of each
-//    (row tile, channel group, tap quad): [split][tap][128 rows][16 ci] bf16 = 48 KiB, so a K-step's weights are a
+//    (row tile, channel group, tap quad): [split][tap][ci half][128 rows][8 ci] bf16 = 48 KiB, so a K-step's weights are a
 //    straight 48 KiB copy done by LDS-DMA (global_load_lds_dwordx4, no VGPRs), double-buffered;
-//  * the input tile of a channel group is converted/split on the fly and stored TRANSPOSED [frame][16 ci] so a
-//    B fragment (8 consecutive channels of one frame) is one aligned ds_read_b128; it is staged once per group and
+//  * the input tile of a channel group is converted/split on the fly and stored TRANSPOSED [ci half][frame][8 ci] so a
+//    B fragment (8 consecutive channels of one frame) is one aligned, bank-conflict-free ds_read_b128; it is staged once per group and
 //    reused by all 8 taps (sliding window resolved by the row index; stride-2 rows are de-interleaved by parity so
 //    the 32 lanes of a fragment read hit consecutive rows);
 //  * one 512-thread workgroup per CU: 128 x 256 tile / 8 waves (2 x 4, 64 x 64 each), K-step = 16 channels x 4 taps =
@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned pack2(__bf16 a, __bf16 b) {
 }
 
 // ---- one-time weight split + re-layout -------------------------------------------------------------------------
-// packed element (mt, g, q, split, tp, co_l, ci_l) <- W[mt*128 + co_l][g*16 + ci_l][q*2 + tp]   (zero outside)
+// packed element (mt, g, q, split, tp, half = ci_l/8, co_l, ci_l%8) <- W[mt*128 + co_l][g*16 + ci_l][q*PB_TP + tp]  (zero outside)
 __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
                                                                  int c_out, int c_in, int n_mt, int n_groups)
 {
@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
         const size_t step = (static_cast<size_t>(mt) * n_groups + g) * PB_QSTEPS + q;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            wp[(((step * 3 + k) * PB_TP + tp) * PB_M + co_l) * PB_CI + ci_l] = s[k];
+            wp[((((step * 3 + k) * PB_TP + tp) * 2 + (ci_l >> 3)) * PB_M + co_l) * 8 + (ci_l & 7)] = s[k];
     }
 }
 
 // ---- the GEMM -----------------------------------------------------------------------------------------------------
-template <int S>
+template <int S, bool LNX>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const PackedConvArgs a)
 {
     using G = GeoP<S>;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
 
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * S - a.lpad;
-    const float* __restrict__ xstats = a.ln_x.stats ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
+    const float* __restrict__ xstats = LNX ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
     const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_QSTEPS * PB_A_STEP_BYTES;
 
     bool mval[2], nval[2];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             const bool ok = e < G::XITEMS && t >= 0 && t < a.frames_in;
             float v0 = (ok && ci < a.c_in) ? xb[static_cast<size_t>(ci) * a.ld_in + t] : 0.f;
             float v1 = (ok && ci + 1 < a.c_in) ? xb[static_cast<size_t>(ci + 1) * a.ld_in + t] : 0.f;
-            if (a.ln_x.stats && ok) {
+            if (LNX && ok) {
                 const float mean = xstats[t], rstd = xstats[a.ld_in + t];
                 if (ci < a.c_in) v0 = ln_apply(v0, mean, rstd, a.ln_x.gamma[ci], a.ln_x.beta[ci]);
                 if (ci + 1 < a.c_in) v1 = ln_apply(v1, mean, rstd, a.ln_x.gamma[ci + 1], a.ln_x.beta[ci + 1]);
@@ -186,22 +186,26 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
                 __bf16 s0[3], s1[3];
                 split3(xreg[i][0], s0[0], s0[1], s0[2]);
                 split3(xreg[i][1], s1[0], s1[1], s1[2]);
-                unsigned* dst = reinterpret_cast<unsigned*>(Xbuf) + G::rowmap(row) * (PB_CI / 2) + p;
+                // image [split][half][row][8 ci]: channel pair p sits in half p >> 2, dword p & 3 of the 16-byte row
+                unsigned* dst = reinterpret_cast<unsigned*>(Xbuf) + ((p >> 2) * G::ROWS + G::rowmap(row)) * 4 + (p & 3);
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dst[k * G::ROWS * (PB_CI / 2)] = pack2(s0[k], s1[k]);
+                for (int k = 0; k < 3; ++k) dst[k * 2 * G::ROWS * 4] = pack2(s0[k], s1[k]);
             }
         }
     };
 
     // per-lane fragment bases (bytes)
-    const int a_lane = (wm * 64 + l31) * (PB_CI * 2) + half * 16;
-    const int x_lane = half * 16;
+    // both LDS images are HALF-major ([half][row][8 channels], 16-byte rows): the 16 lanes of a ds_read_b128 group then
+    // cover 256 contiguous bytes = all 64 banks (a 32-byte row pitch makes every group hit only the even 16-byte slots)
+    const int a_lane = (half * PB_M + wm * 64 + l31) * 16;
+    const int x_lane = half * G::ROWS * 16;
 
     auto mma_step = [&](auto qc, int buf) {
         constexpr int q = decltype(qc)::value;
         const unsigned char* A = Abuf + buf * PB_A_STEP_BYTES + a_lane;
-        // NOT unrolled: hoisting the fragment reads of all four taps above the first MFMA costs 192 VGPRs (spills);
-        // per tap 12 x ds_read_b128 are issued, then 24 MFMAs start as their operands arrive (counted lgkmcnt)
+        // NOT unrolled: hoisting the fragment reads of all four taps above the first MFMA costs 192 VGPRs (spills), and
+        // double-buffering the fragments by hand (+48 VGPRs) spills too and measured slower; per tap 12 x ds_read_b128
+        // are issued, then 24 MFMAs start as their operands arrive (counted lgkmcnt); the SIMD's other wave covers
 #pragma unroll 1
         for (int tp = 0; tp < PB_TP; ++tp) {
             const int tap = q * PB_TP + tp;
@@ -210,28 +214,27 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    af[i][k] = *reinterpret_cast<const bf16x8*>(A + ((k * PB_TP + tp) * PB_M + i * 32) * (PB_CI * 2));
+                    af[i][k] = *reinterpret_cast<const bf16x8*>(A + ((k * PB_TP + tp) * 2 * PB_M + i * 32) * 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = G::rowmap((wn * 64 + j * 32 + l31) * S + tap);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    bfr[j][k] = *reinterpret_cast<const bf16x8*>(Xbuf + (k * G::ROWS + row) * (PB_CI * 2) + x_lane);
+                    bfr[j][k] = *reinterpret_cast<const bf16x8*>(Xbuf + (k * 2 * G::ROWS + row) * 16 + x_lane);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    {
-                        floatx16 c = small[i][j];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], c, 0, 0, 0);   // lo * hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], c, 0, 0, 0);   // hi * lo
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], c, 0, 0, 0);   // mid * mid
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], c, 0, 0, 0);   // mid * hi
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], c, 0, 0, 0);   // hi * mid
-                        small[i][j] = c;
-                        big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], big[i][j], 0, 0, 0);   // hi * hi
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    floatx16 c = small[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], c, 0, 0, 0);   // lo * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], c, 0, 0, 0);   // hi * lo
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], c, 0, 0, 0);   // mid * mid
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], c, 0, 0, 0);   // mid * hi
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], c, 0, 0, 0);   // hi * mid
+                    small[i][j] = c;
+                    big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], big[i][j], 0, 0, 0);   // hi * hi
+                }
         }
     };
 
@@ -291,8 +294,11 @@ template <int S>
 static int launch_packed(PackedConvArgs a, hipStream_t stream)
 {
     using G = GeoP<S>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_bf16x3_kernel<S>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_bf16x3_kernel<S, false>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_bf16x3_kernel<S, true>),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    const hipError_t attr = attr0 != hipSuccess ? attr0 : attr1;
     if (attr != hipSuccess) {
         set_error("nbasr_dense_conv1d_fused_packed: cannot reserve %d bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(attr));
         return static_cast<int>(attr);
@@ -301,7 +307,10 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: too many tiles (%lld)", nwg);
-    hipLaunchKernelGGL((gemm_conv_bf16x3_kernel<S>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+    if (a.ln_x.stats)
+        hipLaunchKernelGGL((gemm_conv_bf16x3_kernel<S, true>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+    else
+        hipLaunchKernelGGL((gemm_conv_bf16x3_kernel<S, false>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
     return launch_status("nbasr_dense_conv1d_fused_packed");
 }
 
