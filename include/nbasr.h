@@ -87,10 +87,12 @@ int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
 /* fp32-accurate variant of the k=8 dense PadConvRelu on the bf16 matrix cores (16x the fp32 MFMA rate): operands are
  * split exactly into three bf16 terms and six cross products are accumulated in fp32 (dropped terms <= 2^-24 of a
  * product).  Weights are split and re-laid-out once per weight version:
- *   bytes = nbasr_packed_dense_weights_bytes(c_out, c_in, 8);  nbasr_pack_dense_weights(w, packed, ...);
- * then nbasr_dense_conv1d_fused_packed(...) takes `packed` in place of w (same arguments otherwise, kernel == 8). */
+ *   bytes = nbasr_packed_dense_weights_bytes(c_out, c_in, 8);  nbasr_pack_dense_weights(w, packed, ..., stride, ...);
+ * then nbasr_dense_conv1d_fused_packed(...) takes `packed` in place of w (same arguments otherwise, kernel == 8).
+ * The packed image depends on the stride of the convolution that will consume it (taps per K-step differ). */
 size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel);
-int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, nbasr_stream_t stream);
+int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
+                             nbasr_stream_t stream);
 int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias,
                                     const float* skip0, const float* skip1, const float* skip2,
                                     float* y, int batch, int c_in, int frames_in, int ld_in,

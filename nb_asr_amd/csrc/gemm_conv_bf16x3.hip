@@ -30,20 +30,25 @@ namespace nbasr {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8, PB_TP = 4;   // tile, channels per group, taps per step
+constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // tile, channels per group, conv taps
 constexpr int PB_THREADS = 512;                                              // 8 waves: 2 (rows) x 4 (frames), 64 x 64 each
-constexpr int PB_QSTEPS = PB_TAPS / PB_TP;                                   // K-steps per channel group
-constexpr int PB_A_STEP_BYTES = 3 * PB_TP * PB_M * PB_CI * 2;                // 49152: one step's weight image
+constexpr int PB_GROUP_BYTES = 3 * PB_TAPS * PB_M * PB_CI * 2;               // 98304: packed weights of one (row tile, channel group)
+constexpr int PB_STAGE_THREADS = 256;                                        // waves 0-3 stage the input tile (they have slack)
+__host__ __device__ constexpr int pb_taps_per_step(int stride) { return stride == 1 ? 4 : 2; }   // LDS budget: 160 KiB
 
 template <int S>
 struct GeoP {
+    static constexpr int TP = pb_taps_per_step(S);               // taps per K-step
+    static constexpr int QSTEPS = PB_TAPS / TP;                  // K-steps per channel group
+    static constexpr int A_STEP_BYTES = 3 * TP * PB_M * PB_CI * 2;
     static constexpr int XR = (PB_N - 1) * S + PB_TAPS;          // input frames needed per channel
     static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
     static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
     static constexpr int X_BYTES = 3 * ROWS * PB_CI * 2;
     static constexpr int XITEMS = XR * (PB_CI / 2);              // (frame, channel pair) items per group
-    static constexpr int XI = (XITEMS + PB_THREADS - 1) / PB_THREADS;
-    static constexpr int LDS_BYTES = 2 * PB_A_STEP_BYTES + X_BYTES;
+    static constexpr int NCHUNK = QSTEPS - 1;                    // the next group's tile is staged in QSTEPS-1 chunks
+    static constexpr int XI = (XITEMS + PB_STAGE_THREADS * NCHUNK - 1) / (PB_STAGE_THREADS * NCHUNK);   // items per stager thread per chunk
+    static constexpr int LDS_BYTES = 2 * A_STEP_BYTES + 2 * X_BYTES;   // weights and input tile both double-buffered
     __device__ static constexpr int rowmap(int row) { return (S == 1) ? row : (row & 1) * XRH + (row >> 1); }
 };
 
@@ -70,10 +75,12 @@ __device__ __forceinline__ unsigned pack2(__bf16 a, __bf16 b) {
 }
 
 // ---- one-time weight split + re-layout -------------------------------------------------------------------------
-// packed element (mt, g, q, split, tp, half = ci_l/8, co_l, ci_l%8) <- W[mt*128 + co_l][g*16 + ci_l][q*PB_TP + tp]  (zero outside)
+// packed element (mt, g, q, split, tp, half = ci_l/8, co_l, ci_l%8) <- W[mt*128 + co_l][g*16 + ci_l][q*TP + tp]  (zero outside);
+// TP = taps per K-step of the kernel that will consume the image (4 for stride 1, 2 for stride 2)
 __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
-                                                                 int c_out, int c_in, int n_mt, int n_groups)
+                                                                 int c_out, int c_in, int n_mt, int n_groups, int PB_TP)
 {
+    const int PB_QSTEPS = PB_TAPS / PB_TP;
     const long long total = static_cast<long long>(n_mt) * n_groups * PB_QSTEPS * PB_TP * PB_M * PB_CI;
     for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
          i += static_cast<long long>(gridDim.x) * blockDim.x) {
@@ -100,9 +107,10 @@ template <int S, bool LNX>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const PackedConvArgs a)
 {
     using G = GeoP<S>;
+    constexpr int TP = G::TP, QS = G::QSTEPS, ASTEP = G::A_STEP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const Abuf = smem;                               // [2][PB_A_STEP_BYTES]
-    unsigned char* const Xbuf = smem + 2 * PB_A_STEP_BYTES;         // [3 splits][ROWS][16 ci] bf16
+    unsigned char* const Abuf = smem;                       // [2][ASTEP]    weights of the current / next K-step
+    unsigned char* const Xbase = smem + 2 * ASTEP;          // [2][X_BYTES]  input tile of the current / next channel group
 
     // XCD-aware, m-major tile order (as gemm_conv.hip)
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -120,11 +128,15 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
+    // Waves 0-3 and 4-7 share the four SIMDs pairwise.  Measured with s_memtime stamps: the pair's older wave wins the
+    // matrix pipe, finishes its MFMAs early and then idles at the barrier while the younger one is the critical path.
+    // So the older half (waves 0-3) does ALL input staging (global loads, 3-way split, LDS writes) in its slack.
+    const bool stager = wave < PB_STAGE_THREADS / 64;
 
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * S - a.lpad;
     const float* __restrict__ xstats = LNX ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
-    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_QSTEPS * PB_A_STEP_BYTES;
+    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_GROUP_BYTES;
 
     bool mval[2], nval[2];
 #pragma unroll
@@ -145,23 +157,24 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             for (int r = 0; r < 16; ++r) { big[i][j][r] = 0.f; small[i][j][r] = 0.f; }
 
     // ---- staging helpers ---------------------------------------------------------------------------------------
-    // weights of K-step `step` (global index within this row tile) -> Abuf[buf] by LDS-DMA: 24 x 1 KiB wave copies
+    // weights of K-step `step` (index within this row tile) -> Abuf[buf] by LDS-DMA, ASTEP/1 KiB wave copies
     auto dma_weights = [&](int step, int buf) {
-        const unsigned char* src = wtile + static_cast<size_t>(step) * PB_A_STEP_BYTES;
+        const unsigned char* src = wtile + static_cast<size_t>(step) * ASTEP;
 #pragma unroll
-        for (int j = 0; j < PB_A_STEP_BYTES / 1024 / 8; ++j) {
-            const int chunk = wave * (PB_A_STEP_BYTES / 1024 / 8) + j;
+        for (int j = 0; j < ASTEP / 1024 / 8; ++j) {
+            const int chunk = wave * (ASTEP / 1024 / 8) + j;
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(src + chunk * 1024 + lane * 16),
-                (__attribute__((address_space(3))) void*)(Abuf + buf * PB_A_STEP_BYTES + chunk * 1024),
+                (__attribute__((address_space(3))) void*)(Abuf + buf * ASTEP + chunk * 1024),
                 16, 0, 0);
         }
     };
     float xreg[G::XI][2];
-    auto load_x = [&](int g) {
+    // stager waves only (tid < PB_STAGE_THREADS); chunk c of a group's tile = items [c*XI*256, (c+1)*XI*256)
+    auto load_x = [&](int g, int c) {
 #pragma unroll
         for (int i = 0; i < G::XI; ++i) {
-            const int e = tid + PB_THREADS * i;
+            const int e = tid + PB_STAGE_THREADS * (c * G::XI + i);
             const int p = e & 7, row = e >> 3;
             const int t = tin0 + row;
             const int ci = g * PB_CI + 2 * p;
@@ -177,17 +190,18 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             xreg[i][1] = v1;
         }
     };
-    auto commit_x = [&]() {
+    auto commit_x = [&](int xbuf, int c) {
+        unsigned* const X = reinterpret_cast<unsigned*>(Xbase + xbuf * G::X_BYTES);
 #pragma unroll
         for (int i = 0; i < G::XI; ++i) {
-            const int e = tid + PB_THREADS * i;
+            const int e = tid + PB_STAGE_THREADS * (c * G::XI + i);
             const int p = e & 7, row = e >> 3;
             if (e < G::XITEMS) {
                 __bf16 s0[3], s1[3];
                 split3(xreg[i][0], s0[0], s0[1], s0[2]);
                 split3(xreg[i][1], s1[0], s1[1], s1[2]);
                 // image [split][half][row][8 ci]: channel pair p sits in half p >> 2, dword p & 3 of the 16-byte row
-                unsigned* dst = reinterpret_cast<unsigned*>(Xbuf) + ((p >> 2) * G::ROWS + G::rowmap(row)) * 4 + (p & 3);
+                unsigned* dst = X + ((p >> 2) * G::ROWS + G::rowmap(row)) * 4 + (p & 3);
 #pragma unroll
                 for (int k = 0; k < 3; ++k) dst[k * 2 * G::ROWS * 4] = pack2(s0[k], s1[k]);
             }
@@ -200,27 +214,27 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     const int a_lane = (half * PB_M + wm * 64 + l31) * 16;
     const int x_lane = half * G::ROWS * 16;
 
-    auto mma_step = [&](auto qc, int buf) {
-        constexpr int q = decltype(qc)::value;
-        const unsigned char* A = Abuf + buf * PB_A_STEP_BYTES + a_lane;
-        // NOT unrolled: hoisting the fragment reads of all four taps above the first MFMA costs 192 VGPRs (spills), and
+    auto mma_step = [&](int q, int abuf, int xbuf) {
+        const unsigned char* A = Abuf + abuf * ASTEP + a_lane;
+        const unsigned char* X = Xbase + xbuf * G::X_BYTES + x_lane;
+        // NOT unrolled: hoisting the fragment reads of all taps above the first MFMA costs 192 VGPRs (spills), and
         // double-buffering the fragments by hand (+48 VGPRs) spills too and measured slower; per tap 12 x ds_read_b128
         // are issued, then 24 MFMAs start as their operands arrive (counted lgkmcnt); the SIMD's other wave covers
 #pragma unroll 1
-        for (int tp = 0; tp < PB_TP; ++tp) {
-            const int tap = q * PB_TP + tp;
+        for (int tp = 0; tp < TP; ++tp) {
+            const int tap = q * TP + tp;
             bf16x8 af[2][3], bfr[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    af[i][k] = *reinterpret_cast<const bf16x8*>(A + ((k * PB_TP + tp) * 2 * PB_M + i * 32) * 16);
+                    af[i][k] = *reinterpret_cast<const bf16x8*>(A + ((k * TP + tp) * 2 * PB_M + i * 32) * 16);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int row = G::rowmap((wn * 64 + j * 32 + l31) * S + tap);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
-                    bfr[j][k] = *reinterpret_cast<const bf16x8*>(Xbuf + (k * 2 * G::ROWS + row) * 16 + x_lane);
+                    bfr[j][k] = *reinterpret_cast<const bf16x8*>(X + (k * 2 * G::ROWS + row) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -238,31 +252,35 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
         }
     };
 
-    // ---- main loop: groups of 16 channels x 4 K-steps of 2 taps ----------------------------------------------
+    // ---- main loop: groups of 16 channels, QS K-steps of TP taps each; ONE barrier per K-step ------------------
+    //   step (g, q):  [q >= 1: stagers split chunk q-1 of group g+1 and write it to X[(g+1) & 1] -- nobody reads that buffer]
+    //                 [q < QS-1: stagers issue the global loads of chunk q of group g+1]   DMA of the next step's weights
+    //                 MFMAs on Abuf[step & 1], X[g & 1]
+    //                 wait for the DMA (and the chunk loads), barrier
     const int ng = a.n_groups;
-    load_x(0);
     dma_weights(0, 0);
-    commit_x();
+    if (stager) {
+#pragma unroll 1
+        for (int c = 0; c < G::NCHUNK; ++c) { load_x(0, c); commit_x(0, c); }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    int step = 0;
     for (int g = 0; g < ng; ++g) {
         const bool more = g + 1 < ng;
-        auto step = [&](auto qc) {
-            constexpr int q = decltype(qc)::value;
-            if (q == 0 && more) load_x(g + 1);                                    // registers, consumed after q = last
-            if (q + 1 < PB_QSTEPS || more) dma_weights(g * PB_QSTEPS + q + 1, (q + 1) & 1);
-            if (wave_active) mma_step(qc, q & 1);     // single code path: two variants double the accumulator live ranges
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's weight DMA (and any x prefetch) has landed
-            __syncthreads();               // ... in every wave, and all fragment reads of this step are done
-            if (q == PB_QSTEPS - 1 && more) {
-                commit_x();
-                __syncthreads();
-            }
-        };
-        static_assert(PB_QSTEPS == 2, "the group loop is written for two K-steps per channel group");
-        step(std::integral_constant<int, 0>{});
-        step(std::integral_constant<int, 1>{});
+#pragma unroll 1
+        for (int q = 0; q < QS; ++q, ++step) {
+            const bool stage = more && stager;
+            // stagers first retire the chunk they loaded during the previous step (their partner waves on the same SIMDs
+            // start their MFMAs meanwhile), then issue the next chunk's loads so they fly under this step's MFMAs
+            if (stage && q >= 1) commit_x((g + 1) & 1, q - 1);
+            if (stage && q < QS - 1) load_x(g + 1, q);
+            if (q + 1 < QS || more) dma_weights(step + 1, (step + 1) & 1);
+            if (wave_active) mma_step(q, step & 1, g & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's weight DMA has landed (this wave's part)
+            __syncthreads();               // ... every wave's part, the new input tile is written, this step's reads are done
+        }
     }
 
     // ---- epilogue: bias + ReLU + min(20) (+ skips), rows of 32 frames per store ------------------------------
@@ -322,19 +340,21 @@ extern "C" size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kern
 {
     if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS) return 0;
     const size_t n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
-    return n_mt * n_groups * PB_QSTEPS * PB_A_STEP_BYTES;
+    return n_mt * n_groups * PB_GROUP_BYTES;
 }
 
-extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, nbasr_stream_t stream)
+extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
+                                        nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
-    NBASR_REQUIRE(kernel == PB_TAPS, NBASR_EINVAL, "nbasr_pack_dense_weights: kernel=%d unsupported (the downsample convs have k=8)", kernel);
+    NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
+                  "nbasr_pack_dense_weights: (kernel=%d, stride=%d) unsupported (the downsample convs have k=8, s in {1,2})", kernel, stride);
     NBASR_REQUIRE(w && packed, NBASR_ENULL, "nbasr_pack_dense_weights: NULL pointer");
     NBASR_REQUIRE(aligned16(packed), NBASR_EALIGN, "nbasr_pack_dense_weights: packed buffer must be 16-byte aligned");
     const int n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
     hipLaunchKernelGGL(pack_dense_weights_kernel, dim3(2048), dim3(256), 0, as_stream(stream), w,
-                       static_cast<__bf16*>(packed), c_out, c_in, n_mt, n_groups);
+                       static_cast<__bf16*>(packed), c_out, c_in, n_mt, n_groups, pb_taps_per_step(stride));
     return launch_status("nbasr_pack_dense_weights");
 }
 

@@ -119,7 +119,7 @@ class ForwardPlan:
         key = (w.data_ptr(), w._version)
         hit = self._packed.get(id(layer))
         if hit is None or hit[0] != key:
-            hit = (key, hip.pack_dense_weights(w.detach()))
+            hit = (key, hip.pack_dense_weights(w.detach(), layer.strides))
             self._packed[id(layer)] = hit
         return hit[1]
 

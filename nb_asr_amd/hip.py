@@ -37,7 +37,7 @@ SIGNATURES = {
     'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
     'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 3),
-    'nbasr_pack_dense_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_pack_dense_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
@@ -188,8 +188,9 @@ def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln
     return y
 
 
-def pack_dense_weights(weight):
-    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its 3 x bf16 split in the kernel's LDS layout."""
+def pack_dense_weights(weight, stride):
+    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its 3 x bf16 split in the LDS layout of the
+    stride-`stride` kernel that will consume it."""
     c_out, c_in, kernel = weight.shape
     nbytes = load_library().nbasr_packed_dense_weights_bytes(c_out, c_in, kernel)
     if nbytes == 0:
@@ -197,7 +198,7 @@ def pack_dense_weights(weight):
     if not weight.is_cuda:
         raise HipError('weight must be on a HIP device')
     packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _check(load_library().nbasr_pack_dense_weights(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel,
+    _check(load_library().nbasr_pack_dense_weights(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride,
                                                    _stream(weight)), 'nbasr_pack_dense_weights')
     return packed
 

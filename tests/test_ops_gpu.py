@@ -118,7 +118,7 @@ def dense_packed(x, w, bias, stride):
     b, cin, t = x.shape
     t_out = (t + stride - 1) // stride
     y = torch.full((b, w.shape[0], hip.round_up4(t_out)), float('nan'), device=DEV)
-    packed = hip.pack_dense_weights(w.to(DEV))
+    packed = hip.pack_dense_weights(w.to(DEV), stride)
     hip.dense_conv1d_fused_packed(x.to(DEV).contiguous(), t, packed, w.shape[0], 8, bias.to(DEV), (), y, stride)
     assert torch.all(y[:, :, t_out:] == 0)
     return y[:, :, :t_out]
@@ -352,6 +352,6 @@ def test_dense_conv_deferred_ln_both_paths(stride):
     got32, got16 = torch.full_like(want, float('nan')), torch.full_like(want, float('nan'))
     hip.dense_conv1d_fused(normed, t, w, bias, [], want, stride)
     hip.dense_conv1d_fused(xp, t, w, bias, [], got32, stride, ln, True, False)
-    hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w), cout, 8, bias, [], got16, stride, ln)
+    hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w, stride), cout, 8, bias, [], got16, stride, ln)
     close(got32, want.cpu(), rtol=1e-5, atol=2e-6)
     close(got16, want.cpu(), rtol=1e-5, atol=2e-6)

@@ -25,7 +25,7 @@ def run(cin, cout, tin, s, b, time_it):
     y32 = torch.full((b, cout, hip.round_up4(tout)), float('nan'), device=DEV)
     y16 = torch.full_like(y32, float('nan'))
     hip.dense_conv1d_fused(xd, tin, wd, bd, (), y32, s)
-    packed = hip.pack_dense_weights(wd)
+    packed = hip.pack_dense_weights(wd, s)
     hip.dense_conv1d_fused_packed(xd, tin, packed, cout, 8, bd, (), y16, s)
     torch.cuda.synchronize()
     msg = f'{cin:5d}->{cout:5d} T={tin:5d} s={s} B={b:3d}: '
