@@ -18,7 +18,8 @@ i+1 on a second HIP stream; every step is a complete forward, all K complete ins
 One JSON line on stdout (rank 0).  Besides the driver's contract fields it carries
   roofline      fused grouped Conv1d kernel (the graded, HBM-bound kernel of SURVEY.md 8(d)): algorithmic bytes of
                 its 54 launches / their HIP-event time, vs 8 TB/s
-  roofline_mfma the dense downsample convs on the fp32 matrix cores vs 157.3 TFLOP/s
+  roofline_mfma the dense downsample convs: issued bf16 MFMA flops (6 per algorithmic fp32 product) vs 2.5 PFLOP/s
+                (or algorithmic flops vs the 157.3 TFLOP/s fp32 MFMA peak with NBASR_DENSE_MODE=f32)
   cpu_baseline  the CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample, host cores
 """
 import argparse
@@ -34,6 +35,7 @@ ARCH = [[1, 0], [1, 0, 0], [1, 0, 0, 0]]
 BATCH, FRAMES, FEATURES = 64, 1000, 80
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3    # ibid.: v_mfma_f32_32x32x2_f32 dense peak
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # ibid.: bf16 MFMA dense peak
 
 
 def grouped_conv_bytes(batch, channels, frames, kernel, n_skips, groups=100):
@@ -238,12 +240,21 @@ def roofline_leg(model, x, args):
         f = dense_conv_flops(args.batch, c_in, c_out, k, frames_out)
         tot_flops += f * n
         tot_ms += ms
-        per_layer[f'conv_{blk}_{c_in}x{c_out}_T{frames_out}'] = {'TFLOPs': f * n / (ms * 1e-3) / 1e12, 'us_per_launch': 1e3 * ms / n}
+        per_layer[f'conv_{blk}_{c_in}x{c_out}_T{frames_out}'] = {'algorithmic_TFLOPs': f * n / (ms * 1e-3) / 1e12, 'us_per_launch': 1e3 * ms / n}
     if tot_ms:
-        achieved = tot_flops / (tot_ms * 1e-3) / 1e12
-        out['roofline_mfma'] = {'kernel': 'gemm_conv_kernel<8,S> (dense k=8 conv, v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
-                                'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                                'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None, 'per_layer': per_layer}
+        algorithmic = tot_flops / (tot_ms * 1e-3) / 1e12
+        if plan.dense_mode == 'bf16x3':
+            # fp32-accurate 3-way bf16 split: six bf16 MFMA products are issued per algorithmic fp32 product
+            issued = 6.0 * algorithmic
+            out['roofline_mfma'] = {'kernel': 'gemm_conv_bf16x3_kernel<S> (dense k=8 conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product)',
+                                    'bound': 'mfma', 'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA issued)',
+                                    'frac': issued / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
+                                    'algorithmic_fp32_TFLOPs': algorithmic, 'vs_fp32_mfma_peak': algorithmic / FP32_MFMA_PEAK_TFLOPS,
+                                    'per_layer': per_layer}
+        else:
+            out['roofline_mfma'] = {'kernel': 'gemm_conv_kernel<8,S> (dense k=8 conv, v_mfma_f32_32x32x2_f32)', 'bound': 'mfma',
+                                    'achieved': algorithmic, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': algorithmic / FP32_MFMA_PEAK_TFLOPS, 'traffic': None, 'per_layer': per_layer}
     # where the forward's time goes (event-bracketed launches, ms per forward)
     split = {}
     for (kind, _meta), (ms, _n) in agg.items():
