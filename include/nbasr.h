@@ -143,6 +143,17 @@ int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* b
                                   float* y, int batch, int channels, int frames, int ld,
                                   int groups, int kernel, int dilation,
                                   const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
+/* As nbasr_grouped_conv1d_fused_ln, and ALSO emits the LayerNorm statistics of the output y (what nbasr_channel_stats(y)
+ * would give) from the convolution's epilogue: workgroups write per-(group quad) partial (mean, M2) to stats_ws
+ * (nbasr_grouped_stats_workspace_bytes), a small second kernel merges them into stats_out (batch, 2, ld).  stats_out ==
+ * stats_ws == NULL gives the plain _ln behaviour. */
+size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups);
+int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias,
+                                     const float* skip0, const float* skip1, const float* skip2,
+                                     float* y, int batch, int channels, int frames, int ld,
+                                     int groups, int kernel, int dilation,
+                                     const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
+                                     float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream);
 int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y,
                       int batch, int channels, int frames, int ld,
                       const nbasr_deferred_ln* ln, int ln_on_skip0, nbasr_stream_t stream);

@@ -18,11 +18,15 @@ namespace nbasr {
 
 // LNX: the main input carries a pending LayerNorm (deferred normalisation, nbasr.h) applied while loading;
 // ln_s0.stats != nullptr: skip0 carries one (inside a cell both are the cell input, with the same statistics).
-template <int CG, int K, int D, bool LNX>
+// STATS: the epilogue also emits this workgroup's partial LayerNorm statistics of y -- per frame the (mean, M2) over the
+// 4 x CG channels of its four groups -- to `part` ([group quad][batch][2][ld]); stats_finalize_kernel merges the quads.
+// This replaces the separate statistics pass over y when y is the last node of a cell.
+template <int CG, int K, int D, bool LNX, bool STATS>
 __global__ __launch_bounds__(256) void grouped_conv_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
-    float* __restrict__ y, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0)
+    float* __restrict__ y, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0,
+    float* __restrict__ part)
 {
     constexpr int LPAD = pad_left(K, D, 1);
     constexpr int SPAN = (K - 1) * D;            // taps reach frames [t - LPAD, t - LPAD + SPAN]
@@ -38,8 +42,8 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
     // wave-uniform group index (scalar registers => s_load for weights and bias)
     const int g = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave);
     const int b = blockIdx.z;
-    if (g >= groups) return;
-    const bool active = q < nq;
+    if (!STATS && g >= groups) return;              // with STATS every wave must reach the workgroup barrier below
+    const bool active = q < nq && g < groups;
 
     const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
     const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         }
     }
 
-#pragma unroll 2
+#pragma unroll 1
     for (int ci = 0; ci < CG; ++ci) {
         const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + row0 + static_cast<size_t>(ci) * ld);
         float xw[NCH * 4];
@@ -99,16 +103,17 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         }
     }
 
-    if (!active) return;
+    if (!STATS && !active) return;
     const int t0 = q * 4;
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;          // statistics of this lane's own 4 frames (skip0)
-    if (s0 && ln_s0.stats) {
+    if (active && s0 && ln_s0.stats) {
         const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_s0.stats + static_cast<size_t>(b) * 2 * ld);
         sm = mrow[q];
         sr = mrow[nq + q];
     }
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
+        if (!active) break;
         const size_t off = row0 + static_cast<size_t>(co) * ld + t0;
         float o[4];
 #pragma unroll
@@ -127,8 +132,74 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         // keep the pitch columns frames..ld-1 at zero (layout invariant, nbasr.h)
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (t0 + r >= frames) o[r] = 0.f;
-        *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + off));
+        if (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];           // keep the final values for the statistics
+        }
     }
+    if (STATS) {
+        // per-lane (mean, M2) over this group's CG channels, exact two-pass in registers
+        __shared__ float sp[4][8][64];
+        float pm[4], p2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sum = 0.f;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) sum += acc[co][r];
+            pm[r] = sum * (1.0f / CG);
+            float m2 = 0.f;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) { const float d = acc[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
+            p2[r] = m2;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sp[wave][r][lane] = pm[r]; sp[wave][4 + r][lane] = p2[r]; }
+        __syncthreads();
+        if (wave == 0 && q < nq) {
+            const int g0 = blockIdx.y * 4;
+            const int nw = min(4, groups - g0);                      // groups (waves) that hold real data
+            float om[4], o2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mean = 0.f;
+                for (int k = 0; k < nw; ++k) mean += sp[k][r][lane];
+                mean /= static_cast<float>(nw);
+                float m2 = 0.f;
+                for (int k = 0; k < nw; ++k) { const float d = sp[k][r][lane] - mean; m2 += sp[k][4 + r][lane] + CG * d * d; }
+                om[r] = mean; o2[r] = m2;
+            }
+            float* prow = part + (static_cast<size_t>(blockIdx.y) * gridDim.z + b) * 2 * ld + t0;
+            *reinterpret_cast<float4*>(prow) = make_float4(om[0], om[1], om[2], om[3]);
+            *reinterpret_cast<float4*>(prow + ld) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        }
+    }
+}
+
+// merge the per-quad partial statistics: stats (batch, 2, ld) <- (mean, rstd) per frame, 0 in the pitch columns
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                             int batch, int frames, int ld, int groups, int cg, float eps)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= ld) return;
+    float* srow = stats + static_cast<size_t>(b) * 2 * ld;
+    if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
+    const int nquads = (groups + 3) / 4;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    for (int k = 0; k < nquads; ++k) {
+        const float nb = static_cast<float>(cg * min(4, groups - 4 * k));
+        const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld;
+        const float pm = prow[t], pq = prow[ld + t];
+        const float tot = cnt + nb;
+        const float delta = pm - mean;
+        mean += delta * (nb / tot);
+        m2 += pq + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+    srow[t] = mean;
+    srow[ld + t] = 1.0f / sqrtf(m2 / cnt + eps);
 }
 
 // y = 0 + skip0 + skip1 + skip2 for a node whose main op is `zero` (reference ops.py:67-68); skip0 may carry a pending
@@ -174,6 +245,7 @@ struct GroupedArgs {
     const float* x; const float* w; const float* bias; const float* s0; const float* s1; const float* s2; float* y;
     int batch, channels, frames, ld, groups;
     LnRef ln_x, ln_s0;
+    float* part;                 // partial-statistics workspace (nullptr: no statistics)
 };
 
 template <int CG, int K, int D>
@@ -181,12 +253,12 @@ static int launch_grouped(const GroupedArgs& a, hipStream_t stream)
 {
     const int nq = a.ld / 4;
     dim3 grid((nq + 63) / 64, (a.groups + 3) / 4, a.batch);
-    if (a.ln_x.stats)
-        hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D, true>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1,
-                           a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0);
-    else
-        hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D, false>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1,
-                           a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0);
+#define NBASR_LAUNCH_GROUPED(LNX, STATS)                                                                                  \
+    hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D, LNX, STATS>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1, \
+                       a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part)
+    if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
+    else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
+#undef NBASR_LAUNCH_GROUPED
     return launch_status("nbasr_grouped_conv1d_fused");
 }
 
@@ -205,12 +277,23 @@ static int dispatch_kd(int kernel, int dilation, const GroupedArgs& a, hipStream
 
 using namespace nbasr;
 
-extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
-                                             const float* skip1, const float* skip2, float* y, int batch, int channels,
-                                             int frames, int ld, int groups, int kernel, int dilation,
-                                             const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
+extern "C" size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups)
+{
+    if (batch <= 0 || ld <= 0 || groups <= 0) return 0;
+    return static_cast<size_t>((groups + 3) / 4) * batch * 2 * ld * sizeof(float);
+}
+
+extern "C" int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias, const float* skip0,
+                                                const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                                int frames, int ld, int groups, int kernel, int dilation,
+                                                const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
+                                                float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream)
 {
     clear_error();
+    NBASR_REQUIRE((stats_out == nullptr) == (stats_ws == nullptr), NBASR_ENULL,
+                  "nbasr_grouped_conv1d_fused_stats: stats_out and stats_ws must be given together");
+    NBASR_REQUIRE(!stats_out || (aligned16(stats_out) && aligned16(stats_ws)), NBASR_EALIGN,
+                  "nbasr_grouped_conv1d_fused_stats: statistics buffers must be 16-byte aligned");
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "nbasr_grouped_conv1d_fused: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
     if (batch == 0 || ld == 0) return NBASR_OK;      // empty batch: nothing to do (empty tensors have NULL storage)
@@ -223,17 +306,31 @@ extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, con
     NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
                   "nbasr_grouped_conv1d_fused_ln: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
     GroupedArgs a{x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups,
-                  ln_ref(ln, ln_on_x != 0), ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr)};
+                  ln_ref(ln, ln_on_x != 0), ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr), stats_ws};
     hipStream_t s = as_stream(stream);
+    int rc;
     switch (channels / groups) {
-        case 6:  return dispatch_kd<6>(kernel, dilation, a, s);
-        case 8:  return dispatch_kd<8>(kernel, dilation, a, s);
-        case 10: return dispatch_kd<10>(kernel, dilation, a, s);
-        case 12: return dispatch_kd<12>(kernel, dilation, a, s);
+        case 6:  rc = dispatch_kd<6>(kernel, dilation, a, s); break;
+        case 8:  rc = dispatch_kd<8>(kernel, dilation, a, s); break;
+        case 10: rc = dispatch_kd<10>(kernel, dilation, a, s); break;
+        case 12: rc = dispatch_kd<12>(kernel, dilation, a, s); break;
         default:
             set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", channels / groups);
             return NBASR_EINVAL;
     }
+    if (rc != NBASR_OK || !stats_out) return rc;
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, s, stats_ws, stats_out, batch, frames,
+                       ld, groups, channels / groups, eps);
+    return launch_status("nbasr_grouped_conv1d_fused_stats");
+}
+
+extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
+                                             const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                             int frames, int ld, int groups, int kernel, int dilation,
+                                             const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
+{
+    return nbasr_grouped_conv1d_fused_stats(x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, kernel,
+                                            dilation, ln, ln_on_x, ln_on_skip0, nullptr, nullptr, 0.f, stream);
 }
 
 extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,

@@ -20,11 +20,12 @@ import torch
 from . import hip
 
 
-def node_into(node, inputs, frames, out, ln0=None):
+def node_into(node, inputs, frames, out, ln0=None, stats=None):
     """Enqueue one cell node: ``out = op(inputs[-1]) + sum(flagged inputs)`` (left-to-right).
 
     ``ln0`` = (stats, gamma, beta): ``inputs[0]`` (the cell input) is stored un-normalised with a pending LayerNorm that
-    the kernel applies while loading -- as the main input when the node is the cell's first, as skip0 when flagged."""
+    the kernel applies while loading -- as the main input when the node is the cell's first, as skip0 when flagged.
+    ``stats`` = (stats_out, workspace, eps): a grouped-conv node also emits the LayerNorm statistics of ``out``."""
     from .ops import PadConvRelu, Linear, Zero, Identity
     if len(inputs) != len(node.branch_ops):
         raise AssertionError('Branch op and input list have different lenghts')
@@ -34,9 +35,12 @@ def node_into(node, inputs, frames, out, ln0=None):
     on_s0 = ln0 is not None and isinstance(node.branch_ops[0], Identity)       # the cell input, if flagged, is skips[0]
     ln = ln0 if (on_x or on_s0) else None
     if isinstance(op, PadConvRelu):
+        st = stats if stats is not None else (None, None, 0.0)
         hip.grouped_conv1d_fused(last, op.conv.weight.detach(), op.conv.bias.detach(), skips, out, frames,
-                                 op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0)
+                                 op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, st[0], st[1], st[2])
     elif isinstance(op, Linear):
+        if stats is not None:
+            raise ValueError('statistics from the epilogue are only available for grouped-conv nodes')
         hip.dense_conv1d_fused(last, frames, op.linear.weight.detach().unsqueeze(-1), op.linear.bias.detach(),
                                skips, out, 1, ln, on_x, on_s0)
     elif isinstance(op, Zero):
@@ -86,8 +90,10 @@ class ForwardPlan:
         self.ln_mode = os.environ.get('NBASR_LN_MODE', 'deferred')
         if self.ln_mode not in ('deferred', 'materialize'):
             raise ValueError(f'NBASR_LN_MODE must be deferred or materialize, got {self.ln_mode!r}')
+        self.epilogue_stats = os.environ.get('NBASR_EPILOGUE_STATS', '1') != '0'
         stat_elems = max(batch * 2 * hip.round_up4(t) for t in self.block_frames)
         self.stats = [torch.empty(max(stat_elems, 4), device=device, dtype=torch.float32) for _ in range(2)]
+        self.stats_ws = hip.grouped_stats_workspace(batch, max(hip.round_up4(t) for t in self.block_frames), 100, device)
         elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
         self.pool = [torch.empty(max(elems, 4), device=device, dtype=torch.float32) for _ in range(4)]
         if model.use_rnn:
@@ -218,20 +224,37 @@ class ForwardPlan:
                 free = [i for i in range(4) if i != cur]
                 if len(layer.nodes) > len(free):
                     raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
+                nxt = model.model[idx + 1] if idx + 1 < n_layers else None
+                feeds_tail = pipe and isinstance(nxt, (nn.Dropout, nn.LSTM))
+                # a deferred cell LayerNorm whose producer is a grouped conv gets its statistics from that node's
+                # epilogue (no statistics pass over the tensor)
+                last_op = layer.nodes[-1].op
+                epilogue_stats = (self.epilogue_stats and layer.use_norm and self.ln_mode == 'deferred' and self._cheap_consumer(nxt) and not feeds_tail
+                                  and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                 outs = [act]
-                for node, dst in zip(layer.nodes, free):
+                for j, (node, dst) in enumerate(zip(layer.nodes, free)):
                     n_skips = sum(type(br).__name__ == 'Identity' for br in node.branch_ops)
                     kind = {'PadConvRelu': 'grouped_conv', 'Linear': 'linear_op', 'Zero': 'skip_sum'}[type(node.op).__name__]
                     meta = (blk, layer.filters, layer.filters, getattr(node.op, 'kernel_size', 1), act_frames, n_skips)
                     view = self._view(dst, layer.filters, act_frames)
-                    ln0 = pending
-                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0)))
+                    ln0, st = pending, None
+                    if epilogue_stats and j == len(layer.nodes) - 1:
+                        self._stat_turn ^= 1
+                        ld = view.shape[2]
+                        new_stats = self.stats[self._stat_turn][: self.batch * 2 * ld].view(self.batch, 2, ld)
+                        st = (new_stats, self.stats_ws, layer.norm_layer.eps)
+                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st)))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
-                nxt = model.model[idx + 1] if idx + 1 < n_layers else None
-                feeds_tail = pipe and isinstance(nxt, (nn.Dropout, nn.LSTM))
                 if feeds_tail:
                     pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)
-                if layer.use_norm:
+                if epilogue_stats:
+                    norm = layer.norm_layer
+                    pending = (new_stats, norm.weight.detach(), norm.bias.detach())
+                    if taps is not None:
+                        copy = torch.empty_like(act)
+                        hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(), copy, act_frames, norm.eps)
+                        taps[idx] = copy[:, :, :act_frames].clone()
+                elif layer.use_norm:
                     pending = self._norm(layer.norm_layer, act, act_frames, (blk, layer.filters, layer.filters, 0, act_frames, 0),
                                          taps, idx, nxt, enc if feeds_tail else None)
                     if feeds_tail:

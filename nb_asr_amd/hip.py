@@ -44,6 +44,9 @@ SIGNATURES = {
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
     'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_grouped_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_grouped_stats_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_grouped_conv1d_fused_stats': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_float_p,
+                                                  ctypes.c_float, _c_stream]),
     'nbasr_skip_sum_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_stream]),
     'nbasr_dense_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_dense_conv1d_fused_packed_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_ln_p, _c_stream]),
@@ -140,15 +143,22 @@ def round_up4(n):
 # is the row pitch ld (a multiple of 4) and `frames` <= ld the number of valid frames
 # ---------------------------------------------------------------------------------------------
 def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dilation, ln=None, ln_on_x=False,
-                         ln_on_skip0=False):
-    """`ln` = (stats, gamma, beta) of a pending LayerNorm carried by x (ln_on_x) and/or skips[0] (ln_on_skip0)."""
+                         ln_on_skip0=False, stats_out=None, stats_ws=None, eps=0.0):
+    """`ln` = (stats, gamma, beta) of a pending LayerNorm carried by x (ln_on_x) and/or skips[0] (ln_on_skip0).
+    `stats_out` (B, 2, ld) + `stats_ws` (grouped_stats_workspace): also emit the LayerNorm statistics of y."""
     b, c, ld = x.shape
     s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_grouped_conv1d_fused_ln(
+    _check(load_library().nbasr_grouped_conv1d_fused_stats(
         _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
         _opt(s[2], 'skip2'), _dev(y, 'y'), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
-        int(ln_on_skip0), _stream(x)), 'nbasr_grouped_conv1d_fused')
+        int(ln_on_skip0), _opt(stats_out, 'stats_out'), _opt(stats_ws, 'stats_ws'), float(eps), _stream(x)),
+        'nbasr_grouped_conv1d_fused')
     return y
+
+
+def grouped_stats_workspace(batch, ld, groups, device):
+    n = load_library().nbasr_grouped_stats_workspace_bytes(batch, ld, groups) // 4
+    return torch.empty(max(n, 4), dtype=torch.float32, device=device)
 
 
 def skip_sum(skips, y, frames, ln=None, ln_on_skip0=False):

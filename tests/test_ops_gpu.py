@@ -355,3 +355,27 @@ def test_dense_conv_deferred_ln_both_paths(stride):
     hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w, stride), cout, 8, bias, [], got16, stride, ln)
     close(got32, want.cpu(), rtol=1e-5, atol=2e-6)
     close(got16, want.cpu(), rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('c,groups,t,k,d', [(40, 4, 133, 5, 1), (600, 100, 37, 7, 2), (36, 3, 260, 5, 2), (1200, 100, 250, 5, 1)])
+def test_grouped_conv_epilogue_statistics(c, groups, t, k, d):
+    """Statistics emitted by the convolution's epilogue == a separate statistics pass over its output."""
+    torch.manual_seed(c + t)
+    b = 3
+    x = torch.randn(b, c, t) * 1.5
+    xp, _ = pitched(x)
+    w, bias = torch.randn(c, c // groups, k, device=DEV) * 0.3, torch.randn(c, device=DEV) * 0.2
+    sk = torch.randn_like(xp)
+    sk[:, :, t:] = 0
+    y = torch.full_like(xp, float('nan'))
+    got = torch.full((b, 2, xp.shape[2]), float('nan'), device=DEV)
+    ws = hip.grouped_stats_workspace(b, xp.shape[2], groups, DEV)
+    hip.grouped_conv1d_fused(xp, w, bias, [sk], y, t, groups, k, d, None, False, False, got, ws, 1e-3)
+    want = torch.empty_like(got)
+    hip.channel_stats(y, want, t, 1e-3)
+    plain = torch.empty_like(y)
+    hip.grouped_conv1d_fused(xp, w, bias, [sk], plain, t, groups, k, d)
+    assert torch.equal(plain, y)                                      # the output itself is unchanged
+    close(got[:, 0], want[:, 0].cpu(), rtol=1e-5, atol=2e-6)
+    close(got[:, 1], want[:, 1].cpu(), rtol=1e-5, atol=2e-6)
+    assert torch.all(got[:, :, t:] == 0)
