@@ -55,6 +55,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH, help='utterances per GPU')
     ap.add_argument('--frames', type=int, default=FRAMES)
+    ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
+                    help='weak: --batch utterances per GPU (default); strong: --batch utterances in total, split over the ranks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='time plain back-to-back model(x) calls only')
@@ -74,6 +76,12 @@ def main():
     from nb_asr_amd.weights import keyed_fill_, keyed_input
     from nb_asr_amd.parallel import ShardedForward
 
+    if args.scaling == 'strong':
+        from nb_asr_amd.parallel import shard_bounds
+        lo, hi = shard_bounds(args.batch, world, rank)
+        global_batch, args.batch = args.batch, hi - lo
+        if args.batch * world != global_batch:
+            sys.exit(f'--scaling strong needs --batch divisible by the number of GPUs ({global_batch} over {world})')
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
     runner = ShardedForward(world_size=world, rank=rank, device=device)      # RCCL process group when world > 1
@@ -149,7 +157,7 @@ def main():
         'value_sequential': args.batch * world * args.steps / elapsed_seq,
         'ms_per_step_sequential': 1e3 * elapsed_seq / args.steps,
         'higher_is_better': True,
-        'scaling': 'weak',
+        'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic N(0,1) filterbanks (B,80,T) from a keyed generator; random-init He-uniform weights (keyed)',

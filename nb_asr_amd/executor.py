@@ -170,7 +170,10 @@ class ForwardPlan:
 
     def _pipeline_buffers(self, channels, frames):
         if self.side_stream is None:
-            self.side_stream = torch.cuda.Stream(device=self.device)
+            # high priority: its own hardware queue (an ordinary second stream can end up sharing the main stream's queue,
+            # e.g. once RCCL has created its streams, and the overlap silently disappears), and the short dependent LSTM
+            # steps get dispatched ahead of the encoder's bulk work
+            self.side_stream = torch.cuda.Stream(device=self.device, priority=-1)
             ld = hip.round_up4(frames)
             self.enc_out = [torch.empty(self.batch, channels, ld, device=self.device, dtype=torch.float32) for _ in range(2)]
         self._turn ^= 1

@@ -30,7 +30,9 @@ class ShardedForward:
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else rank
         self.device = device
         self._own_group = False
-        if self.world_size > 1 and not dist.is_initialized():
+        force = os.environ.get('NBASR_FORCE_DIST') == '1'       # exercise the collective path with a single rank (tests)
+        self.collective = self.world_size > 1 or force
+        if self.collective and not dist.is_initialized():
             if backend is None:
                 backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -45,7 +47,7 @@ class ShardedForward:
     # -- collectives -------------------------------------------------------------------------------------------
     def gather_logits(self, local):
         """All-gather equally sized (b, T', classes) shards into (world*b, T', classes), rank order."""
-        if self.world_size == 1:
+        if not self.collective:
             return local
         local = local.contiguous()
         out = torch.empty((self.world_size * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -73,11 +75,11 @@ class ShardedForward:
         return self.gather_ragged(model(global_x[begin:end]), global_x.shape[0])
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.collective:
             dist.barrier()
 
     def max_over_ranks(self, value):
-        if self.world_size == 1:
+        if not self.collective:
             return value
         dev = self.device if (self.device is not None and dist.get_backend() == 'nccl') else 'cpu'
         t = torch.tensor([value], dtype=torch.float64, device=dev)
