@@ -145,9 +145,12 @@ int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* b
                                   const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
 /* As nbasr_grouped_conv1d_fused_ln, and ALSO emits the LayerNorm statistics of the output y (what nbasr_channel_stats(y)
  * would give) from the convolution's epilogue: workgroups write per-(group quad) partial (mean, M2) to stats_ws
- * (nbasr_grouped_stats_workspace_bytes), a small second kernel merges them into stats_out (batch, 2, ld).  stats_out ==
- * stats_ws == NULL gives the plain _ln behaviour. */
+ * (nbasr_grouped_stats_workspace_bytes), a small second kernel merges them into stats_out (batch, 2, ld).  With
+ * stats_out == NULL only the partials are written and nbasr_grouped_stats_finalize merges them later; stats_ws == NULL
+ * gives the plain _ln behaviour. */
 size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups);
+int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                 int groups, float eps, nbasr_stream_t stream);
 int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias,
                                      const float* skip0, const float* skip1, const float* skip2,
                                      float* y, int batch, int channels, int frames, int ld,
@@ -173,6 +176,15 @@ int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh,
 int nbasr_linear_head_bct_ln(const float* x, const float* w, const float* bias, float* logits,
                              int batch, int features, int frames, int ld, int classes,
                              const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+
+/* Post-logits step of the reference's trainer (training/torch/trainer.py:217-219, 229-247), SURVEY.md 8 row f2:
+ *   log_probs(batch, frames, classes) = log_softmax(logits, classes)                      (NULL: not wanted)
+ *   greedy CTC decoding: per-frame argmax over the first lengths[b] frames (lengths NULL: all frames; the trainer uses
+ *   audio_len // 4), repeats collapsed, `blank` dropped (F.ctc_loss default blank = 0) -> tokens(batch, frames) int32,
+ *   padded with -1, token_counts(batch).  (tokens NULL: not wanted.)  The reference's beam search is a third-party C++
+ *   library outside its tree and is not reproduced. */
+int nbasr_ctc_postprocess(const float* logits, const int* lengths, float* log_probs, int* tokens, int* token_counts,
+                          int batch, int frames, int classes, int blank, nbasr_stream_t stream);
 
 /* Copy (batch, channels, frames) with pitch ld_src into pitch ld_dst, zero-filling columns
  * frames..ld_dst-1 (used to bring caller tensors into the pitched internal layout). */

@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         sm = mrow[q];
         sr = mrow[nq + q];
     }
+    if (active) {
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
-        if (!active) break;
         const size_t off = row0 + static_cast<size_t>(co) * ld + t0;
         float o[4];
 #pragma unroll
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[co][r] = o[r];           // keep the final values for the statistics
         }
+    }
     }
     if (STATS) {
         // per-lane (mean, M2) over this group's CG channels, exact two-pass in registers
@@ -290,9 +291,9 @@ extern "C" int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, 
                                                 float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE((stats_out == nullptr) == (stats_ws == nullptr), NBASR_ENULL,
-                  "nbasr_grouped_conv1d_fused_stats: stats_out and stats_ws must be given together");
-    NBASR_REQUIRE(!stats_out || (aligned16(stats_out) && aligned16(stats_ws)), NBASR_EALIGN,
+    NBASR_REQUIRE(!stats_out || stats_ws, NBASR_ENULL,
+                  "nbasr_grouped_conv1d_fused_stats: stats_out needs the partial-statistics workspace stats_ws");
+    NBASR_REQUIRE(aligned16(stats_out) && aligned16(stats_ws), NBASR_EALIGN,
                   "nbasr_grouped_conv1d_fused_stats: statistics buffers must be 16-byte aligned");
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "nbasr_grouped_conv1d_fused: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
@@ -318,10 +319,21 @@ extern "C" int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, 
             set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", channels / groups);
             return NBASR_EINVAL;
     }
-    if (rc != NBASR_OK || !stats_out) return rc;
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, s, stats_ws, stats_out, batch, frames,
-                       ld, groups, channels / groups, eps);
-    return launch_status("nbasr_grouped_conv1d_fused_stats");
+    if (rc != NBASR_OK || !stats_out) return rc;       // stats_ws alone: partials only, merge later with nbasr_grouped_stats_finalize
+    return nbasr_grouped_stats_finalize(stats_ws, stats_out, batch, channels, frames, ld, groups, eps, stream);
+}
+
+extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                            int groups, float eps, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && groups > 0 && channels % groups == 0 && frames >= 0 && ld >= frames, NBASR_EINVAL,
+                  "nbasr_grouped_stats_finalize: bad sizes");
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, as_stream(stream), stats_ws, stats_out,
+                       batch, frames, ld, groups, channels / groups, eps);
+    return launch_status("nbasr_grouped_stats_finalize");
 }
 
 extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,

@@ -35,9 +35,10 @@ def node_into(node, inputs, frames, out, ln0=None, stats=None):
     on_s0 = ln0 is not None and isinstance(node.branch_ops[0], Identity)       # the cell input, if flagged, is skips[0]
     ln = ln0 if (on_x or on_s0) else None
     if isinstance(op, PadConvRelu):
-        st = stats if stats is not None else (None, None, 0.0)
+        # with `stats` the epilogue writes partial statistics to the workspace; the caller merges them (finalize)
         hip.grouped_conv1d_fused(last, op.conv.weight.detach(), op.conv.bias.detach(), skips, out, frames,
-                                 op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, st[0], st[1], st[2])
+                                 op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, None,
+                                 stats[1] if stats is not None else None, 0.0)
     elif isinstance(op, Linear):
         if stats is not None:
             raise ValueError('statistics from the epilogue are only available for grouped-conv nodes')
@@ -252,6 +253,9 @@ class ForwardPlan:
                     pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)
                 if epilogue_stats:
                     norm = layer.norm_layer
+                    self._timed('stats_finalize', (blk, layer.filters, layer.filters, 0, act_frames, 0),
+                                lambda: hip.grouped_stats_finalize(self.stats_ws, new_stats, layer.filters, act_frames,
+                                                                   last_op.groups, norm.eps))
                     pending = (new_stats, norm.weight.detach(), norm.bias.detach())
                     if taps is not None:
                         copy = torch.empty_like(act)

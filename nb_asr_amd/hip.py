@@ -45,6 +45,7 @@ SIGNATURES = {
     'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_grouped_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_grouped_stats_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_grouped_stats_finalize': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [ctypes.c_float, _c_stream]),
     'nbasr_grouped_conv1d_fused_stats': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_float_p,
                                                   ctypes.c_float, _c_stream]),
     'nbasr_skip_sum_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_stream]),
@@ -52,6 +53,7 @@ SIGNATURES = {
     'nbasr_dense_conv1d_fused_packed_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_forward_ln': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_linear_head_bct_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    'nbasr_ctc_postprocess': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
     'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
 }
 
@@ -154,6 +156,14 @@ def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dila
         int(ln_on_skip0), _opt(stats_out, 'stats_out'), _opt(stats_ws, 'stats_ws'), float(eps), _stream(x)),
         'nbasr_grouped_conv1d_fused')
     return y
+
+
+def grouped_stats_finalize(stats_ws, stats_out, channels, frames, groups, eps):
+    b, _, ld = stats_out.shape
+    _check(load_library().nbasr_grouped_stats_finalize(_dev(stats_ws, 'stats_ws'), _dev(stats_out, 'stats_out'), b, channels,
+                                                       frames, ld, groups, float(eps), _stream(stats_out)),
+           'nbasr_grouped_stats_finalize')
+    return stats_out
 
 
 def grouped_stats_workspace(batch, ld, groups, device):
@@ -267,3 +277,20 @@ def repitch(src, dst, frames):
     _check(load_library().nbasr_repitch(_dev(src, 'src'), _dev(dst, 'dst'), rows, frames, src.shape[-1],
                                         dst.shape[-1], _stream(src)), 'nbasr_repitch')
     return dst
+
+
+def ctc_postprocess(logits, lengths=None, want_log_probs=True, want_tokens=True, blank=0):
+    """logits (B, T', C) -> (log_probs or None, tokens (B, T') int32 padded with -1 or None, token_counts (B) or None)."""
+    _dev(logits, 'logits')
+    b, t, c = logits.shape
+    if lengths is not None:
+        if not lengths.is_cuda or lengths.dtype != torch.int32 or not lengths.is_contiguous() or lengths.numel() != b:
+            raise HipError('lengths must be a contiguous int32 device tensor with one entry per utterance')
+    log_probs = torch.empty_like(logits) if want_log_probs else None
+    tokens = torch.empty(b, t, dtype=torch.int32, device=logits.device) if want_tokens else None
+    counts = torch.empty(b, dtype=torch.int32, device=logits.device) if want_tokens else None
+    _check(load_library().nbasr_ctc_postprocess(
+        logits.data_ptr(), None if lengths is None else lengths.data_ptr(), None if log_probs is None else log_probs.data_ptr(),
+        None if tokens is None else tokens.data_ptr(), None if counts is None else counts.data_ptr(), b, t, c, blank,
+        _stream(logits)), 'nbasr_ctc_postprocess')
+    return log_probs, tokens, counts

@@ -17,6 +17,8 @@ a "truth" to measure both against):
 * ``layer_norm_channels``-- ``model.py:125-128`` / ``model.py:55-58``
 * ``lstm_forward``       -- ``model.py:118-121`` (nn.LSTM: gates i,f,g,o; two biases; zero state)
 * ``asr_forward``        -- ``model.py:116-131`` with the layer stack of ``model.py:72-103``
+* ``log_softmax / output_lengths / ctc_greedy`` -- the trainer's post-logits step,
+                            ``training/torch/trainer.py:217-219`` (greedy = width-1 case of its beam decode)
 
 PINNING: the reference has no tests or golden vectors for this path.  The
 oracle is pinned against outputs of the reference itself, imported in the build container:
@@ -231,4 +233,30 @@ def flops_per_forward(arch_vec, batch, frames, use_rnn=True):
     else:
         out['head'] = 2.0 * batch * t * 49 * FILTERS[-1]
     out['total'] = math.fsum(out.values())
+    return out
+
+
+# ---- post-logits step (reference training/torch/trainer.py:217-219, 229-247) ------------------------------------------------
+def log_softmax(logits):
+    """F.log_softmax(output, dim=2) of trainer.py:218."""
+    return torch.log_softmax(logits, dim=2)
+
+
+def output_lengths(audio_len):
+    """output_len = audio_len // 4 (trainer.py:219)."""
+    return [int(n) // 4 for n in audio_len]
+
+
+def ctc_greedy(logits, lengths=None, blank=0):
+    """Width-1 CTC decoding: per-frame argmax (first maximum), collapse repeats, drop blanks.  Plain python loops."""
+    out = []
+    for b in range(logits.shape[0]):
+        n = logits.shape[1] if lengths is None else max(0, min(int(lengths[b]), logits.shape[1]))
+        best = torch.argmax(logits[b, :n], dim=1).tolist() if n else []
+        seq, prev = [], None
+        for tok in best:
+            if tok != blank and tok != prev:
+                seq.append(tok)
+            prev = tok
+        out.append(seq)
     return out
