@@ -214,23 +214,31 @@ def roofline_leg(model, x, args):
     tot_bytes = tot_ms = 0.0
     per_block, launches = {}, 0
     for (kind, meta), (ms, n) in agg.items():
-        if kind != 'grouped_conv':
+        if kind == 'grouped_conv':
+            blk, c, _, k, frames, n_skips = meta
+            b = grouped_conv_bytes(args.batch, c, frames, k, n_skips)
+        elif kind == 'grouped_cell':
+            # one launch = the three node operations of a cell: credited with the algorithmic bytes of those three ops
+            # (SURVEY.md 8(d) per-op figure x the ops one launch processes); the intermediates never leave the CU
+            blk, c, ks, skips, frames, _ = meta
+            b = sum(grouped_conv_bytes(args.batch, c, frames, kj, sj) for kj, sj in zip(ks, skips))
+            k = 'x'.join(str(v) for v in ks)
+        else:
             continue
-        blk, c, _, k, frames, n_skips = meta
-        b = grouped_conv_bytes(args.batch, c, frames, k, n_skips)
         tot_bytes += b * n
         tot_ms += ms
         launches += n
-        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}', {'bytes_per_launch': b, 'ms': 0.0, 'n': 0})
+        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}_{kind}', {'bytes_per_launch': b, 'ms': 0.0, 'n': 0})
         e['ms'] += ms
         e['n'] += n
     if launches:
-        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_conv_kernel')
+        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_kernel')
         if args.batch != BATCH or args.frames != FRAMES:
             traffic, traffic_src = None, None          # the committed counters are for the default workload only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
         out['roofline'] = {
-            'kernel': 'grouped_conv_kernel<CG,K,D> (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum)',
+            'kernel': 'grouped_cell_kernel<CG> / grouped_conv_kernel<CG,K,D,..> (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
+                      ' [+LayerNorm on load]; a cell launch runs its three node ops with the intermediates in LDS)',
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,
             'bytes_per_launch_avg': tot_bytes / launches, 'us_per_launch_avg': 1e3 * tot_ms / launches,

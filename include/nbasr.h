@@ -157,6 +157,17 @@ int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float
                                      int groups, int kernel, int dilation,
                                      const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
                                      float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream);
+/* A whole SearchCell whose three node operations are grouped convolutions, in one launch (reference model.py:49-59 over
+ * model.py:13-22 and ops.py:24-30): x1 = op0(x0) + s00 x0; x2 = op1(x1) + s10 x0 + s11 x1; x3 = op2(x2) + s20 x0 + s21 x1 + s22 x2.
+ * The intermediates stay in LDS; the result is bit-identical to three nbasr_grouped_conv1d_fused launches.
+ * skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.  `ln` (may be NULL): pending LayerNorm of x0.
+ * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup (<= 4096 frames, LDS <= 160 KiB). */
+int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups);
+int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,
+                             const float* w1, const float* b1, int k1, int d1,
+                             const float* w2, const float* b2, int k2, int d2, int skip_mask, float* y,
+                             int batch, int channels, int frames, int ld, int groups,
+                             const nbasr_deferred_ln* ln, nbasr_stream_t stream);
 int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y,
                       int batch, int channels, int frames, int ld,
                       const nbasr_deferred_ln* ln, int ln_on_skip0, nbasr_stream_t stream);

@@ -92,6 +92,10 @@ class ForwardPlan:
         if self.ln_mode not in ('deferred', 'materialize'):
             raise ValueError(f'NBASR_LN_MODE must be deferred or materialize, got {self.ln_mode!r}')
         self.epilogue_stats = os.environ.get('NBASR_EPILOGUE_STATS', '1') != '0'
+        # opt-in: cells whose three nodes are grouped convs run as ONE launch (x1, x2 stay in LDS).  Bit-identical, but at
+        # B=64/T=1000 it is VALU/latency-bound (45-50 TFLOP/s at 2-3 waves per SIMD): 139/263/210/164 us per cell vs
+        # 177/264/159/117 us for three HBM-bound launches -- a win only in block 0, so it is off by default
+        self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '0') == '1'
         stat_elems = max(batch * 2 * hip.round_up4(t) for t in self.block_frames)
         self.stats = [torch.empty(max(stat_elems, 4), device=device, dtype=torch.float32) for _ in range(2)]
         self.stats_ws = hip.grouped_stats_workspace(batch, max(hip.round_up4(t) for t in self.block_frames), 100, device)
@@ -233,10 +237,26 @@ class ForwardPlan:
                 # a deferred cell LayerNorm whose producer is a grouped conv gets its statistics from that node's
                 # epilogue (no statistics pass over the tensor)
                 last_op = layer.nodes[-1].op
-                epilogue_stats = (self.epilogue_stats and layer.use_norm and self.ln_mode == 'deferred' and self._cheap_consumer(nxt) and not feeds_tail
+                fused = (self.cell_fusion and len(layer.nodes) == 3
+                         and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)
+                         and hip.grouped_cell_fits(layer.filters, hip.round_up4(act_frames), last_op.groups))
+                if fused:
+                    mask = 0
+                    for bit, (j, i) in enumerate(((0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (2, 2))):
+                        if type(layer.nodes[j].branch_ops[i]).__name__ == 'Identity':
+                            mask |= 1 << bit
+                    view = self._view(free[2], layer.filters, act_frames)
+                    specs = [(n.op.conv.weight.detach(), n.op.conv.bias.detach(), n.op.kernel_size, n.op.dilation) for n in layer.nodes]
+                    n_skips = [sum(type(br).__name__ == 'Identity' for br in n.branch_ops) for n in layer.nodes]
+                    meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_skips), act_frames, 0)
+                    src, ln0 = act, pending
+                    self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0))
+                    outs = [act, None, None, view]
+                epilogue_stats = (not fused and self.epilogue_stats and layer.use_norm and self.ln_mode == 'deferred' and self._cheap_consumer(nxt) and not feeds_tail
                                   and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
-                outs = [act]
-                for j, (node, dst) in enumerate(zip(layer.nodes, free)):
+                if not fused:
+                    outs = [act]
+                for j, (node, dst) in enumerate(zip(layer.nodes, free) if not fused else ()):
                     n_skips = sum(type(br).__name__ == 'Identity' for br in node.branch_ops)
                     kind = {'PadConvRelu': 'grouped_conv', 'Linear': 'linear_op', 'Zero': 'skip_sum'}[type(node.op).__name__]
                     meta = (blk, layer.filters, layer.filters, getattr(node.op, 'kernel_size', 1), act_frames, n_skips)

@@ -48,6 +48,9 @@ SIGNATURES = {
     'nbasr_grouped_stats_finalize': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [ctypes.c_float, _c_stream]),
     'nbasr_grouped_conv1d_fused_stats': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_float_p,
                                                   ctypes.c_float, _c_stream]),
+    'nbasr_grouped_cell_fits': (_c_int, [_c_int] * 3),
+    'nbasr_grouped_cell_fused': (_c_int, [_c_float_p, _c_float_p, _c_float_p, _c_int, _c_int, _c_float_p, _c_float_p, _c_int, _c_int,
+                                          _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_skip_sum_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_stream]),
     'nbasr_dense_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_dense_conv1d_fused_packed_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_ln_p, _c_stream]),
@@ -155,6 +158,21 @@ def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dila
         _opt(s[2], 'skip2'), _dev(y, 'y'), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
         int(ln_on_skip0), _opt(stats_out, 'stats_out'), _opt(stats_ws, 'stats_ws'), float(eps), _stream(x)),
         'nbasr_grouped_conv1d_fused')
+    return y
+
+
+def grouped_cell_fits(channels, ld, groups):
+    return bool(load_library().nbasr_grouped_cell_fits(channels, ld, groups))
+
+
+def grouped_cell_fused(x0, nodes, skip_mask, y, frames, groups, ln=None):
+    """nodes: three (weight, bias, kernel, dilation); skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22."""
+    b, c, ld = x0.shape
+    args = []
+    for w, bias, k, d in nodes:
+        args += [_dev(w, 'weight'), _dev(bias, 'bias'), k, d]
+    _check(load_library().nbasr_grouped_cell_fused(_dev(x0, 'x0'), *args, skip_mask, _dev(y, 'y'), b, c, frames, ld, groups,
+                                                   _ln(ln), _stream(x0)), 'nbasr_grouped_cell_fused')
     return y
 
 

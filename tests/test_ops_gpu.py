@@ -379,3 +379,43 @@ def test_grouped_conv_epilogue_statistics(c, groups, t, k, d):
     close(got[:, 0], want[:, 0].cpu(), rtol=1e-5, atol=2e-6)
     close(got[:, 1], want[:, 1].cpu(), rtol=1e-5, atol=2e-6)
     assert torch.all(got[:, :, t:] == 0)
+
+
+@pytest.mark.parametrize('c,groups,t', [(40, 4, 133), (600, 100, 37), (48, 4, 1000), (30, 5, 257), (1200, 100, 250)])
+@pytest.mark.parametrize('kds,mask', [(((5, 1), (5, 1), (5, 1)), 0), (((7, 1), (7, 2), (5, 2)), 63), (((5, 2), (7, 2), (7, 1)), 0b101010),
+                                      (((7, 2), (5, 1), (7, 2)), 0b010101)])
+@pytest.mark.parametrize('with_ln', [False, True])
+def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, mask, with_ln):
+    torch.manual_seed(c + t + mask)
+    b = 2
+    x = torch.randn(b, c, t) * 1.5 + 0.3
+    xp, _ = pitched(x)
+    ln = None
+    if with_ln:
+        stats = torch.empty(b, 2, xp.shape[2], device=DEV)
+        hip.channel_stats(xp, stats, t, 1e-3)
+        ln = (stats, torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.2)
+    nodes = [(torch.randn(c, c // groups, k, device=DEV) * 0.3, torch.randn(c, device=DEV) * 0.2, k, d) for k, d in kds]
+    assert hip.grouped_cell_fits(c, xp.shape[2], groups)
+    got = torch.full_like(xp, float('nan'))
+    hip.grouped_cell_fused(xp, nodes, mask, got, t, groups, ln)
+    # reference: the per-node kernel three times
+    x1, x2, x3 = (torch.full_like(xp, float('nan')) for _ in range(3))
+    s = [bool(mask >> i & 1) for i in range(6)]
+    hip.grouped_conv1d_fused(xp, *nodes[0][:2], [xp] if s[0] else [], x1, t, groups, *nodes[0][2:], ln, ln is not None, ln is not None and s[0])
+    hip.grouped_conv1d_fused(x1, *nodes[1][:2], ([xp] if s[1] else []) + ([x1] if s[2] else []), x2, t, groups, *nodes[1][2:],
+                             ln if s[1] else None, False, ln is not None and s[1])
+    hip.grouped_conv1d_fused(x2, *nodes[2][:2], ([xp] if s[3] else []) + ([x1] if s[4] else []) + ([x2] if s[5] else []), x3, t, groups,
+                             *nodes[2][2:], ln if s[3] else None, False, ln is not None and s[3])
+    assert torch.equal(got, x3)
+    assert torch.all(got[:, :, t:] == 0)
+
+
+def test_fused_cell_limits():
+    assert not hip.grouped_cell_fits(600, 4100, 100)          # > 4096 frames per workgroup
+    assert not hip.grouped_cell_fits(1200, 2048, 100)         # 2 * 12 * 2048 * 4 B > 160 KiB
+    assert hip.grouped_cell_fits(800, 1600, 100) and hip.grouped_cell_fits(600, 1000, 100)
+    x = torch.zeros(1, 24, 16, device=DEV)
+    w, bias = torch.zeros(24, 6, 3, device=DEV), torch.zeros(24, device=DEV)
+    with pytest.raises(hip.HipError, match='conv5'):
+        hip.grouped_cell_fused(x, [(w, bias, 3, 1)] * 3, 0, torch.empty_like(x), 16, 4)
