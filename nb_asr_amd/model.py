@@ -123,6 +123,18 @@ class ASRModel(nn.Module):
         taps = {}
         return self.forward(input, _taps=taps), taps
 
+    def forward_graph(self, input):
+        """Forward replayed from a captured HIP graph (one host call for ~350 kernel launches; re-captured when a
+        parameter changes).  The returned tensor is overwritten by the next ``forward_graph`` call on the same shape."""
+        _check_dropout(self)
+        if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES or not input.is_cuda:
+            raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor on a HIP device')
+        key = (input.shape[0], input.shape[2], input.device.index)
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = ForwardPlan(self, input.shape[0], input.shape[2], input.device)
+        return plan.run_graph(input.detach().contiguous())
+
     def forward_async(self, input):
         """Pipelined forward for back-to-back batches: the encoder runs on the current stream, the latency-bound
         LSTM + head on the plan's side stream, so the NEXT call's encoder overlaps with this call's LSTM.  Returns a

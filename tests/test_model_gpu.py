@@ -193,3 +193,17 @@ class TestConfig4Shape:
         truth = oracle.asr_forward(params, cases.ARCH_D, x[sel], use_rnn=True, dtype=torch.float64)
         noise = cases.worst_ratio(want, truth, 1e-4, 1e-5)
         assert cases.worst_ratio(y[sel], want, 1e-4, 1e-5) <= max(1.0, 2.5 * noise)
+
+
+def test_graph_replay_matches_eager_and_tracks_weight_updates():
+    """forward_graph replays the whole forward (~350 launches) from one captured HIP graph; it must agree bit-for-bit
+    with the eager path, follow new inputs, and be re-captured when a parameter changes."""
+    m = build(cases.ARCH_D, True, 'lively')
+    x1, x2 = keyed_input(2, 96, seed=1).to(DEV), keyed_input(2, 96, seed=2).to(DEV)
+    with torch.no_grad():
+        want1, want2 = m(x1).clone(), m(x2).clone()
+        assert torch.equal(m.forward_graph(x1), want1)
+        assert torch.equal(m.forward_graph(x2), want2)          # replay with new input contents
+        m.model[28].bias.add_(0.5)                               # in-place update bumps the parameter version
+        got = m.forward_graph(x1)
+        assert torch.equal(got, m(x1)) and not torch.equal(got, want1)
