@@ -207,3 +207,25 @@ def test_graph_replay_matches_eager_and_tracks_weight_updates():
         m.model[28].bias.add_(0.5)                               # in-place update bumps the parameter version
         got = m.forward_graph(x1)
         assert torch.equal(got, m(x1)) and not torch.equal(got, want1)
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_architectures_vs_oracle(seed):
+    """Architectures drawn from the whole search space (all six ops, any skip pattern), random batch / length, both heads:
+    HIP forward vs the CPU oracle with the usual noise-aware tolerance.  Exercises every node-op x skip x LayerNorm-deferral
+    combination the executor can route (grouped conv, linear, zero; deferred / materialised / epilogue statistics)."""
+    import random
+    rng = random.Random(1000 + seed)
+    arch = nb.get_random_architectures(1, seed=4000 + seed)[0]
+    use_rnn = bool(seed % 2)
+    b, t = rng.choice([1, 2, 3]), rng.choice([5, 31, 64, 97, 130, 201])
+    m = build(arch, use_rnn, 'lively', seed=500 + seed)
+    x = keyed_input(b, t, seed=seed)
+    params = {k: v.cpu() for k, v in m.state_dict().items()}
+    want = oracle.asr_forward(params, arch, x, use_rnn=use_rnn)
+    truth = oracle.asr_forward(params, arch, x, use_rnn=use_rnn, dtype=torch.float64)
+    with torch.no_grad():
+        got = m(x.to(DEV))
+    noise = cases.worst_ratio(want, truth, 1e-4, 1e-5)
+    ratio = cases.worst_ratio(got, want, 1e-4, 1e-5)
+    assert ratio <= max(1.0, 2.5 * noise), f'arch {arch} b={b} t={t} rnn={use_rnn}: err/tol {ratio:.2f}, fp32 noise floor {noise:.2f}'
