@@ -88,7 +88,9 @@ int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
  * split exactly into three bf16 terms and six cross products are accumulated in fp32 (dropped terms <= 2^-24 of a
  * product).  Weights are split and re-laid-out once per weight version:
  *   bytes = nbasr_packed_dense_weights_bytes(c_out, c_in, 8);  nbasr_pack_dense_weights(w, packed, ..., stride, ...);
- * then nbasr_dense_conv1d_fused_packed(...) takes `packed` in place of w (same arguments otherwise, kernel == 8).
+ * then nbasr_dense_conv1d_fused_packed(...) takes `packed` in place of w (same arguments otherwise, kernel == 8),
+ * except that x must follow the activation layout strictly: 16-byte aligned, ld_in a multiple of 4 and columns
+ * frames_in..ld_in-1 zero (the kernel fetches aligned 4-frame quads; nbasr_repitch brings a caller tensor into it).
  * The packed image depends on the stride of the convolution that will consume it (taps per K-step differ). */
 size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel);
 int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,

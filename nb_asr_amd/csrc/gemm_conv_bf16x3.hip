@@ -33,7 +33,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // tile, channels per group, conv taps
 constexpr int PB_THREADS = 512;                                              // 8 waves: 2 (rows) x 4 (frames), 64 x 64 each
 constexpr int PB_GROUP_BYTES = 3 * PB_TAPS * PB_M * PB_CI * 2;               // 98304: packed weights of one (row tile, channel group)
-constexpr int PB_STAGE_THREADS = 256;                                        // waves 0-3 stage the input tile (they have slack)
 __host__ __device__ constexpr int pb_taps_per_step(int stride) { return stride == 1 ? 4 : 2; }   // LDS budget: 160 KiB
 
 template <int S>
@@ -45,9 +44,12 @@ struct GeoP {
     static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
     static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
     static constexpr int X_BYTES = 3 * ROWS * PB_CI * 2;
-    static constexpr int XITEMS = XR * (PB_CI / 2);              // (frame, channel pair) items per group
+    // the tile is fetched as ALIGNED 4-frame quads (one global_load_dwordx4 per channel): NQUADS covers XR rows at any
+    // misalignment of the tile's first frame; an item = (quad, channel pair), 8 consecutive quads x 8 pairs per wave
+    static constexpr int NQUADS = ((XR + 3 + 3) / 4 + 7) / 8 * 8;
+    static constexpr int XITEMS = NQUADS * (PB_CI / 2);
     static constexpr int NCHUNK = QSTEPS - 1;                    // the next group's tile is staged in QSTEPS-1 chunks
-    static constexpr int XI = (XITEMS + PB_STAGE_THREADS * NCHUNK - 1) / (PB_STAGE_THREADS * NCHUNK);   // items per stager thread per chunk
+    static constexpr int XI = (XITEMS + PB_THREADS * NCHUNK - 1) / (PB_THREADS * NCHUNK);   // items per thread per chunk
     static constexpr int LDS_BYTES = 2 * A_STEP_BYTES + 2 * X_BYTES;   // weights and input tile both double-buffered
     __device__ static constexpr int rowmap(int row) { return (S == 1) ? row : (row & 1) * XRH + (row >> 1); }
 };
@@ -128,10 +130,12 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
-    // Waves 0-3 and 4-7 share the four SIMDs pairwise.  Measured with s_memtime stamps: the pair's older wave wins the
-    // matrix pipe, finishes its MFMAs early and then idles at the barrier while the younger one is the critical path.
-    // So the older half (waves 0-3) does ALL input staging (global loads, 3-way split, LDS writes) in its slack.
-    const bool stager = wave < PB_STAGE_THREADS / 64;
+    // Waves 0-3 and 4-7 share the four SIMDs pairwise and run the SAME K-step between two barriers.  Measured with
+    // s_memtime stamps: issuing the step's vector-memory work (6 x 1 KiB LDS-DMA pieces cost ~250 cycles each to issue,
+    // the tile gathers likewise) at the top of the step in every wave left the matrix pipe idle for ~1500 of ~9500 cycles.
+    // So the two halves run the step in OPPOSITE order: the older wave stages first and multiplies last, the younger one
+    // multiplies first and stages last -- each wave's memory phase sits beside its partner's MFMAs.
+    const bool older = wave < 4;
 
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * S - a.lpad;
@@ -169,22 +173,36 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
                 16, 0, 0);
         }
     };
-    float xreg[G::XI][2];
-    // stager waves only (tid < PB_STAGE_THREADS); chunk c of a group's tile = items [c*XI*256, (c+1)*XI*256)
+    typedef float floatx4 __attribute__((ext_vector_type(4)));
+    floatx4 xreg[G::XI][2];
+    // item e of a chunk: quad (e >> 6) * 8 + (e & 7) (frames a0 + 4 * quad .. + 3, a0 = tin0 rounded down to a multiple
+    // of 4), channel pair (e >> 3) & 7.  Quads are aligned, so each is wholly inside [0, ld_in) or wholly outside; the
+    // pitch columns frames_in..ld_in-1 are zero by the layout contract (nbasr.h) and their rstd is 0.
+    const int a0 = tin0 & ~3, xoff = tin0 - a0;
     auto load_x = [&](int g, int c) {
 #pragma unroll
         for (int i = 0; i < G::XI; ++i) {
-            const int e = tid + PB_STAGE_THREADS * (c * G::XI + i);
-            const int p = e & 7, row = e >> 3;
-            const int t = tin0 + row;
+            const int e = tid + PB_THREADS * (c * G::XI + i);
+            const int p = (e >> 3) & 7;
+            const int t = a0 + 4 * ((e >> 6) * 8 + (e & 7));
             const int ci = g * PB_CI + 2 * p;
-            const bool ok = e < G::XITEMS && t >= 0 && t < a.frames_in;
-            float v0 = (ok && ci < a.c_in) ? xb[static_cast<size_t>(ci) * a.ld_in + t] : 0.f;
-            float v1 = (ok && ci + 1 < a.c_in) ? xb[static_cast<size_t>(ci + 1) * a.ld_in + t] : 0.f;
+            const bool ok = e < G::XITEMS && t >= 0 && t < a.ld_in;
+            floatx4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+            if (ok && ci < a.c_in) v0 = *reinterpret_cast<const floatx4*>(xb + static_cast<size_t>(ci) * a.ld_in + t);
+            if (ok && ci + 1 < a.c_in) v1 = *reinterpret_cast<const floatx4*>(xb + static_cast<size_t>(ci + 1) * a.ld_in + t);
             if (LNX && ok) {
-                const float mean = xstats[t], rstd = xstats[a.ld_in + t];
-                if (ci < a.c_in) v0 = ln_apply(v0, mean, rstd, a.ln_x.gamma[ci], a.ln_x.beta[ci]);
-                if (ci + 1 < a.c_in) v1 = ln_apply(v1, mean, rstd, a.ln_x.gamma[ci + 1], a.ln_x.beta[ci + 1]);
+                const floatx4 mean = *reinterpret_cast<const floatx4*>(xstats + t);
+                const floatx4 rstd = *reinterpret_cast<const floatx4*>(xstats + a.ld_in + t);
+                if (ci < a.c_in) {
+                    const float gm = a.ln_x.gamma[ci], bt = a.ln_x.beta[ci];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v0[j] = ln_apply(v0[j], mean[j], rstd[j], gm, bt);
+                }
+                if (ci + 1 < a.c_in) {
+                    const float gm = a.ln_x.gamma[ci + 1], bt = a.ln_x.beta[ci + 1];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v1[j] = ln_apply(v1[j], mean[j], rstd[j], gm, bt);
+                }
             }
             xreg[i][0] = v0;
             xreg[i][1] = v1;
@@ -194,14 +212,20 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
         unsigned* const X = reinterpret_cast<unsigned*>(Xbase + xbuf * G::X_BYTES);
 #pragma unroll
         for (int i = 0; i < G::XI; ++i) {
-            const int e = tid + PB_STAGE_THREADS * (c * G::XI + i);
-            const int p = e & 7, row = e >> 3;
-            if (e < G::XITEMS) {
+            const int e = tid + PB_THREADS * (c * G::XI + i);
+            const int p = (e >> 3) & 7;
+            const int row0 = 4 * ((e >> 6) * 8 + (e & 7)) - xoff;
+            if (e >= G::XITEMS) continue;
+            // image [split][half][row][8 ci]: channel pair p sits in half p >> 2, dword p & 3 of the 16-byte row
+            unsigned* const col = X + (p >> 2) * G::ROWS * 4 + (p & 3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = row0 + j;
+                if (row < 0 || row >= G::XR) continue;
                 __bf16 s0[3], s1[3];
-                split3(xreg[i][0], s0[0], s0[1], s0[2]);
-                split3(xreg[i][1], s1[0], s1[1], s1[2]);
-                // image [split][half][row][8 ci]: channel pair p sits in half p >> 2, dword p & 3 of the 16-byte row
-                unsigned* dst = X + ((p >> 2) * G::ROWS + G::rowmap(row)) * 4 + (p & 3);
+                split3(xreg[i][0][j], s0[0], s0[1], s0[2]);
+                split3(xreg[i][1][j], s1[0], s1[1], s1[2]);
+                unsigned* dst = col + G::rowmap(row) * 4;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) dst[k * 2 * G::ROWS * 4] = pack2(s0[k], s1[k]);
             }
@@ -259,10 +283,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     //                 wait for the DMA (and the chunk loads), barrier
     const int ng = a.n_groups;
     dma_weights(0, 0);
-    if (stager) {
 #pragma unroll 1
-        for (int c = 0; c < G::NCHUNK; ++c) { load_x(0, c); commit_x(0, c); }
-    }
+    for (int c = 0; c < G::NCHUNK; ++c) { load_x(0, c); commit_x(0, c); }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -271,13 +293,23 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
         const bool more = g + 1 < ng;
 #pragma unroll 1
         for (int q = 0; q < QS; ++q, ++step) {
-            const bool stage = more && stager;
-            // stagers first retire the chunk they loaded during the previous step (their partner waves on the same SIMDs
-            // start their MFMAs meanwhile), then issue the next chunk's loads so they fly under this step's MFMAs
-            if (stage && q >= 1) commit_x((g + 1) & 1, q - 1);
-            if (stage && q < QS - 1) load_x(g + 1, q);
-            if (q + 1 < QS || more) dma_weights(step + 1, (step + 1) & 1);
+            const bool prefetch = q + 1 < QS || more;       // there is a next K-step: fetch its weights
+            const bool chunk = more && q < QS - 1;          // chunk q of the next group's input tile is staged in this step
+            if (older) {
+                // retire the chunk loaded during the previous step, issue this step's loads and the DMA, THEN the MFMAs:
+                // the SIMD partner (a younger wave) has the matrix pipe to itself meanwhile
+                if (more && q >= 1) commit_x((g + 1) & 1, q - 1);
+                if (chunk) load_x(g + 1, q);
+                if (prefetch) dma_weights(step + 1, (step + 1) & 1);
+            } else if (chunk) {
+                load_x(g + 1, q);                           // in flight under this wave's own MFMAs
+            }
             if (wave_active) mma_step(q, step & 1, g & 1);
+            if (!older) {
+                // younger waves stage AFTER their MFMAs, beside the older partner's MFMAs
+                if (chunk) commit_x((g + 1) & 1, q);
+                if (prefetch) dma_weights(step + 1, (step + 1) & 1);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's weight DMA has landed (this wave's part)
             __syncthreads();               // ... every wave's part, the new input tile is written, this step's reads are done
         }
@@ -369,11 +401,12 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
                   "nbasr_dense_conv1d_fused_packed: (kernel=%d, stride=%d) unsupported; packed path covers k=8, s in {1,2}", kernel, stride);
     const int frames_out = (frames_in + stride - 1) / stride;
     NBASR_REQUIRE(ld_in >= frames_in, NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: ld_in=%d < frames_in=%d", ld_in, frames_in);
+    NBASR_REQUIRE(ld_in % 4 == 0, NBASR_EALIGN, "nbasr_dense_conv1d_fused_packed: ld_in=%d must be a multiple of 4", ld_in);
     NBASR_REQUIRE(ld_out >= frames_out && ld_out % 4 == 0, NBASR_EALIGN,
                   "nbasr_dense_conv1d_fused_packed: ld_out=%d must be >= %d output frames and a multiple of 4", ld_out, frames_out);
     if (batch == 0 || frames_out == 0) return NBASR_OK;
     NBASR_REQUIRE(x && packed_w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed: x, packed_w, bias, y must be non-NULL");
-    NBASR_REQUIRE(aligned16(packed_w), NBASR_EALIGN, "nbasr_dense_conv1d_fused_packed: packed weights must be 16-byte aligned");
+    NBASR_REQUIRE(aligned16(packed_w) && aligned16(x), NBASR_EALIGN, "nbasr_dense_conv1d_fused_packed: x and packed weights must be 16-byte aligned");
     PackedConvArgs a{};
     a.x = x; a.wp = static_cast<const unsigned char*>(packed_w); a.bias = bias; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
     a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;

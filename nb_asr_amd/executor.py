@@ -228,6 +228,10 @@ class ForwardPlan:
             raise hip.HipError(f'input must be float32 (got {x.dtype})')
         x = x.detach().contiguous()
         act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
+        if self.dense_mode == 'bf16x3' and (x.shape[-1] % 4 or x.data_ptr() % 16):
+            # the packed dense conv fetches aligned 4-frame quads: bring a ragged-length input into the pitched layout
+            cur = 2
+            act = hip.repitch(x, self._view(cur, x.shape[1], self.frames), self.frames)
         pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
         pipe = bool(pipelined) and model.use_rnn and taps is None
         pipe_k, tail_ctx = None, None

@@ -119,7 +119,7 @@ def dense_packed(x, w, bias, stride):
     t_out = (t + stride - 1) // stride
     y = torch.full((b, w.shape[0], hip.round_up4(t_out)), float('nan'), device=DEV)
     packed = hip.pack_dense_weights(w.to(DEV), stride)
-    hip.dense_conv1d_fused_packed(x.to(DEV).contiguous(), t, packed, w.shape[0], 8, bias.to(DEV), (), y, stride)
+    hip.dense_conv1d_fused_packed(pitched(x)[0], t, packed, w.shape[0], 8, bias.to(DEV), (), y, stride)
     assert torch.all(y[:, :, t_out:] == 0)
     return y[:, :, :t_out]
 

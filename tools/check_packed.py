@@ -21,7 +21,9 @@ def run(cin, cout, tin, s, b, time_it):
     w = torch.randn(cout, cin, 8) * (2.0 / (cin * 8)) ** 0.5
     bias = torch.randn(cout) * 0.1
     tout = (tin + s - 1) // s
-    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    xd = torch.zeros(b, cin, hip.round_up4(tin), device=DEV)
+    xd[:, :, :tin] = x.to(DEV)
+    wd, bd = w.to(DEV), bias.to(DEV)
     y32 = torch.full((b, cout, hip.round_up4(tout)), float('nan'), device=DEV)
     y16 = torch.full_like(y32, float('nan'))
     hip.dense_conv1d_fused(xd, tin, wd, bd, (), y32, s)
