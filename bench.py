@@ -262,7 +262,7 @@ def roofline_leg(model, x, args):
         if plan.dense_mode == 'bf16x3':
             # fp32-accurate 3-way bf16 split: six bf16 MFMA products are issued per algorithmic fp32 product
             issued = 6.0 * algorithmic
-            out['roofline_mfma'] = {'kernel': 'gemm_conv_bf16x3_kernel<S> (dense k=8 conv, 6 x v_mfma_f32_32x32x16_bf16 per fp32 product)',
+            out['roofline_mfma'] = {'kernel': 'gemm_conv_bf16x3_kernel<S> (dense k=8 conv, 6 x v_mfma_f32_16x16x32_bf16 per fp32 product)',
                                     'bound': 'mfma', 'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA issued)',
                                     'frac': issued / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
                                     'algorithmic_fp32_TFLOPs': algorithmic, 'vs_fp32_mfma_peak': algorithmic / FP32_MFMA_PEAK_TFLOPS,

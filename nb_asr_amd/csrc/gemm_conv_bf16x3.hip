@@ -1,5 +1,6 @@
 // Dense k=8 PadConvRelu (reference model.py:82-89, ops.py:24-30) as an fp32-ACCURATE implicit GEMM on the bf16
-// matrix cores of gfx950 (v_mfma_f32_32x32x16_bf16, 16x the rate of the fp32 MFMA).
+// matrix cores of gfx950 (v_mfma_f32_16x16x32_bf16, 16x the rate of the fp32 MFMA; the 16x16x32 shape holds a higher clock
+// than 32x32x16 under the chip's power management: +7-11 % measured on these layers at equal cycles per flop).
 //
 // Every fp32 operand is split EXACTLY into three bf16 terms  v = hi + mid + lo  (hi = rne(v), mid = rne(v - hi),
 // lo = rne(v - hi - mid): 3 x 8 significand bits cover fp32's 24) and the product is evaluated as the six terms
@@ -8,19 +9,20 @@
 // bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so the result carries fp32-level error
 // (checked against an fp64 oracle in tests/).  6 MFMAs at 16x the rate = 2.67x the fp32 matrix peak.
 //
-// GEMM view per utterance: M = c_out, N = output frames, K = (c_in, tap).  Since an MFMA sums 16 consecutive k that
-// must sit in one lane's registers, k runs over 16 input CHANNELS for a fixed tap:
+// GEMM view per utterance: M = c_out, N = output frames, K = (c_in, tap).  The 32 k of one MFMA are 16 input CHANNELS of
+// TWO consecutive taps (a lane holds 8 consecutive k = 8 channels of one tap):
 //     D[co][t] += sum_{ci<16} W[co][g*16+ci][tap] * x[g*16+ci][t*stride + tap - lpad]      for every (group g, tap)
 //  * weights are split and re-laid-out ONCE (nbasr_pack_dense_weights) into the exact LDS image of each
 //    (row tile, channel group, tap quad): [split][tap][ci half][128 rows][8 ci] bf16 = 48 KiB, so a K-step's weights are a
 //    straight 48 KiB copy done by LDS-DMA (global_load_lds_dwordx4, no VGPRs), double-buffered;
-//  * the input tile of a channel group is converted/split on the fly and stored TRANSPOSED [ci half][frame][8 ci] so a
-//    B fragment (8 consecutive channels of one frame) is one aligned, bank-conflict-free ds_read_b128; it is staged once per group and
-//    reused by all 8 taps (sliding window resolved by the row index; stride-2 rows are de-interleaved by parity so
-//    the 32 lanes of a fragment read hit consecutive rows);
-//  * one 512-thread workgroup per CU: 128 x 256 tile / 8 waves (2 x 4, 64 x 64 each), K-step = 16 channels x 4 taps =
-//    96 MFMAs per wave, one barrier per step; the hi*hi products accumulate in their own register set, so the large
-//    running sum is rounded once per 16 k (the chain length of a 16-way blocked fp32 summation).
+//  * the input tile of a channel group is fetched as aligned 4-frame quads, split on the fly and stored TRANSPOSED
+//    [ci half][frame][8 ci] so a B fragment (8 consecutive channels of one frame) is one aligned, bank-conflict-free
+//    ds_read_b128; it is staged once per group and reused by all 8 taps (sliding window resolved by the row index;
+//    stride-2 rows are de-interleaved by parity so the 16 lanes of a fragment read hit consecutive rows);
+//  * one 512-thread workgroup per CU: 128 x 256 tile / 8 waves (2 x 4, 64 x 64 each = 4 x 4 MFMA tiles), K-step =
+//    16 channels x 4 taps (2 for stride 2), one barrier per step; the two halves of the workgroup run a step in opposite
+//    order (stage-then-multiply / multiply-then-stage) so a wave's memory phase sits beside its SIMD partner's MFMAs;
+//  * the hi*hi products accumulate in their own register set, so the large running sum is rounded once per 32 k.
 #include "common.h"
 
 #include <type_traits>
@@ -28,6 +30,7 @@
 namespace nbasr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // tile, channels per group, conv taps
@@ -128,7 +131,6 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
     // Waves 0-3 and 4-7 share the four SIMDs pairwise and run the SAME K-step between two barriers.  Measured with
     // s_memtime stamps: issuing the step's vector-memory work (6 x 1 KiB LDS-DMA pieces cost ~250 cycles each to issue,
@@ -142,23 +144,18 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     const float* __restrict__ xstats = LNX ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
     const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_GROUP_BYTES;
 
-    bool mval[2], nval[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        mval[i] = (m0 + wm * 64 + i * 32) < a.c_out;
-        nval[i] = (n0 + wn * 64 + i * 32) < a.ld_out;
-    }
-    const bool wave_active = mval[0] && nval[0];      // a wave whose whole 64 x 64 tile is out of range issues no MFMAs
+    // a wave whose whole 64 x 64 tile is out of range issues no MFMAs
+    const bool wave_active = (m0 + wm * 64) < a.c_out && (n0 + wn * 64) < a.ld_out;
 
     // two accumulator sets: `big` only ever receives hi*hi (ONE rounding of the large running sum per 16 k, the
     // accumulation-chain length of a 16-way blocked fp32 sum); the five small cross terms go to `small`
-    floatx16 big[2][2], small[2][2];
+    floatx4 big[4][4], small[4][4];                   // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { big[i][j][r] = 0.f; small[i][j][r] = 0.f; }
+            for (int r = 0; r < 4; ++r) { big[i][j][r] = 0.f; small[i][j][r] = 0.f; }
 
     // ---- staging helpers ---------------------------------------------------------------------------------------
     // weights of K-step `step` (index within this row tile) -> Abuf[buf] by LDS-DMA, ASTEP/1 KiB wave copies
@@ -173,7 +170,6 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
                 16, 0, 0);
         }
     };
-    typedef float floatx4 __attribute__((ext_vector_type(4)));
     floatx4 xreg[G::XI][2];
     // item e of a chunk: quad (e >> 6) * 8 + (e & 7) (frames a0 + 4 * quad .. + 3, a0 = tin0 rounded down to a multiple
     // of 4), channel pair (e >> 3) & 7.  Quads are aligned, so each is wholly inside [0, ld_in) or wholly outside; the
@@ -232,47 +228,46 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
         }
     };
 
-    // per-lane fragment bases (bytes)
-    // both LDS images are HALF-major ([half][row][8 channels], 16-byte rows): the 16 lanes of a ds_read_b128 group then
-    // cover 256 contiguous bytes = all 64 banks (a 32-byte row pitch makes every group hit only the even 16-byte slots)
-    const int a_lane = (half * PB_M + wm * 64 + l31) * 16;
-    const int x_lane = half * G::ROWS * 16;
+    // per-lane fragment bases (bytes).  v_mfma_f32_16x16x32_bf16: lane l supplies row/column l & 15 and k = 8 * (l >> 4) ..
+    // + 7; the 32 k of one MFMA are the 16 channels of TWO consecutive taps: k quarter kq = l >> 4 -> tap kq >> 1 of the
+    // pair, channel half kq & 1.  Both LDS images are [..][tap][half][row][8 channels] with 16-byte rows, so the 16 lanes
+    // of a quarter read 256 contiguous bytes (all 64 banks) and a fragment is one ds_read_b128.
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int a_lane = (((kq >> 1) * 2 + (kq & 1)) * PB_M + wm * 64 + l15) * 16;
+    const int x_lane = (kq & 1) * G::ROWS * 16;
 
     auto mma_step = [&](int q, int abuf, int xbuf) {
         const unsigned char* A = Abuf + abuf * ASTEP + a_lane;
         const unsigned char* X = Xbase + xbuf * G::X_BYTES + x_lane;
-        // NOT unrolled: hoisting the fragment reads of all taps above the first MFMA costs 192 VGPRs (spills), and
-        // double-buffering the fragments by hand (+48 VGPRs) spills too and measured slower; per tap 12 x ds_read_b128
-        // are issued, then 24 MFMAs start as their operands arrive (counted lgkmcnt); the SIMD's other wave covers
 #pragma unroll 1
-        for (int tp = 0; tp < TP; ++tp) {
-            const int tap = q * TP + tp;
-            bf16x8 af[2][3], bfr[2][3];
+        for (int pp = 0; pp < TP / 2; ++pp) {
+            const int tap = q * TP + 2 * pp + (kq >> 1);
+            bf16x8 bfr[4][3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    af[i][k] = *reinterpret_cast<const bf16x8*>(A + ((k * TP + tp) * 2 * PB_M + i * 32) * 16);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int row = G::rowmap((wn * 64 + j * 32 + l31) * S + tap);
+            for (int j = 0; j < 4; ++j) {
+                const int row = G::rowmap((wn * 64 + j * 16 + l15) * S + tap);
 #pragma unroll
                 for (int k = 0; k < 3; ++k)
                     bfr[j][k] = *reinterpret_cast<const bf16x8*>(X + (k * 2 * G::ROWS + row) * 16);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i) {
+                bf16x8 af[3];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    floatx16 c = small[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], c, 0, 0, 0);   // lo * hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], c, 0, 0, 0);   // hi * lo
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], c, 0, 0, 0);   // mid * mid
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], c, 0, 0, 0);   // mid * hi
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], c, 0, 0, 0);   // hi * mid
+                for (int k = 0; k < 3; ++k)
+                    af[k] = *reinterpret_cast<const bf16x8*>(A + ((k * TP + 2 * pp) * 2 * PB_M + i * 16) * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    floatx4 c = small[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[j][0], c, 0, 0, 0);   // lo * hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[j][2], c, 0, 0, 0);   // hi * lo
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[j][1], c, 0, 0, 0);   // mid * mid
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[j][0], c, 0, 0, 0);   // mid * hi
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[j][1], c, 0, 0, 0);   // hi * mid
                     small[i][j] = c;
-                    big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], big[i][j], 0, 0, 0);   // hi * hi
+                    big[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[j][0], big[i][j], 0, 0, 0);   // hi * hi
                 }
+            }
         }
     };
 
@@ -315,19 +310,18 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
         }
     }
 
-    // ---- epilogue: bias + ReLU + min(20) (+ skips), rows of 32 frames per store ------------------------------
+    // ---- epilogue: bias + ReLU + min(20) (+ skips); a store covers 4 rows x 16 consecutive frames -----------------
+    if (!wave_active) return;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (!(mval[i] && nval[j])) continue;
-            const int mb = m0 + wm * 64 + i * 32;
-            const int n = n0 + wn * 64 + j * 32 + l31;
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l15;
             if (n >= a.ld_out) continue;
             const bool live = n < a.frames_out;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2) + 4 * half;
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + kq * 4 + r;
                 if (m >= a.c_out) continue;
                 float v = relu_clamp((big[i][j][r] + small[i][j][r]) + a.bias[m]);
                 const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
