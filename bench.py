@@ -259,11 +259,18 @@ def roofline_leg(model, x, args):
         per_layer[f'conv_{blk}_{c_in}x{c_out}_T{frames_out}'] = {'algorithmic_TFLOPs': f * n / (ms * 1e-3) / 1e12, 'us_per_launch': 1e3 * ms / n}
     if tot_ms:
         algorithmic = tot_flops / (tot_ms * 1e-3) / 1e12
-        if plan.dense_mode == 'bf16x3':
-            # fp32-accurate 3-way bf16 split: six bf16 MFMA products are issued per algorithmic fp32 product
-            issued = 6.0 * algorithmic
-            out['roofline_mfma'] = {'kernel': 'gemm_conv_bf16x3_kernel<S> (dense k=8 conv, 6 x v_mfma_f32_16x16x32_bf16 per fp32 product)',
-                                    'bound': 'mfma', 'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA issued)',
+        if plan.dense_mode != 'f32':
+            # fp32-accurate operand splitting: 6 bf16 MFMA products (3-way bf16 split) or 3 fp16 MFMA products (2-way fp16
+            # split) are issued per algorithmic fp32 product; bf16 and fp16 MFMAs have the same dense peak
+            issued_flops = 0.0
+            for (kind, meta), (ms, n) in agg.items():
+                if kind == 'dense_conv':
+                    scheme = plan.dense_schemes.get(meta[0], 'bf16x3')
+                    per_layer[f'conv_{meta[0]}_{meta[1]}x{meta[2]}_T{meta[4]}']['scheme'] = scheme
+                    issued_flops += (3.0 if scheme == 'f16x2' else 6.0) * dense_conv_flops(args.batch, meta[1], meta[2], meta[3], meta[4]) * n
+            issued = issued_flops / (tot_ms * 1e-3) / 1e12
+            out['roofline_mfma'] = {'kernel': 'gemm_conv_split_kernel<P,S> (dense k=8 conv on v_mfma_f32_16x16x32_{f16,bf16}: 3 fp16 or 6 bf16 products per fp32 product)',
+                                    'bound': 'mfma', 'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (16-bit MFMA issued)',
                                     'frac': issued / BF16_MFMA_PEAK_TFLOPS, 'traffic': None,
                                     'algorithmic_fp32_TFLOPs': algorithmic, 'vs_fp32_mfma_peak': algorithmic / FP32_MFMA_PEAK_TFLOPS,
                                     'per_layer': per_layer}

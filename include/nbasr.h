@@ -72,6 +72,11 @@ int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, f
 int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y,
                              int batch, int channels, int frames, int ld, float eps,
                              nbasr_stream_t stream);
+/* The same, and absmax[b] = max |y[b, :, :]| (device pointer, `batch` floats, overwritten): the range information the
+ * 2-way fp16 dense convolution below needs, produced while the normalised tensor is being written. */
+int nbasr_layernorm_channels_absmax(const float* x, const float* gamma, const float* beta, float* y, float* absmax,
+                                    int batch, int channels, int frames, int ld, float eps,
+                                    nbasr_stream_t stream);
 
 /* Dense PadConvRelu (groups = 1) on the fp32 matrix cores, fused bias + relu + clamp (+ skips):
  *   kernel == 8: the four downsample convs (reference model.py:82-89, ops.py:24-30), stride 1|2;
@@ -99,6 +104,23 @@ int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const 
                                     const float* skip0, const float* skip1, const float* skip2,
                                     float* y, int batch, int c_in, int frames_in, int ld_in,
                                     int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
+
+/* The same convolution with HALF the matrix instructions: operands are split into two fp16 terms, v = hi + lo' 2^-11
+ * (11 + 11 significand bits plus the rounding sign cover fp32's 24; the residual is stored pre-scaled so that it stays a
+ * normal fp16 number) and three cross products are accumulated in fp32 (dropped term <= 2^-24 of a product).
+ * fp16's narrow exponent range is handled by exact power-of-two scalings that the epilogue undoes: each weight row is
+ * normalised at pack time, and each utterance of x by 2^k derived from x_absmax[b], a caller-supplied UPPER BOUND of
+ * max|x[b, :, :]| (device pointer, `batch` floats, finite; nbasr_layernorm_channels_absmax writes it as a by-product).
+ * A bound that is too small makes fp16 overflow possible (undefined results); a loose bound only costs precision of
+ * elements more than 2^-29 below it.  Otherwise same arguments, layout contract and error behaviour as the bf16 entry
+ * points; the packed images are NOT interchangeable between the two schemes. */
+size_t nbasr_packed_dense_weights_bytes_f16(int c_out, int c_in, int kernel);
+int nbasr_pack_dense_weights_f16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
+                                 nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_f16(const float* x, const float* x_absmax, const void* packed_w, const float* bias,
+                                        const float* skip0, const float* skip1, const float* skip2,
+                                        float* y, int batch, int c_in, int frames_in, int ld_in,
+                                        int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
 
 /* nn.LSTM(input_size=c_in, hidden_size=hidden, batch_first) forward with zero initial state
  * (reference model.py:100 and 118-121): gates i,f,g,o; biases b_ih + b_hh.

@@ -9,6 +9,20 @@
 // bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so the result carries fp32-level error
 // (checked against an fp64 oracle in tests/).  6 MFMAs at 16x the rate = 2.67x the fp32 matrix peak.
 //
+// Second scheme, HALF the MFMAs (policy SplitF16x2): fp16 carries 11 significand bits, so TWO terms suffice,
+//     v = hi + lo' * 2^-11,   hi = rne16(v),   lo' = rne16((v - hi) * 2^11)      |v - hi - lo' 2^-11| <= 2^-24 |v|
+// (the residual is pre-scaled by 2^11 so it stays a NORMAL fp16 number; fp16 subnormal inputs are honoured by the MFMA
+// -- tools/ubench/mfma_f16_denorm.hip -- so tiny operands only lose bits below 2^-36 absolute), and
+//     a*b ~= ah*bh + 2^-11 (ah*bl' + al'*bh)            dropped: al*bl <= 2^-24 |a*b|
+// i.e. 3 MFMAs per fp32 product (5.3x the fp32 matrix peak).  fp16's RANGE (6e-5 .. 65504 for normal numbers) is the
+// catch, and the model's activations really do leave it (with the reference's default initialisation they shrink to 1e-9).
+// Both operands are therefore brought into range by EXACT power-of-two scalings that the epilogue undoes:
+//   * x of utterance b is multiplied by 2^kx[b] so that its largest magnitude lands in [2^14, 2^15); the caller passes
+//     absmax[b] >= max|x[b]| (nbasr_layernorm_channels_absmax produces it for free while writing x);
+//   * row co of w is multiplied by 2^kw[co] at pack time (largest magnitude of the row -> [2^13, 2^14)).
+// Elements down to 2^-29 of their utterance's / row's maximum keep full precision; smaller ones are off by at most
+// 2^-51 of that maximum, far below fp32 resolution of any sum they enter.
+//
 // GEMM view per utterance: M = c_out, N = output frames, K = (c_in, tap).  The 32 k of one MFMA are 16 input CHANNELS of
 // TWO consecutive taps (a lane holds 8 consecutive k = 8 channels of one tap):
 //     D[co][t] += sum_{ci<16} W[co][g*16+ci][tap] * x[g*16+ci][t*stride + tap - lpad]      for every (group g, tap)
@@ -29,24 +43,62 @@
 
 namespace nbasr {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // tile, channels per group, conv taps
 constexpr int PB_THREADS = 512;                                              // 8 waves: 2 (rows) x 4 (frames), 64 x 64 each
-constexpr int PB_GROUP_BYTES = 3 * PB_TAPS * PB_M * PB_CI * 2;               // 98304: packed weights of one (row tile, channel group)
-__host__ __device__ constexpr int pb_taps_per_step(int stride) { return stride == 1 ? 4 : 2; }   // LDS budget: 160 KiB
 
-template <int S>
+// ---- the two operand-splitting schemes ---------------------------------------------------------------------------
+struct SplitBf16x3 {
+    static constexpr int NS = 3;
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    static constexpr float SMALL_SCALE = 1.f;
+    static constexpr bool SCALED = false;                        // bf16 has fp32's exponent range
+    __host__ __device__ static constexpr int taps_per_step(int stride) { return stride == 1 ? 4 : 2; }   // LDS budget: 160 KiB
+    __device__ static __forceinline__ void split(float v, unsigned short (&s)[NS]) {
+        const __bf16 hi = static_cast<__bf16>(v);
+        const float r1 = v - static_cast<float>(hi);
+        const __bf16 mid = static_cast<__bf16>(r1);
+        const __bf16 lo = static_cast<__bf16>(r1 - static_cast<float>(mid));
+        s[0] = __builtin_bit_cast(unsigned short, hi);
+        s[1] = __builtin_bit_cast(unsigned short, mid);
+        s[2] = __builtin_bit_cast(unsigned short, lo);
+    }
+    __device__ static __forceinline__ floatx4 mfma(vec8 a, vec8 b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static constexpr const char* NAME = "nbasr_dense_conv1d_fused_packed";
+};
+
+struct SplitF16x2 {
+    static constexpr int NS = 2;
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    static constexpr float SMALL_SCALE = 1.f / 2048.f;           // the cross terms carry lo' = lo * 2^11
+    static constexpr bool SCALED = true;                         // operands are range-normalised by powers of two
+    __host__ __device__ static constexpr int taps_per_step(int) { return 4; }
+    __device__ static __forceinline__ void split(float v, unsigned short (&s)[NS]) {
+        const _Float16 hi = static_cast<_Float16>(v);
+        const _Float16 lo = static_cast<_Float16>((v - static_cast<float>(hi)) * 2048.f);
+        s[0] = __builtin_bit_cast(unsigned short, hi);
+        s[1] = __builtin_bit_cast(unsigned short, lo);
+    }
+    __device__ static __forceinline__ floatx4 mfma(vec8 a, vec8 b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    static constexpr const char* NAME = "nbasr_dense_conv1d_fused_packed_f16";
+};
+
+template <class P> constexpr int pb_group_bytes() { return P::NS * PB_TAPS * PB_M * PB_CI * 2; }   // packed weights of one (row tile, channel group)
+
+template <class P, int S>
 struct GeoP {
-    static constexpr int TP = pb_taps_per_step(S);               // taps per K-step
+    static constexpr int TP = P::taps_per_step(S);               // taps per K-step
     static constexpr int QSTEPS = PB_TAPS / TP;                  // K-steps per channel group
-    static constexpr int A_STEP_BYTES = 3 * TP * PB_M * PB_CI * 2;
+    static constexpr int A_STEP_BYTES = P::NS * TP * PB_M * PB_CI * 2;
     static constexpr int XR = (PB_N - 1) * S + PB_TAPS;          // input frames needed per channel
     static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
     static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
-    static constexpr int X_BYTES = 3 * ROWS * PB_CI * 2;
+    static constexpr int X_BYTES = P::NS * ROWS * PB_CI * 2;
     // the tile is fetched as ALIGNED 4-frame quads (one global_load_dwordx4 per channel): NQUADS covers XR rows at any
     // misalignment of the tile's first frame; an item = (quad, channel pair), 8 consecutive quads x 8 pairs per wave
     static constexpr int NQUADS = ((XR + 3 + 3) / 4 + 7) / 8 * 8;
@@ -64,25 +116,54 @@ struct PackedConvArgs {
     int c_in, frames_in, ld_in, c_out, frames_out, ld_out, lpad;
     int n_groups, n_mt, n_nt, batch;
     LnRef ln_x;                  // pending LayerNorm of the input (deferred normalisation, nbasr.h)
+    const float* x_absmax;       // SCALED schemes: (batch) upper bounds of max|x[b]|
+    const float* w_inv_scale;    // SCALED schemes: (n_mt * 128) 2^-kw[co], tail of the packed buffer
 };
 
-__device__ __forceinline__ void split3(float v, __bf16& hi, __bf16& mid, __bf16& lo) {
-    hi = static_cast<__bf16>(v);
-    const float r1 = v - static_cast<float>(hi);
-    mid = static_cast<__bf16>(r1);
-    const float r2 = r1 - static_cast<float>(mid);
-    lo = static_cast<__bf16>(r2);
+// 2^k that moves a magnitude with biased exponent field e to [2^target, 2^(target+1)), and its inverse; (1, 1) for zero
+__host__ __device__ inline void pow2_normaliser(float absmax, int target, float& scale, float& inv)
+{
+    unsigned bits;
+    __builtin_memcpy(&bits, &absmax, 4);
+    const int e = static_cast<int>((bits >> 23) & 0xffu);
+    int k = (bits & 0x7fffffffu) ? (127 + target) - e : 0;
+    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    const unsigned sb = static_cast<unsigned>(127 + k) << 23, ib = static_cast<unsigned>(127 - k) << 23;
+    __builtin_memcpy(&scale, &sb, 4);
+    __builtin_memcpy(&inv, &ib, 4);
 }
 
-__device__ __forceinline__ unsigned pack2(__bf16 a, __bf16 b) {
-    return static_cast<unsigned>(__builtin_bit_cast(unsigned short, a)) |
-           (static_cast<unsigned>(__builtin_bit_cast(unsigned short, b)) << 16);
+__device__ __forceinline__ unsigned pack2(unsigned short a, unsigned short b) {
+    return static_cast<unsigned>(a) | (static_cast<unsigned>(b) << 16);
 }
 
 // ---- one-time weight split + re-layout -------------------------------------------------------------------------
 // packed element (mt, g, q, split, tp, half = ci_l/8, co_l, ci_l%8) <- W[mt*128 + co_l][g*16 + ci_l][q*TP + tp]  (zero outside);
-// TP = taps per K-step of the kernel that will consume the image (4 for stride 1, 2 for stride 2)
-__global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __restrict__ w, __bf16* __restrict__ wp,
+// TP = taps per K-step of the kernel that will consume the image
+// SCALED schemes: scales[co] = 2^kw[co], scales[rows + co] = 2^-kw[co]   (rows = n_mt * 128; rows beyond c_out: 1)
+__global__ __launch_bounds__(256) void weight_row_scales_kernel(const float* __restrict__ w, float* __restrict__ scales,
+                                                                int c_out, int row_elems, int rows)
+{
+    __shared__ float s_max[4];
+    const int co = blockIdx.x;
+    float m = 0.f;
+    if (co < c_out)
+        for (int i = threadIdx.x; i < row_elems; i += 256) m = fmaxf(m, fabsf(w[static_cast<size_t>(co) * row_elems + i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float scale, inv;
+        pow2_normaliser(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), 13, scale, inv);
+        scales[co] = scale;
+        scales[rows + co] = inv;
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                                                 const float* __restrict__ row_scale,
                                                                  int c_out, int c_in, int n_mt, int n_groups, int PB_TP)
 {
     const int PB_QSTEPS = PB_TAPS / PB_TP;
@@ -97,21 +178,23 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
         const int g = e % n_groups; e /= n_groups;
         const int mt = static_cast<int>(e);
         const int co = mt * PB_M + co_l, ci = g * PB_CI + ci_l, tap = q * PB_TP + tp;
-        const float v = (co < c_out && ci < c_in) ? w[(static_cast<size_t>(co) * c_in + ci) * PB_TAPS + tap] : 0.f;
-        __bf16 s[3];
-        split3(v, s[0], s[1], s[2]);
+        float v = (co < c_out && ci < c_in) ? w[(static_cast<size_t>(co) * c_in + ci) * PB_TAPS + tap] : 0.f;
+        if (P::SCALED) v *= row_scale[co];
+        unsigned short s[P::NS];
+        P::split(v, s);
         const size_t step = (static_cast<size_t>(mt) * n_groups + g) * PB_QSTEPS + q;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            wp[((((step * 3 + k) * PB_TP + tp) * 2 + (ci_l >> 3)) * PB_M + co_l) * 8 + (ci_l & 7)] = s[k];
+        for (int k = 0; k < P::NS; ++k)
+            wp[((((step * P::NS + k) * PB_TP + tp) * 2 + (ci_l >> 3)) * PB_M + co_l) * 8 + (ci_l & 7)] = s[k];
     }
 }
 
 // ---- the GEMM -----------------------------------------------------------------------------------------------------
-template <int S, bool LNX>
-__global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const PackedConvArgs a)
+template <class P, int S, bool LNX>
+__global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const PackedConvArgs a)
 {
-    using G = GeoP<S>;
+    using G = GeoP<P, S>;
+    using vec8 = typename P::vec8;
     constexpr int TP = G::TP, QS = G::QSTEPS, ASTEP = G::A_STEP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const Abuf = smem;                       // [2][ASTEP]    weights of the current / next K-step
@@ -142,13 +225,13 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * S - a.lpad;
     const float* __restrict__ xstats = LNX ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
-    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * PB_GROUP_BYTES;
+    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * pb_group_bytes<P>();
 
     // a wave whose whole 64 x 64 tile is out of range issues no MFMAs
     const bool wave_active = (m0 + wm * 64) < a.c_out && (n0 + wn * 64) < a.ld_out;
 
-    // two accumulator sets: `big` only ever receives hi*hi (ONE rounding of the large running sum per 16 k, the
-    // accumulation-chain length of a 16-way blocked fp32 sum); the five small cross terms go to `small`
+    // two accumulator sets: `big` only ever receives hi*hi (ONE rounding of the large running sum per 32 k, the
+    // accumulation-chain length of a blocked fp32 sum); the small cross terms go to `small`
     floatx4 big[4][4], small[4][4];                   // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -175,6 +258,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     // of 4), channel pair (e >> 3) & 7.  Quads are aligned, so each is wholly inside [0, ld_in) or wholly outside; the
     // pitch columns frames_in..ld_in-1 are zero by the layout contract (nbasr.h) and their rstd is 0.
     const int a0 = tin0 & ~3, xoff = tin0 - a0;
+    float x_scale = 1.f, x_inv = 1.f;                 // SCALED schemes: 2^kx[b] and its inverse (uniform over the workgroup)
+    if constexpr (P::SCALED) pow2_normaliser(a.x_absmax[b], 14, x_scale, x_inv);
     auto load_x = [&](int g, int c) {
 #pragma unroll
         for (int i = 0; i < G::XI; ++i) {
@@ -200,6 +285,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
                     for (int j = 0; j < 4; ++j) v1[j] = ln_apply(v1[j], mean[j], rstd[j], gm, bt);
                 }
             }
+            if constexpr (P::SCALED) { v0 *= x_scale; v1 *= x_scale; }
             xreg[i][0] = v0;
             xreg[i][1] = v1;
         }
@@ -218,12 +304,12 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             for (int j = 0; j < 4; ++j) {
                 const int row = row0 + j;
                 if (row < 0 || row >= G::XR) continue;
-                __bf16 s0[3], s1[3];
-                split3(xreg[i][0][j], s0[0], s0[1], s0[2]);
-                split3(xreg[i][1][j], s1[0], s1[1], s1[2]);
+                unsigned short s0[P::NS], s1[P::NS];
+                P::split(xreg[i][0][j], s0);
+                P::split(xreg[i][1][j], s1);
                 unsigned* dst = col + G::rowmap(row) * 4;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dst[k * 2 * G::ROWS * 4] = pack2(s0[k], s1[k]);
+                for (int k = 0; k < P::NS; ++k) dst[k * 2 * G::ROWS * 4] = pack2(s0[k], s1[k]);
             }
         }
     };
@@ -242,30 +328,32 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
 #pragma unroll 1
         for (int pp = 0; pp < TP / 2; ++pp) {
             const int tap = q * TP + 2 * pp + (kq >> 1);
-            bf16x8 bfr[4][3];
+            vec8 bfr[4][P::NS];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = G::rowmap((wn * 64 + j * 16 + l15) * S + tap);
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    bfr[j][k] = *reinterpret_cast<const bf16x8*>(X + (k * 2 * G::ROWS + row) * 16);
+                for (int k = 0; k < P::NS; ++k)
+                    bfr[j][k] = *reinterpret_cast<const vec8*>(X + (k * 2 * G::ROWS + row) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                bf16x8 af[3];
+                vec8 af[P::NS];
 #pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    af[k] = *reinterpret_cast<const bf16x8*>(A + ((k * TP + 2 * pp) * 2 * PB_M + i * 16) * 16);
+                for (int k = 0; k < P::NS; ++k)
+                    af[k] = *reinterpret_cast<const vec8*>(A + ((k * TP + 2 * pp) * 2 * PB_M + i * 16) * 16);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     floatx4 c = small[i][j];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[2], bfr[j][0], c, 0, 0, 0);   // lo * hi
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[j][2], c, 0, 0, 0);   // hi * lo
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[j][1], c, 0, 0, 0);   // mid * mid
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[1], bfr[j][0], c, 0, 0, 0);   // mid * hi
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[j][1], c, 0, 0, 0);   // hi * mid
+                    if constexpr (P::NS == 3) {
+                        c = P::mfma(af[2], bfr[j][0], c);   // lo * hi
+                        c = P::mfma(af[0], bfr[j][2], c);   // hi * lo
+                        c = P::mfma(af[1], bfr[j][1], c);   // mid * mid
+                    }
+                    c = P::mfma(af[1], bfr[j][0], c);       // mid * hi   (fp16: lo' * hi)
+                    c = P::mfma(af[0], bfr[j][1], c);       // hi * mid   (fp16: hi * lo')
                     small[i][j] = c;
-                    big[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0], bfr[j][0], big[i][j], 0, 0, 0);   // hi * hi
+                    big[i][j] = P::mfma(af[0], bfr[j][0], big[i][j]);   // hi * hi
                 }
             }
         }
@@ -323,7 +411,9 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * 64 + i * 16 + kq * 4 + r;
                 if (m >= a.c_out) continue;
-                float v = relu_clamp((big[i][j][r] + small[i][j][r]) + a.bias[m]);
+                float acc = big[i][j][r] + small[i][j][r] * P::SMALL_SCALE;
+                if constexpr (P::SCALED) acc *= x_inv * a.w_inv_scale[m];      // exact: powers of two
+                float v = relu_clamp(acc + a.bias[m]);
                 const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
                 if (a.s0) v += a.s0[off];
                 if (a.s1) v += a.s1[off];
@@ -334,43 +424,42 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_bf16x3_kernel(const P
     }
 }
 
-template <int S>
+template <class P, int S>
 static int launch_packed(PackedConvArgs a, hipStream_t stream)
 {
-    using G = GeoP<S>;
-    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_bf16x3_kernel<S, false>),
+    using G = GeoP<P, S>;
+    constexpr bool HAS_LNX = !P::SCALED;      // the scaled scheme needs the range of the normalised tensor: no LayerNorm on load
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_bf16x3_kernel<S, true>),
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, HAS_LNX>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     const hipError_t attr = attr0 != hipSuccess ? attr0 : attr1;
     if (attr != hipSuccess) {
-        set_error("nbasr_dense_conv1d_fused_packed: cannot reserve %d bytes of LDS: %s", G::LDS_BYTES, hipGetErrorString(attr));
+        set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
+    NBASR_REQUIRE(HAS_LNX || !a.ln_x.stats, NBASR_EINVAL, "%s: this scheme takes no deferred LayerNorm", P::NAME);
     a.n_mt = (a.c_out + PB_M - 1) / PB_M;
     a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
-    NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: too many tiles (%lld)", nwg);
+    NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
     if (a.ln_x.stats)
-        hipLaunchKernelGGL((gemm_conv_bf16x3_kernel<S, true>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+        hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, HAS_LNX>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
     else
-        hipLaunchKernelGGL((gemm_conv_bf16x3_kernel<S, false>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
-    return launch_status("nbasr_dense_conv1d_fused_packed");
+        hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+    return launch_status(P::NAME);
 }
 
-}  // namespace nbasr
-
-using namespace nbasr;
-
-extern "C" size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel)
+template <class P>
+static size_t packed_bytes(int c_out, int c_in, int kernel)
 {
     if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS) return 0;
     const size_t n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
-    return n_mt * n_groups * PB_GROUP_BYTES;
+    return n_mt * n_groups * pb_group_bytes<P>() + (P::SCALED ? 2 * n_mt * PB_M * sizeof(float) : 0);   // + row scales and inverses
 }
 
-extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
-                                        nbasr_stream_t stream)
+template <class P>
+static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
@@ -379,35 +468,67 @@ extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out,
     NBASR_REQUIRE(w && packed, NBASR_ENULL, "nbasr_pack_dense_weights: NULL pointer");
     NBASR_REQUIRE(aligned16(packed), NBASR_EALIGN, "nbasr_pack_dense_weights: packed buffer must be 16-byte aligned");
     const int n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
-    hipLaunchKernelGGL(pack_dense_weights_kernel, dim3(2048), dim3(256), 0, as_stream(stream), w,
-                       static_cast<__bf16*>(packed), c_out, c_in, n_mt, n_groups, pb_taps_per_step(stride));
+    float* scales = nullptr;
+    if (P::SCALED) {
+        scales = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + static_cast<size_t>(n_mt) * n_groups * pb_group_bytes<P>());
+        hipLaunchKernelGGL(weight_row_scales_kernel, dim3(n_mt * PB_M), dim3(256), 0, as_stream(stream), w, scales, c_out,
+                           c_in * PB_TAPS, n_mt * PB_M);
+    }
+    hipLaunchKernelGGL(pack_dense_weights_kernel<P>, dim3(2048), dim3(256), 0, as_stream(stream), w,
+                       static_cast<unsigned short*>(packed), scales, c_out, c_in, n_mt, n_groups, P::taps_per_step(stride));
     return launch_status("nbasr_pack_dense_weights");
 }
 
+template <class P>
 static int dense_packed_impl(const float* x, const void* packed_w, const float* bias, const float* skip0,
                              const float* skip1, const float* skip2, float* y, int batch, int c_in,
                              int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                             const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+                             const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: bad sizes");
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
-                  "nbasr_dense_conv1d_fused_packed: (kernel=%d, stride=%d) unsupported; packed path covers k=8, s in {1,2}", kernel, stride);
+                  "%s: (kernel=%d, stride=%d) unsupported; packed path covers k=8, s in {1,2}", P::NAME, kernel, stride);
     const int frames_out = (frames_in + stride - 1) / stride;
-    NBASR_REQUIRE(ld_in >= frames_in, NBASR_EINVAL, "nbasr_dense_conv1d_fused_packed: ld_in=%d < frames_in=%d", ld_in, frames_in);
-    NBASR_REQUIRE(ld_in % 4 == 0, NBASR_EALIGN, "nbasr_dense_conv1d_fused_packed: ld_in=%d must be a multiple of 4", ld_in);
+    NBASR_REQUIRE(ld_in >= frames_in, NBASR_EINVAL, "%s: ld_in=%d < frames_in=%d", P::NAME, ld_in, frames_in);
+    NBASR_REQUIRE(ld_in % 4 == 0, NBASR_EALIGN, "%s: ld_in=%d must be a multiple of 4", P::NAME, ld_in);
     NBASR_REQUIRE(ld_out >= frames_out && ld_out % 4 == 0, NBASR_EALIGN,
-                  "nbasr_dense_conv1d_fused_packed: ld_out=%d must be >= %d output frames and a multiple of 4", ld_out, frames_out);
+                  "%s: ld_out=%d must be >= %d output frames and a multiple of 4", P::NAME, ld_out, frames_out);
     if (batch == 0 || frames_out == 0) return NBASR_OK;
-    NBASR_REQUIRE(x && packed_w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed: x, packed_w, bias, y must be non-NULL");
-    NBASR_REQUIRE(aligned16(packed_w) && aligned16(x), NBASR_EALIGN, "nbasr_dense_conv1d_fused_packed: x and packed weights must be 16-byte aligned");
+    NBASR_REQUIRE(x && packed_w && bias && y, NBASR_ENULL, "%s: x, packed_w, bias, y must be non-NULL", P::NAME);
+    NBASR_REQUIRE(aligned16(packed_w) && aligned16(x), NBASR_EALIGN, "%s: x and packed weights must be 16-byte aligned", P::NAME);
     PackedConvArgs a{};
     a.x = x; a.wp = static_cast<const unsigned char*>(packed_w); a.bias = bias; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
     a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
     a.lpad = pad_left(kernel, 1, stride); a.n_groups = (c_in + PB_CI - 1) / PB_CI; a.batch = batch;
-    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_ln: deferred LayerNorm needs stats, gamma and beta");
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "%s: deferred LayerNorm needs stats, gamma and beta", P::NAME);
     a.ln_x = ln_ref(ln, true);
-    return stride == 1 ? launch_packed<1>(a, as_stream(stream)) : launch_packed<2>(a, as_stream(stream));
+    if (P::SCALED) {
+        NBASR_REQUIRE(x_absmax, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
+        a.x_absmax = x_absmax;
+        a.w_inv_scale = reinterpret_cast<const float*>(a.wp + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * a.n_groups * pb_group_bytes<P>())
+                        + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * PB_M;
+    }
+    return stride == 1 ? launch_packed<P, 1>(a, as_stream(stream)) : launch_packed<P, 2>(a, as_stream(stream));
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel) { return packed_bytes<SplitBf16x3>(c_out, c_in, kernel); }
+extern "C" size_t nbasr_packed_dense_weights_bytes_f16(int c_out, int c_in, int kernel) { return packed_bytes<SplitF16x2>(c_out, c_in, kernel); }
+
+extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
+                                        nbasr_stream_t stream)
+{
+    return pack_impl<SplitBf16x3>(w, packed, c_out, c_in, kernel, stride, stream);
+}
+
+extern "C" int nbasr_pack_dense_weights_f16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
+                                            nbasr_stream_t stream)
+{
+    return pack_impl<SplitF16x2>(w, packed, c_out, c_in, kernel, stride, stream);
 }
 
 extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias, const float* skip0,
@@ -415,14 +536,23 @@ extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packe
                                                int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
                                                nbasr_stream_t stream)
 {
-    return dense_packed_impl(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel,
-                             stride, nullptr, stream);
+    return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                          kernel, stride, nullptr, nullptr, stream);
 }
 
 extern "C" int nbasr_dense_conv1d_fused_packed_ln(const float* x, const void* packed_w, const float* bias, float* y, int batch,
                                                   int c_in, int frames_in, int ld_in, int c_out, int ld_out, int kernel,
                                                   int stride, const nbasr_deferred_ln* ln, nbasr_stream_t stream)
 {
-    return dense_packed_impl(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                             kernel, stride, ln, stream);
+    return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out,
+                                          ld_out, kernel, stride, ln, nullptr, stream);
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed_f16(const float* x, const float* x_absmax, const void* packed_w, const float* bias,
+                                                   const float* skip0, const float* skip1, const float* skip2, float* y,
+                                                   int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
+                                                   int kernel, int stride, nbasr_stream_t stream)
+{
+    return dense_packed_impl<SplitF16x2>(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                         kernel, stride, nullptr, x_absmax, stream);
 }

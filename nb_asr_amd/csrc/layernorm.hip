@@ -73,9 +73,12 @@ __device__ __forceinline__ void tile_statistics(const float* x, int channels, in
     __syncthreads();
 }
 
+// ABSMAX: also fold max|y| of each utterance into absmax[b] (float bits, non-negative floats order like unsigned ints);
+// the 2-way fp16 dense conv (gemm_conv_split.hip) scales its input by a power of two derived from it
+template <bool ABSMAX>
 __global__ __launch_bounds__(256) void layernorm_channels_kernel(
     const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* y, int channels, int frames, int ld, float eps)   // x may alias y (in-place)
+    float* y, int channels, int frames, int ld, float eps, unsigned* __restrict__ absmax)   // x may alias y (in-place)
 {
     __shared__ float s_mean[LN_ROWS][LN_QS * 4];
     __shared__ float s_m2[LN_ROWS][LN_QS * 4];
@@ -94,12 +97,13 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
     tile_statistics(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
 
     // pass 2: normalise, scale, shift; keep the pitch columns at zero
-    if (!active) return;
+    if (!active && !ABSMAX) return;
     float mu[4], rs[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) { mu[r] = s_mu[ql * 4 + r]; rs[r] = s_rstd[ql * 4 + r]; }
     const int t0 = q * 4;
-    for (int c = row; c < channels; c += LN_ROWS) {
+    float amax = 0.f;
+    for (int c = row; active && c < channels; c += LN_ROWS) {
         const size_t off = base + static_cast<size_t>(c) * ld;
         const float4 v = *reinterpret_cast<const float4*>(x + off);
         const float g = gamma[c], bt = beta[c];
@@ -108,8 +112,14 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
         for (int r = 0; r < 4; ++r) {
             o[r] = (o[r] - mu[r]) * rs[r] * g + bt;
             if (t0 + r >= frames) o[r] = 0.f;
+            if (ABSMAX) amax = fmaxf(amax, fabsf(o[r]));
         }
         *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (ABSMAX) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) amax = fmaxf(amax, __shfl_xor(amax, m));
+        if ((threadIdx.x & 63) == 0) atomicMax(absmax + b, __float_as_uint(amax));
     }
 }
 
@@ -148,21 +158,42 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 
 using namespace nbasr;
 
+static int layernorm_impl(const char* what, const float* x, const float* gamma, const float* beta, float* y, float* absmax,
+                          int batch, int channels, int frames, int ld, float eps, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "%s: bad sizes", what);
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "%s: ld=%d must be >= frames=%d and a multiple of 4", what, ld, frames);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && gamma && beta && y, NBASR_ENULL, "%s: NULL pointer", what);
+    NBASR_REQUIRE(aligned16(x) && aligned16(y), NBASR_EALIGN, "%s: x, y must be 16-byte aligned", what);
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "%s: batch %d > 65535", what, batch);
+    const int nq = ld / 4;
+    const dim3 grid((nq + LN_QS - 1) / LN_QS, batch);
+    if (absmax) {
+        const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * batch, as_stream(stream));
+        if (e != hipSuccess) { set_error("%s: hipMemsetAsync failed: %s", what, hipGetErrorString(e)); return static_cast<int>(e); }
+        hipLaunchKernelGGL(layernorm_channels_kernel<true>, grid, dim3(256), 0, as_stream(stream),
+                           x, gamma, beta, y, channels, frames, ld, eps, reinterpret_cast<unsigned*>(absmax));
+    } else {
+        hipLaunchKernelGGL(layernorm_channels_kernel<false>, grid, dim3(256), 0, as_stream(stream),
+                           x, gamma, beta, y, channels, frames, ld, eps, static_cast<unsigned*>(nullptr));
+    }
+    return launch_status(what);
+}
+
 extern "C" int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y, int batch,
                                         int channels, int frames, int ld, float eps, nbasr_stream_t stream)
 {
+    return layernorm_impl("nbasr_layernorm_channels", x, gamma, beta, y, nullptr, batch, channels, frames, ld, eps, stream);
+}
+
+extern "C" int nbasr_layernorm_channels_absmax(const float* x, const float* gamma, const float* beta, float* y, float* absmax,
+                                               int batch, int channels, int frames, int ld, float eps, nbasr_stream_t stream)
+{
     clear_error();
-    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_layernorm_channels: bad sizes");
-    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_layernorm_channels: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
-    if (batch == 0 || ld == 0) return NBASR_OK;
-    NBASR_REQUIRE(x && gamma && beta && y, NBASR_ENULL, "nbasr_layernorm_channels: NULL pointer");
-    NBASR_REQUIRE(aligned16(x) && aligned16(y), NBASR_EALIGN, "nbasr_layernorm_channels: x, y must be 16-byte aligned");
-    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_layernorm_channels: batch %d > 65535", batch);
-    if (batch == 0 || ld == 0) return NBASR_OK;
-    const int nq = ld / 4;
-    hipLaunchKernelGGL(layernorm_channels_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
-                       x, gamma, beta, y, channels, frames, ld, eps);
-    return launch_status("nbasr_layernorm_channels");
+    NBASR_REQUIRE(absmax != nullptr || batch == 0, NBASR_ENULL, "nbasr_layernorm_channels_absmax: absmax is NULL");
+    return layernorm_impl("nbasr_layernorm_channels_absmax", x, gamma, beta, y, absmax, batch, channels, frames, ld, eps, stream);
 }
 
 extern "C" int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,

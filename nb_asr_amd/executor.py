@@ -80,12 +80,17 @@ class ForwardPlan:
             self.block_frames.append(t)
         self.out_frames = self.block_frames[-1]
         self.timer = None
-        # dense k=8 convs: 'bf16x3' = fp32-accurate 3-way bf16 split on the bf16 matrix cores (default),
-        # 'f32' = the exact-fp32 MFMA kernel
-        self.dense_mode = os.environ.get('NBASR_DENSE_MODE', 'bf16x3')
-        if self.dense_mode not in ('bf16x3', 'f32'):
-            raise ValueError(f'NBASR_DENSE_MODE must be bf16x3 or f32, got {self.dense_mode!r}')
-        self._packed = {}            # id(layer) -> (weight data_ptr, weight version, packed tensor)
+        # dense k=8 convs, all fp32-accurate:
+        #   'auto' (default) = 2-way fp16 split (3 MFMAs per product) wherever the input has just been written by the
+        #                      LayerNorm kernel (which also emits the per-utterance max|x| the scheme's range scaling
+        #                      needs), the 3-way bf16 split (6 MFMAs per product, fp32's exponent range) elsewhere;
+        #   'bf16x3' = 3-way bf16 split everywhere;  'f32' = the exact-fp32 MFMA kernel
+        self.dense_mode = os.environ.get('NBASR_DENSE_MODE', 'auto')
+        if self.dense_mode not in ('auto', 'bf16x3', 'f32'):
+            raise ValueError(f'NBASR_DENSE_MODE must be auto, bf16x3 or f32, got {self.dense_mode!r}')
+        self._packed = {}            # (id(layer), scheme) -> (weight key, packed tensor)
+        self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
+        self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
         # 'materialize' = the stand-alone LayerNorm kernel writes the normalised tensor
         self.ln_mode = os.environ.get('NBASR_LN_MODE', 'deferred')
@@ -125,20 +130,25 @@ class ForwardPlan:
         self.timer.append((kind, meta, start, stop))
         return out
 
-    def _packed_weights(self, layer):
+    def _packed_weights(self, layer, scheme):
         """Split/re-laid-out copy of a downsample conv's weights, rebuilt whenever the parameter changes."""
         w = layer.conv.weight
         key = (w.data_ptr(), w._version)
-        hit = self._packed.get(id(layer))
+        hit = self._packed.get((id(layer), scheme))
         if hit is None or hit[0] != key:
-            hit = (key, hip.pack_dense_weights(w.detach(), layer.strides))
-            self._packed[id(layer)] = hit
+            hit = (key, hip.pack_dense_weights(w.detach(), layer.strides, scheme))
+            self._packed[(id(layer), scheme)] = hit
         return hit[1]
 
-    def _dense(self, layer, act, act_frames, out, ln):
-        if self.dense_mode == 'bf16x3' and layer.kernel_size == 8:
-            return hip.dense_conv1d_fused_packed(act, act_frames, self._packed_weights(layer), layer.conv.out_channels,
-                                                 layer.kernel_size, layer.conv.bias.detach(), (), out, layer.strides, ln)
+    def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None):
+        """``absmax``: (B,) device bounds of max|act[b]| when `act` was just written by the LayerNorm kernel, else None."""
+        if self.dense_mode != 'f32' and layer.kernel_size == 8:
+            scheme = 'f16x2' if self.dense_mode == 'auto' and absmax is not None and ln is None else 'bf16x3'
+            self.dense_schemes[blk] = scheme
+            return hip.dense_conv1d_fused_packed(act, act_frames, self._packed_weights(layer, scheme), layer.conv.out_channels,
+                                                 layer.kernel_size, layer.conv.bias.detach(), (), out, layer.strides, ln, scheme,
+                                                 absmax if scheme == 'f16x2' else None)
+        self.dense_schemes[blk] = 'f32'
         return hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(), (), out,
                                       layer.strides, ln, ln is not None, False)
 
@@ -157,8 +167,12 @@ class ForwardPlan:
         ``out``)."""
         if self.ln_mode == 'materialize' or not self._cheap_consumer(nxt) or out is not None:
             dst = act if out is None else out
+            from .ops import PadConvRelu
+            want_range = self.dense_mode == 'auto' and isinstance(nxt, PadConvRelu) and nxt.groups == 1 and nxt.kernel_size == 8
+            absmax = self.absmax[: act.shape[0]] if want_range else None
             self._timed('layernorm', kind_meta, lambda: hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(),
-                                                                               dst, act_frames, norm.eps))
+                                                                               dst, act_frames, norm.eps, absmax))
+            self._act_absmax = absmax
             return None
         self._stat_turn ^= 1
         b, _, ld = act.shape
@@ -228,11 +242,12 @@ class ForwardPlan:
             raise hip.HipError(f'input must be float32 (got {x.dtype})')
         x = x.detach().contiguous()
         act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
-        if self.dense_mode == 'bf16x3' and (x.shape[-1] % 4 or x.data_ptr() % 16):
+        if self.dense_mode != 'f32' and (x.shape[-1] % 4 or x.data_ptr() % 16):
             # the packed dense conv fetches aligned 4-frame quads: bring a ragged-length input into the pitched layout
             cur = 2
             act = hip.repitch(x, self._view(cur, x.shape[1], self.frames), self.frames)
         pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
+        self._act_absmax = None                          # set by _norm when it wrote `act` together with max|act[b]|
         pipe = bool(pipelined) and model.use_rnn and taps is None
         pipe_k, tail_ctx = None, None
         self._stat_turn = 0
@@ -245,10 +260,10 @@ class ForwardPlan:
                 dst = 0 if cur != 0 else 1
                 t_out = self.block_frames[blk]
                 out = self._view(dst, layer.conv.out_channels, t_out)
-                ln, src, src_frames = pending, act, act_frames
+                ln, src, src_frames, amax, blk_now = pending, act, act_frames, self._act_absmax, blk
                 self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
-                            lambda: self._dense(layer, src, src_frames, out, ln))
-                act, act_frames, cur, pending = out, t_out, dst, None
+                            lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now))
+                act, act_frames, cur, pending, self._act_absmax = out, t_out, dst, None, None
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.LayerNorm):

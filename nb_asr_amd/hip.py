@@ -35,10 +35,14 @@ SIGNATURES = {
     'nbasr_grouped_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_stream]),
     'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_stream]),
     'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    'nbasr_layernorm_channels_absmax': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
     'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_pack_dense_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_packed_dense_weights_bytes_f16': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_pack_dense_weights_f16': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_dense_conv1d_fused_packed_f16': (_c_int, [_c_float_p] * 8 + [_c_int] * 8 + [_c_stream]),
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
@@ -206,8 +210,16 @@ def channel_stats(x, stats, frames, eps):
     return stats
 
 
-def layernorm_channels(x, gamma, beta, y, frames, eps):
+def layernorm_channels(x, gamma, beta, y, frames, eps, absmax=None):
+    """LayerNorm over channels; with ``absmax`` (a (B,) float32 device tensor) also max|y[b]| per utterance."""
     b, c, ld = x.shape
+    if absmax is not None:
+        if absmax.numel() != b:
+            raise HipError('absmax must hold one float per utterance')
+        _check(load_library().nbasr_layernorm_channels_absmax(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
+                                                              _dev(y, 'y'), _dev(absmax, 'absmax'), b, c, frames, ld,
+                                                              float(eps), _stream(x)), 'nbasr_layernorm_channels_absmax')
+        return y
     _check(load_library().nbasr_layernorm_channels(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
                                                    _dev(y, 'y'), b, c, frames, ld, float(eps), _stream(x)),
            'nbasr_layernorm_channels')
@@ -226,38 +238,62 @@ def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln
     return y
 
 
-def pack_dense_weights(weight, stride):
-    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its 3 x bf16 split in the LDS layout of the
-    stride-`stride` kernel that will consume it."""
+def pack_dense_weights(weight, stride, scheme='bf16x3'):
+    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its split (3 x bf16, or 2 x fp16 for
+    ``scheme='f16x2'``) in the LDS layout of the stride-`stride` kernel that will consume it."""
+    sfx = _scheme_suffix(scheme)
+    lib = load_library()
     c_out, c_in, kernel = weight.shape
-    nbytes = load_library().nbasr_packed_dense_weights_bytes(c_out, c_in, kernel)
+    nbytes = getattr(lib, 'nbasr_packed_dense_weights_bytes' + sfx)(c_out, c_in, kernel)
     if nbytes == 0:
         raise HipError(f'packed dense path does not cover weight shape {tuple(weight.shape)}')
     if not weight.is_cuda:
         raise HipError('weight must be on a HIP device')
     packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _check(load_library().nbasr_pack_dense_weights(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride,
-                                                   _stream(weight)), 'nbasr_pack_dense_weights')
+    _check(getattr(lib, 'nbasr_pack_dense_weights' + sfx)(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel,
+                                                          stride, _stream(weight)), 'nbasr_pack_dense_weights' + sfx)
     return packed
 
 
-def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride, ln=None):
+def _scheme_suffix(scheme):
+    if scheme not in ('bf16x3', 'f16x2'):
+        raise HipError(f"unknown operand-split scheme {scheme!r} (expected 'bf16x3' or 'f16x2')")
+    return '' if scheme == 'bf16x3' else '_f16'
+
+
+def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride, ln=None, scheme='bf16x3',
+                              x_absmax=None):
+    """Dense k=8 conv on packed weights; ``scheme`` must be the one the weights were packed with.  'f16x2' needs
+    ``x_absmax``: a (B,) float32 device tensor of upper bounds of max|x[b]| (see nbasr.h) and takes no deferred LayerNorm."""
+    sfx = _scheme_suffix(scheme)
+    lib = load_library()
     b, c_in, ld_in = x.shape
     ld_out = y.shape[2]
     s = list(skips) + [None] * (3 - len(skips))
     if not packed.is_cuda or packed.dtype != torch.uint8:
         raise HipError('packed weights must be the uint8 device tensor returned by pack_dense_weights')
+    if packed.numel() != getattr(lib, 'nbasr_packed_dense_weights_bytes' + sfx)(c_out, c_in, kernel):
+        raise HipError(f'packed weights have {packed.numel()} bytes: not a {scheme} image of a ({c_out}, {c_in}, {kernel}) weight')
+    name = 'nbasr_dense_conv1d_fused_packed' + sfx
+    if scheme == 'f16x2':
+        if ln is not None:
+            raise HipError('the f16x2 scheme takes no deferred LayerNorm (it needs the range of the normalised tensor)')
+        if x_absmax is None or x_absmax.numel() != b:
+            raise HipError('the f16x2 scheme needs x_absmax: one float32 bound of max|x[b]| per utterance')
+        _check(lib.nbasr_dense_conv1d_fused_packed_f16(
+            _dev(x, 'x'), _dev(x_absmax, 'x_absmax'), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
+            _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)), name)
+        return y
     if ln is not None:
         if any(t is not None for t in s):
             raise HipError('the packed path takes a deferred LayerNorm only without skip inputs')
-        _check(load_library().nbasr_dense_conv1d_fused_packed_ln(
+        _check(getattr(lib, name + '_ln')(
             _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out,
-            kernel, stride, _ln(ln), _stream(x)), 'nbasr_dense_conv1d_fused_packed')
+            kernel, stride, _ln(ln), _stream(x)), name + '_ln')
         return y
-    _check(load_library().nbasr_dense_conv1d_fused_packed(
+    _check(getattr(lib, name)(
         _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
-        _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)),
-        'nbasr_dense_conv1d_fused_packed')
+        _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)), name)
     return y
 
 

@@ -5,6 +5,8 @@ North-star tolerance for logits: rtol 1e-4 / atol 1e-5 against the reference's C
 fp32 noise floor (reference vs an fp64 evaluation of the same weights, stored as `ref_noise_ratio`) is itself
 close to that bound get proportional slack, exactly like the oracle's own pinning test.
 """
+import os
+
 import pytest
 import torch
 
@@ -229,3 +231,25 @@ def test_random_architectures_vs_oracle(seed):
     noise = cases.worst_ratio(want, truth, 1e-4, 1e-5)
     ratio = cases.worst_ratio(got, want, 1e-4, 1e-5)
     assert ratio <= max(1.0, 2.5 * noise), f'arch {arch} b={b} t={t} rnn={use_rnn}: err/tol {ratio:.2f}, fp32 noise floor {noise:.2f}'
+
+
+def test_dense_scheme_selection():
+    """Default dense mode: the model input takes the 3-way bf16 split, convs fed by the LayerNorm kernel (which supplies
+    the per-utterance range) the 2-way fp16 split; NBASR_DENSE_MODE=bf16x3 keeps everything on bf16."""
+    model = build(cases.ARCH_A, True, 'xavier')
+    x = keyed_input(2, 64, seed=3).to(DEV)
+    with torch.no_grad():
+        y0 = model(x)
+    plan = next(iter(model._plans.values()))
+    assert plan.dense_schemes == {0: 'bf16x3', 1: 'f16x2', 2: 'f16x2', 3: 'f16x2'}
+    os.environ['NBASR_DENSE_MODE'] = 'bf16x3'
+    try:
+        model._plans.clear()
+        with torch.no_grad():
+            y1 = model(x)
+        plan = next(iter(model._plans.values()))
+        assert set(plan.dense_schemes.values()) == {'bf16x3'}
+    finally:
+        del os.environ['NBASR_DENSE_MODE']
+        model._plans.clear()
+    assert cases.worst_ratio(y0, y1.cpu(), 1e-4, 1e-5) <= 1.0

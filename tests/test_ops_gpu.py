@@ -114,34 +114,40 @@ def test_dense_conv_shapes_vs_oracle(cin, cout, t, s):
     close(dense(x, w, bias, s), oracle.pad_conv_relu(x, w, bias, 1, s, 1))
 
 
-def dense_packed(x, w, bias, stride):
+SCHEMES = ['bf16x3', 'f16x2']
+
+
+def dense_packed(x, w, bias, stride, scheme='bf16x3'):
     b, cin, t = x.shape
     t_out = (t + stride - 1) // stride
     y = torch.full((b, w.shape[0], hip.round_up4(t_out)), float('nan'), device=DEV)
-    packed = hip.pack_dense_weights(w.to(DEV), stride)
-    hip.dense_conv1d_fused_packed(pitched(x)[0], t, packed, w.shape[0], 8, bias.to(DEV), (), y, stride)
+    packed = hip.pack_dense_weights(w.to(DEV), stride, scheme)
+    amax = x.abs().amax(dim=(1, 2)).to(DEV) if scheme == 'f16x2' else None
+    hip.dense_conv1d_fused_packed(pitched(x)[0], t, packed, w.shape[0], 8, bias.to(DEV), (), y, stride, scheme=scheme, x_absmax=amax)
     assert torch.all(y[:, :, t_out:] == 0)
     return y[:, :, :t_out]
 
 
+@pytest.mark.parametrize('scheme', SCHEMES)
 @pytest.mark.parametrize('cin,cout,t,s,b', cases.DENSE_CASES)
-def test_dense_conv_split_bf16_golden(op_fx, cin, cout, t, s, b):
-    """The 3-way bf16 split path (default for the downsample convs) meets the same tolerance as the fp32 MFMA path."""
+def test_dense_conv_split_golden(op_fx, cin, cout, t, s, b, scheme):
+    """The operand-split paths (3-way bf16, 2-way fp16) meet the same tolerance as the fp32 MFMA path."""
     tag = f'dense/cin{cin}_cout{cout}_t{t}_s{s}'
     p = cases.keyed_params({'conv.weight': (cout, cin, 8), 'conv.bias': (cout,)}, tag)
-    close(dense_packed(cases.keyed_x(tag, (b, cin, t)), p['conv.weight'], p['conv.bias'], s), op_fx[tag])
+    close(dense_packed(cases.keyed_x(tag, (b, cin, t)), p['conv.weight'], p['conv.bias'], s, scheme), op_fx[tag])
 
 
 @pytest.mark.parametrize('cin,cout,t,s', [(8, 8, 1, 1), (8, 8, 1, 2), (12, 130, 129, 1), (12, 130, 257, 2), (80, 600, 300, 1),
                                           (600, 136, 140, 2), (20, 33, 7, 2), (17, 260, 515, 1), (1000, 1200, 260, 2)])
-def test_dense_conv_split_bf16_vs_fp64(cin, cout, t, s):
+@pytest.mark.parametrize('scheme', SCHEMES)
+def test_dense_conv_split_vs_fp64(cin, cout, t, s, scheme):
     """fp32-level accuracy claim: error against an fp64 evaluation is at most 2.5x that of the exact-fp32 MFMA kernel
     (both measured relative to the output scale), and absolutely below 2e-6 of the scale."""
     torch.manual_seed(cin + cout + t)
     x, w, bias = torch.randn(2, cin, t), torch.randn(cout, cin, 8) * (2.0 / (cin * 8)) ** 0.5, torch.randn(cout) * 0.1
     want = oracle.pad_conv_relu(x.double(), w.double(), bias.double(), 1, s, 1)
     scale = float(want.abs().max())
-    e16 = float((dense_packed(x, w, bias, s).cpu().double() - want).pow(2).mean().sqrt()) / scale
+    e16 = float((dense_packed(x, w, bias, s, scheme).cpu().double() - want).pow(2).mean().sqrt()) / scale
     e32 = float((dense(x, w, bias, s).cpu().double() - want).pow(2).mean().sqrt()) / scale
     assert e16 <= max(2.5 * e32, 3e-8) and e16 < 2e-6, (e16, e32)
 
@@ -156,6 +162,66 @@ def test_packed_weights_extreme_values_split_exactly():
     y = dense_packed(x, w, torch.zeros(cout), 1)
     want = oracle.pad_conv_relu(x, w, torch.zeros(cout), 1, 1, 1)
     assert torch.equal(y.cpu(), want)                      # exact: one non-zero product per output, split is lossless
+
+
+def test_f16_split_represents_values_of_any_magnitude_to_two_ulp():
+    """hi + lo' 2^-11 carries 11 + 11 bits and a sign: a 24-bit fp32 value is represented to 2^-22 relative (2 ulp) worst
+    case, whatever its magnitude -- weight ROWS spanning 23 decades (each row is normalised on its own) and inputs of any
+    overall scale (each utterance is normalised on its own)."""
+    torch.manual_seed(0)
+    cin, cout, t = 16, 128, 40
+    w = torch.randn(cout, cin, 8).sign() * (0.5 + torch.rand(cout, cin, 8)) * torch.logspace(-20, 3, cout).view(-1, 1, 1)
+    for impulse in (1.0, 3.0e-9, 2.0 ** 40):
+        x = torch.zeros(1, cin, t)
+        x[0, 3, 20] = impulse
+        y = dense_packed(x, w, torch.zeros(cout), 1, 'f16x2').cpu().double()
+        want = oracle.pad_conv_relu(x.double(), w.double(), torch.zeros(cout).double(), 1, 1, 1)
+        assert float(want.max()) > 0
+        assert bool(((y - want).abs() <= 2.0 ** -21 * want.abs()).all()), impulse   # one product per output: 2 ulp each operand
+
+
+@pytest.mark.parametrize('x_scale', [1e-9, 1.0, 1e6])
+def test_f16_split_accuracy_is_scale_invariant(x_scale):
+    """The vanishing-activation regime (LayerNorm outputs of 1e-9 with the reference's default init) and
+    large inputs keep the same error relative to the output scale; rows of tiny weights keep their own relative accuracy."""
+    torch.manual_seed(3)
+    cin, cout, t, s = 136, 200, 131, 2
+    x = torch.randn(2, cin, t) * x_scale
+    x[1] *= 1e-3                                              # utterances are normalised separately
+    # weights compensate the input scale (outputs stay below the clamp at 20, where errors would be hidden or, relative
+    # to the clamped row maximum, exaggerated); rows additionally span six decades
+    w = torch.randn(cout, cin, 8) * (2.0 / (cin * 8)) ** 0.5 * torch.logspace(-6, 0, cout).view(-1, 1, 1) / x_scale
+    bias = torch.zeros(cout)
+    want = oracle.pad_conv_relu(x.double(), w.double(), bias.double(), 1, s, 1)
+    got = dense_packed(x, w, bias, s, 'f16x2').cpu().double()
+    row_scale = want.abs().amax(dim=2, keepdim=True)          # per (utterance, output row)
+    live = row_scale > 0
+    rel = ((got - want).abs() / torch.where(live, row_scale, torch.ones_like(row_scale)))[live.expand_as(want)]
+    assert float(rel.max()) < 2e-6, float(rel.max())
+
+
+def test_layernorm_absmax_by_product():
+    c, t = 40, 150
+    x, xp, ln, normed = _ln_setup(c, t, seed=11)
+    gamma, beta = ln[1], ln[2]
+    y = torch.empty_like(xp)
+    amax = torch.full((xp.shape[0],), -1.0, device=DEV)
+    hip.layernorm_channels(xp, gamma, beta, y, t, 1e-3, amax)
+    assert torch.equal(y, normed)
+    assert torch.equal(amax.cpu(), normed.abs().amax(dim=(1, 2)).cpu())
+
+
+def test_packed_scheme_mismatch_is_rejected():
+    w = torch.randn(128, 16, 8, device=DEV)
+    xp, t = pitched(torch.randn(1, 16, 12))
+    y = torch.empty(1, 128, 12, device=DEV)
+    with pytest.raises(hip.HipError):
+        hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w, 1, 'f16x2'), 128, 8, torch.zeros(128, device=DEV), (), y, 1)
+    with pytest.raises(hip.HipError):                       # f16x2 without the range information
+        hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w, 1, 'f16x2'), 128, 8, torch.zeros(128, device=DEV), (), y, 1,
+                                      scheme='f16x2')
+    with pytest.raises(hip.HipError):
+        hip.pack_dense_weights(w, 1, 'fp8')
 
 
 @pytest.mark.parametrize('c,t,b', cases.LINEAR_CASES)

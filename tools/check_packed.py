@@ -26,9 +26,13 @@ def run(cin, cout, tin, s, b, time_it):
     wd, bd = w.to(DEV), bias.to(DEV)
     y32 = torch.full((b, cout, hip.round_up4(tout)), float('nan'), device=DEV)
     y16 = torch.full_like(y32, float('nan'))
+    yh = torch.full_like(y32, float('nan'))
     hip.dense_conv1d_fused(xd, tin, wd, bd, (), y32, s)
     packed = hip.pack_dense_weights(wd, s)
+    packed_h = hip.pack_dense_weights(wd, s, 'f16x2')
+    amax = xd.abs().amax(dim=(1, 2))
     hip.dense_conv1d_fused_packed(xd, tin, packed, cout, 8, bd, (), y16, s)
+    hip.dense_conv1d_fused_packed(xd, tin, packed_h, cout, 8, bd, (), yh, s, scheme='f16x2', x_absmax=amax)
     torch.cuda.synchronize()
     msg = f'{cin:5d}->{cout:5d} T={tin:5d} s={s} B={b:3d}: '
     if not time_it:
@@ -36,12 +40,14 @@ def run(cin, cout, tin, s, b, time_it):
         scale = float(want.abs().max())
         e32 = (y32[:, :, :tout].cpu().double() - want)
         e16 = (y16[:, :, :tout].cpu().double() - want)
-        pad_ok = bool(torch.all(y16[:, :, tout:] == 0))
-        msg += (f'max|err|/scale fp32-mfma {float(e32.abs().max()) / scale:.2e} split-bf16 {float(e16.abs().max()) / scale:.2e}   '
-                f'rms fp32-mfma {float((e32 ** 2).mean().sqrt()) / scale:.2e} split-bf16 {float((e16 ** 2).mean().sqrt()) / scale:.2e}  pad_ok={pad_ok}')
+        eh = (yh[:, :, :tout].cpu().double() - want)
+        pad_ok = bool(torch.all(y16[:, :, tout:] == 0)) and bool(torch.all(yh[:, :, tout:] == 0))
+        msg += (f'max|err|/scale fp32-mfma {float(e32.abs().max()) / scale:.2e} bf16x3 {float(e16.abs().max()) / scale:.2e} f16x2 {float(eh.abs().max()) / scale:.2e}  '
+                f'rms fp32-mfma {float((e32 ** 2).mean().sqrt()) / scale:.2e} bf16x3 {float((e16 ** 2).mean().sqrt()) / scale:.2e} f16x2 {float((eh ** 2).mean().sqrt()) / scale:.2e} pad_ok={pad_ok}')
     else:
         for name, fn in (('fp32-mfma', lambda: hip.dense_conv1d_fused(xd, tin, wd, bd, (), y32, s)),
-                         ('split-bf16', lambda: hip.dense_conv1d_fused_packed(xd, tin, packed, cout, 8, bd, (), y16, s))):
+                         ('bf16x3', lambda: hip.dense_conv1d_fused_packed(xd, tin, packed, cout, 8, bd, (), y16, s)),
+                         ('f16x2', lambda: hip.dense_conv1d_fused_packed(xd, tin, packed_h, cout, 8, bd, (), yh, s, scheme='f16x2', x_absmax=amax))):
             for _ in range(3): fn()
             torch.cuda.synchronize()
             ts = []
