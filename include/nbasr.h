@@ -132,6 +132,17 @@ int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh,
                        float* h_out, int batch, int c_in, int frames, int ld, int hidden,
                        nbasr_stream_t stream);
 
+/* The two halves of nbasr_lstm_forward as separate calls, so that a caller can run the input projection (one large GEMM)
+ * on one stream and the latency-bound recurrence (frames dependent steps) on another:
+ *   gates_ws(frames, batch, 4*hidden) = x . w_ih^T + b_ih + b_hh ;   then h_out from gates_ws, w_hh (cell_ws: scratch).
+ * `ln` (may be NULL) is the pending LayerNorm of x, as in nbasr_lstm_forward_ln below. */
+struct nbasr_deferred_ln;
+int nbasr_lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh,
+                                float* gates_ws, int batch, int c_in, int frames, int ld, int hidden,
+                                const struct nbasr_deferred_ln* ln, nbasr_stream_t stream);
+int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, float* cell_ws, float* h_out,
+                          int batch, int frames, int hidden, nbasr_stream_t stream);
+
 /* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
  * logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias. */
 int nbasr_linear_head(const float* h, const float* w, const float* bias, float* logits,

@@ -188,25 +188,50 @@ __global__ __launch_bounds__(256) void head_kernel(
 
 using namespace nbasr;
 
+static int lstm_check(const char* what, int batch, int c_in, int frames, int ld, int hidden)
+{
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames >= 0 && hidden > 0 && ld >= frames, NBASR_EINVAL, "%s: bad sizes", what);
+    NBASR_REQUIRE(hidden % 4 == 0 && c_in % 4 == 0, NBASR_EALIGN, "%s: hidden=%d and c_in=%d must be multiples of 4", what, hidden, c_in);
+    return NBASR_OK;
+}
+
+extern "C" int nbasr_lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh,
+                                           float* gates_ws, int batch, int c_in, int frames, int ld, int hidden,
+                                           const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+{
+    clear_error();
+    const int rc = lstm_check("nbasr_lstm_input_projection", batch, c_in, frames, ld, hidden);
+    if (rc != NBASR_OK) return rc;
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && w_ih && b_ih && b_hh && gates_ws, NBASR_ENULL, "nbasr_lstm_input_projection: NULL pointer");
+    NBASR_REQUIRE(aligned16(w_ih), NBASR_EALIGN, "nbasr_lstm_input_projection: w_ih must be 16-byte aligned");
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_lstm_input_projection: deferred LayerNorm needs stats, gamma and beta");
+    return lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, ln_ref(ln, true), as_stream(stream));
+}
+
+extern "C" int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, float* cell_ws, float* h_out, int batch,
+                                     int frames, int hidden, nbasr_stream_t stream)
+{
+    clear_error();
+    const int rc = lstm_check("nbasr_lstm_recurrence", batch, 4, frames, frames, hidden);
+    if (rc != NBASR_OK) return rc;
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(gates_ws && w_hh && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_recurrence: NULL pointer");
+    NBASR_REQUIRE(aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence: w_hh, h_out must be 16-byte aligned");
+    const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
+    for (int t = 0; t < frames; ++t)
+        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
+    return launch_status("nbasr_lstm_recurrence");
+}
+
 extern "C" int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
                                      const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
                                      int c_in, int frames, int ld, int hidden, const nbasr_deferred_ln* ln,
                                      nbasr_stream_t stream)
 {
-    clear_error();
-    NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames >= 0 && hidden > 0 && ld >= frames, NBASR_EINVAL, "nbasr_lstm_forward: bad sizes");
-    if (batch == 0 || frames == 0) return NBASR_OK;
-    NBASR_REQUIRE(x && w_ih && w_hh && b_ih && b_hh && gates_ws && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_forward: NULL pointer");
-    NBASR_REQUIRE(hidden % 4 == 0 && c_in % 4 == 0, NBASR_EALIGN, "nbasr_lstm_forward: hidden=%d and c_in=%d must be multiples of 4", hidden, c_in);
-    NBASR_REQUIRE(aligned16(w_ih) && aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_forward: w_ih, w_hh, h_out must be 16-byte aligned");
-    hipStream_t s = as_stream(stream);
-    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_lstm_forward_ln: deferred LayerNorm needs stats, gamma and beta");
-    int rc = lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, ln_ref(ln, true), s);
+    const int rc = nbasr_lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, hidden, ln, stream);
     if (rc != NBASR_OK) return rc;
-    const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
-    for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, s, gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
-    return launch_status("nbasr_lstm_forward");
+    return nbasr_lstm_recurrence(gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, stream);
 }
 
 extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,

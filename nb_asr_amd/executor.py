@@ -213,17 +213,28 @@ class ForwardPlan:
         self._graph.replay()
         return self._y_static
 
+    def _ensure_pipeline(self):
+        if self.side_stream is not None:
+            return
+        from .model import FILTERS
+        # high priority: its own hardware queue (an ordinary second stream can end up sharing the main stream's queue,
+        # e.g. once RCCL has created its streams, and the overlap silently disappears), and the short dependent LSTM
+        # steps get dispatched ahead of the encoder's bulk work.
+        # (Measured and rejected: giving the tail 8-32 compute units of its own through CU-masked streams.  The 128
+        # workgroups of a step then run in several rounds and the whole pipeline slows 2-3x; tools/ubench/cu_mask_map.hip
+        # documents the mask layout.)
+        self.side_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        ld = hip.round_up4(self.out_frames)
+        self.enc_out = [torch.empty(self.batch, FILTERS[-1], ld, device=self.device, dtype=torch.float32) for _ in range(2)]
+        self.gates_pipe = [self.gates_ws, torch.empty_like(self.gates_ws)]
+
     def _pipeline_buffers(self, channels, frames):
-        if self.side_stream is None:
-            # high priority: its own hardware queue (an ordinary second stream can end up sharing the main stream's queue,
-            # e.g. once RCCL has created its streams, and the overlap silently disappears), and the short dependent LSTM
-            # steps get dispatched ahead of the encoder's bulk work
-            self.side_stream = torch.cuda.Stream(device=self.device, priority=-1)
-            ld = hip.round_up4(frames)
-            self.enc_out = [torch.empty(self.batch, channels, ld, device=self.device, dtype=torch.float32) for _ in range(2)]
+        self._ensure_pipeline()
+        if tuple(self.enc_out[0].shape[1:]) != (channels, hip.round_up4(frames)):
+            raise RuntimeError('unexpected encoder output shape for the pipelined tail')
         self._turn ^= 1
         k = self._turn
-        if self.tail_done[k] is not None:            # the LSTM that read this buffer two forwards ago
+        if self.tail_done[k] is not None:            # the LSTM that read these buffers two forwards ago
             torch.cuda.current_stream(self.device).wait_event(self.tail_done[k])
         return k, self.enc_out[k]
 
@@ -340,17 +351,21 @@ class ForwardPlan:
                 if taps is not None:                      # identity: eval mode or p == 0 (checked by the model)
                     taps[idx] = taps[idx - 1]
             elif isinstance(layer, nn.LSTM):
+                ln, src, src_frames = pending, act, act_frames
+                w_ih, w_hh = layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach()
+                b_ih, b_hh = layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach()
+                gates = self.gates_pipe[pipe_k] if pipe else self.gates_ws
+                # the input projection is one large GEMM: it stays with the encoder; only the recurrence moves over
+                self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                            lambda: hip.lstm_input_projection(src, src_frames, w_ih, b_ih, b_hh, gates, layer.hidden_size, ln))
                 if pipe:                                   # everything from here on runs on the side stream
                     ready = torch.cuda.Event()
                     ready.record(torch.cuda.current_stream(self.device))
                     self.side_stream.wait_event(ready)
                     tail_ctx = torch.cuda.stream(self.side_stream)
                     tail_ctx.__enter__()
-                ln, src, src_frames = pending, act, act_frames
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_forward(src, src_frames, layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach(),
-                                                     layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach(), self.gates_ws,
-                                                     self.cell_ws, self.h_out, ln))
+                            lambda: hip.lstm_recurrence(gates, w_hh, self.cell_ws, self.h_out))
                 act, pending = self.h_out, None            # (batch, frames, hidden)
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)

@@ -44,6 +44,8 @@ SIGNATURES = {
     'nbasr_pack_dense_weights_f16': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_f16': (_c_int, [_c_float_p] * 8 + [_c_int] * 8 + [_c_stream]),
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_lstm_input_projection': (_c_int, [_c_float_p] * 5 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    'nbasr_lstm_recurrence': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
     'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
@@ -304,6 +306,24 @@ def lstm_forward(x, frames, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out, ln
         _dev(x, 'x'), _dev(w_ih, 'w_ih'), _dev(w_hh, 'w_hh'), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'),
         _dev(gates_ws, 'gates_ws'), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
         b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_forward')
+    return h_out
+
+
+def lstm_input_projection(x, frames, w_ih, b_ih, b_hh, gates_ws, hidden, ln=None):
+    """gates_ws (frames, batch, 4*hidden) <- x . w_ih^T + b_ih + b_hh for all frames (first half of lstm_forward)."""
+    b, c_in, ld = x.shape
+    _check(load_library().nbasr_lstm_input_projection(
+        _dev(x, 'x'), _dev(w_ih, 'w_ih'), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
+        b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_input_projection')
+    return gates_ws
+
+
+def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):
+    """h_out (batch, frames, hidden) from the projected gates (second half of lstm_forward), on the current stream."""
+    b, frames, hidden = h_out.shape
+    _check(load_library().nbasr_lstm_recurrence(_dev(gates_ws, 'gates_ws'), _dev(w_hh, 'w_hh'), _dev(cell_ws, 'cell_ws'),
+                                                _dev(h_out, 'h_out'), b, frames, hidden, _stream(h_out)),
+           'nbasr_lstm_recurrence')
     return h_out
 
 
