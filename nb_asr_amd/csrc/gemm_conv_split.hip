@@ -412,7 +412,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                 const int m = m0 + wm * 64 + i * 16 + kq * 4 + r;
                 if (m >= a.c_out) continue;
                 float acc = big[i][j][r] + small[i][j][r] * P::SMALL_SCALE;
-                if constexpr (P::SCALED) acc *= x_inv * a.w_inv_scale[m];      // exact: powers of two
+                if constexpr (P::SCALED) acc = acc * x_inv * a.w_inv_scale[m];  // exact: powers of two, applied one after the other
+                                                                               // (their product alone could leave fp32's range)
                 float v = relu_clamp(acc + a.bias[m]);
                 const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
                 if (a.s0) v += a.s0[off];
