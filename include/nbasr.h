@@ -237,6 +237,25 @@ int nbasr_ctc_postprocess(const float* logits, const int* lengths, float* log_pr
 int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,
                   nbasr_stream_t stream);
 
+/* ---- feature front-end (reference training/torch/timit.py:78-97) --------------------------------------
+ * torchaudio MelSpectrogram(16 kHz, n_fft = win = 400, hop 160, 80 mels, power 2, centred reflect-padded frames, periodic
+ * Hann window, HTK mel scale) -> log -> (x - mean) / (variance + eps), produced directly in the model's input layout
+ * (batch, 80, frames).  The DFT and the mel filterbank are plain matrices applied per frame (nbasr_pointwise_linear); the
+ * host side (nb_asr_amd/frontend.py) builds them.  `lengths` (may be NULL = every utterance has `samples` samples): int32
+ * device array of per-utterance sample counts; an utterance has lengths[b] / hop + 1 frames, later frames are zero.
+ *   frames(batch, win, ld_frames)[b][k][t] = wave[b][reflect(t*hop + k - win/2)]
+ *   y(batch, c_out, ld_out) = w(c_out, c_in) . x(batch, c_in, ld_in) + bias          (no activation; c_in % 4 == 0)
+ *   power(batch, rows_out, ld)[b][f][t] = spec[b][f][t]^2 + spec[b][bins + f][t]^2   (rows bins..rows_out-1 zero)
+ *   feats(batch, n_mels, ld)[b][m][t] = (log(mel[b][m][t]) - mean[m]) * inv_scale[m] for t < frames(b), else 0 */
+int nbasr_frame_signal(const float* wave, const int* lengths, float* frames, int batch, int samples, int ld_wave,
+                       int win, int hop, int ld_frames, nbasr_stream_t stream);
+int nbasr_pointwise_linear(const float* x, const float* w, const float* bias, float* y, int batch, int c_in,
+                           int frames, int ld_in, int c_out, int ld_out, nbasr_stream_t stream);
+int nbasr_power_spectrum(const float* spec, float* power, int batch, int bins, int rows_out, int ld,
+                         nbasr_stream_t stream);
+int nbasr_log_normalize(const float* mel, const int* lengths, const float* mean, const float* inv_scale, float* feats,
+                        int batch, int samples, int hop, int n_mels, int ld, nbasr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,6 +16,7 @@ from . import search_space
 from . import graph_utils
 from . import utils
 from . import ctc
+from . import frontend
 from .search_space import (all_ops, get_search_space, get_all_architectures, get_random_architectures,
                            get_model_hash, arch_vec_to_names)
 

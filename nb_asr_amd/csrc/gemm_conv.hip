@@ -326,3 +326,23 @@ extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const fl
     return nbasr_dense_conv1d_fused_ln(x, w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
                                        kernel, stride, nullptr, 0, 0, stream);
 }
+
+// y(batch, c_out, ld_out) = w(c_out, c_in) . x(batch, c_in, ld_in) + bias, no activation: the plain per-frame linear map
+// (the front-end's DFT and mel filterbank, frontend.hip); pitch columns frames..ld_out-1 are written as zero
+extern "C" int nbasr_pointwise_linear(const float* x, const float* w, const float* bias, float* y, int batch, int c_in,
+                                      int frames, int ld_in, int c_out, int ld_out, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames >= 0, NBASR_EINVAL, "nbasr_pointwise_linear: bad sizes");
+    NBASR_REQUIRE(ld_in >= frames, NBASR_EINVAL, "nbasr_pointwise_linear: ld_in=%d < frames=%d", ld_in, frames);
+    NBASR_REQUIRE(ld_out >= frames && ld_out % 4 == 0, NBASR_EALIGN,
+                  "nbasr_pointwise_linear: ld_out=%d must be >= %d frames and a multiple of 4", ld_out, frames);
+    NBASR_REQUIRE(c_in % 4 == 0 && aligned16(w), NBASR_EALIGN, "nbasr_pointwise_linear: c_in=%d must be a multiple of 4 and w 16-byte aligned", c_in);
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_pointwise_linear: x, w, bias, y must be non-NULL");
+    GemmConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.c_in = c_in; a.frames_in = frames; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames; a.ld_out = ld_out;
+    a.lpad = 0; a.ktot = c_in; a.batch = batch;
+    return launch_gemm_conv<1, 1, false, false>(a, as_stream(stream), "nbasr_pointwise_linear");
+}

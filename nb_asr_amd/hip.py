@@ -44,6 +44,10 @@ SIGNATURES = {
     'nbasr_pack_dense_weights_f16': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_f16': (_c_int, [_c_float_p] * 8 + [_c_int] * 8 + [_c_stream]),
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_frame_signal': (_c_int, [_c_float_p, ctypes.c_void_p, _c_float_p] + [_c_int] * 6 + [_c_stream]),
+    'nbasr_pointwise_linear': (_c_int, [_c_float_p] * 4 + [_c_int] * 6 + [_c_stream]),
+    'nbasr_power_spectrum': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_log_normalize': (_c_int, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 3 + [_c_int] * 5 + [_c_stream]),
     'nbasr_lstm_input_projection': (_c_int, [_c_float_p] * 5 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_recurrence': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
@@ -325,6 +329,45 @@ def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):
                                                 _dev(h_out, 'h_out'), b, frames, hidden, _stream(h_out)),
            'nbasr_lstm_recurrence')
     return h_out
+
+
+def _lengths_ptr(lengths, batch):
+    if lengths is None:
+        return None
+    if not lengths.is_cuda or lengths.dtype != torch.int32 or not lengths.is_contiguous() or lengths.numel() != batch:
+        raise HipError('lengths must be a contiguous int32 device tensor with one entry per utterance')
+    return lengths.data_ptr()
+
+
+def frame_signal(wave, lengths, frames, win, hop):
+    """wave (B, L) -> frames (B, win, ld): centred, reflect-padded analysis frames, sample-in-window major."""
+    b, ld_wave = wave.shape
+    _check(load_library().nbasr_frame_signal(_dev(wave, 'wave'), _lengths_ptr(lengths, b), _dev(frames, 'frames'), b, ld_wave,
+                                             ld_wave, win, hop, frames.shape[2], _stream(wave)), 'nbasr_frame_signal')
+    return frames
+
+
+def pointwise_linear(x, frames, weight, bias, y):
+    """y (B, c_out, ld_out) = weight (c_out, c_in) . x (B, c_in, ld_in) + bias, no activation."""
+    b, c_in, ld_in = x.shape
+    _check(load_library().nbasr_pointwise_linear(_dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _dev(y, 'y'), b, c_in,
+                                                 frames, ld_in, weight.shape[0], y.shape[2], _stream(x)), 'nbasr_pointwise_linear')
+    return y
+
+
+def power_spectrum(spec, bins, power):
+    b, _, ld = spec.shape
+    _check(load_library().nbasr_power_spectrum(_dev(spec, 'spec'), _dev(power, 'power'), b, bins, power.shape[1], ld, _stream(spec)),
+           'nbasr_power_spectrum')
+    return power
+
+
+def log_normalize(mel, lengths, mean, inv_scale, feats, samples, hop):
+    b, n_mels, ld = mel.shape
+    _check(load_library().nbasr_log_normalize(_dev(mel, 'mel'), _lengths_ptr(lengths, b), _dev(mean, 'mean'),
+                                              _dev(inv_scale, 'inv_scale'), _dev(feats, 'feats'), b, samples, hop, n_mels, ld,
+                                              _stream(mel)), 'nbasr_log_normalize')
+    return feats
 
 
 def linear_head(h, weight, bias, logits):
