@@ -237,6 +237,24 @@ int nbasr_ctc_postprocess(const float* logits, const int* lengths, float* log_pr
 int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,
                   nbasr_stream_t stream);
 
+/* ---- per-frame linear maps on the fp16 matrix cores (fp32-accurate two-way operand split, see the _f16 convolution) ------
+ * The `linear` node op (reference ops.py:42-50 + the node's skip sum, model.py:13-22) and the LSTM input projection.  The
+ * activation is split once by a streaming pre-pass into `ws` (nbasr_pointwise_workspace_bytes; scratch, no state between
+ * calls) with one exact power-of-two scale per (utterance, 256-frame tile); the weights are packed once per weight version
+ * (nbasr_pointwise_packed_weights_bytes / nbasr_pack_pointwise_weights, row-wise power-of-two scales).  No range contract:
+ * both scalings are computed from the data.  Arguments otherwise as nbasr_dense_conv1d_fused_ln with kernel = 1 and as
+ * nbasr_lstm_input_projection. */
+size_t nbasr_pointwise_packed_weights_bytes(int c_out, int c_in);
+size_t nbasr_pointwise_workspace_bytes(int batch, int c_in, int ld);
+int nbasr_pack_pointwise_weights(const float* w, void* packed, int c_out, int c_in, nbasr_stream_t stream);
+int nbasr_linear_fused_packed(const float* x, void* ws, const void* packed_w, const float* bias,
+                              const float* skip0, const float* skip1, const float* skip2, float* y,
+                              int batch, int channels_in, int frames, int ld, int channels_out,
+                              const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
+int nbasr_lstm_input_projection_packed(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                       const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                       int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+
 /* ---- feature front-end (reference training/torch/timit.py:78-97) --------------------------------------
  * torchaudio MelSpectrogram(16 kHz, n_fft = win = 400, hop 160, 80 mels, power 2, centred reflect-padded frames, periodic
  * Hann window, HTK mel scale) -> log -> (x - mean) / (variance + eps), produced directly in the model's input layout

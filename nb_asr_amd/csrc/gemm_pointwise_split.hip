@@ -1,0 +1,430 @@
+// Per-frame linear maps  y[b][co][t] = sum_ci W[co][ci] x[b][ci][t] + bias  on the fp16 matrix cores, fp32-accurate through
+// the two-way operand split of gemm_conv_split.hip (v = hi + lo' 2^-11, three MFMAs per product):
+//   * the `linear` node op of a search cell (reference ops.py:42-50: permute, Linear, ReLU, min(20), permute) + the node's
+//     skip sum (model.py:13-22);
+//   * the LSTM input projection (model.py:100,118-121), stored time-major.
+// Unlike the k=8 convolution a pointwise map re-uses nothing along the frame axis, so splitting x inside the GEMM would cost
+// as much vector work as the MFMAs it feeds (and every row tile would repeat it).  The activation is therefore split ONCE
+// by a streaming pre-pass into the exact LDS image the GEMM wants, and the GEMM moves BOTH operands with LDS-DMA only:
+//
+//   presplit:  x (batch, C, ld) fp32 [+ pending LayerNorm]  ->  image[b][frame tile of 256][K-step of 32 channels]
+//              [split][16-channel block][8-channel half][256 frames][8 channels] fp16   (32 KiB per (tile, K-step), contiguous)
+//              with ONE power-of-two scale per (utterance, frame tile): a pointwise map never mixes frames, so the scale
+//              can be that local; the largest magnitude of the tile lands in [2^14, 2^15);
+//   GEMM:      128 x 256 tile per 512-thread workgroup (8 waves of 64 x 64 = 4 x 4 MFMA tiles), K-step = 32 channels = one
+//              v_mfma_f32_16x16x32_f16 k-block; per step 16 KiB of packed weights + 32 KiB of image by global_load_lds,
+//              double-buffered, one barrier per step; `big` / `small` accumulators as in the convolution kernel;
+//              epilogue: exact rescale, bias, [ReLU, min(20)], [skip sum with LayerNorm on skip0], store -- or the
+//              time-major store of the LSTM gates.
+#include "common.h"
+
+namespace nbasr {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+
+constexpr int PW_M = 128, PW_N = 256, PW_K = 32;                 // tile and K-step
+constexpr int PW_THREADS = 512;
+constexpr int PW_A_STEP = 2 * 2 * 2 * PW_M * 16;                 // [split][block][half][128 rows][8 ch] = 16 KiB
+constexpr int PW_X_STEP = 2 * 2 * 2 * PW_N * 16;                 // [split][block][half][256 frames][8 ch] = 32 KiB
+constexpr int PW_LDS = 2 * (PW_A_STEP + PW_X_STEP);              // 96 KiB
+
+__host__ __device__ inline void pw_pow2(float absmax, int target, float& scale, float& inv)
+{
+    unsigned bits;
+    __builtin_memcpy(&bits, &absmax, 4);
+    const int e = static_cast<int>((bits >> 23) & 0xffu);
+    int k = (bits & 0x7fffffffu) ? (127 + target) - e : 0;
+    k = k > 126 ? 126 : (k < -126 ? -126 : k);
+    const unsigned sb = static_cast<unsigned>(127 + k) << 23, ib = static_cast<unsigned>(127 - k) << 23;
+    __builtin_memcpy(&scale, &sb, 4);
+    __builtin_memcpy(&inv, &ib, 4);
+}
+
+__device__ __forceinline__ void pw_split8(const float (&v)[8], float scale, halfx8& hi, halfx8& lo)
+{
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float s = v[c] * scale;
+        const _Float16 h = static_cast<_Float16>(s);
+        hi[c] = h;
+        lo[c] = static_cast<_Float16>((s - static_cast<float>(h)) * 2048.f);
+    }
+}
+
+// ---- weights: (c_out, c_in) -> [row tile][K-step][split][block][half][128 rows][8 ch] + per-row 2^kw and 2^-kw -----------
+__global__ __launch_bounds__(256) void pw_row_scales_kernel(const float* __restrict__ w, float* __restrict__ scales, int c_out,
+                                                            int c_in, int rows)
+{
+    __shared__ float s_max[4];
+    const int co = blockIdx.x;
+    float m = 0.f;
+    if (co < c_out)
+        for (int i = threadIdx.x; i < c_in; i += 256) m = fmaxf(m, fabsf(w[static_cast<size_t>(co) * c_in + i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float scale, inv;
+        pw_pow2(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])), 13, scale, inv);
+        scales[co] = scale;
+        scales[rows + co] = inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void pw_pack_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
+                                                              const float* __restrict__ row_scale, int c_out, int c_in,
+                                                              int n_mt, int n_ks)
+{
+    const long long total = static_cast<long long>(n_mt) * n_ks * PW_M * PW_K;
+    for (long long i = static_cast<long long>(blockIdx.x) * blockDim.x + threadIdx.x; i < total;
+         i += static_cast<long long>(gridDim.x) * blockDim.x) {
+        long long e = i;
+        const int ci_l = e % PW_K; e /= PW_K;
+        const int co_l = e % PW_M; e /= PW_M;
+        const int ks = e % n_ks; e /= n_ks;
+        const int mt = static_cast<int>(e);
+        const int co = mt * PW_M + co_l, ci = ks * PW_K + ci_l;
+        const float v = (co < c_out && ci < c_in) ? w[static_cast<size_t>(co) * c_in + ci] * row_scale[co] : 0.f;
+        const _Float16 hi = static_cast<_Float16>(v);
+        const _Float16 lo = static_cast<_Float16>((v - static_cast<float>(hi)) * 2048.f);
+        const int blk = ci_l >> 4, half = (ci_l >> 3) & 1, c8 = ci_l & 7;
+        const size_t step = static_cast<size_t>(mt) * n_ks + ks;
+        const size_t base = step * (PW_A_STEP / 2) + ((static_cast<size_t>(blk) * 2 + half) * PW_M + co_l) * 8 + c8;
+        wp[base] = __builtin_bit_cast(unsigned short, hi);
+        wp[base + (PW_A_STEP / 4)] = __builtin_bit_cast(unsigned short, lo);       // split 1 = second half of the step image
+    }
+}
+
+// ---- activation pre-split -----------------------------------------------------------------------------------------------
+// grid (frame tiles, batch), 1024 threads = 256 frames x 4 channel slices; pass 1: largest |x| of the tile; pass 2: scale,
+// split, write the image rows (16 B per lane, lanes along frames: 1 KiB contiguous per wave store; slice s takes the
+// K-steps s, s + 4, ...).  inv_scale[b * n_nt + nt] = 2^-k of the tile.
+template <bool LNX>
+__global__ __launch_bounds__(1024) void pw_presplit_kernel(const float* __restrict__ x, unsigned char* __restrict__ image,
+                                                           float* __restrict__ inv_scale, int c_in, int frames, int ld,
+                                                           int n_ks, const LnRef ln)
+{
+    __shared__ float s_max[16];
+    const int nt = blockIdx.x, b = blockIdx.y;
+    const int lane_t = threadIdx.x & (PW_N - 1);             // frame within the tile
+    const int slice = threadIdx.x >> 8;                      // wave-uniform
+    const int t = nt * PW_N + lane_t;
+    const bool live = t < frames;
+    const float* __restrict__ xb = x + static_cast<size_t>(b) * c_in * ld + t;
+    float mean = 0.f, rstd = 0.f;
+    if (LNX && live) {
+        const float* st = ln.stats + static_cast<size_t>(b) * 2 * ld;
+        mean = st[t]; rstd = st[ld + t];
+    }
+    auto fetch = [&](int ci) {
+        float v = (live && ci < c_in) ? xb[static_cast<size_t>(ci) * ld] : 0.f;
+        if (LNX && live && ci < c_in) v = ln_apply(v, mean, rstd, ln.gamma[ci], ln.beta[ci]);
+        return v;
+    };
+    float m = 0.f;
+    for (int ks = slice; ks < n_ks; ks += 4)
+#pragma unroll 8
+        for (int c = 0; c < PW_K; ++c) m = fmaxf(m, fabsf(fetch(ks * PW_K + c)));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    float tile_max = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) tile_max = fmaxf(tile_max, s_max[w]);
+    float scale, inv;
+    pw_pow2(tile_max, 14, scale, inv);
+    if (threadIdx.x == 0) inv_scale[static_cast<size_t>(b) * gridDim.x + nt] = inv;
+    unsigned char* tile = image + (static_cast<size_t>(b) * gridDim.x + nt) * n_ks * PW_X_STEP;
+    for (int ks = slice; ks < n_ks; ks += 4) {
+#pragma unroll
+        for (int bh = 0; bh < 4; ++bh) {                     // (16-channel block, 8-channel half)
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = fetch(ks * PW_K + bh * 8 + c);
+            halfx8 hi, lo;
+            pw_split8(v, scale, hi, lo);
+            unsigned char* row = tile + static_cast<size_t>(ks) * PW_X_STEP + (bh * PW_N + lane_t) * 16;
+            *reinterpret_cast<halfx8*>(row) = hi;
+            *reinterpret_cast<halfx8*>(row + PW_X_STEP / 2) = lo;
+        }
+    }
+}
+
+// ---- the GEMM -----------------------------------------------------------------------------------------------------------------
+struct PointwiseArgs {
+    const unsigned char* image; const float* x_inv; const unsigned char* wp; const float* w_inv;
+    const float* bias; const float* bias2; const float* s0; const float* s1; const float* s2; float* y;
+    int c_out, frames, ld_out, n_ks, n_mt, n_nt, batch;
+    int row_stride_t, row_stride_b;          // SWAP store: y[(t * row_stride_t + b * row_stride_b) * c_out + m]
+    LnRef ln_s0;
+};
+
+template <bool SWAP, bool RELU>
+__global__ __launch_bounds__(PW_THREADS, 2) void pw_gemm_kernel(const PointwiseArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Abuf = smem;                       // [2][PW_A_STEP]
+    unsigned char* const Xbuf = smem + 2 * PW_A_STEP;       // [2][PW_X_STEP]
+
+    // XCD-aware, m-major tile order: the workgroups of an XCD share weight tiles in its L2
+    const int nwg = gridDim.x, id = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
+    const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
+    const int per_m = a.n_nt * a.batch;
+    const int mt_i = L / per_m;
+    const int rem = L - mt_i * per_m;
+    const int b = rem / a.n_nt;
+    const int nt_i = rem - b * a.n_nt;
+    const int m0 = mt_i * PW_M, n0 = nt_i * PW_N;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int l15 = lane & 15, kq = lane >> 4;
+    const bool wave_active = (m0 + wm * 64) < a.c_out && (n0 + wn * 64) < a.ld_out;
+
+    const unsigned char* __restrict__ wsrc = a.wp + static_cast<size_t>(mt_i) * a.n_ks * PW_A_STEP;
+    const unsigned char* __restrict__ xsrc = a.image + (static_cast<size_t>(b) * a.n_nt + nt_i) * a.n_ks * PW_X_STEP;
+
+    floatx4 big[4][4], small[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { big[i][j][r] = 0.f; small[i][j][r] = 0.f; }
+
+    // one K-step = 48 x 1 KiB LDS-DMA pieces (16 weights + 32 image), 6 per wave
+    auto dma_step = [&](int ks, int buf) {
+        const unsigned char* ws = wsrc + static_cast<size_t>(ks) * PW_A_STEP;
+        const unsigned char* xs = xsrc + static_cast<size_t>(ks) * PW_X_STEP;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int piece = wave * 2 + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ws + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Abuf + buf * PW_A_STEP + piece * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = wave * 4 + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xs + piece * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(Xbuf + buf * PW_X_STEP + piece * 1024), 16, 0, 0);
+        }
+    };
+
+    // per-lane fragment bases: k quarter kq -> 16-channel block kq >> 1, 8-channel half kq & 1
+    const int a_lane = ((kq * PW_M) + wm * 64 + l15) * 16;
+    const int x_lane = ((kq * PW_N) + wn * 64 + l15) * 16;
+
+    dma_step(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll 1
+    for (int ks = 0; ks < a.n_ks; ++ks) {
+        const int buf = ks & 1;
+        if (ks + 1 < a.n_ks) dma_step(ks + 1, buf ^ 1);
+        if (wave_active) {
+            const unsigned char* A = Abuf + buf * PW_A_STEP + a_lane;
+            const unsigned char* X = Xbuf + buf * PW_X_STEP + x_lane;
+            halfx8 bh[4], bl[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bh[j] = *reinterpret_cast<const halfx8*>(X + j * 16 * 16);
+                bl[j] = *reinterpret_cast<const halfx8*>(X + PW_X_STEP / 2 + j * 16 * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const halfx8 ah = *reinterpret_cast<const halfx8*>(A + i * 16 * 16);
+                const halfx8 al = *reinterpret_cast<const halfx8*>(A + PW_A_STEP / 2 + i * 16 * 16);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    floatx4 c = small[i][j];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[j], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[j], c, 0, 0, 0);
+                    small[i][j] = c;
+                    big[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[j], big[i][j], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    if (!wave_active) return;
+    const float x_inv = a.x_inv[static_cast<size_t>(b) * a.n_nt + nt_i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + l15;
+            const int mb = m0 + wm * 64 + i * 16 + kq * 4;
+            if (SWAP) {
+                if (n >= a.frames || mb >= a.c_out) continue;
+                floatx4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r;
+                    float v = 0.f;
+                    if (m < a.c_out) {
+                        v = (big[i][j][r] + small[i][j][r] * (1.f / 2048.f)) * x_inv * a.w_inv[m] + a.bias[m];
+                        if (a.bias2) v += a.bias2[m];
+                        if (RELU) v = relu_clamp(v);
+                    }
+                    o[r] = v;
+                }
+                float* dst = a.y + (static_cast<size_t>(n) * a.row_stride_t + static_cast<size_t>(b) * a.row_stride_b) * a.c_out + mb;
+                if (mb + 3 < a.c_out) *reinterpret_cast<floatx4*>(dst) = o;
+                else for (int r = 0; r < 4 && mb + r < a.c_out; ++r) dst[r] = o[r];
+            } else {
+                if (n >= a.ld_out) continue;
+                const bool live = n < a.frames;
+                float s0m = 0.f, s0r = 0.f;
+                if (a.s0 && a.ln_s0.stats) {
+                    const float* st = a.ln_s0.stats + static_cast<size_t>(b) * 2 * a.ld_out;
+                    s0m = st[n]; s0r = st[a.ld_out + n];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mb + r;
+                    if (m >= a.c_out) continue;
+                    float v = (big[i][j][r] + small[i][j][r] * (1.f / 2048.f)) * x_inv * a.w_inv[m] + a.bias[m];
+                    if (RELU) v = relu_clamp(v);
+                    const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
+                    if (a.s0) v += a.ln_s0.stats ? ln_apply(a.s0[off], s0m, s0r, a.ln_s0.gamma[m], a.ln_s0.beta[m]) : a.s0[off];
+                    if (a.s1) v += a.s1[off];
+                    if (a.s2) v += a.s2[off];
+                    a.y[off] = live ? v : 0.f;
+                }
+            }
+        }
+    }
+}
+
+template <bool SWAP, bool RELU>
+static int pw_launch(PointwiseArgs a, hipStream_t stream, const char* what)
+{
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_kernel<SWAP, RELU>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+    if (attr != hipSuccess) {
+        set_error("%s: cannot reserve %d bytes of LDS: %s", what, PW_LDS, hipGetErrorString(attr));
+        return static_cast<int>(attr);
+    }
+    const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
+    NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", what, nwg);
+    hipLaunchKernelGGL((pw_gemm_kernel<SWAP, RELU>), dim3(static_cast<unsigned>(nwg)), dim3(PW_THREADS), PW_LDS, stream, a);
+    return launch_status(what);
+}
+
+static inline int pw_n_ks(int c_in) { return (c_in + PW_K - 1) / PW_K; }
+static inline int pw_n_mt(int c_out) { return (c_out + PW_M - 1) / PW_M; }
+static inline int pw_n_nt(int ld) { return (ld + PW_N - 1) / PW_N; }
+static inline size_t pw_image_bytes(int batch, int c_in, int ld) { return static_cast<size_t>(batch) * pw_n_nt(ld) * pw_n_ks(c_in) * PW_X_STEP; }
+
+// presplit x into ws (image, then batch * n_nt inverse scales); `ln` = pending LayerNorm of x (stats == nullptr: none)
+static int pw_presplit(const float* x, void* ws, int batch, int c_in, int frames, int ld, LnRef ln, hipStream_t stream, const char* what)
+{
+    unsigned char* image = static_cast<unsigned char*>(ws);
+    float* inv = reinterpret_cast<float*>(image + pw_image_bytes(batch, c_in, ld));
+    const dim3 grid(pw_n_nt(ld), batch);
+    if (ln.stats) hipLaunchKernelGGL(pw_presplit_kernel<true>, grid, dim3(1024), 0, stream, x, image, inv, c_in, frames, ld, pw_n_ks(c_in), ln);
+    else          hipLaunchKernelGGL(pw_presplit_kernel<false>, grid, dim3(1024), 0, stream, x, image, inv, c_in, frames, ld, pw_n_ks(c_in), ln);
+    return launch_status(what);
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" size_t nbasr_pointwise_packed_weights_bytes(int c_out, int c_in)
+{
+    if (c_out <= 0 || c_in <= 0) return 0;
+    return static_cast<size_t>(pw_n_mt(c_out)) * pw_n_ks(c_in) * PW_A_STEP + 2 * static_cast<size_t>(pw_n_mt(c_out)) * PW_M * sizeof(float);
+}
+
+extern "C" size_t nbasr_pointwise_workspace_bytes(int batch, int c_in, int ld)
+{
+    if (batch <= 0 || c_in <= 0 || ld <= 0) return 0;
+    return pw_image_bytes(batch, c_in, ld) + static_cast<size_t>(batch) * pw_n_nt(ld) * sizeof(float);
+}
+
+extern "C" int nbasr_pack_pointwise_weights(const float* w, void* packed, int c_out, int c_in, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_pointwise_weights: bad sizes");
+    NBASR_REQUIRE(w && packed, NBASR_ENULL, "nbasr_pack_pointwise_weights: NULL pointer");
+    NBASR_REQUIRE(aligned16(packed), NBASR_EALIGN, "nbasr_pack_pointwise_weights: packed buffer must be 16-byte aligned");
+    const int n_mt = pw_n_mt(c_out), n_ks = pw_n_ks(c_in);
+    float* scales = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + static_cast<size_t>(n_mt) * n_ks * PW_A_STEP);
+    hipLaunchKernelGGL(pw_row_scales_kernel, dim3(n_mt * PW_M), dim3(256), 0, as_stream(stream), w, scales, c_out, c_in, n_mt * PW_M);
+    hipLaunchKernelGGL(pw_pack_weights_kernel, dim3(1024), dim3(256), 0, as_stream(stream), w, static_cast<unsigned short*>(packed), scales,
+                       c_out, c_in, n_mt, n_ks);
+    return launch_status("nbasr_pack_pointwise_weights");
+}
+
+static int pw_common_checks(const char* what, const float* x, const void* ws, const void* packed_w, const float* bias, float* y,
+                            int batch, int c_in, int frames, int ld_in, int c_out)
+{
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames >= 0 && ld_in >= frames, NBASR_EINVAL, "%s: bad sizes", what);
+    if (batch == 0 || frames == 0) return 1;
+    NBASR_REQUIRE(x && ws && packed_w && bias && y, NBASR_ENULL, "%s: x, workspace, packed_w, bias, y must be non-NULL", what);
+    NBASR_REQUIRE(aligned16(ws) && aligned16(packed_w), NBASR_EALIGN, "%s: workspace and packed weights must be 16-byte aligned", what);
+    return NBASR_OK;
+}
+
+extern "C" int nbasr_linear_fused_packed(const float* x, void* ws, const void* packed_w, const float* bias, const float* skip0,
+                                         const float* skip1, const float* skip2, float* y, int batch, int channels_in,
+                                         int frames, int ld, int channels_out, const nbasr_deferred_ln* ln, int ln_on_x,
+                                         int ln_on_skip0, nbasr_stream_t stream)
+{
+    clear_error();
+    const int rc0 = pw_common_checks("nbasr_linear_fused_packed", x, ws, packed_w, bias, y, batch, channels_in, frames, ld, channels_out);
+    if (rc0 != NBASR_OK) return rc0 == 1 ? NBASR_OK : rc0;
+    NBASR_REQUIRE(ld % 4 == 0, NBASR_EALIGN, "nbasr_linear_fused_packed: ld=%d must be a multiple of 4", ld);
+    const bool any_ln = ln && (ln_on_x || (ln_on_skip0 && skip0));
+    NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_linear_fused_packed: deferred LayerNorm needs stats, gamma and beta");
+    NBASR_REQUIRE(!(ln && ln_on_x && ln_on_skip0 && skip0) || channels_in == channels_out, NBASR_EINVAL,
+                  "nbasr_linear_fused_packed: one descriptor for x and skip0 needs equal shapes");
+    hipStream_t s = as_stream(stream);
+    int rc = pw_presplit(x, ws, batch, channels_in, frames, ld, ln_ref(ln, ln_on_x != 0), s, "nbasr_linear_fused_packed(presplit)");
+    if (rc != NBASR_OK) return rc;
+    PointwiseArgs a{};
+    const unsigned char* wp = static_cast<const unsigned char*>(packed_w);
+    a.image = static_cast<const unsigned char*>(ws);
+    a.x_inv = reinterpret_cast<const float*>(a.image + pw_image_bytes(batch, channels_in, ld));
+    a.wp = wp;
+    a.n_mt = pw_n_mt(channels_out); a.n_ks = pw_n_ks(channels_in); a.n_nt = pw_n_nt(ld);
+    a.w_inv = reinterpret_cast<const float*>(wp + static_cast<size_t>(a.n_mt) * a.n_ks * PW_A_STEP) + static_cast<size_t>(a.n_mt) * PW_M;
+    a.bias = bias; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
+    a.c_out = channels_out; a.frames = frames; a.ld_out = ld; a.batch = batch;
+    a.ln_s0 = ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr);
+    return pw_launch<false, true>(a, s, "nbasr_linear_fused_packed");
+}
+
+extern "C" int nbasr_lstm_input_projection_packed(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                                  const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                                  int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+{
+    clear_error();
+    const int rc0 = pw_common_checks("nbasr_lstm_input_projection_packed", x, ws, packed_w_ih, b_ih, gates_ws, batch, c_in, frames, ld, 4 * hidden);
+    if (rc0 != NBASR_OK) return rc0 == 1 ? NBASR_OK : rc0;
+    NBASR_REQUIRE(b_hh != nullptr, NBASR_ENULL, "nbasr_lstm_input_projection_packed: b_hh is NULL");
+    NBASR_REQUIRE(hidden % 4 == 0 && aligned16(gates_ws), NBASR_EALIGN, "nbasr_lstm_input_projection_packed: hidden %% 4 and 16-byte aligned gates_ws required");
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_lstm_input_projection_packed: deferred LayerNorm needs stats, gamma and beta");
+    hipStream_t s = as_stream(stream);
+    int rc = pw_presplit(x, ws, batch, c_in, frames, ld, ln_ref(ln, true), s, "nbasr_lstm_input_projection_packed(presplit)");
+    if (rc != NBASR_OK) return rc;
+    PointwiseArgs a{};
+    const unsigned char* wp = static_cast<const unsigned char*>(packed_w_ih);
+    a.image = static_cast<const unsigned char*>(ws);
+    a.x_inv = reinterpret_cast<const float*>(a.image + pw_image_bytes(batch, c_in, ld));
+    a.wp = wp;
+    a.n_mt = pw_n_mt(4 * hidden); a.n_ks = pw_n_ks(c_in); a.n_nt = pw_n_nt(ld);
+    a.w_inv = reinterpret_cast<const float*>(wp + static_cast<size_t>(a.n_mt) * a.n_ks * PW_A_STEP) + static_cast<size_t>(a.n_mt) * PW_M;
+    a.bias = b_ih; a.bias2 = b_hh; a.y = gates_ws;
+    a.c_out = 4 * hidden; a.frames = frames; a.ld_out = ld; a.batch = batch;
+    a.row_stride_t = batch; a.row_stride_b = 1;
+    return pw_launch<true, false>(a, s, "nbasr_lstm_input_projection_packed");
+}

@@ -20,12 +20,14 @@ import torch
 from . import hip
 
 
-def node_into(node, inputs, frames, out, ln0=None, stats=None):
+def node_into(node, inputs, frames, out, ln0=None, stats=None, linear_ctx=None):
     """Enqueue one cell node: ``out = op(inputs[-1]) + sum(flagged inputs)`` (left-to-right).
 
     ``ln0`` = (stats, gamma, beta): ``inputs[0]`` (the cell input) is stored un-normalised with a pending LayerNorm that
     the kernel applies while loading -- as the main input when the node is the cell's first, as skip0 when flagged.
-    ``stats`` = (stats_out, workspace, eps): a grouped-conv node also emits the LayerNorm statistics of ``out``."""
+    ``stats`` = (stats_out, workspace, eps): a grouped-conv node also emits the LayerNorm statistics of ``out``.
+    ``linear_ctx`` = (packed_weights(op), workspace(c_in, ld)) callables of a ForwardPlan: `linear` ops then run on the fp16
+    matrix cores (packed weights, pre-split activations); None = the exact-fp32 MFMA GEMM."""
     from .ops import PadConvRelu, Linear, Zero, Identity
     if len(inputs) != len(node.branch_ops):
         raise AssertionError('Branch op and input list have different lenghts')
@@ -42,8 +44,13 @@ def node_into(node, inputs, frames, out, ln0=None, stats=None):
     elif isinstance(op, Linear):
         if stats is not None:
             raise ValueError('statistics from the epilogue are only available for grouped-conv nodes')
-        hip.dense_conv1d_fused(last, frames, op.linear.weight.detach().unsqueeze(-1), op.linear.bias.detach(),
-                               skips, out, 1, ln, on_x, on_s0)
+        if linear_ctx is not None:
+            packed, workspace = linear_ctx
+            hip.linear_fused_packed(last, frames, packed(op.linear), op.linear.out_features, op.linear.bias.detach(), skips, out,
+                                    workspace(last.shape[1], last.shape[2]), ln, on_x, on_s0)
+        else:
+            hip.dense_conv1d_fused(last, frames, op.linear.weight.detach().unsqueeze(-1), op.linear.bias.detach(),
+                                   skips, out, 1, ln, on_x, on_s0)
     elif isinstance(op, Zero):
         hip.skip_sum(skips, out, frames, ln if on_s0 else None, on_s0)
     else:
@@ -89,6 +96,12 @@ class ForwardPlan:
         if self.dense_mode not in ('auto', 'bf16x3', 'f32'):
             raise ValueError(f'NBASR_DENSE_MODE must be auto, bf16x3 or f32, got {self.dense_mode!r}')
         self._packed = {}            # (id(layer), scheme) -> (weight key, packed tensor)
+        # per-frame linear maps (`linear` node ops, LSTM input projection): 'f16x2' = fp16 matrix cores with pre-split
+        # activations (default), 'f32' = the exact-fp32 MFMA GEMM
+        self.linear_mode = os.environ.get('NBASR_LINEAR_MODE', 'f16x2')
+        if self.linear_mode not in ('f16x2', 'f32'):
+            raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
+        self._pw_ws = None           # scratch of the pre-split activation image, grown on demand
         self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
@@ -139,6 +152,22 @@ class ForwardPlan:
             hit = (key, hip.pack_dense_weights(w.detach(), layer.strides, scheme))
             self._packed[(id(layer), scheme)] = hit
         return hit[1]
+
+    def _packed_linear(self, linear):
+        """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""
+        w = linear.weight if hasattr(linear, 'weight') else linear
+        key = (w.data_ptr(), w._version)
+        hit = self._packed.get((id(w), 'pointwise'))
+        if hit is None or hit[0] != key:
+            hit = (key, hip.pack_pointwise_weights(w.detach()))
+            self._packed[(id(w), 'pointwise')] = hit
+        return hit[1]
+
+    def _pointwise_ws(self, c_in, ld):
+        need = hip.load_library().nbasr_pointwise_workspace_bytes(self.batch, c_in, ld)
+        if self._pw_ws is None or self._pw_ws.numel() < need:
+            self._pw_ws = hip.pointwise_workspace(self.batch, c_in, ld, self.device)
+        return self._pw_ws
 
     def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None):
         """``absmax``: (B,) device bounds of max|act[b]| when `act` was just written by the LayerNorm kernel, else None."""
@@ -262,6 +291,7 @@ class ForwardPlan:
         pipe = bool(pipelined) and model.use_rnn and taps is None
         pipe_k, tail_ctx = None, None
         self._stat_turn = 0
+        lin_ctx = (self._packed_linear, self._pointwise_ws) if self.linear_mode == 'f16x2' else None
         blk = -1
         logits = None
         n_layers = len(model.model)
@@ -323,7 +353,7 @@ class ForwardPlan:
                         ld = view.shape[2]
                         new_stats = self.stats[self._stat_turn][: self.batch * 2 * ld].view(self.batch, 2, ld)
                         st = (new_stats, self.stats_ws, layer.norm_layer.eps)
-                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st)))
+                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx)))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 if feeds_tail:
                     pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)
@@ -356,8 +386,14 @@ class ForwardPlan:
                 b_ih, b_hh = layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach()
                 gates = self.gates_pipe[pipe_k] if pipe else self.gates_ws
                 # the input projection is one large GEMM: it stays with the encoder; only the recurrence moves over
-                self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_input_projection(src, src_frames, w_ih, b_ih, b_hh, gates, layer.hidden_size, ln))
+                if self.linear_mode == 'f16x2':
+                    packed_ih, ws = self._packed_linear(layer.weight_ih_l0), self._pointwise_ws(src.shape[1], src.shape[2])
+                    self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_input_projection_packed(src, src_frames, packed_ih, b_ih, b_hh, gates,
+                                                                         layer.hidden_size, ws, ln))
+                else:
+                    self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_input_projection(src, src_frames, w_ih, b_ih, b_hh, gates, layer.hidden_size, ln))
                 if pipe:                                   # everything from here on runs on the side stream
                     ready = torch.cuda.Event()
                     ready.record(torch.cuda.current_stream(self.device))

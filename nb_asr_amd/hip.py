@@ -44,6 +44,11 @@ SIGNATURES = {
     'nbasr_pack_dense_weights_f16': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_f16': (_c_int, [_c_float_p] * 8 + [_c_int] * 8 + [_c_stream]),
     'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_pointwise_packed_weights_bytes': (ctypes.c_size_t, [_c_int] * 2),
+    'nbasr_pointwise_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_pack_pointwise_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 2 + [_c_stream]),
+    'nbasr_linear_fused_packed': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_lstm_input_projection_packed': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_frame_signal': (_c_int, [_c_float_p, ctypes.c_void_p, _c_float_p] + [_c_int] * 6 + [_c_stream]),
     'nbasr_pointwise_linear': (_c_int, [_c_float_p] * 4 + [_c_int] * 6 + [_c_stream]),
     'nbasr_power_spectrum': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
@@ -329,6 +334,50 @@ def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):
                                                 _dev(h_out, 'h_out'), b, frames, hidden, _stream(h_out)),
            'nbasr_lstm_recurrence')
     return h_out
+
+
+def pack_pointwise_weights(weight):
+    """(c_out, c_in) fp32 weight of a per-frame linear map -> opaque uint8 tensor (2 x fp16 split in LDS-image order + row scales)."""
+    c_out, c_in = weight.shape
+    nbytes = load_library().nbasr_pointwise_packed_weights_bytes(c_out, c_in)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _check(load_library().nbasr_pack_pointwise_weights(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, _stream(weight)),
+           'nbasr_pack_pointwise_weights')
+    return packed
+
+
+def pointwise_workspace(batch, c_in, ld, device):
+    """Scratch for the pre-split activation image of linear_fused_packed / lstm_input_projection_packed."""
+    return torch.empty(max(load_library().nbasr_pointwise_workspace_bytes(batch, c_in, ld), 16), dtype=torch.uint8, device=device)
+
+
+def _check_pointwise(packed, ws, c_out, c_in, batch, ld):
+    lib = load_library()
+    if not packed.is_cuda or packed.dtype != torch.uint8 or packed.numel() != lib.nbasr_pointwise_packed_weights_bytes(c_out, c_in):
+        raise HipError(f'packed weights are not the pack_pointwise_weights image of a ({c_out}, {c_in}) weight')
+    if not ws.is_cuda or ws.dtype != torch.uint8 or ws.numel() < lib.nbasr_pointwise_workspace_bytes(batch, c_in, ld):
+        raise HipError('workspace too small: allocate it with pointwise_workspace(batch, c_in, ld, device)')
+
+
+def linear_fused_packed(x, frames, packed, c_out, bias, skips, y, ws, ln=None, ln_on_x=False, ln_on_skip0=False):
+    """The `linear` node op on the fp16 matrix cores: y = min(relu(W x + b), 20) + skips (see nbasr.h)."""
+    b, c_in, ld = x.shape
+    _check_pointwise(packed, ws, c_out, c_in, b, ld)
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_linear_fused_packed(
+        _dev(x, 'x'), ws.data_ptr(), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
+        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames, ld, c_out, _ln(ln), int(ln_on_x), int(ln_on_skip0), _stream(x)),
+        'nbasr_linear_fused_packed')
+    return y
+
+
+def lstm_input_projection_packed(x, frames, packed_w_ih, b_ih, b_hh, gates_ws, hidden, ws, ln=None):
+    b, c_in, ld = x.shape
+    _check_pointwise(packed_w_ih, ws, 4 * hidden, c_in, b, ld)
+    _check(load_library().nbasr_lstm_input_projection_packed(
+        _dev(x, 'x'), ws.data_ptr(), packed_w_ih.data_ptr(), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
+        b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_input_projection_packed')
+    return gates_ws
 
 
 def _lengths_ptr(lengths, batch):

@@ -232,6 +232,70 @@ def test_linear_op_golden(op_fx, c, t, b):
     close(y, op_fx[tag])
 
 
+def linear_packed(x, w, bias, skips=(), ln=None, on_x=False, on_s0=False, xp=None):
+    """`linear` node op on the fp16 matrix cores (pre-split activations)."""
+    b, c, t = x.shape
+    xp = pitched(x)[0] if xp is None else xp
+    y = torch.full((b, w.shape[0], xp.shape[2]), float('nan'), device=DEV)
+    ws = hip.pointwise_workspace(b, c, xp.shape[2], DEV)
+    hip.linear_fused_packed(xp, t, hip.pack_pointwise_weights(w.to(DEV)), w.shape[0], bias.to(DEV), list(skips), y, ws, ln, on_x, on_s0)
+    assert torch.all(y[:, :, t:] == 0)
+    return y[:, :, :t]
+
+
+@pytest.mark.parametrize('c,t,b', cases.LINEAR_CASES)
+def test_linear_op_packed_golden(op_fx, c, t, b):
+    tag = f'linear/c{c}_t{t}'
+    p = cases.keyed_params({'linear.weight': (c, c), 'linear.bias': (c,)}, tag)
+    close(linear_packed(cases.keyed_x(tag, (b, c, t)), p['linear.weight'], p['linear.bias']), op_fx[tag])
+
+
+@pytest.mark.parametrize('c_in,c_out,t,x_scale', [(24, 24, 37, 1.0), (600, 600, 300, 1.0), (136, 200, 515, 1e-9), (1200, 40, 7, 1e5),
+                                                  (33 * 4, 130, 257, 1.0)])
+def test_linear_op_packed_vs_fp64(c_in, c_out, t, x_scale):
+    """Same accuracy bar as the split convolution: error vs fp64 within 2.5x of the exact-fp32 MFMA kernel; the per-tile and
+    per-row power-of-two scalings make it independent of the overall magnitudes (frames of one utterance differ by 1e3)."""
+    torch.manual_seed(c_in + t)
+    x = torch.randn(2, c_in, t) * x_scale
+    x[:, :, t // 2:] *= 1e-3
+    w = torch.randn(c_out, c_in) * (2.0 / c_in) ** 0.5 * torch.logspace(-4, 0, c_out).view(-1, 1) / x_scale
+    bias = torch.zeros(c_out)
+    want = oracle.linear_relu(x.double(), w.double(), bias.double())
+    scale = want.abs().amax(dim=(0, 2), keepdim=True).clamp_min(1e-300)          # per output row
+    got16 = linear_packed(x, w, bias).cpu().double()
+    got32 = dense(x, w.unsqueeze(-1).contiguous(), bias, 1).cpu().double()
+    e16 = float(((got16 - want) / scale).pow(2).mean().sqrt())
+    e32 = float(((got32 - want) / scale).pow(2).mean().sqrt())
+    assert e16 <= max(2.5 * e32, 3e-8) and e16 < 2e-6, (e16, e32)
+
+
+def test_linear_op_packed_skips_and_deferred_ln():
+    c, t = 40, 150
+    x, xp, ln, normed = _ln_setup(c, t, seed=5)
+    w, bias = torch.randn(c, c) * 0.2, torch.randn(c) * 0.1
+    other = pitched(torch.randn(2, c, t))[0]
+    want = torch.empty_like(xp)
+    hip.dense_conv1d_fused(normed, t, w.unsqueeze(-1).contiguous().to(DEV), bias.to(DEV), [normed, other], want, 1)
+    got = linear_packed(x, w, bias, [xp, other], ln, True, True, xp=xp)
+    close(got, want[:, :, :t].cpu(), rtol=1e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize('b,c_in,t,hidden', [(3, 1200, 63, 500), (2, 40, 5, 12), (16, 136, 250, 64)])
+def test_lstm_input_projection_packed_vs_fp32(b, c_in, t, hidden):
+    torch.manual_seed(t)
+    xp, _ = pitched(torch.randn(b, c_in, t))
+    w_ih, b_ih, b_hh = torch.randn(4 * hidden, c_in, device=DEV) * 0.05, torch.randn(4 * hidden, device=DEV), torch.randn(4 * hidden, device=DEV)
+    g32 = torch.full((t, b, 4 * hidden), float('nan'), device=DEV)
+    g16 = torch.full_like(g32, float('nan'))
+    hip.lstm_input_projection(xp, t, w_ih, b_ih, b_hh, g32, hidden)
+    hip.lstm_input_projection_packed(xp, t, hip.pack_pointwise_weights(w_ih), b_ih, b_hh, g16, hidden,
+                                     hip.pointwise_workspace(b, c_in, xp.shape[2], DEV))
+    want = torch.einsum('oc,bct->tbo', w_ih.double().cpu(), xp[:, :, :t].double().cpu()) + (b_ih + b_hh).double().cpu()
+    e32 = float((g32.cpu().double() - want).abs().max())
+    e16 = float((g16.cpu().double() - want).abs().max())
+    assert torch.isfinite(g16).all() and e16 <= max(2.5 * e32, 1e-6), (e16, e32)
+
+
 def test_zero_and_skip_sum(op_fx):
     xp, t = pitched(torch.tensor([[[float('nan'), float('inf'), 1.0, -2.0]]]))
     y = torch.full_like(xp, 7.0)
