@@ -48,6 +48,24 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1 and b'unsupported' in lib.nbasr_last_error()
     rc = lib.nbasr_linear_head(16, 16, 16, 16, 10, 500, 65, None)
     assert rc == -1
+    # the packed / split entry points and the front-end validate the same way
+    rc = lib.nbasr_dense_conv1d_fused_packed(16, 16, 16, None, None, None, 16, 1, 600, 10, 10, 800, 12, 8, 1, None)   # ld_in % 4
+    assert rc == -2 and b'multiple of 4' in lib.nbasr_last_error()
+    rc = lib.nbasr_dense_conv1d_fused_packed_f16(16, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, None)
+    assert rc == -3 and b'x_absmax' in lib.nbasr_last_error()
+    rc = lib.nbasr_pack_dense_weights_f16(16, 16, 128, 16, 5, 1, None)
+    assert rc == -1 and b'unsupported' in lib.nbasr_last_error()
+    rc = lib.nbasr_linear_fused_packed(16, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 600, None, 0, 0, None)
+    assert rc == -3 and b'workspace' in lib.nbasr_last_error()
+    rc = lib.nbasr_lstm_input_projection_packed(16, 16, 16, 16, 16, 16, 1, 1200, 16, 16, 501, None, None)
+    assert rc == -2
+    rc = lib.nbasr_frame_signal(16, None, 16, 1, 100, 100, 400, 160, 4, None)                 # too short for reflect padding
+    assert rc == -1 and b'reflect' in lib.nbasr_last_error()
+    rc = lib.nbasr_pointwise_linear(16, 16, 16, 16, 1, 401, 10, 12, 80, 12, None)               # c_in % 4
+    assert rc == -2
+    assert lib.nbasr_pointwise_workspace_bytes(64, 1200, 252) == 64 * 38 * 32768 + 64 * 4
+    assert lib.nbasr_pointwise_packed_weights_bytes(2000, 1200) == 16 * 38 * 16384 + 2 * 16 * 128 * 4
+    assert lib.nbasr_packed_dense_weights_bytes_f16(800, 600, 8) == 7 * 38 * 2 * 8 * 128 * 16 * 2 + 2 * 7 * 128 * 4
 
 
 def test_missing_library_fails_loudly(tmp_path):
