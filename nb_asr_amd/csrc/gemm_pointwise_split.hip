@@ -123,6 +123,8 @@ __global__ __launch_bounds__(1024) void pw_presplit_kernel(const float* __restri
         if (LNX && live && ci < c_in) v = ln_apply(v, mean, rstd, ln.gamma[ci], ln.beta[ci]);
         return v;
     };
+    // gridDim.z > 1 (few frame tiles: the LSTM projection has one per utterance): every z-slice of workgroups reduces the
+    // WHOLE tile's maximum (the re-reads hit L2) and writes only its own share of the K-steps
     float m = 0.f;
     for (int ks = slice; ks < n_ks; ks += 4)
 #pragma unroll 8
@@ -136,9 +138,9 @@ __global__ __launch_bounds__(1024) void pw_presplit_kernel(const float* __restri
     for (int w = 0; w < 16; ++w) tile_max = fmaxf(tile_max, s_max[w]);
     float scale, inv;
     pw_pow2(tile_max, 14, scale, inv);
-    if (threadIdx.x == 0) inv_scale[static_cast<size_t>(b) * gridDim.x + nt] = inv;
+    if (threadIdx.x == 0 && blockIdx.z == 0) inv_scale[static_cast<size_t>(b) * gridDim.x + nt] = inv;
     unsigned char* tile = image + (static_cast<size_t>(b) * gridDim.x + nt) * n_ks * PW_X_STEP;
-    for (int ks = slice; ks < n_ks; ks += 4) {
+    for (int ks = slice + 4 * blockIdx.z; ks < n_ks; ks += 4 * gridDim.z) {
 #pragma unroll
         for (int bh = 0; bh < 4; ++bh) {                     // (16-channel block, 8-channel half)
             float v[8];
@@ -328,7 +330,7 @@ static int pw_presplit(const float* x, void* ws, int batch, int c_in, int frames
 {
     unsigned char* image = static_cast<unsigned char*>(ws);
     float* inv = reinterpret_cast<float*>(image + pw_image_bytes(batch, c_in, ld));
-    const dim3 grid(pw_n_nt(ld), batch);
+    const dim3 grid(pw_n_nt(ld), batch, pw_n_nt(ld) * batch < 512 ? 4 : 1);
     if (ln.stats) hipLaunchKernelGGL(pw_presplit_kernel<true>, grid, dim3(1024), 0, stream, x, image, inv, c_in, frames, ld, pw_n_ks(c_in), ln);
     else          hipLaunchKernelGGL(pw_presplit_kernel<false>, grid, dim3(1024), 0, stream, x, image, inv, c_in, frames, ld, pw_n_ks(c_in), ln);
     return launch_status(what);
