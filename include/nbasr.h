@@ -78,6 +78,10 @@ int nbasr_layernorm_channels_absmax(const float* x, const float* gamma, const fl
                                     int batch, int channels, int frames, int ld, float eps,
                                     nbasr_stream_t stream);
 
+/* absmax[b] = max |x[b, 0..n-1]| for `batch` utterances of n contiguous floats each (n % 4 == 0, x 16-byte aligned): the
+ * x_absmax argument of nbasr_dense_conv1d_fused_packed_f16 for an input that does not come out of the LayerNorm kernel. */
+int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_stream_t stream);
+
 /* Dense PadConvRelu (groups = 1) on the fp32 matrix cores, fused bias + relu + clamp (+ skips):
  *   kernel == 8: the four downsample convs (reference model.py:82-89, ops.py:24-30), stride 1|2;
  *   kernel == 1: the `linear` node op (reference ops.py:42-50), stride must be 1.

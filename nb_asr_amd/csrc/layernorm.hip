@@ -196,6 +196,40 @@ extern "C" int nbasr_layernorm_channels_absmax(const float* x, const float* gamm
     return layernorm_impl("nbasr_layernorm_channels_absmax", x, gamma, beta, y, absmax, batch, channels, frames, ld, eps, stream);
 }
 
+// absmax[b] = max |x[b, :]| over n contiguous floats per utterance (n % 4 == 0): the range information of the 2-way fp16
+// dense convolution when its input does not come out of the LayerNorm kernel (the model input)
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ absmax, size_t n4)
+{
+    const int b = blockIdx.y;
+    const float4* __restrict__ xb = reinterpret_cast<const float4*>(x) + static_cast<size_t>(b) * n4;
+    float m = 0.f;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        const float4 v = xb[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
+}
+
+extern "C" int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && n >= 0 && n % 4 == 0, NBASR_EINVAL, "nbasr_absmax: batch >= 0 and n %% 4 == 0 required (n=%lld)", n);
+    if (batch == 0) return NBASR_OK;
+    NBASR_REQUIRE(absmax, NBASR_ENULL, "nbasr_absmax: absmax is NULL");
+    const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * batch, as_stream(stream));
+    if (e != hipSuccess) { set_error("nbasr_absmax: hipMemsetAsync failed: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    if (n == 0) return NBASR_OK;
+    NBASR_REQUIRE(x, NBASR_ENULL, "nbasr_absmax: x is NULL");
+    NBASR_REQUIRE(aligned16(x), NBASR_EALIGN, "nbasr_absmax: x must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_absmax: batch %d > 65535", batch);
+    const size_t n4 = static_cast<size_t>(n / 4);
+    const unsigned gx = static_cast<unsigned>(n4 / 1024 + 1 < 64 ? n4 / 1024 + 1 : 64);
+    hipLaunchKernelGGL(absmax_kernel, dim3(gx, batch), dim3(256), 0, as_stream(stream), x, reinterpret_cast<unsigned*>(absmax), n4);
+    return launch_status("nbasr_absmax");
+}
+
 extern "C" int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
                                    nbasr_stream_t stream)
 {

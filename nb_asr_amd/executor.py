@@ -103,6 +103,7 @@ class ForwardPlan:
             raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
         self._pw_ws = None           # scratch of the pre-split activation image, grown on demand
         self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
+        self.absmax_in = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|model input| per utterance
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
         # 'materialize' = the stand-alone LayerNorm kernel writes the normalised tensor
@@ -288,6 +289,9 @@ class ForwardPlan:
             act = hip.repitch(x, self._view(cur, x.shape[1], self.frames), self.frames)
         pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
         self._act_absmax = None                          # set by _norm when it wrote `act` together with max|act[b]|
+        if self.dense_mode == 'auto' and act.shape[0] > 0:
+            # the model input is unbounded: one small reduction gives the first conv its range, too
+            self._act_absmax = hip.absmax(act, self.absmax_in[: act.shape[0]])
         pipe = bool(pipelined) and model.use_rnn and taps is None
         pipe_k, tail_ctx = None, None
         self._stat_turn = 0

@@ -35,6 +35,7 @@ SIGNATURES = {
     'nbasr_grouped_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_stream]),
     'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_stream]),
     'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    'nbasr_absmax': (_c_int, [_c_float_p] * 2 + [_c_int, ctypes.c_longlong, _c_stream]),
     'nbasr_layernorm_channels_absmax': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
     'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 3),
@@ -235,6 +236,13 @@ def layernorm_channels(x, gamma, beta, y, frames, eps, absmax=None):
                                                    _dev(y, 'y'), b, c, frames, ld, float(eps), _stream(x)),
            'nbasr_layernorm_channels')
     return y
+
+
+def absmax(x, out):
+    """out[b] = max |x[b]| over everything but the leading dimension (x contiguous, numel per utterance % 4 == 0)."""
+    b = x.shape[0]
+    _check(load_library().nbasr_absmax(_dev(x, 'x'), _dev(out, 'absmax'), b, x.numel() // max(b, 1), _stream(x)), 'nbasr_absmax')
+    return out
 
 
 def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln_on_x=False, ln_on_skip0=False):

@@ -200,6 +200,15 @@ def test_f16_split_accuracy_is_scale_invariant(x_scale):
     assert float(rel.max()) < 2e-6, float(rel.max())
 
 
+def test_absmax_kernel():
+    x = torch.randn(3, 80, 252, device=DEV)
+    x[1] *= 1e-12
+    x[2, 7, 100] = -3.5e6
+    out = torch.full((3,), -1.0, device=DEV)
+    hip.absmax(x, out)
+    assert torch.equal(out.cpu(), x.abs().amax(dim=(1, 2)).cpu())
+
+
 def test_layernorm_absmax_by_product():
     c, t = 40, 150
     x, xp, ln, normed = _ln_setup(c, t, seed=11)
