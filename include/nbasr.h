@@ -146,6 +146,12 @@ int nbasr_lstm_input_projection(const float* x, const float* w_ih, const float* 
                                 const struct nbasr_deferred_ln* ln, nbasr_stream_t stream);
 int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, float* cell_ws, float* h_out,
                           int batch, int frames, int hidden, nbasr_stream_t stream);
+/* The recurrence on a fragment-ordered copy of w_hh (nbasr_lstm_packed_whh_bytes / nbasr_lstm_pack_whh, once per weight
+ * version): identical arithmetic and results, but every operand load of a wave is 1 KiB contiguous instead of 16 rows x 64 B. */
+size_t nbasr_lstm_packed_whh_bytes(int hidden);
+int nbasr_lstm_pack_whh(const float* w_hh, void* packed, int hidden, nbasr_stream_t stream);
+int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out,
+                                 int batch, int frames, int hidden, nbasr_stream_t stream);
 
 /* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
  * logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias. */

@@ -28,9 +28,13 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 constexpr int LSTM_WAVES = 8;
 constexpr int LSTM_CHUNKS = 4;      // 16-deep k chunks per wave per round (8 waves x 4 x 16 = 512 >= hidden 500)
 
+// PACKED: w_hh is the fragment-ordered copy made by lstm_pack_whh_kernel -- every 16-byte operand load of a wave is then
+// 1 KiB contiguous.  In the (4H, H) layout a wave-load touches 16 rows x 64 B; stamps showed the 160 such loads of a
+// workgroup taking 5 500 cycles to land (L1 line rate, not latency) and another 4 500 of skew at the barrier.
+template <bool PACKED>
 __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
     const float* __restrict__ gates_in,   // (frames, batch, 4*hidden): input projection incl. biases, time-major
-    const float* __restrict__ w_hh,       // (4*hidden, hidden)
+    const float* __restrict__ w_hh,       // (4*hidden, hidden), or its packed copy
     float* __restrict__ cell,             // (batch, hidden) running cell state
     float* h_out,                         // (batch, frames, hidden); row t-1 is read, row t written
     int batch, int frames, int hidden, int t)
@@ -61,7 +65,8 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
     for (int g = 0; g < 4; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     if (t > 0) {
-        const int kchunks = (hidden + 15) / 16;              // 16 k per chunk
+        const int kchunks = PACKED ? ((hidden + 15) / 16 + LSTM_CHUNKS - 1) / LSTM_CHUNKS * LSTM_CHUNKS   // packed image: padded
+                                   : (hidden + 15) / 16;   // 16 k per chunk
         const bool row_ok = (j0 + i16) < hidden;
         const bool col_ok = (b0 + i16) < batch;
         const float* hrow = h_out + (static_cast<size_t>(b0 + i16) * frames + (t - 1)) * hidden;
@@ -72,14 +77,19 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
 #pragma unroll
             for (int c = 0; c < LSTM_CHUNKS; ++c) {
                 const int k = (base + c) * 16 + kq * 4;
-                const bool kok = k < hidden;                  // hidden % 4 == 0: whole float4 in or out
+                const bool kok = k < hidden;                  // hidden % 4 == 0: whole float4 in or out (packed image: chunks padded
+                                                              // to a multiple of LSTM_CHUNKS with zeros)
                 hv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (col_ok && kok) hv[c] = *reinterpret_cast<const float4*>(hrow + k);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    wv[c][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row_ok && kok)
-                        wv[c][g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
+                    if (PACKED) {                          // zero-padded to whole chunks and row tiles: no predicate
+                        wv[c][g] = reinterpret_cast<const float4*>(w_hh)[((static_cast<size_t>(blockIdx.x) * kchunks + base + c) * 4 + g) * 64 + lane];
+                    } else {
+                        wv[c][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (row_ok && kok)
+                            wv[c][g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
+                    }
                 }
             }
             // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
@@ -117,6 +127,25 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
     const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
     cell[static_cast<size_t>(eb) * hidden + ej] = c_new;
     h_out[(static_cast<size_t>(eb) * frames + t) * hidden + ej] = h_new;
+}
+
+// packed[((slice * kchunks_p + kc) * 4 + g) * 64 + lane] (float4) = w_hh[g*H + slice*16 + (lane & 15)][kc*16 + (lane >> 4)*4 .. +3],
+// zero outside the matrix; kchunks_p = chunks rounded up to a multiple of LSTM_CHUNKS
+__global__ __launch_bounds__(256) void lstm_pack_whh_kernel(const float* __restrict__ w_hh, float4* __restrict__ packed, int hidden,
+                                                            int slices, int kchunks_p)
+{
+    const size_t total = static_cast<size_t>(slices) * kchunks_p * 4 * 64;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        size_t e = i;
+        const int lane = e % 64; e /= 64;
+        const int g = e % 4; e /= 4;
+        const int kc = e % kchunks_p; e /= kchunks_p;
+        const int slice = static_cast<int>(e);
+        const int row = slice * 16 + (lane & 15), k = kc * 16 + (lane >> 4) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < hidden && k < hidden) v = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + row) * hidden + k);
+        packed[i] = v;
+    }
 }
 
 // logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias; classes <= 64.
@@ -220,8 +249,44 @@ extern "C" int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, f
     NBASR_REQUIRE(aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence: w_hh, h_out must be 16-byte aligned");
     const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
     for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
+        hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
     return launch_status("nbasr_lstm_recurrence");
+}
+
+static inline int lstm_slices(int hidden) { return (hidden + 15) / 16; }
+static inline int lstm_kchunks_p(int hidden) { return ((hidden + 15) / 16 + LSTM_CHUNKS - 1) / LSTM_CHUNKS * LSTM_CHUNKS; }
+
+extern "C" size_t nbasr_lstm_packed_whh_bytes(int hidden)
+{
+    if (hidden <= 0) return 0;
+    return static_cast<size_t>(lstm_slices(hidden)) * lstm_kchunks_p(hidden) * 4 * 64 * sizeof(float4);
+}
+
+extern "C" int nbasr_lstm_pack_whh(const float* w_hh, void* packed, int hidden, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(hidden > 0 && hidden % 4 == 0, NBASR_EALIGN, "nbasr_lstm_pack_whh: hidden=%d must be a positive multiple of 4", hidden);
+    NBASR_REQUIRE(w_hh && packed, NBASR_ENULL, "nbasr_lstm_pack_whh: NULL pointer");
+    NBASR_REQUIRE(aligned16(w_hh) && aligned16(packed), NBASR_EALIGN, "nbasr_lstm_pack_whh: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(lstm_pack_whh_kernel, dim3(512), dim3(256), 0, as_stream(stream), w_hh, static_cast<float4*>(packed), hidden,
+                       lstm_slices(hidden), lstm_kchunks_p(hidden));
+    return launch_status("nbasr_lstm_pack_whh");
+}
+
+extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, int batch,
+                                            int frames, int hidden, nbasr_stream_t stream)
+{
+    clear_error();
+    const int rc = lstm_check("nbasr_lstm_recurrence_packed", batch, 4, frames, frames, hidden);
+    if (rc != NBASR_OK) return rc;
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(gates_ws && packed_whh && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_recurrence_packed: NULL pointer");
+    NBASR_REQUIRE(aligned16(packed_whh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence_packed: packed_whh, h_out must be 16-byte aligned");
+    const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
+    for (int t = 0; t < frames; ++t)
+        hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws,
+                           static_cast<const float*>(packed_whh), cell_ws, h_out, batch, frames, hidden, t);
+    return launch_status("nbasr_lstm_recurrence_packed");
 }
 
 extern "C" int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,

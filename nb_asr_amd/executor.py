@@ -164,6 +164,15 @@ class ForwardPlan:
             self._packed[(id(w), 'pointwise')] = hit
         return hit[1]
 
+    def _packed_whh(self, w):
+        """Fragment-ordered copy of the LSTM's recurrent weight, rebuilt whenever the parameter changes."""
+        key = (w.data_ptr(), w._version)
+        hit = self._packed.get((id(w), 'whh'))
+        if hit is None or hit[0] != key:
+            hit = (key, hip.lstm_pack_whh(w.detach()))
+            self._packed[(id(w), 'whh')] = hit
+        return hit[1]
+
     def _pointwise_ws(self, c_in, ld):
         need = hip.load_library().nbasr_pointwise_workspace_bytes(self.batch, c_in, ld)
         if self._pw_ws is None or self._pw_ws.numel() < need:
@@ -404,8 +413,9 @@ class ForwardPlan:
                     self.side_stream.wait_event(ready)
                     tail_ctx = torch.cuda.stream(self.side_stream)
                     tail_ctx.__enter__()
+                packed_hh = self._packed_whh(layer.weight_hh_l0)
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_recurrence(gates, w_hh, self.cell_ws, self.h_out))
+                            lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
                 act, pending = self.h_out, None            # (batch, frames, hidden)
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)

@@ -56,6 +56,9 @@ SIGNATURES = {
     'nbasr_log_normalize': (_c_int, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 3 + [_c_int] * 5 + [_c_stream]),
     'nbasr_lstm_input_projection': (_c_int, [_c_float_p] * 5 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_recurrence': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_lstm_packed_whh_bytes': (ctypes.c_size_t, [_c_int]),
+    'nbasr_lstm_pack_whh': (_c_int, [_c_float_p] * 2 + [_c_int, _c_stream]),
+    'nbasr_lstm_recurrence_packed': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
     'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
@@ -333,6 +336,24 @@ def lstm_input_projection(x, frames, w_ih, b_ih, b_hh, gates_ws, hidden, ln=None
         _dev(x, 'x'), _dev(w_ih, 'w_ih'), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
         b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_input_projection')
     return gates_ws
+
+
+def lstm_pack_whh(w_hh):
+    """(4H, H) recurrent weight -> opaque uint8 tensor in the operand-fragment order of the step kernel."""
+    hidden = w_hh.shape[1]
+    packed = torch.empty(load_library().nbasr_lstm_packed_whh_bytes(hidden), dtype=torch.uint8, device=w_hh.device)
+    _check(load_library().nbasr_lstm_pack_whh(_dev(w_hh, 'w_hh'), packed.data_ptr(), hidden, _stream(w_hh)), 'nbasr_lstm_pack_whh')
+    return packed
+
+
+def lstm_recurrence_packed(gates_ws, packed_whh, cell_ws, h_out):
+    b, frames, hidden = h_out.shape
+    if not packed_whh.is_cuda or packed_whh.dtype != torch.uint8 or packed_whh.numel() != load_library().nbasr_lstm_packed_whh_bytes(hidden):
+        raise HipError('packed_whh must be the uint8 device tensor returned by lstm_pack_whh for this hidden size')
+    _check(load_library().nbasr_lstm_recurrence_packed(_dev(gates_ws, 'gates_ws'), packed_whh.data_ptr(), _dev(cell_ws, 'cell_ws'),
+                                                       _dev(h_out, 'h_out'), b, frames, hidden, _stream(h_out)),
+           'nbasr_lstm_recurrence_packed')
+    return h_out
 
 
 def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):

@@ -200,6 +200,18 @@ def test_f16_split_accuracy_is_scale_invariant(x_scale):
     assert float(rel.max()) < 2e-6, float(rel.max())
 
 
+@pytest.mark.parametrize('b,t,h', [(3, 7, 500), (17, 5, 36), (64, 3, 500), (2, 4, 12)])
+def test_lstm_recurrence_packed_is_bit_identical(b, t, h):
+    torch.manual_seed(h + b)
+    gates = torch.randn(t, b, 4 * h, device=DEV)
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.2
+    out0, out1 = torch.full((b, t, h), float('nan'), device=DEV), torch.full((b, t, h), float('nan'), device=DEV)
+    cell = torch.empty(b, h, device=DEV)
+    hip.lstm_recurrence(gates, w_hh, cell, out0)
+    hip.lstm_recurrence_packed(gates, hip.lstm_pack_whh(w_hh), cell, out1)
+    assert torch.isfinite(out1).all() and torch.equal(out0, out1)
+
+
 def test_absmax_kernel():
     x = torch.randn(3, 80, 252, device=DEV)
     x[1] *= 1e-12
