@@ -28,13 +28,9 @@ __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf
 constexpr int LSTM_WAVES = 8;
 constexpr int LSTM_CHUNKS = 4;      // 16-deep k chunks per wave per round (8 waves x 4 x 16 = 512 >= hidden 500)
 
-// PACKED: w_hh is the fragment-ordered copy made by lstm_pack_whh_kernel -- every 16-byte operand load of a wave is then
-// 1 KiB contiguous.  In the (4H, H) layout a wave-load touches 16 rows x 64 B; stamps showed the 160 such loads of a
-// workgroup taking 5 500 cycles to land (L1 line rate, not latency) and another 4 500 of skew at the barrier.
-template <bool PACKED>
 __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
     const float* __restrict__ gates_in,   // (frames, batch, 4*hidden): input projection incl. biases, time-major
-    const float* __restrict__ w_hh,       // (4*hidden, hidden), or its packed copy
+    const float* __restrict__ w_hh,       // (4*hidden, hidden)
     float* __restrict__ cell,             // (batch, hidden) running cell state
     float* h_out,                         // (batch, frames, hidden); row t-1 is read, row t written
     int batch, int frames, int hidden, int t)
@@ -65,8 +61,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
     for (int g = 0; g < 4; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     if (t > 0) {
-        const int kchunks = PACKED ? ((hidden + 15) / 16 + LSTM_CHUNKS - 1) / LSTM_CHUNKS * LSTM_CHUNKS   // packed image: padded
-                                   : (hidden + 15) / 16;   // 16 k per chunk
+        const int kchunks = (hidden + 15) / 16;              // 16 k per chunk
         const bool row_ok = (j0 + i16) < hidden;
         const bool col_ok = (b0 + i16) < batch;
         const float* hrow = h_out + (static_cast<size_t>(b0 + i16) * frames + (t - 1)) * hidden;
@@ -77,19 +72,14 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
 #pragma unroll
             for (int c = 0; c < LSTM_CHUNKS; ++c) {
                 const int k = (base + c) * 16 + kq * 4;
-                const bool kok = k < hidden;                  // hidden % 4 == 0: whole float4 in or out (packed image: chunks padded
-                                                              // to a multiple of LSTM_CHUNKS with zeros)
+                const bool kok = k < hidden;                  // hidden % 4 == 0: whole float4 in or out
                 hv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (col_ok && kok) hv[c] = *reinterpret_cast<const float4*>(hrow + k);
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    if (PACKED) {                          // zero-padded to whole chunks and row tiles: no predicate
-                        wv[c][g] = reinterpret_cast<const float4*>(w_hh)[((static_cast<size_t>(blockIdx.x) * kchunks + base + c) * 4 + g) * 64 + lane];
-                    } else {
-                        wv[c][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (row_ok && kok)
-                            wv[c][g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
-                    }
+                    wv[c][g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (row_ok && kok)
+                        wv[c][g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
                 }
             }
             // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
@@ -129,23 +119,108 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
     h_out[(static_cast<size_t>(eb) * frames + t) * hidden + ej] = h_new;
 }
 
-// packed[((slice * kchunks_p + kc) * 4 + g) * 64 + lane] (float4) = w_hh[g*H + slice*16 + (lane & 15)][kc*16 + (lane >> 4)*4 .. +3],
-// zero outside the matrix; kchunks_p = chunks rounded up to a multiple of LSTM_CHUNKS
+// ---- the recurrence on a fragment-ordered copy of w_hh -------------------------------------------------------------------
+// Stamps on the kernel above: the 160 operand wave-loads of a workgroup (each touching 16 rows x 64 B of the (4H, H) matrix)
+// need 4 100 - 8 000 cycles to land -- the L2 -> CU fill rate (~20 B/clk per CU), not latency -- while half of the CUs have
+// no workgroup at all.  So (1) the weight is re-laid-out ONCE so that every wave-load is 1 KiB contiguous, and (2) a
+// workgroup owns 8 hidden units instead of 16 (252 workgroups at H = 500, B = 64: 96 KiB of operands each instead of 160).
+// MFMA tile rows are (hidden unit, gate) = (row >> 2, row & 3), so the four gates of a (unit, utterance) pair sit in the four
+// accumulator registers of ONE lane (C/D row = (lane >> 4) * 4 + reg): after the cross-wave K reduction the cell update
+// needs no further exchange.  Same fmaf chains per output as the kernel above up to the order of the 8 wave partials.
+constexpr int LSTMP_HU = 8;                                   // hidden units per workgroup (2 MFMA row tiles of 4 units x 4 gates)
+
+// packed[((slice * kchunks_p + kc) * 2 + mt) * 64 + lane] (float4) = w_hh[gate*H + unit][kc*16 + (lane >> 4)*4 .. +3] with
+// unit = slice*8 + mt*4 + ((lane & 15) >> 2), gate = lane & 3; zero outside the matrix; kchunks_p: chunks rounded up to 4
 __global__ __launch_bounds__(256) void lstm_pack_whh_kernel(const float* __restrict__ w_hh, float4* __restrict__ packed, int hidden,
                                                             int slices, int kchunks_p)
 {
-    const size_t total = static_cast<size_t>(slices) * kchunks_p * 4 * 64;
+    const size_t total = static_cast<size_t>(slices) * kchunks_p * 2 * 64;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < total; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
         size_t e = i;
         const int lane = e % 64; e /= 64;
-        const int g = e % 4; e /= 4;
+        const int mt = e % 2; e /= 2;
         const int kc = e % kchunks_p; e /= kchunks_p;
         const int slice = static_cast<int>(e);
-        const int row = slice * 16 + (lane & 15), k = kc * 16 + (lane >> 4) * 4;
+        const int unit = slice * LSTMP_HU + mt * 4 + ((lane & 15) >> 2), gate = lane & 3, k = kc * 16 + (lane >> 4) * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < hidden && k < hidden) v = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + row) * hidden + k);
+        if (unit < hidden && k < hidden) v = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(gate) * hidden + unit) * hidden + k);
         packed[i] = v;
     }
+}
+
+__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_packed_kernel(
+    const float* __restrict__ gates_in,   // (frames, batch, 4*hidden)
+    const float4* __restrict__ wp,        // packed w_hh
+    float* __restrict__ cell, float* h_out, int batch, int frames, int hidden, int kchunks_p, int t)
+{
+    __shared__ float red[LSTM_WAVES][2][4][64];    // [wave][row tile][reg = gate][lane]
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int j0 = blockIdx.x * LSTMP_HU, b0 = blockIdx.y * 16;
+
+    // epilogue role of threads 0..127: one (hidden unit, utterance) each; gate pre-activations issued first (HBM / L2)
+    const int jj = threadIdx.x & 7, bb = (threadIdx.x >> 3) & 15;
+    const int ej = j0 + jj, eb = b0 + bb;
+    const bool e_ok = threadIdx.x < 128 && ej < hidden && eb < batch;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_prev = 0.f;
+    if (e_ok) {
+        const float* gin = gates_in + (static_cast<size_t>(t) * batch + eb) * (4 * hidden);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = gin[g * hidden + ej];
+        if (t > 0) c_prev = cell[static_cast<size_t>(eb) * hidden + ej];
+    }
+
+    floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+    if (t > 0) {
+        const bool col_ok = (b0 + i16) < batch;
+        const float* hrow = h_out + (static_cast<size_t>(b0 + i16) * frames + (t - 1)) * hidden;
+        const float4* wslice = wp + static_cast<size_t>(blockIdx.x) * kchunks_p * 2 * 64 + lane;
+        for (int base = wave * LSTM_CHUNKS; base < kchunks_p; base += LSTM_WAVES * LSTM_CHUNKS) {
+            float4 hv[LSTM_CHUNKS], wv[LSTM_CHUNKS][2];
+#pragma unroll
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+                const int k = (base + c) * 16 + kq * 4;
+                hv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (col_ok && k < hidden) hv[c] = *reinterpret_cast<const float4*>(hrow + k);
+                wv[c][0] = wslice[static_cast<size_t>(base + c) * 2 * 64];
+                wv[c][1] = wslice[static_cast<size_t>(base + c) * 2 * 64 + 64];
+            }
+#pragma unroll
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].x, hv[c].x, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].y, hv[c].y, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].z, hv[c].z, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].w, hv[c].w, acc[m], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][m][r][lane] = acc[m][r];
+    __syncthreads();
+
+    // tile row = unit_in_tile * 4 + gate = (lane >> 4) * 4 + reg, column = utterance = lane & 15
+    //   => unit jj of the slice: tile jj >> 2, lane = (jj & 3) * 16 + bb, reg = gate
+    if (!e_ok) return;
+    const int mt = jj >> 2, pl = (jj & 3) * 16 + bb;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float s = red[0][mt][g][pl];
+#pragma unroll
+        for (int w = 1; w < LSTM_WAVES; ++w) s += red[w][mt][g][pl];
+        pre[g] += s;
+    }
+    const float c_new = sigmoidf_(pre[1]) * c_prev + sigmoidf_(pre[0]) * tanhf(pre[2]);
+    const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
+    cell[static_cast<size_t>(eb) * hidden + ej] = c_new;
+    h_out[(static_cast<size_t>(eb) * frames + t) * hidden + ej] = h_new;
 }
 
 // logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias; classes <= 64.
@@ -249,17 +324,17 @@ extern "C" int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, f
     NBASR_REQUIRE(aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence: w_hh, h_out must be 16-byte aligned");
     const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
     for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_kernel<false>, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
+        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
     return launch_status("nbasr_lstm_recurrence");
 }
 
-static inline int lstm_slices(int hidden) { return (hidden + 15) / 16; }
+static inline int lstm_slices(int hidden) { return (hidden + LSTMP_HU - 1) / LSTMP_HU; }
 static inline int lstm_kchunks_p(int hidden) { return ((hidden + 15) / 16 + LSTM_CHUNKS - 1) / LSTM_CHUNKS * LSTM_CHUNKS; }
 
 extern "C" size_t nbasr_lstm_packed_whh_bytes(int hidden)
 {
     if (hidden <= 0) return 0;
-    return static_cast<size_t>(lstm_slices(hidden)) * lstm_kchunks_p(hidden) * 4 * 64 * sizeof(float4);
+    return static_cast<size_t>(lstm_slices(hidden)) * lstm_kchunks_p(hidden) * 2 * 64 * sizeof(float4);
 }
 
 extern "C" int nbasr_lstm_pack_whh(const float* w_hh, void* packed, int hidden, nbasr_stream_t stream)
@@ -282,10 +357,10 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     if (batch == 0 || frames == 0) return NBASR_OK;
     NBASR_REQUIRE(gates_ws && packed_whh && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_recurrence_packed: NULL pointer");
     NBASR_REQUIRE(aligned16(packed_whh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence_packed: packed_whh, h_out must be 16-byte aligned");
-    const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
+    const dim3 grid(lstm_slices(hidden), (batch + 15) / 16);
     for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_kernel<true>, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws,
-                           static_cast<const float*>(packed_whh), cell_ws, h_out, batch, frames, hidden, t);
+        hipLaunchKernelGGL(lstm_step_packed_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws,
+                           static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, lstm_kchunks_p(hidden), t);
     return launch_status("nbasr_lstm_recurrence_packed");
 }
 

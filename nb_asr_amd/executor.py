@@ -413,9 +413,13 @@ class ForwardPlan:
                     self.side_stream.wait_event(ready)
                     tail_ctx = torch.cuda.stream(self.side_stream)
                     tail_ctx.__enter__()
-                packed_hh = self._packed_whh(layer.weight_hh_l0)
-                self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
+                if os.environ.get('NBASR_LSTM_UNPACKED') == '1':       # diagnostics: the (4H, H)-layout step kernel
+                    self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_recurrence(gates, w_hh, self.cell_ws, self.h_out))
+                else:
+                    packed_hh = self._packed_whh(layer.weight_hh_l0)
+                    self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
                 act, pending = self.h_out, None            # (batch, frames, hidden)
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)
