@@ -18,7 +18,8 @@
 // catch, and the model's activations really do leave it (with the reference's default initialisation they shrink to 1e-9).
 // Both operands are therefore brought into range by EXACT power-of-two scalings that the epilogue undoes:
 //   * x of utterance b is multiplied by 2^kx[b] so that its largest magnitude lands in [2^14, 2^15); the caller passes
-//     absmax[b] >= max|x[b]| (nbasr_layernorm_channels_absmax produces it for free while writing x);
+//     absmax[b] >= max|x[b]| (nbasr_layernorm_channels_absmax produces it for free while writing x, nbasr_absmax
+//     reduces it for the model input);
 //   * row co of w is multiplied by 2^kw[co] at pack time (largest magnitude of the row -> [2^13, 2^14)).
 // Elements down to 2^-29 of their utterance's / row's maximum keep full precision; smaller ones are off by at most
 // 2^-51 of that maximum, far below fp32 resolution of any sum they enter.
@@ -27,15 +28,16 @@
 // TWO consecutive taps (a lane holds 8 consecutive k = 8 channels of one tap):
 //     D[co][t] += sum_{ci<16} W[co][g*16+ci][tap] * x[g*16+ci][t*stride + tap - lpad]      for every (group g, tap)
 //  * weights are split and re-laid-out ONCE (nbasr_pack_dense_weights) into the exact LDS image of each
-//    (row tile, channel group, tap quad): [split][tap][ci half][128 rows][8 ci] bf16 = 48 KiB, so a K-step's weights are a
-//    straight 48 KiB copy done by LDS-DMA (global_load_lds_dwordx4, no VGPRs), double-buffered;
+//    (row tile, channel group, tap quad): [split][tap][ci half][128 rows][8 ci] 16-bit = 32 KiB (fp16 x 2) or 48 KiB
+//    (bf16 x 3), so a K-step's weights are a straight copy done by LDS-DMA (global_load_lds_dwordx4, no VGPRs), double-buffered;
 //  * the input tile of a channel group is fetched as aligned 4-frame quads, split on the fly and stored TRANSPOSED
 //    [ci half][frame][8 ci] so a B fragment (8 consecutive channels of one frame) is one aligned, bank-conflict-free
 //    ds_read_b128; it is staged once per group and reused by all 8 taps (sliding window resolved by the row index;
 //    stride-2 rows are de-interleaved by parity so the 16 lanes of a fragment read hit consecutive rows);
 //  * one 512-thread workgroup per CU: 128 x 256 tile / 8 waves (2 x 4, 64 x 64 each = 4 x 4 MFMA tiles), K-step =
-//    16 channels x 4 taps (2 for stride 2), one barrier per step; the two halves of the workgroup run a step in opposite
-//    order (stage-then-multiply / multiply-then-stage) so a wave's memory phase sits beside its SIMD partner's MFMAs;
+//    16 channels x 4 taps (2 for bf16 x 3 at stride 2: LDS budget), one barrier per step; the two halves of the workgroup run
+//    a step in opposite order (stage-then-multiply / multiply-then-stage) so a wave's memory phase sits beside its SIMD
+//    partner's MFMAs, and the multiply-first half runs at s_setprio 1 so that it really finishes first;
 //  * the hi*hi products accumulate in their own register set, so the large running sum is rounded once per 32 k.
 #include "common.h"
 
