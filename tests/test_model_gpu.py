@@ -81,6 +81,9 @@ def test_prunable_copy_without_cell_norms():
     ratio = cases.worst_ratio(got, want, 1e-4, 1e-5)
     print(f'prunable copy: worst err/tol {ratio:.3f}, cpu fp32 noise floor {noise:.3f}')
     assert ratio <= max(1.0, 2.5 * noise)
+    # no cell LayerNorm -> no range information reaches convs 1-3: they fall back to the range-free 3-way bf16 split
+    plan = next(iter(pruned._plans.values()))
+    assert plan.dense_schemes == {0: 'f16x2', 1: 'bf16x3', 2: 'bf16x3', 3: 'bf16x3'}
 
 
 def test_reference_style_usage():
