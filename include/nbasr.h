@@ -126,6 +126,22 @@ int nbasr_dense_conv1d_fused_packed_f16(const float* x, const float* x_absmax, c
                                         float* y, int batch, int c_in, int frames_in, int ld_in,
                                         int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
 
+/* The LayerNorm-fed form of the fp16 convolution: the LayerNorm writes the convolution's operand directly.
+ * nbasr_layernorm_split_image normalises x (batch, channels, ld) and writes it as the pre-split fp16 image
+ *   image[b][16-channel group][split][8-channel half][1 + ld rows][8 ch]   (row 0 zero, frame t at row t + 1;
+ *   nbasr_split_image_bytes(batch, channels, ld) bytes), scaled per utterance by the power of two that brings bound[b] into
+ * [2^14, 2^15), where bound[b] (batch floats, written here) is an upper bound of max|LayerNorm(x)[b]| computed together with
+ * the statistics (stats: (batch, 2, ld) as nbasr_channel_stats).  Two kernels, 2 reads (the second L2-warm) + 1 write: the same
+ * traffic as nbasr_layernorm_channels.  nbasr_dense_conv1d_fused_packed_f16_img then gathers its input tiles from the image
+ * by LDS-DMA (no vector work in the GEMM); x_absmax must be that bound array.  No skips (the downsample convs have none). */
+size_t nbasr_split_image_bytes(int batch, int channels, int ld);
+int nbasr_layernorm_split_image(const float* x, const float* gamma, const float* beta, float* stats, float* bound,
+                                void* image, int batch, int channels, int frames, int ld, float eps,
+                                nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_f16_img(const void* x_image, const float* x_absmax, const void* packed_w,
+                                            const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
+                                            int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
+
 /* nn.LSTM(input_size=c_in, hidden_size=hidden, batch_first) forward with zero initial state
  * (reference model.py:100 and 118-121): gates i,f,g,o; biases b_ih + b_hh.
  * x: (batch, c_in, ld) encoder layout (the reference's permute is folded into the loader);

@@ -120,6 +120,7 @@ struct PackedConvArgs {
     LnRef ln_x;                  // pending LayerNorm of the input (deferred normalisation, nbasr.h)
     const float* x_absmax;       // SCALED schemes: (batch) upper bounds of max|x[b]|
     const float* w_inv_scale;    // SCALED schemes: (n_mt * 128) 2^-kw[co], tail of the packed buffer
+    int x_is_image;              // x points to the pre-split fp16 image (XIMG kernels)
 };
 
 // 2^k that moves a magnitude with biased exponent field e to [2^target, 2^(target+1)), and its inverse; (1, 1) for zero
@@ -192,9 +193,13 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
 }
 
 // ---- the GEMM -----------------------------------------------------------------------------------------------------
-template <class P, int S, bool LNX>
+// XIMG: x is not the fp32 activation but its pre-split fp16 image written by the normalise-and-split LayerNorm kernel
+// (layernorm.hip): [b][16-channel group][split][8-channel half][1 + ld_in rows][8 ch], row 0 all zero, frame t at row t + 1,
+// already scaled by 2^kx[b].  The input tile then needs no vector work at all: it is gathered by LDS-DMA like the weights.
+template <class P, int S, bool LNX, bool XIMG = false>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const PackedConvArgs a)
 {
+    static_assert(!(XIMG && LNX) && !(XIMG && !P::SCALED), "the image path is the scaled fp16 scheme without LayerNorm on load");
     using G = GeoP<P, S>;
     using vec8 = typename P::vec8;
     constexpr int TP = G::TP, QS = G::QSTEPS, ASTEP = G::A_STEP_BYTES;
@@ -253,6 +258,26 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                 (const __attribute__((address_space(1))) void*)(src + chunk * 1024 + lane * 16),
                 (__attribute__((address_space(3))) void*)(Abuf + buf * ASTEP + chunk * 1024),
                 16, 0, 0);
+        }
+    };
+    // XIMG: tile of channel group g -> X[xbuf], pieces of 1 KiB (64 lanes x one 16-byte image row each); piece i of a group
+    // is issued in K-step i % QS by wave (i / QS) % 8.  LDS slot (split, half, row rr) <- image row of frame
+    // tin0 + rr (stride 1) or tin0 + 2 (rr % XRH) + rr / XRH (stride 2: parity planes); frames outside [0, ld_in) -> zero row 0
+    auto dma_x = [&](int g, int xbuf, int q) {
+        constexpr int NP = (G::X_BYTES + 1023) / 1024;
+        const unsigned char* img = reinterpret_cast<const unsigned char*>(a.x) +
+                                   (static_cast<size_t>(b) * a.n_groups + g) * 4 * static_cast<size_t>(a.ld_in + 1) * 16;
+#pragma unroll 1
+        for (int i = wave * QS + q; i < NP; i += 8 * QS) {
+            const int o = i * 1024 + lane * 16;
+            if (o < G::X_BYTES) {
+                const int plane = o / (G::ROWS * 16), rr = (o - plane * (G::ROWS * 16)) >> 4;
+                const int frame = tin0 + (S == 1 ? rr : 2 * (rr % G::XRH) + rr / G::XRH);
+                const int row = (frame >= 0 && frame < a.ld_in) ? frame + 1 : 0;
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(img + (static_cast<size_t>(plane) * (a.ld_in + 1) + row) * 16),
+                    (__attribute__((address_space(3))) void*)(Xbase + xbuf * G::X_BYTES + i * 1024), 16, 0, 0);
+            }
         }
     };
     floatx4 xreg[G::XI][2];
@@ -402,8 +427,13 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     //                 wait for the DMA (and the chunk loads), barrier
     const int ng = a.n_groups;
     dma_weights(0, 0);
+    if constexpr (XIMG) {
 #pragma unroll 1
-    for (int c = 0; c < G::NCHUNK; ++c) { load_x(0, c); commit_x(0, c); }
+        for (int q = 0; q < QS; ++q) dma_x(0, 0, q);
+    } else {
+#pragma unroll 1
+        for (int c = 0; c < G::NCHUNK; ++c) { load_x(0, c); commit_x(0, c); }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -422,16 +452,24 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             if (older) {
                 // retire the chunk loaded during the previous step, issue this step's loads and the DMA, THEN the MFMAs:
                 // the SIMD partner (a younger wave) has the matrix pipe to itself meanwhile
-                if (more && q >= 1) commit_x((g + 1) & 1, q - 1);
-                if (chunk) load_x(g + 1, q);
+                if constexpr (XIMG) {
+                    if (more) dma_x(g + 1, (g + 1) & 1, q);
+                } else {
+                    if (more && q >= 1) commit_x((g + 1) & 1, q - 1);
+                    if (chunk) load_x(g + 1, q);
+                }
                 if (prefetch) dma_weights(step + 1, (step + 1) & 1);
-            } else if (chunk) {
+            } else if (!XIMG && chunk) {
                 load_x(g + 1, q);                           // in flight under this wave's own MFMAs
             }
             if (wave_active) mma_step(q, step & 1, g & 1);
             if (!older) {
                 // younger waves stage AFTER their MFMAs, beside the older partner's MFMAs
-                if (chunk) commit_x((g + 1) & 1, q);
+                if constexpr (XIMG) {
+                    if (more) dma_x(g + 1, (g + 1) & 1, q);
+                } else {
+                    if (chunk) commit_x((g + 1) & 1, q);
+                }
                 if (prefetch) dma_weights(step + 1, (step + 1) & 1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's weight DMA has landed (this wave's part)
@@ -485,6 +523,18 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
+    if constexpr (P::SCALED) {
+        if (a.x_is_image) {
+            static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true>),
+                                                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+            if (attr2 != hipSuccess) {
+                set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr2));
+                return static_cast<int>(attr2);
+            }
+            hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+            return launch_status(P::NAME);
+        }
+    }
     if (a.ln_x.stats)
         hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, HAS_LNX>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
     else
@@ -525,7 +575,7 @@ template <class P>
 static int dense_packed_impl(const float* x, const void* packed_w, const float* bias, const float* skip0,
                              const float* skip1, const float* skip2, float* y, int batch, int c_in,
                              int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                             const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream)
+                             const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream, bool x_is_image = false)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
@@ -548,6 +598,7 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
     if (P::SCALED) {
         NBASR_REQUIRE(x_absmax, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
         a.x_absmax = x_absmax;
+        a.x_is_image = x_is_image ? 1 : 0;
         a.w_inv_scale = reinterpret_cast<const float*>(a.wp + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * a.n_groups * pb_group_bytes<P>())
                         + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * PB_M;
     }
@@ -597,4 +648,18 @@ extern "C" int nbasr_dense_conv1d_fused_packed_f16(const float* x, const float* 
 {
     return dense_packed_impl<SplitF16x2>(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
                                          kernel, stride, nullptr, x_absmax, stream);
+}
+
+extern "C" size_t nbasr_split_image_bytes(int batch, int channels, int ld)
+{
+    if (batch <= 0 || channels <= 0 || ld < 0) return 0;
+    return static_cast<size_t>(batch) * ((channels + PB_CI - 1) / PB_CI) * 4 * (static_cast<size_t>(ld) + 1) * 16;
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed_f16_img(const void* x_image, const float* x_absmax, const void* packed_w,
+                                                       const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
+                                                       int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream)
+{
+    return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
+                                         frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, x_absmax, stream, true);
 }

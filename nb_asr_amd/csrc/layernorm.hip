@@ -18,12 +18,16 @@ constexpr int LN_ROWS = 16;   // channel rows in flight per workgroup
 constexpr int LN_QS = 16;     // 16-byte chunks (4 frames each) per row segment
 
 // Statistics of one 64-frame tile: fills s_mu / s_rstd (LDS) for the tile's frame columns.  Called by all 256 threads.
+// MINMAX: also the per-frame extrema of x over the channels (s_lo / s_hi: [LN_ROWS][64] partials in, merged into row 0).
+template <bool MINMAX = false>
 __device__ __forceinline__ void tile_statistics(const float* x, int channels, int ld, float eps, size_t base, bool active,
                                                 int row, int ql, float (*s_mean)[LN_QS * 4], float (*s_m2)[LN_QS * 4],
-                                                float* s_cnt, float* s_mu, float* s_rstd)
+                                                float* s_cnt, float* s_mu, float* s_rstd,
+                                                float (*s_lo)[LN_QS * 4] = nullptr, float (*s_hi)[LN_QS * 4] = nullptr)
 {
     // per-lane shifted sums over this lane's channel subset
     float shift[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float lo[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f}, hi[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
     int n = 0;
     if (active) {
         for (int c = row; c < channels; c += LN_ROWS) {
@@ -38,6 +42,7 @@ __device__ __forceinline__ void tile_statistics(const float* x, int channels, in
                 const float d = e[r] - shift[r];
                 s1[r] += d;
                 s2[r] = __builtin_fmaf(d, d, s2[r]);
+                if (MINMAX) { lo[r] = fminf(lo[r], e[r]); hi[r] = fmaxf(hi[r], e[r]); }
             }
             ++n;
         }
@@ -48,6 +53,7 @@ __device__ __forceinline__ void tile_statistics(const float* x, int channels, in
         const float dm = n ? s1[r] / fn : 0.f;
         s_mean[row][ql * 4 + r] = shift[r] + dm;
         s_m2[row][ql * 4 + r] = n ? fmaxf(s2[r] - dm * s1[r], 0.f) : 0.f;
+        if (MINMAX) { s_lo[row][ql * 4 + r] = lo[r]; s_hi[row][ql * 4 + r] = hi[r]; }
     }
     if (ql == 0) s_cnt[row] = fn;
     __syncthreads();
@@ -69,6 +75,12 @@ __device__ __forceinline__ void tile_statistics(const float* x, int channels, in
         }
         s_mu[col] = mean;
         s_rstd[col] = 1.0f / sqrtf(m2 / fmaxf(cnt, 1.f) + eps);
+        if (MINMAX) {
+            float l = s_lo[0][col], h = s_hi[0][col];
+#pragma unroll
+            for (int k = 1; k < LN_ROWS; ++k) { l = fminf(l, s_lo[k][col]); h = fmaxf(h, s_hi[k][col]); }
+            s_lo[0][col] = l; s_hi[0][col] = h;       // only this thread touches column `col` of rows 0..15 here
+        }
     }
     __syncthreads();
 }
@@ -194,6 +206,152 @@ extern "C" int nbasr_layernorm_channels_absmax(const float* x, const float* gamm
     clear_error();
     NBASR_REQUIRE(absmax != nullptr || batch == 0, NBASR_ENULL, "nbasr_layernorm_channels_absmax: absmax is NULL");
     return layernorm_impl("nbasr_layernorm_channels_absmax", x, gamma, beta, y, absmax, batch, channels, frames, ld, eps, stream);
+}
+
+// ---- LayerNorm whose consumer is the fp16-split dense convolution: statistics + range bound, then normalise + split ------
+// The convolution wants its input as a pre-split fp16 image scaled by ONE power of two per utterance (gemm_conv_split.hip,
+// XIMG).  The scale must be known before the first row is written, so the LayerNorm runs as two kernels with the same total
+// traffic as the fused one (2 reads, the second L2-warm, + 1 write):
+//   1. channel_stats_bound_kernel: per-frame (mean, rstd) as channel_stats_kernel, and an upper bound of the normalised
+//      magnitudes  max_c |x_c - mean| * rstd * max|gamma| + max|beta|  (from the per-frame extrema tracked in the same
+//      pass) folded into bound[b] (atomicMax on float bits);
+//   2. normalize_split_kernel: y = (x - mean) rstd gamma + beta, scaled by 2^k(bound[b]), split v = hi + lo' 2^-11, written
+//      as image[b][16-channel group][split][8-channel half][1 + ld rows][8 ch] (row 0 zero, frame t at row t + 1).
+__global__ __launch_bounds__(256) void channel_stats_bound_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ stats,
+                                                                  unsigned* __restrict__ bound, int channels, int frames, int ld, float eps)
+{
+    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
+    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
+    __shared__ float s_cnt[LN_ROWS];
+    __shared__ float s_mu[LN_QS * 4];
+    __shared__ float s_rstd[LN_QS * 4];
+    __shared__ float s_gb[8];
+    __shared__ float s_lo[LN_ROWS][LN_QS * 4];
+    __shared__ float s_hi[LN_ROWS][LN_QS * 4];
+
+    const int ql = threadIdx.x & (LN_QS - 1);
+    const int row = threadIdx.x / LN_QS;
+    const int nq = ld >> 2;
+    const int q = blockIdx.x * LN_QS + ql;
+    const int b = blockIdx.y;
+    const bool active = q < nq;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+
+    // max|gamma|, max|beta| (every workgroup recomputes them: `channels` values)
+    float gm = 0.f, bm = 0.f;
+    for (int c = threadIdx.x; c < channels; c += 256) { gm = fmaxf(gm, fabsf(gamma[c])); bm = fmaxf(bm, fabsf(beta[c])); }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { gm = fmaxf(gm, __shfl_xor(gm, d)); bm = fmaxf(bm, __shfl_xor(bm, d)); }
+    if ((threadIdx.x & 63) == 0) { s_gb[threadIdx.x >> 6] = gm; s_gb[4 + (threadIdx.x >> 6)] = bm; }
+
+    tile_statistics<true>(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd, s_lo, s_hi);   // ends with a barrier
+    gm = fmaxf(fmaxf(s_gb[0], s_gb[1]), fmaxf(s_gb[2], s_gb[3]));
+    bm = fmaxf(fmaxf(s_gb[4], s_gb[5]), fmaxf(s_gb[6], s_gb[7]));
+
+    float dev = 0.f;
+    if (threadIdx.x < LN_QS * 4) {
+        const int t = blockIdx.x * (LN_QS * 4) + threadIdx.x;
+        if (t < ld) {
+            const bool live = t < frames;
+            float* srow = stats + static_cast<size_t>(b) * 2 * ld;
+            srow[t] = live ? s_mu[threadIdx.x] : 0.f;
+            srow[ld + t] = live ? s_rstd[threadIdx.x] : 0.f;
+            // max_c |x_c - mean| = max(hi - mean, mean - lo): no second pass over the tile
+            if (live) dev = fmaxf(s_hi[0][threadIdx.x] - s_mu[threadIdx.x], s_mu[threadIdx.x] - s_lo[0][threadIdx.x]) * s_rstd[threadIdx.x];
+        }
+    }
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) dev = fmaxf(dev, __shfl_xor(dev, d));
+        // a little headroom for the rounding of the bound itself and of the normalisation it bounds
+        if (threadIdx.x == 0) atomicMax(bound + b, __float_as_uint((dev * gm + bm) * 1.0001f));
+    }
+}
+
+__global__ __launch_bounds__(256) void normalize_split_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ bound, unsigned char* __restrict__ image,
+                                                              int channels, int frames, int ld)
+{
+    typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
+    // 16 frame quads x 16 channel octets per pass; a thread turns 8 channels x 4 frames into 4 + 4 image rows of 16 bytes
+    const int ql = threadIdx.x & 15, oct0 = threadIdx.x >> 4;
+    const int nq = ld >> 2;
+    const int q = blockIdx.x * 16 + ql;
+    const int b = blockIdx.y;
+    const int n_groups = (channels + 15) >> 4;
+    const size_t rows = static_cast<size_t>(ld) + 1;
+    unsigned char* const img_b = image + static_cast<size_t>(b) * n_groups * 4 * rows * 16;
+    // the zero rows (row 0 of every plane): one workgroup per utterance writes them
+    if (blockIdx.x == 0) {
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int pl = threadIdx.x; pl < n_groups * 4; pl += 256) *reinterpret_cast<uint4*>(img_b + static_cast<size_t>(pl) * rows * 16) = z;
+    }
+    if (q >= nq) return;
+    // 2^k that brings the bound into [2^14, 2^15)
+    float scale = 1.f;
+    {
+        const unsigned bits = __float_as_uint(bound[b]);
+        const int e = static_cast<int>((bits >> 23) & 0xffu);
+        int k = (bits & 0x7fffffffu) ? (127 + 14) - e : 0;
+        k = k > 126 ? 126 : (k < -126 ? -126 : k);
+        scale = __uint_as_float(static_cast<unsigned>(127 + k) << 23);
+    }
+    const float* st = stats + static_cast<size_t>(b) * 2 * ld + q * 4;
+    const float4 mu = *reinterpret_cast<const float4*>(st), rs = *reinterpret_cast<const float4*>(st + ld);
+    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w};
+    const float* xb = x + static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+    const int n_oct = (channels + 7) >> 3;
+    for (int oct = oct0; oct < 2 * n_groups; oct += 16) {
+        float v[8][4];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ch = oct * 8 + c;
+            float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float g = 0.f, be = 0.f;
+            if (oct < n_oct && ch < channels) { t4 = *reinterpret_cast<const float4*>(xb + static_cast<size_t>(ch) * ld); g = gamma[ch]; be = beta[ch]; }
+            const float e4[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[c][r] = (ch < channels) ? ln_apply(e4[r], m4[r], r4[r], g, be) * scale : 0.f;
+        }
+        // group = oct >> 1, half = oct & 1; planes of a group: [split][half]
+        unsigned char* plane_hi = img_b + ((static_cast<size_t>(oct >> 1) * 4 + (oct & 1)) * rows + 1 + static_cast<size_t>(q) * 4) * 16;
+        unsigned char* plane_lo = plane_hi + 2 * rows * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            halfx8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const _Float16 h = static_cast<_Float16>(v[c][r]);
+                hi[c] = h;
+                lo[c] = static_cast<_Float16>((v[c][r] - static_cast<float>(h)) * 2048.f);
+            }
+            *reinterpret_cast<halfx8*>(plane_hi + r * 16) = hi;
+            *reinterpret_cast<halfx8*>(plane_lo + r * 16) = lo;
+        }
+    }
+}
+
+extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, const float* beta, float* stats, float* bound,
+                                           void* image, int batch, int channels, int frames, int ld, float eps,
+                                           nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_layernorm_split_image: bad sizes");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_layernorm_split_image: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && gamma && beta && stats && bound && image, NBASR_ENULL, "nbasr_layernorm_split_image: NULL pointer");
+    NBASR_REQUIRE(aligned16(x) && aligned16(stats) && aligned16(image), NBASR_EALIGN, "nbasr_layernorm_split_image: x, stats, image must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_layernorm_split_image: batch %d > 65535", batch);
+    const hipError_t e = hipMemsetAsync(bound, 0, sizeof(float) * batch, as_stream(stream));
+    if (e != hipSuccess) { set_error("nbasr_layernorm_split_image: hipMemsetAsync failed: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    const int nq = ld / 4;
+    hipLaunchKernelGGL(channel_stats_bound_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
+                       x, gamma, beta, stats, reinterpret_cast<unsigned*>(bound), channels, frames, ld, eps);
+    hipLaunchKernelGGL(normalize_split_kernel, dim3((nq + 15) / 16, batch), dim3(256), 0, as_stream(stream),
+                       x, stats, gamma, beta, bound, static_cast<unsigned char*>(image), channels, frames, ld);
+    return launch_status("nbasr_layernorm_split_image");
 }
 
 // absmax[b] = max |x[b, :]| over n contiguous floats per utterance (n % 4 == 0): the range information of the 2-way fp16

@@ -102,6 +102,10 @@ class ForwardPlan:
         if self.linear_mode not in ('f16x2', 'f32'):
             raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
         self._pw_ws = None           # scratch of the pre-split activation image, grown on demand
+        # LayerNorm -> dense conv hand-off as a pre-split fp16 image (NBASR_IMAGE_MODE=0: fp32 tensor + in-GEMM staging)
+        self.image_mode = os.environ.get('NBASR_IMAGE_MODE', '1') != '0'
+        self._image = None
+        self._act_image = None
         self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
         self.absmax_in = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|model input| per utterance
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
@@ -179,8 +183,15 @@ class ForwardPlan:
             self._pw_ws = hip.pointwise_workspace(self.batch, c_in, ld, self.device)
         return self._pw_ws
 
-    def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None):
-        """``absmax``: (B,) device bounds of max|act[b]| when `act` was just written by the LayerNorm kernel, else None."""
+    def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None, image=None):
+        """``absmax``: (B,) device bounds of max|act[b]| when `act` was just written by the LayerNorm kernel, else None.
+        ``image`` = (image, bound): the LayerNorm of `act` was written as the pre-split operand image instead."""
+        if image is not None:
+            self.dense_schemes[blk] = 'f16x2-image'
+            b, c, ld = act.shape
+            return hip.dense_conv1d_fused_packed_f16_img(image[0], image[1], b, c, act_frames, ld, self._packed_weights(layer, 'f16x2'),
+                                                         layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out,
+                                                         layer.strides)
         if self.dense_mode != 'f32' and layer.kernel_size == 8:
             scheme = 'f16x2' if self.dense_mode == 'auto' and absmax is not None and ln is None else 'bf16x3'
             self.dense_schemes[blk] = scheme
@@ -208,6 +219,21 @@ class ForwardPlan:
             dst = act if out is None else out
             from .ops import PadConvRelu
             want_range = self.dense_mode == 'auto' and isinstance(nxt, PadConvRelu) and nxt.groups == 1 and nxt.kernel_size == 8
+            if want_range and self.image_mode and taps is None and out is None:
+                # the consumer is the fp16-split convolution: write its pre-split operand image instead of the fp32 tensor
+                # (same traffic; the convolution then gathers its tiles by LDS-DMA and does no vector staging)
+                b, c, ld = act.shape
+                need = hip.load_library().nbasr_split_image_bytes(b, c, ld)
+                if self._image is None or self._image.numel() < need:
+                    self._image = hip.split_image(b, c, ld, self.device)
+                self._stat_turn ^= 1
+                stats = self.stats[self._stat_turn][: b * 2 * ld].view(b, 2, ld)
+                bound = self.absmax[:b]
+                self._timed('layernorm', kind_meta, lambda: hip.layernorm_split_image(act, norm.weight.detach(), norm.bias.detach(),
+                                                                                   stats, bound, self._image, act_frames, norm.eps))
+                self._act_image = (self._image, bound)
+                self._act_absmax = None
+                return None
             absmax = self.absmax[: act.shape[0]] if want_range else None
             self._timed('layernorm', kind_meta, lambda: hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(),
                                                                                dst, act_frames, norm.eps, absmax))
@@ -298,6 +324,7 @@ class ForwardPlan:
             act = hip.repitch(x, self._view(cur, x.shape[1], self.frames), self.frames)
         pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
         self._act_absmax = None                          # set by _norm when it wrote `act` together with max|act[b]|
+        self._act_image = None                           # set by _norm when it wrote the LayerNorm of `act` as the conv's image
         if self.dense_mode == 'auto' and act.shape[0] > 0:
             # the model input is unbounded: one small reduction gives the first conv its range, too
             self._act_absmax = hip.absmax(act, self.absmax_in[: act.shape[0]])
@@ -314,10 +341,10 @@ class ForwardPlan:
                 dst = 0 if cur != 0 else 1
                 t_out = self.block_frames[blk]
                 out = self._view(dst, layer.conv.out_channels, t_out)
-                ln, src, src_frames, amax, blk_now = pending, act, act_frames, self._act_absmax, blk
+                ln, src, src_frames, amax, blk_now, img = pending, act, act_frames, self._act_absmax, blk, self._act_image
                 self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
-                            lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now))
-                act, act_frames, cur, pending, self._act_absmax = out, t_out, dst, None, None
+                            lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now, img))
+                act, act_frames, cur, pending, self._act_absmax, self._act_image = out, t_out, dst, None, None, None
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.LayerNorm):

@@ -35,6 +35,9 @@ SIGNATURES = {
     'nbasr_grouped_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_stream]),
     'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_stream]),
     'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    'nbasr_split_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_layernorm_split_image': (_c_int, [_c_float_p] * 6 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    'nbasr_dense_conv1d_fused_packed_f16_img': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
     'nbasr_absmax': (_c_int, [_c_float_p] * 2 + [_c_int, ctypes.c_longlong, _c_stream]),
     'nbasr_layernorm_channels_absmax': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
@@ -238,6 +241,34 @@ def layernorm_channels(x, gamma, beta, y, frames, eps, absmax=None):
     _check(load_library().nbasr_layernorm_channels(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
                                                    _dev(y, 'y'), b, c, frames, ld, float(eps), _stream(x)),
            'nbasr_layernorm_channels')
+    return y
+
+
+def split_image(batch, channels, ld, device):
+    """Buffer for the pre-split fp16 image of a (batch, channels, ld) activation (layernorm_split_image)."""
+    return torch.empty(max(load_library().nbasr_split_image_bytes(batch, channels, ld), 16), dtype=torch.uint8, device=device)
+
+
+def layernorm_split_image(x, gamma, beta, stats, bound, image, frames, eps):
+    """LayerNorm(x) written as the fp16-split image of the dense convolution; also fills stats (B, 2, ld) and bound (B)."""
+    b, c, ld = x.shape
+    if image.dtype != torch.uint8 or image.numel() < load_library().nbasr_split_image_bytes(b, c, ld):
+        raise HipError('image buffer too small: allocate it with split_image(batch, channels, ld, device)')
+    _check(load_library().nbasr_layernorm_split_image(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'), _dev(stats, 'stats'),
+                                                      _dev(bound, 'bound'), image.data_ptr(), b, c, frames, ld, float(eps), _stream(x)),
+           'nbasr_layernorm_split_image')
+    return image
+
+
+def dense_conv1d_fused_packed_f16_img(image, bound, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride):
+    lib = load_library()
+    if packed.numel() != lib.nbasr_packed_dense_weights_bytes_f16(c_out, c_in, kernel):
+        raise HipError(f'packed weights are not an f16x2 image of a ({c_out}, {c_in}, {kernel}) weight')
+    if image.numel() < lib.nbasr_split_image_bytes(batch, c_in, ld_in):
+        raise HipError('image buffer too small for (batch, c_in, ld_in)')
+    _check(lib.nbasr_dense_conv1d_fused_packed_f16_img(image.data_ptr(), _dev(bound, 'bound'), packed.data_ptr(), _dev(bias, 'bias'),
+                                                       _dev(y, 'y'), batch, c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride,
+                                                       _stream(y)), 'nbasr_dense_conv1d_fused_packed_f16_img')
     return y
 
 

@@ -244,7 +244,7 @@ def test_dense_scheme_selection():
     with torch.no_grad():
         y0 = model(x)
     plan = next(iter(model._plans.values()))
-    assert plan.dense_schemes == {0: 'f16x2', 1: 'f16x2', 2: 'f16x2', 3: 'f16x2'}
+    assert plan.dense_schemes == {0: 'f16x2', 1: 'f16x2-image', 2: 'f16x2-image', 3: 'f16x2-image'}
     os.environ['NBASR_DENSE_MODE'] = 'bf16x3'
     try:
         model._plans.clear()

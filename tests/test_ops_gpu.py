@@ -570,3 +570,37 @@ def test_fused_cell_limits():
     w, bias = torch.zeros(24, 6, 3, device=DEV), torch.zeros(24, device=DEV)
     with pytest.raises(hip.HipError, match='conv5'):
         hip.grouped_cell_fused(x, [(w, bias, 3, 1)] * 3, 0, torch.empty_like(x), 16, 4)
+
+
+@pytest.mark.parametrize('c,cout,t,stride,b', [(40, 72, 150, 1, 2), (40, 72, 151, 2, 2), (600, 136, 300, 1, 1), (136, 200, 515, 2, 3), (24, 40, 1, 1, 2),
+                                               (1000, 136, 260, 2, 1)])
+def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
+    """LayerNorm written as the convolution's pre-split operand image + image-gathering convolution == materialised LayerNorm +
+    fp16-split convolution, to fp32 resolution (the per-utterance scale comes from a bound instead of the exact maximum)."""
+    torch.manual_seed(c + t)
+    x = torch.randn(b, c, t) * 2.0 + 0.7
+    x[0] *= 1e-6                                                # per-utterance scaling: one utterance in the eps-dominated regime
+    g, be = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+    xp, _ = pitched(x)
+    ld = xp.shape[2]
+    normed = torch.empty_like(xp)
+    amax = torch.empty(b, device=DEV)
+    hip.layernorm_channels(xp, g.to(DEV), be.to(DEV), normed, t, 1e-3, amax)
+    w, bias = torch.randn(cout, c, 8, device=DEV) * (2.0 / (c * 8)) ** 0.5, torch.randn(cout, device=DEV) * 0.1
+    t_out = (t + stride - 1) // stride
+    want = torch.full((b, cout, hip.round_up4(t_out)), float('nan'), device=DEV)
+    got = torch.full_like(want, float('nan'))
+    packed = hip.pack_dense_weights(w, stride, 'f16x2')
+    hip.dense_conv1d_fused_packed(normed, t, packed, cout, 8, bias, (), want, stride, scheme='f16x2', x_absmax=amax)
+    stats, bound = torch.empty(b, 2, ld, device=DEV), torch.empty(b, device=DEV)
+    image = hip.split_image(b, c, ld, DEV)
+    image.fill_(0x7f)                                           # poison: every row the conv reads must have been written
+    hip.layernorm_split_image(xp, g.to(DEV), be.to(DEV), stats, bound, image, t, 1e-3)
+    assert bool((bound >= amax).all()) and bool((bound <= 4.0 * amax + 1e-30).all())
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed, cout, 8, bias, got, stride)
+    assert torch.all(got[:, :, t_out:] == 0)
+    truth = oracle.pad_conv_relu(normed[:, :, :t].cpu().double(), w.cpu().double(), bias.cpu().double(), 1, stride, 1)
+    scale = truth.abs().amax(dim=(1, 2), keepdim=True).clamp_min(1e-300)
+    e_img = float(((got[:, :, :t_out].cpu().double() - truth) / scale).abs().max())
+    e_ref = float(((want[:, :, :t_out].cpu().double() - truth) / scale).abs().max())
+    assert e_img <= max(2.0 * e_ref, 2e-6), (e_img, e_ref)
