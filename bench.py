@@ -172,9 +172,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline_leg(model, args)
     runner.barrier()
+    runner.close()
+    # RCCL writes its version banner to the C-level stdout buffer, which would otherwise be flushed at exit, AFTER the result:
+    # drain it first so that the JSON line is the last thing this process prints
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
     if rank == 0:
         print(json.dumps(result), flush=True)
-    runner.close()
 
 
 def pmc_traffic_per_launch(kernel_prefix):
