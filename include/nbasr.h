@@ -253,10 +253,31 @@ int nbasr_linear_head_bct_ln(const float* x, const float* w, const float* bias, 
  *   log_probs(batch, frames, classes) = log_softmax(logits, classes)                      (NULL: not wanted)
  *   greedy CTC decoding: per-frame argmax over the first lengths[b] frames (lengths NULL: all frames; the trainer uses
  *   audio_len // 4), repeats collapsed, `blank` dropped (F.ctc_loss default blank = 0) -> tokens(batch, frames) int32,
- *   padded with -1, token_counts(batch).  (tokens NULL: not wanted.)  The reference's beam search is a third-party C++
- *   library outside its tree and is not reproduced. */
+ *   padded with -1, token_counts(batch).  (tokens NULL: not wanted.)  The beam search the reference decodes with is
+ *   nbasr_ctc_beam_search below. */
 int nbasr_ctc_postprocess(const float* logits, const int* lengths, float* log_probs, int* tokens, int* token_counts,
                           int batch, int frames, int classes, int blank, nbasr_stream_t stream);
+
+/* ---- validation decode (replaces reference training/torch/trainer.py:229-247 Trainer.decode) ----------
+ * nbasr_ctc_beam_search: CTC prefix beam search without a language model, the algorithm of the reference's decoder
+ *   CTCBeamDecoder(vocab, beam_width=12, log_probs_input=True) (ctcdecode, third-party C++, trainer.py:71,237; its defaults
+ *   cutoff_top_n = 40, cutoff_prob = 1.0, blank_id = 0).  log_probs(batch, frames, classes): log-probabilities
+ *   (nbasr_ctc_postprocess's log_probs); lengths(batch) or NULL: frames of each utterance that count.  Outputs, best beam
+ *   first: beams(batch, beam_width, frames) int32 token sequences padded with 0, scores(batch, beam_width) = -log P of each
+ *   beam (ctcdecode's convention; FLT_MAX for beams that do not exist), beam_lens(batch, beam_width).  ws: scratch of
+ *   nbasr_ctc_beam_workspace_bytes (8-byte aligned, no state between calls).  Limits: classes <= 64, beam_width <= 32.
+ *   Log-probabilities <= -FLT_MAX (ctcdecode's "-infinity") count as pruned classes.
+ * nbasr_token_error_counts: per utterance, map both label sequences through `table` (n_table entries; NULL/0: identity --
+ *   the reference folds 48 -> 39 phonemes with PhonemeEncoder.fold_encoded, encoder.py:64-75), drop `blank`, and compute the
+ *   Levenshtein distance: counts(batch, 2) int32 = (distance, reference length after blank removal); the error rate of
+ *   torch_edit_distance.compute_wer is distance / length.  hyp(batch, ld_hyp), ref(batch, ld_ref) int32 with their lengths.
+ *   counts = (-1, -1) for an utterance with more than 2048 tokens after blank removal, (-1, -2) for a label outside the table. */
+size_t nbasr_ctc_beam_workspace_bytes(int batch, int frames, int classes, int beam_width);
+int nbasr_ctc_beam_search(const float* log_probs, const int* lengths, void* ws, int* beams, float* scores, int* beam_lens,
+                          int batch, int frames, int classes, int beam_width, int blank, int cutoff_top_n,
+                          nbasr_stream_t stream);
+int nbasr_token_error_counts(const int* hyp, const int* hyp_len, int ld_hyp, const int* ref, const int* ref_len, int ld_ref,
+                             const int* table, int n_table, int blank, int* counts, int batch, nbasr_stream_t stream);
 
 /* Copy (batch, channels, frames) with pitch ld_src into pitch ld_dst, zero-filling columns
  * frames..ld_dst-1 (used to bring caller tensors into the pitched internal layout). */

@@ -1,13 +1,18 @@
-"""The step after the forward pass: log_softmax, length mapping, greedy CTC decoding.
+"""The step after the forward pass: log_softmax, length mapping, CTC decoding, phoneme error rate.
 
 Mirrors what the reference's ``Trainer.step`` / ``Trainer.decode`` do with the model output
 (``training/torch/trainer.py:217-219, 229-247``): ``output = F.log_softmax(output, dim=2)``,
-``output_len = audio_len // 4``, then decoding.  The reference decodes with ``ctcdecode``'s beam search (third-party C++,
-not in its tree); the greedy decoder here is the width-1 case with the same blank (class 0) and collapse rule.
+``output_len = audio_len // 4``, then ``CTCBeamDecoder(vocab, beam_width=12, log_probs_input=True).decode`` (ctcdecode,
+third-party C++, not in the reference's tree), ``PhonemeEncoder.fold_encoded(., 39)`` on the best beam and on the targets,
+``torch_edit_distance.compute_wer`` and the mean.  All of it runs on the device: ``beam_decode`` (prefix beam search),
+``fold_table`` (the 48 -> 39 label table, with the reference's relabelling order), ``error_rates`` (label table + blank
+removal + Levenshtein distance) and ``decode_per`` = the whole of ``Trainer.decode``.  ``greedy_decode`` is the cheap
+width-1 relative (per-frame argmax, collapse, drop blank).
 """
 import torch
 
 from . import hip
+from .phonemes import fold_table  # noqa: F401  (part of this module's interface)
 
 
 def output_lengths(audio_len):
@@ -33,3 +38,52 @@ def greedy_decode(logits, audio_len=None, blank=0, return_log_probs=False):
     tokens, counts = tokens.cpu(), counts.cpu()
     seqs = [tokens[i, : int(counts[i])] for i in range(tokens.shape[0])]
     return (seqs, log_probs) if return_log_probs else seqs
+
+
+def _lengths(lengths, batch, device):
+    if lengths is None:
+        return None
+    lengths = torch.as_tensor(lengths)
+    if lengths.numel() != batch:
+        raise ValueError(f'expected {batch} lengths, got {lengths.numel()}')
+    return lengths.to(device=device, dtype=torch.int32).contiguous()
+
+
+def beam_decode(log_probs, output_len=None, beam_width=12, blank=0, cutoff_top_n=40):
+    """CTC prefix beam search over log-probabilities (B, T', C), the reference's
+    ``CTCBeamDecoder(vocab, beam_width=12, log_probs_input=True).decode(output, output_len)`` (trainer.py:71,237).
+
+    ``output_len``: valid output frames per utterance (``output_lengths(audio_len)``), tensor or sequence, or None.
+    Returns ``(beams, scores, out_len)`` on the device like ctcdecode does (minus its per-token time steps): beams
+    (B, beam_width, T') int32 best first (entries beyond ``out_len`` are 0), scores (B, beam_width) = -log P (lower is
+    better), out_len (B, beam_width) int32."""
+    if log_probs.dim() != 3:
+        raise ValueError(f'log_probs must be (batch, frames, classes), got {tuple(log_probs.shape)}')
+    return hip.ctc_beam_search(log_probs.contiguous(), _lengths(output_len, log_probs.shape[0], log_probs.device),
+                               beam_width, blank, cutoff_top_n)
+
+
+def error_rates(hyp, hyp_len, ref, ref_len, blank=0, table=None):
+    """Per-utterance token error rate, ``torch_edit_distance.compute_wer(hyp, ref, hyp_len, ref_len, blank, sep=[])``
+    (trainer.py:245): Levenshtein distance / reference length, after mapping both sides through ``table`` (optional int32
+    label table, e.g. ``fold_table()``) and dropping ``blank``.  Returns a float32 device tensor (B); an empty reference
+    gives inf (nan when the hypothesis is empty too), as the division does in the reference."""
+    dev = hyp.device
+    b = hyp.shape[0]
+    counts = hip.token_error_counts(hyp.to(torch.int32).contiguous(), _lengths(hyp_len, b, dev), ref.to(device=dev, dtype=torch.int32).contiguous(),
+                                    _lengths(ref_len, b, dev), None if table is None else table.to(device=dev, dtype=torch.int32).contiguous(),
+                                    blank)
+    if bool((counts[:, 0] < 0).any()):
+        raise hip.HipError('error_rates: a sequence exceeds 2048 tokens or holds a label outside the table')
+    return counts[:, 0].float() / counts[:, 1].float()
+
+
+def decode_per(log_probs, output_len, targets, targets_len, beam_width=12, fold_to=39, num_classes=48):
+    """``Trainer.decode`` (trainer.py:229-247): best beam and targets folded to ``fold_to`` phonemes, error rate per
+    utterance, mean over the batch.  ``log_probs`` (B, T', num_classes + 1) on the device; targets (B, L) labels of the
+    ``num_classes`` set (0 = blank / padding).  Returns a 0-dim float32 device tensor."""
+    beams, _, beams_len = beam_decode(log_probs, output_len, beam_width=beam_width)
+    table = fold_table(num_classes, fold_to).to(log_probs.device) if fold_to < num_classes else None
+    per = error_rates(beams[:, 0].contiguous(), beams_len[:, 0].contiguous(), targets, targets_len, blank=0, table=table)
+    return per.mean()
+

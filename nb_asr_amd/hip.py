@@ -79,6 +79,10 @@ SIGNATURES = {
     'nbasr_lstm_forward_ln': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_linear_head_bct_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_ctc_postprocess': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_ctc_beam_workspace_bytes': (ctypes.c_size_t, [_c_int] * 4),
+    'nbasr_ctc_beam_search': (_c_int, [_c_float_p] * 6 + [_c_int] * 6 + [_c_stream]),
+    'nbasr_token_error_counts': (_c_int, [_c_float_p, _c_float_p, _c_int, _c_float_p, _c_float_p, _c_int, _c_float_p, _c_int, _c_int,
+                                          _c_float_p, _c_int, _c_stream]),
     'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
 }
 
@@ -520,3 +524,52 @@ def ctc_postprocess(logits, lengths=None, want_log_probs=True, want_tokens=True,
         None if tokens is None else tokens.data_ptr(), None if counts is None else counts.data_ptr(), b, t, c, blank,
         _stream(logits)), 'nbasr_ctc_postprocess')
     return log_probs, tokens, counts
+
+
+def _int_tensor(t, what, device, shape=None):
+    if not t.is_cuda or t.device != device or t.dtype != torch.int32 or not t.is_contiguous():
+        raise HipError(f'{what} must be a contiguous int32 tensor on {device}')
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise HipError(f'{what} must have shape {tuple(shape)}, got {tuple(t.shape)}')
+    return t
+
+
+def ctc_beam_search(log_probs, lengths=None, beam_width=12, blank=0, cutoff_top_n=40):
+    """log_probs (B, T', C) float32 log-probabilities -> (beams (B, W, T') int32 best first, scores (B, W) = -log P,
+    beam_lens (B, W) int32).  ``lengths``: int32 device tensor (B) of valid output frames, or None."""
+    _dev(log_probs, 'log_probs')
+    b, t, c = log_probs.shape
+    if lengths is not None:
+        _int_tensor(lengths, 'lengths', log_probs.device, (b,))
+    dev = log_probs.device
+    beams = torch.empty(b, beam_width, t, dtype=torch.int32, device=dev)
+    scores = torch.empty(b, beam_width, dtype=torch.float32, device=dev)
+    lens = torch.empty(b, beam_width, dtype=torch.int32, device=dev)
+    lib = load_library()
+    ws = torch.empty(max(lib.nbasr_ctc_beam_workspace_bytes(b, t, c, beam_width), 8) // 8, dtype=torch.int64, device=dev)
+    _check(lib.nbasr_ctc_beam_search(log_probs.data_ptr(), None if lengths is None else lengths.data_ptr(), ws.data_ptr(),
+                                     beams.data_ptr(), scores.data_ptr(), lens.data_ptr(), b, t, c, beam_width, blank, cutoff_top_n,
+                                     _stream(log_probs)), 'nbasr_ctc_beam_search')
+    return beams, scores, lens
+
+
+def token_error_counts(hyp, hyp_len, ref, ref_len, table=None, blank=0):
+    """hyp (B, Lh), ref (B, Lr) int32 label matrices with their lengths (B) -> counts (B, 2) int32 = (Levenshtein distance,
+    reference length) after mapping through ``table`` (int32, optional) and dropping ``blank``."""
+    if hyp.dim() != 2 or ref.dim() != 2 or hyp.shape[0] != ref.shape[0]:
+        raise HipError('hyp and ref must be (batch, length) matrices over the same batch')
+    dev = hyp.device
+    b = hyp.shape[0]
+    for t, what in ((hyp, 'hyp'), (ref, 'ref')):
+        _int_tensor(t, what, dev)
+    _int_tensor(hyp_len, 'hyp_len', dev, (b,))
+    _int_tensor(ref_len, 'ref_len', dev, (b,))
+    if table is not None:
+        _int_tensor(table, 'table', dev)
+    counts = torch.empty(b, 2, dtype=torch.int32, device=dev)
+    _check(load_library().nbasr_token_error_counts(
+        hyp.data_ptr(), hyp_len.data_ptr(), hyp.shape[1], ref.data_ptr(), ref_len.data_ptr(), ref.shape[1],
+        None if table is None else table.data_ptr(), 0 if table is None else table.numel(), blank, counts.data_ptr(), b,
+        torch.cuda.current_stream(dev).cuda_stream), 'nbasr_token_error_counts')
+    return counts
+
