@@ -134,6 +134,18 @@ def test_gpu_beam_search_matches_oracle(b, frames, classes, width, top_n, sharp)
 
 
 @pytest.mark.gpu
+def test_gpu_beam_search_narrow_beams_sweep():
+    """Narrow beams over few classes: prefixes drop out of the beam and come back all the time, which is where prefix identity
+    (ctcdecode's trie: a re-created prefix is the parent of its still-live extensions again) decides the result."""
+    from nb_asr_amd import ctc
+    rng = np.random.default_rng(7)
+    for case in range(40):
+        width, classes, frames = int(rng.integers(2, 5)), int(rng.integers(3, 6)), int(rng.integers(20, 61))
+        lp = _log_probs((2, frames, classes), 1000 + case, sharp=float(rng.choice([0.3, 1.0, 2.0])))
+        _check_beams(lp, None, width, 40, ctc.beam_decode(lp.to('cuda:0'), None, beam_width=width))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('seed', range(6))
 def test_gpu_beam_search_best_beam_is_the_most_probable_labelling(seed):
     """First-principles check that needs no oracle beam search: with a beam wider than the number of labellings the best beam
