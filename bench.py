@@ -32,6 +32,7 @@ import time
 import torch
 
 ARCH = [[1, 0], [1, 0, 0], [1, 0, 0, 0]]
+ARCHS = {'conv5': ARCH, 'dense-skip': [[3, 1], [4, 1, 1], [2, 1, 1, 1]]}      # BASELINE configs[1..3] / configs[3]
 BATCH, FRAMES, FEATURES = 64, 1000, 80
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_MFMA_PEAK_TFLOPS = 157.3    # ibid.: v_mfma_f32_32x32x2_f32 dense peak
@@ -57,6 +58,8 @@ def main():
     ap.add_argument('--frames', type=int, default=FRAMES)
     ap.add_argument('--scaling', choices=('weak', 'strong'), default='weak',
                     help='weak: --batch utterances per GPU (default); strong: --batch utterances in total, split over the ranks')
+    ap.add_argument('--arch', choices=sorted(ARCHS), default='conv5',
+                    help="conv5: the benchmark architecture (default); dense-skip: BASELINE configs[3]'s architecture, run in fp32")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='time plain back-to-back model(x) calls only')
@@ -86,7 +89,8 @@ def main():
     torch.cuda.set_device(device)
     runner = ShardedForward(world_size=world, rank=rank, device=device)      # RCCL process group when world > 1
 
-    model = nb.get_model(ARCH, use_rnn=True, dropout_rate=0.0)
+    arch = ARCHS[args.arch]
+    model = nb.get_model(arch, use_rnn=True, dropout_rate=0.0)
     keyed_fill_(model, seed=1235, mode='lively')
     model = model.to(device).eval()
     x = keyed_input(args.batch, args.frames, seed=rank).to(device)           # resident in HBM before timing
@@ -161,7 +165,8 @@ def main():
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic N(0,1) filterbanks (B,80,T) from a keyed generator; random-init He-uniform weights (keyed)',
-        'config': {'workload': 'BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True fp32, HIP conv + HIP LSTM',
+        'config': {'workload': ('BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True fp32, HIP conv + HIP LSTM'
+                                if args.arch == 'conv5' else f'arch_vec {arch} (BASELINE configs[3] architecture) use_rnn=True, in fp32'),
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames, 'features': FEATURES,
                    'parallelism': f'batch-sharded x{world}, one RCCL all-gather of logits' if world > 1 else 'single GPU',
                    'pipelined': not args.no_pipeline},
@@ -301,11 +306,11 @@ def cpu_baseline_leg(model, args):
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     xs = keyed_input(sample_b, args.frames, seed=0)
     with torch.no_grad():
-        oracle.asr_forward(params, ARCH, xs, use_rnn=True)                  # warm-up
+        oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)                  # warm-up
         times = []
         for _ in range(3):
             t0 = time.perf_counter()
-            oracle.asr_forward(params, ARCH, xs, use_rnn=True)
+            oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)
             times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return {'value': sample_b / med, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',

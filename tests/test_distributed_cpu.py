@@ -83,3 +83,45 @@ def test_single_process_is_a_no_op():
     assert runner.max_over_ranks(1.5) == 1.5
     runner.barrier()
     runner.close()
+
+
+# ---- the same two-rank path with the real HIP model: both ranks share the one GPU of the test box, gloo moves the logits ----
+
+def _gpu_worker(rank, world, port, out_queue):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import nb_asr_amd as nb
+    from nb_asr_amd.weights import keyed_fill_, keyed_input
+    dev = torch.device('cuda', 0)
+    runner = ShardedForward(world_size=world, rank=rank, device=dev, backend='gloo')
+    model = nb.get_model([[3, 1], [4, 1, 1], [2, 1, 1, 1]], use_rnn=True, dropout_rate=0.0)
+    keyed_fill_(model, 1235, 'lively')
+    model = model.to(dev).eval()
+    global_x = keyed_input(5, 61, seed=3).to(dev)          # 5 utterances over 2 ranks: shards of 3 and 2
+    with torch.no_grad():
+        want = model(global_x).clone()
+        got = runner.forward_global(model, global_x)
+        local = runner.forward(model, keyed_input(2, 61, seed=10 + rank).to(dev))
+        parts = [model(keyed_input(2, 61, seed=10 + r).to(dev)).clone() for r in range(world)]
+    ok_global = torch.equal(got, want)                      # utterances are independent: sharding must not change a bit
+    ok_local = torch.equal(local, torch.cat(parts))
+    runner.barrier()
+    runner.close()
+    out_queue.put((rank, ok_global, ok_local))
+
+
+@pytest.mark.gpu
+def test_two_rank_sharded_forward_with_the_hip_model():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, ok_global, ok_local in results:
+        assert ok_global, f'rank {rank}: sharded logits differ from the unsharded forward'
+        assert ok_local, f'rank {rank}: all-gathered logits are not the per-rank results in rank order'
