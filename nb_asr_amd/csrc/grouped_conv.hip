@@ -57,8 +57,12 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         for (int r = 0; r < 4; ++r) acc[co][r] = bv;
     }
 
-    // per-frame LayerNorm statistics of the window (shared by all input channels)
-    float mw[LNX ? NCH * 4 : 1], rw[LNX ? NCH * 4 : 1];
+    // per-frame LayerNorm statistics of the window (shared by all input channels), kept as frame PAIRS so that the
+    // normalisation below is packed arithmetic: -mean, rstd and a 0/1 mask (rstd == 0 marks frames outside the utterance,
+    // which must stay exactly 0).  (x + -mean) * rstd, fma(., gamma, beta), * mask rounds exactly like ln_apply.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = LNX ? NCH * 2 : 1;
+    f2 nmw[NP], rw[NP], kw[NP];
     if (LNX) {
         const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_x.stats + static_cast<size_t>(b) * 2 * ld);
         const float4* __restrict__ rrow = mrow + nq;
@@ -67,10 +71,10 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
             const int qq = q - QL + c;
             float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = m;
             if (active && qq >= 0 && qq < nq) { m = mrow[qq]; r = rrow[qq]; }
-            mw[(4 * c + 0) % (LNX ? NCH * 4 : 1)] = m.x; mw[(4 * c + 1) % (LNX ? NCH * 4 : 1)] = m.y;
-            mw[(4 * c + 2) % (LNX ? NCH * 4 : 1)] = m.z; mw[(4 * c + 3) % (LNX ? NCH * 4 : 1)] = m.w;
-            rw[(4 * c + 0) % (LNX ? NCH * 4 : 1)] = r.x; rw[(4 * c + 1) % (LNX ? NCH * 4 : 1)] = r.y;
-            rw[(4 * c + 2) % (LNX ? NCH * 4 : 1)] = r.z; rw[(4 * c + 3) % (LNX ? NCH * 4 : 1)] = r.w;
+            nmw[(2 * c) % NP] = f2{-m.x, -m.y}; nmw[(2 * c + 1) % NP] = f2{-m.z, -m.w};
+            rw[(2 * c) % NP] = f2{r.x, r.y};    rw[(2 * c + 1) % NP] = f2{r.z, r.w};
+            kw[(2 * c) % NP] = f2{r.x != 0.f ? 1.f : 0.f, r.y != 0.f ? 1.f : 0.f};
+            kw[(2 * c + 1) % NP] = f2{r.z != 0.f ? 1.f : 0.f, r.w != 0.f ? 1.f : 0.f};
         }
     }
 
@@ -87,9 +91,14 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         }
         if (LNX) {
             const float gam = ln_x.gamma[g * CG + ci], bet = ln_x.beta[g * CG + ci];     // wave-uniform: scalar loads
+            const f2 gam2 = f2{gam, gam}, bet2 = f2{bet, bet};
 #pragma unroll
-            for (int e = 0; e < NCH * 4; ++e)
-                xw[e] = ln_apply(xw[e], mw[e % (LNX ? NCH * 4 : 1)], rw[e % (LNX ? NCH * 4 : 1)], gam, bet);
+            for (int p = 0; p < NCH * 2; ++p) {
+                f2 v = f2{xw[2 * p], xw[2 * p + 1]};
+                v = (v + nmw[p % NP]) * rw[p % NP];
+                v = __builtin_elementwise_fma(v, gam2, bet2) * kw[p % NP];
+                xw[2 * p] = v.x; xw[2 * p + 1] = v.y;
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
