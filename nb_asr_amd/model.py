@@ -16,6 +16,8 @@ Interface mirror of the reference's ``nasbench_asr/model/torch/model.py``: ``Nod
 ``executor.ForwardPlan``; the nested torch modules are parameter containers.  Inputs must live on
 a HIP device -- there is no CPU path in this package.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -81,6 +83,8 @@ class SearchCell(nn.Module):
 
 
 class ASRModel(nn.Module):
+    _warned_no_autograd = False
+
     def __init__(self, arch_desc, num_classes=48, use_rnn=False, use_norm=True, dropout_rate=0.0, **kwargs):
         super().__init__()
         self.arch_desc = arch_desc
@@ -148,6 +152,11 @@ class ASRModel(nn.Module):
             raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor, got {tuple(getattr(input, "shape", ()))}')
         if not input.is_cuda:
             raise hip.HipError('ASRModel.forward needs its input on a HIP device; this package has no CPU path')
+        if self.training and torch.is_grad_enabled() and not ASRModel._warned_no_autograd:
+            ASRModel._warned_no_autograd = True
+            warnings.warn('nb_asr_amd runs the forward pass only: the logits are not attached to the autograd graph, so '
+                          'loss.backward() will not reach the parameters (training support is SURVEY.md 8 row f4, not built). '
+                          'Call model.eval() / torch.no_grad() for inference.', stacklevel=2)
         key = (input.shape[0], input.shape[2], input.device.index)
         plan = self._plans.get(key)
         if plan is None:

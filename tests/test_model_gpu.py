@@ -256,3 +256,24 @@ def test_dense_scheme_selection():
         del os.environ['NBASR_DENSE_MODE']
         model._plans.clear()
     assert cases.worst_ratio(y0, y1.cpu(), 1e-4, 1e-5) <= 1.0
+
+
+def test_forward_under_autograd_warns_that_logits_are_detached():
+    """Training support is not built: a forward in training mode with autograd on must say so instead of
+    leaving the user with an opaque 'does not require grad' at backward time."""
+    import warnings
+    from nb_asr_amd.model import ASRModel
+    m = nb.get_model([[1, 0], [1, 0, 0], [1, 0, 0, 0]], use_rnn=True, dropout_rate=0.0)
+    keyed_fill_(m, 1235, 'lively')
+    m = m.to(DEV)                                     # get_model returns the module in training mode, like the reference
+    x = keyed_input(1, 40, seed=0).to(DEV)
+    ASRModel._warned_no_autograd = False
+    with pytest.warns(UserWarning, match='not attached to the autograd graph'):
+        out = m(x)
+    assert out.grad_fn is None and not out.requires_grad
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        m(x)                                          # once per process
+        with torch.no_grad():
+            m(x)
+        m.eval()(x)
