@@ -97,6 +97,36 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long v)
     return ab > cd ? ab : cd;
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_max(unsigned v)
+{
+    const unsigned o = static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), CTRL, 0xF, 0xF, false));
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned wave_max(unsigned v)
+{
+    v = dpp_max<0xB1>(v);
+    v = dpp_max<0x4E>(v);
+    v = dpp_max<0x141>(v);
+    v = dpp_max<0x140>(v);
+    const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const unsigned c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+
+// the best 64-bit key of the wavefront (0: none).  The score occupies the high word, so a 32-bit maximum finds it; only when
+// two lanes tie on the score exactly do the low words (last class, slot) have to be compared
+__device__ __forceinline__ unsigned long long wave_best_key(unsigned long long mine)
+{
+    const unsigned hi = static_cast<unsigned>(mine >> 32);
+    const unsigned top_hi = wave_max(hi);
+    if (top_hi == 0u) return 0ull;
+    const unsigned long long holders = __ballot(hi == top_hi);
+    if (__popcll(holders) == 1) return rl(mine, __builtin_ctzll(holders));
+    return wave_max(hi == top_hi ? mine : 0ull);
+}
+
 // rotate a value by one lane around the wavefront (DPP wave_rol:1)
 __device__ __forceinline__ int wave_rotate(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x134, 0xF, 0xF, false); }
 __device__ __forceinline__ float wave_rotate(float v) { return __int_as_float(wave_rotate(__float_as_int(v))); }
@@ -183,7 +213,7 @@ __global__ __launch_bounds__(64) void ctc_beam_search_kernel(
         unsigned long long my_pick = 0ull;
         int n_next = 0;
         for (int r = 0; r < width; ++r) {
-            const unsigned long long top = wave_max(mine);
+            const unsigned long long top = wave_best_key(mine);
             if (top == 0ull) break;                                    // fewer candidates than the beam is wide
             if (lane == r) my_pick = top;
             bool rescan = false;
