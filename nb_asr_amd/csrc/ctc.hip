@@ -1,8 +1,8 @@
 // The step right after the forward pass (reference training/torch/trainer.py:217-219, 229-247):
 //   log_probs = log_softmax(logits, dim = classes);   output_len = audio_len // 4;   decode.
-// The reference decodes with the ctcdecode beam search (a C++ dependency that is not part of the reference tree); what is
-// built here is the part with a pinned definition: log_softmax, the length mapping and GREEDY CTC decoding
-// (per-frame argmax, collapse repeats, drop the blank = class 0, F.ctc_loss's default blank).
+// This file: log_softmax, the length mapping and GREEDY CTC decoding (per-frame argmax, collapse repeats, drop the blank =
+// class 0, F.ctc_loss's default blank).  The beam search the reference's Trainer.decode uses (ctcdecode), the phoneme folding
+// and the error rate are in ctc_decode.hip.
 //
 // One 256-thread workgroup per utterance: a thread owns a frame (49 contiguous floats), computes max / log-sum-exp / argmax
 // in registers, then the surviving tokens are compacted with a workgroup prefix sum so the output order is the frame order.
