@@ -272,6 +272,14 @@ int nbasr_ctc_postprocess(const float* logits, const int* lengths, float* log_pr
  *   Levenshtein distance: counts(batch, 2) int32 = (distance, reference length after blank removal); the error rate of
  *   torch_edit_distance.compute_wer is distance / length.  hyp(batch, ld_hyp), ref(batch, ld_ref) int32 with their lengths.
  *   counts = (-1, -1) for an utterance with more than 2048 tokens after blank removal, (-1, -2) for a label outside the table. */
+/* nbasr_ctc_loss: the reference's loss value (training/torch/trainer.py:36-42, reported by its validation loop):
+ *   F.ctc_loss(log_probs, targets, output_len, targets_len, reduction='none', zero_infinity=True) [/ output_len when
+ *   divide_by_length != 0]; the mean over the batch is left to the caller.  log_probs(batch, frames, classes) batch-major (the
+ *   reference permutes to (T, B, C) for torch; no permute here), lengths(batch) valid frames, targets(batch, ld_targets) int32
+ *   labels with target_lengths(batch) (ld_targets <= 1024), losses(batch) out.  Forward value only (no gradient: f4).
+ *   A label outside [0, classes) gives NaN for that utterance. */
+int nbasr_ctc_loss(const float* log_probs, const int* lengths, const int* targets, const int* target_lengths, float* losses,
+                   int batch, int frames, int classes, int ld_targets, int blank, int divide_by_length, nbasr_stream_t stream);
 size_t nbasr_ctc_beam_workspace_bytes(int batch, int frames, int classes, int beam_width);
 int nbasr_ctc_beam_search(const float* log_probs, const int* lengths, void* ws, int* beams, float* scores, int* beam_lens,
                           int batch, int frames, int classes, int beam_width, int blank, int cutoff_top_n,

@@ -293,6 +293,84 @@ __global__ __launch_bounds__(64) void ctc_beam_search_kernel(
     }
 }
 
+// ---- CTC loss (forward value) -----------------------------------------------------------------------------------------------
+// The reference's loss (training/torch/trainer.py:36-42): F.ctc_loss(log_probs (T, B, C), targets, output_len, targets_len,
+// reduction='none', zero_infinity=True) / output_len, then the mean over the batch (the mean is left to the caller).
+// Standard alpha recursion in log space over the blank-extended label sequence l' (2L + 1 positions), as ATen's ctc_loss does
+// it: alpha_t(s) = logsumexp(alpha_{t-1}(s), alpha_{t-1}(s-1), alpha_{t-1}(s-2) if l'_s != blank and l'_s != l'_{s-2}) +
+// log_probs[t][l'_s];  nll = -logsumexp(alpha_{T-1}(2L), alpha_{T-1}(2L-1)).  One wavefront per utterance, positions strided
+// over the lanes, alpha double-buffered in LDS (a single wavefront needs no barrier: its LDS operations execute in issue
+// order, wave_sync only keeps the compiler from reordering them).
+constexpr int CTC_MAX_LABELS = 1024;
+
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(64) void ctc_loss_kernel(const float* __restrict__ log_probs, const int* __restrict__ lengths,
+                                                      const int* __restrict__ targets, const int* __restrict__ target_lengths,
+                                                      float* __restrict__ losses, int frames, int classes, int ld_targets, int blank,
+                                                      int divide_by_length)
+{
+    __shared__ float s_alpha[2][2 * CTC_MAX_LABELS + 1];
+    __shared__ int s_label[2 * CTC_MAX_LABELS + 1];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int len = min(max(lengths[b], 0), frames);
+    const int n_lab = min(max(target_lengths[b], 0), ld_targets);
+    const int n_pos = 2 * n_lab + 1;
+    const float ninf = -INFINITY;
+    const float* __restrict__ lp_b = log_probs + static_cast<size_t>(b) * frames * classes;
+    bool bad = false;
+    for (int s = lane; s < n_pos; s += 64) {
+        int lab = blank;
+        if (s & 1) {
+            lab = targets[static_cast<size_t>(b) * ld_targets + (s >> 1)];
+            if (lab < 0 || lab >= classes) { bad = true; lab = blank; }
+        }
+        s_label[s] = lab;
+    }
+    wave_sync();
+    float nll = INFINITY;
+    if (len > 0) {
+        // t = 0: only the first blank and the first label are reachable
+        for (int s = lane; s < n_pos; s += 64) s_alpha[0][s] = s < 2 ? lp_b[s_label[s]] : ninf;
+        wave_sync();
+        int cur = 0;
+        for (int t = 1; t < len; ++t) {
+            const float* __restrict__ row = lp_b + static_cast<size_t>(t) * classes;
+            const float* prev = s_alpha[cur];
+            float* next = s_alpha[cur ^ 1];
+            for (int s = lane; s < n_pos; s += 64) {
+                const int lab = s_label[s];
+                const float lp = row[lab];
+                const float a = prev[s];
+                const float a1 = s > 0 ? prev[s - 1] : ninf;
+                const float a2 = (s > 1 && lab != blank && lab != s_label[s - 2]) ? prev[s - 2] : ninf;
+                const float m = fmaxf(a, fmaxf(a1, a2));
+                next[s] = m == ninf ? ninf : logf(expf(a - m) + expf(a1 - m) + expf(a2 - m)) + m + lp;
+            }
+            cur ^= 1;
+            wave_sync();
+        }
+        if (lane == 0) {
+            const float l1 = s_alpha[cur][n_pos - 1], l2 = n_pos > 1 ? s_alpha[cur][n_pos - 2] : ninf;
+            const float m = fmaxf(l1, l2);
+            nll = m == ninf ? INFINITY : -(logf(expf(l1 - m) + expf(l2 - m)) + m);
+        }
+    } else if (n_lab == 0) {
+        nll = 0.f;                                                // nothing to emit in no frames: probability 1
+    }
+    const bool any_bad = __any(bad);
+    if (lane == 0) {
+        float out = (nll == INFINITY) ? 0.f : nll;               // zero_infinity=True
+        if (divide_by_length) out = out / static_cast<float>(lengths[b]);       // the reference divides by output_len as given
+        losses[b] = any_bad ? NAN : out;
+    }
+}
+
 // ---- label table + blank removal + Levenshtein distance, one workgroup per utterance -------------------------------------
 // D[i][j] over anti-diagonals d = i + j: the cells of a diagonal are independent, three diagonals rotate through LDS
 // (indexed by i).  Integer arithmetic: exact.
@@ -403,6 +481,21 @@ extern "C" int nbasr_ctc_beam_search(const float* log_probs, const int* lengths,
     hipLaunchKernelGGL(ctc_beam_search_kernel, dim3(batch), dim3(64), 0, s, src, lengths, static_cast<int2*>(ws), beams, scores,
                        beam_lens, frames, classes, beam_width, blank);
     return launch_status("nbasr_ctc_beam_search");
+}
+
+extern "C" int nbasr_ctc_loss(const float* log_probs, const int* lengths, const int* targets, const int* target_lengths, float* losses,
+                              int batch, int frames, int classes, int ld_targets, int blank, int divide_by_length, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && frames >= 0 && classes > 0 && ld_targets >= 0 && blank >= 0 && blank < classes, NBASR_EINVAL,
+                  "nbasr_ctc_loss: bad sizes (batch=%d frames=%d classes=%d ld_targets=%d blank=%d)", batch, frames, classes, ld_targets, blank);
+    NBASR_REQUIRE(ld_targets <= CTC_MAX_LABELS, NBASR_EINVAL, "nbasr_ctc_loss: at most %d labels per utterance, got ld_targets=%d", CTC_MAX_LABELS, ld_targets);
+    if (batch == 0) return NBASR_OK;
+    NBASR_REQUIRE(lengths && target_lengths && losses && (frames == 0 || log_probs) && (ld_targets == 0 || targets), NBASR_ENULL,
+                  "nbasr_ctc_loss: NULL pointer");
+    hipLaunchKernelGGL(ctc_loss_kernel, dim3(batch), dim3(64), 0, as_stream(stream), log_probs, lengths, targets, target_lengths, losses,
+                       frames, classes, ld_targets, blank, divide_by_length);
+    return launch_status("nbasr_ctc_loss");
 }
 
 extern "C" int nbasr_token_error_counts(const int* hyp, const int* hyp_len, int ld_hyp, const int* ref, const int* ref_len, int ld_ref,

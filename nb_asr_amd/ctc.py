@@ -87,3 +87,15 @@ def decode_per(log_probs, output_len, targets, targets_len, beam_width=12, fold_
     per = error_rates(beams[:, 0].contiguous(), beams_len[:, 0].contiguous(), targets, targets_len, blank=0, table=table)
     return per.mean()
 
+
+def ctc_loss(log_probs, output_len, targets, targets_len, blank=0):
+    """The reference's loss value (``get_loss()``, trainer.py:36-42): ``F.ctc_loss(log_probs.permute(1, 0, 2), targets, output_len,
+    targets_len, reduction='none', zero_infinity=True) / output_len`` averaged over the batch -- what ``Trainer.step`` reports
+    for validation and test batches.  ``log_probs`` (B, T', C) stays batch-major on the device.  Forward value only: it is not
+    attached to the autograd graph (training is SURVEY.md 8 row f4)."""
+    dev = log_probs.device
+    b = log_probs.shape[0]
+    per = hip.ctc_loss(log_probs.contiguous(), _lengths(output_len, b, dev), targets.to(device=dev, dtype=torch.int32).contiguous(),
+                       _lengths(targets_len, b, dev), blank, divide_by_length=True)
+    return per.mean()
+

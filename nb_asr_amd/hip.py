@@ -79,6 +79,7 @@ SIGNATURES = {
     'nbasr_lstm_forward_ln': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_linear_head_bct_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_ctc_postprocess': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_ctc_loss': (_c_int, [_c_float_p] * 5 + [_c_int] * 6 + [_c_stream]),
     'nbasr_ctc_beam_workspace_bytes': (ctypes.c_size_t, [_c_int] * 4),
     'nbasr_ctc_beam_search': (_c_int, [_c_float_p] * 6 + [_c_int] * 6 + [_c_stream]),
     'nbasr_token_error_counts': (_c_int, [_c_float_p, _c_float_p, _c_int, _c_float_p, _c_float_p, _c_int, _c_float_p, _c_int, _c_int,
@@ -572,4 +573,22 @@ def token_error_counts(hyp, hyp_len, ref, ref_len, table=None, blank=0):
         None if table is None else table.data_ptr(), 0 if table is None else table.numel(), blank, counts.data_ptr(), b,
         torch.cuda.current_stream(dev).cuda_stream), 'nbasr_token_error_counts')
     return counts
+
+
+def ctc_loss(log_probs, lengths, targets, target_lengths, blank=0, divide_by_length=False):
+    """log_probs (B, T', C) float32, lengths (B) int32, targets (B, L) int32, target_lengths (B) int32 (all on the device)
+    -> per-utterance negative log-likelihood (B) float32 with zero_infinity semantics, optionally divided by ``lengths``."""
+    _dev(log_probs, 'log_probs')
+    b, t, c = log_probs.shape
+    dev = log_probs.device
+    _int_tensor(lengths, 'lengths', dev, (b,))
+    _int_tensor(target_lengths, 'target_lengths', dev, (b,))
+    _int_tensor(targets, 'targets', dev)
+    if targets.dim() != 2 or targets.shape[0] != b:
+        raise HipError(f'targets must be (batch, labels), got {tuple(targets.shape)}')
+    losses = torch.empty(b, dtype=torch.float32, device=dev)
+    _check(load_library().nbasr_ctc_loss(log_probs.data_ptr(), lengths.data_ptr(), targets.data_ptr(), target_lengths.data_ptr(),
+                                         losses.data_ptr(), b, t, c, targets.shape[1], blank, 1 if divide_by_length else 0,
+                                         _stream(log_probs)), 'nbasr_ctc_loss')
+    return losses
 

@@ -18,6 +18,8 @@ Pinning status, per function:
   beams ordered by score then by last character) and is anchored on first principles instead: for small cases and a beam wide
   enough to be exhaustive its best beam must equal the labelling of maximum total CTC probability found by enumerating every
   alignment (``ctc_labelling_log_probs``).
+* ``ctc_loss``: PINNED -- the reference's loss is a call into ATen (``F.ctc_loss``, trainer.py:36-42), and the same call on
+  CPU tensors is the oracle, exactly as the reference would compute it on its CPU path.
 * ``edit_distance`` / ``error_rate``: PARITY UNPINNED against ``torch_edit_distance`` (1ytic/pytorch-edit-distance, setup.py,
   not installed): token-level Levenshtein distance after removing blanks, divided by the reference length -- the standard
   phoneme error rate.
@@ -184,3 +186,19 @@ def error_counts(hyp, hyp_len, ref, ref_len, blank=0, table=None):
         h, r = [v for v in h if v != blank], [v for v in r if v != blank]
         out.append((edit_distance(h, r), len(r)))
     return out
+
+
+# ---- loss -------------------------------------------------------------------------------------------------------------------
+
+def ctc_loss(log_probs, output_len, targets, targets_len, reduce=True):
+    """Reference training/torch/trainer.py:36-42 ``get_loss()``: log_probs (B, T', C) torch CPU tensor.  Returns the batch mean
+    of nll / output_len (``reduce=False``: the per-utterance values before the mean)."""
+    import torch
+    import torch.nn.functional as F
+    output_len = torch.as_tensor(output_len, dtype=torch.long)
+    targets_len = torch.as_tensor(targets_len, dtype=torch.long)
+    loss = F.ctc_loss(log_probs.permute(1, 0, 2), torch.as_tensor(targets, dtype=torch.long), output_len, targets_len,
+                      reduction='none', zero_infinity=True)
+    loss = loss / output_len
+    return loss.mean() if reduce else loss
+

@@ -260,3 +260,56 @@ def test_gpu_beam_search_argument_errors():
         hip.ctc_beam_search(torch.zeros(1, 4, 49, device='cuda:0'), beam_width=33)
     beams, scores, lens = hip.ctc_beam_search(torch.zeros(0, 4, 49, device='cuda:0'))
     assert beams.shape == (0, 12, 4)
+
+
+# ---- CTC loss value ---------------------------------------------------------------------------------------------------------
+
+def test_oracle_ctc_loss_known_answers():
+    # one frame, one label: nll = -log p(label); two frames 'a': paths (a,a), (a,_), (_,a)
+    lp = torch.log(torch.tensor([[[0.25, 0.75]]]))
+    assert float(oracle.ctc_loss(lp, [1], [[1]], [1])) == pytest.approx(-np.log(0.75), rel=1e-6)
+    lp = torch.log(torch.tensor([[[0.4, 0.6], [0.3, 0.7]]]))
+    want = -np.log(0.6 * 0.7 + 0.6 * 0.3 + 0.4 * 0.7) / 2
+    assert float(oracle.ctc_loss(lp, [2], [[1]], [1])) == pytest.approx(want, rel=1e-6)
+    # more labels than frames: infinite loss, zeroed (zero_infinity=True)
+    assert float(oracle.ctc_loss(lp, [2], [[1, 1, 1]], [3])) == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('b,frames,classes,max_labels', [(6, 40, 49, 12), (3, 250, 49, 70), (2, 7, 5, 4), (4, 130, 49, 200)])
+def test_gpu_ctc_loss_matches_torch(b, frames, classes, max_labels):
+    from nb_asr_amd import ctc, hip
+    gen = torch.Generator().manual_seed(frames + max_labels)
+    lp = _log_probs((b, frames, classes), 300 + frames, 1.5)
+    targets = torch.randint(1, classes, (b, max_labels), generator=gen, dtype=torch.int32)
+    targets[:, 1::3] = targets[:, 0:-1:3][:, : targets[:, 1::3].shape[1]]                 # repeated labels need a blank between them
+    out_len = torch.tensor([frames, frames - 1, max(frames // 2, 1), frames, 3, frames][:b], dtype=torch.int32)
+    tgt_len = torch.tensor([min(max_labels, frames // 3), 0, 1, max_labels, 2, min(max_labels, 5)][:b], dtype=torch.int32)
+    dev = 'cuda:0'
+    per = hip.ctc_loss(lp.to(dev), out_len.to(dev), targets.to(dev), tgt_len.to(dev), 0, True).cpu()
+    want = oracle.ctc_loss(lp, out_len, targets, tgt_len, reduce=False)
+    assert torch.allclose(per, want, rtol=2e-5, atol=1e-6), (per, want)
+    if b > 3 and max_labels > frames:
+        assert float(want[3]) == 0.0 and float(per[3]) == 0.0                              # infeasible: zeroed, like the reference
+    got = float(ctc.ctc_loss(lp.to(dev), out_len, targets.to(dev), tgt_len))
+    assert got == pytest.approx(float(oracle.ctc_loss(lp, out_len, targets, tgt_len)), rel=2e-5)
+    raw = hip.ctc_loss(lp.to(dev), out_len.to(dev), targets.to(dev), tgt_len.to(dev), 0, False).cpu()
+    assert torch.allclose(raw, want * out_len, rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_ctc_loss_edge_cases():
+    from nb_asr_amd import hip
+    dev = 'cuda:0'
+    lp = _log_probs((3, 6, 5), 9).to(dev)
+    targets = torch.tensor([[1, 2, 9], [1, 1, 1], [0, 0, 0]], dtype=torch.int32, device=dev)
+    lens = torch.tensor([6, 0, 6], dtype=torch.int32, device=dev)
+    tl = torch.tensor([3, 0, 0], dtype=torch.int32, device=dev)
+    per = hip.ctc_loss(lp, lens, targets, tl, 0, False).cpu()
+    assert per[0] != per[0]                                   # label 9 outside the 5 classes: NaN, loudly
+    assert float(per[1]) == 0.0                               # no frames, no labels
+    want = -float(lp[2, :, 0].sum())                          # no labels: all frames blank
+    assert float(per[2]) == pytest.approx(want, rel=1e-6)
+    with pytest.raises(hip.HipError, match='1024'):
+        hip.ctc_loss(lp, lens, torch.zeros(3, 2000, dtype=torch.int32, device=dev), tl)
+

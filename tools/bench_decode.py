@@ -54,6 +54,8 @@ def main():
         print(f'{name}: fold + error rate, hyp {int(hyp_len.float().mean())} vs ref 60 tokens: {med * 1e3:8.1f} us (min {mn * 1e3:8.1f})')
         med, mn = timeit(lambda: ctc.greedy_decode(logits, None), a.iters)
         print(f'{name}: log_softmax + greedy decode (with the copy of the tokens to the host): {med * 1e3:8.1f} us')
+        med, mn = timeit(lambda: ctc.ctc_loss(lp, out_len, targets, targets_len), a.iters)
+        print(f'{name}: CTC loss value (60 labels per utterance): {med * 1e3:8.1f} us')
         med, mn = timeit(lambda: ctc.decode_per(lp, out_len, targets, targets_len), a.iters)
         print(f'{name}: Trainer.decode as a whole (beam 12 -> fold 39 -> error rate -> mean): {med * 1e3:8.1f} us')
 
