@@ -99,3 +99,37 @@ def ctc_loss(log_probs, output_len, targets, targets_len, blank=0):
                        _lengths(targets_len, b, dev), blank, divide_by_length=True)
     return per.mean()
 
+
+def evaluation_step(model, audio, audio_len, targets, targets_len, beam_width=12):
+    """``Trainer.step(inputs, training=False)`` followed by ``Trainer.decode`` (trainer.py:207-247) for one batch:
+    forward -> log_softmax -> ``output_len = audio_len // 4`` -> loss value and phoneme error rate.
+    ``audio`` (B, 80, T) on the model's device.  Returns ``(loss, per)`` as 0-dim device tensors."""
+    with torch.no_grad():
+        log_probs = log_softmax(model(audio))
+    output_len = output_lengths(torch.as_tensor(audio_len))
+    loss = ctc_loss(log_probs, output_len, targets, targets_len)
+    per = decode_per(log_probs, output_len, targets, targets_len, beam_width=beam_width)
+    return loss, per
+
+
+def evaluate(model, batches, beam_width=12):
+    """The reference's validation / test loop (trainer.py:150-158, 190-200): running averages of the per-batch loss and
+    phoneme error rate (its ``AvgMeter``: every batch weighs the same).  ``batches`` yields
+    ``((audio, audio_len), (targets, targets_len))`` like the reference's data loaders.  Returns ``(loss, per)`` floats."""
+    was_training = model.training
+    model.eval()
+    n, loss_avg, per_avg = 0, 0.0, 0.0
+    try:
+        for (audio, audio_len), (targets, targets_len) in batches:
+            loss, per = evaluation_step(model, audio, audio_len, targets, targets_len, beam_width)
+            loss, per = loss.item(), per.item()
+            if n == 0:
+                loss_avg, per_avg = loss, per
+            else:
+                loss_avg = loss_avg * (n / (n + 1)) + loss / (n + 1)
+                per_avg = per_avg * (n / (n + 1)) + per / (n + 1)
+            n += 1
+    finally:
+        model.train(was_training)
+    return loss_avg, per_avg
+

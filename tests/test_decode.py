@@ -313,3 +313,38 @@ def test_gpu_ctc_loss_edge_cases():
     with pytest.raises(hip.HipError, match='1024'):
         hip.ctc_loss(lp, lens, torch.zeros(3, 2000, dtype=torch.int32, device=dev), tl)
 
+
+@pytest.mark.gpu
+def test_gpu_evaluate_is_the_reference_validation_loop():
+    """Two batches through ctc.evaluate vs the same steps assembled from the oracles (loss: ATen; decode: decode oracle)."""
+    import nb_asr_amd as nb
+    from nb_asr_amd import ctc
+    from nb_asr_amd.weights import keyed_fill_, keyed_input
+    from oracle import asr_oracle
+    arch = [[1, 0], [1, 0, 0], [1, 0, 0, 0]]
+    m = nb.get_model(arch, use_rnn=True, dropout_rate=0.0)
+    keyed_fill_(m, 1235, 'lively')
+    params = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.to('cuda:0')
+    gen = torch.Generator().manual_seed(3)
+    table = oracle.fold_table(oracle.index_mapping(_rows(), 1, 2))
+    batches, want_loss, want_per = [], [], []
+    for k, (b, t) in enumerate([(3, 120), (2, 90)]):
+        audio = keyed_input(b, t, seed=20 + k)
+        audio_len = [t, t - 17, t // 2][:b]
+        targets = torch.randint(1, 49, (b, 9), generator=gen, dtype=torch.int32)
+        targets_len = torch.tensor([9, 4, 6][:b], dtype=torch.int32)
+        batches.append(((audio.to('cuda:0'), audio_len), (targets.to('cuda:0'), targets_len)))
+        lp = asr_oracle.log_softmax(asr_oracle.asr_forward(params, arch, audio, use_rnn=True))
+        out_len = asr_oracle.output_lengths(audio_len)
+        want_loss.append(float(oracle.ctc_loss(lp, out_len, targets, targets_len)))
+        hyps = [oracle.ctc_beam_search(lp[i, : out_len[i]].numpy(), 12)[0][0] for i in range(b)]
+        width = max(len(h) for h in hyps) or 1
+        counts = oracle.error_counts([h + [0] * (width - len(h)) for h in hyps], [len(h) for h in hyps], targets.tolist(),
+                                     targets_len.tolist(), 0, table)
+        want_per.append(float(np.mean([np.float32(d) / np.float32(n) for d, n in counts])))
+    loss, per = ctc.evaluate(m, batches)
+    assert m.training                                              # restored (get_model returns a module in training mode)
+    assert loss == pytest.approx(np.mean(want_loss), rel=1e-4)
+    assert per == pytest.approx(np.mean(want_per), rel=1e-6)
+
