@@ -114,6 +114,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
 
     if (!STATS && !active) return;
     const int t0 = q * 4;
+    const bool ragged = __any(active && t0 + 3 >= frames) != 0;   // wave-uniform
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;          // statistics of this lane's own 4 frames (skip0)
     if (active && s0 && ln_s0.stats) {
         const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_s0.stats + static_cast<size_t>(b) * 2 * ld);
@@ -138,9 +139,11 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         }
         if (s1) { const float4 v = *reinterpret_cast<const float4*>(s1 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         if (s2) { const float4 v = *reinterpret_cast<const float4*>(s2 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        // keep the pitch columns frames..ld-1 at zero (layout invariant, nbasr.h)
+        // keep the pitch columns frames..ld-1 at zero (layout invariant, nbasr.h); only the wave that holds the ragged chunk
+        if (ragged) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) if (t0 + r >= frames) o[r] = 0.f;
+            for (int r = 0; r < 4; ++r) if (t0 + r >= frames) o[r] = 0.f;
+        }
         typedef float f4v __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + off));
         if (STATS) {
