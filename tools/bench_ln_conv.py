@@ -19,8 +19,9 @@ def timeit(fn):
     return statistics.median(ts)
 
 
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for c, cout, t, s in ((600, 800, 1000, 1), (800, 1000, 1000, 2), (1000, 1200, 500, 2)):
-    b = 64
+    b = BATCH
     x = torch.randn(b, c, hip.round_up4(t), device=DEV)
     g, be = torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.2
     w, bias = torch.randn(cout, c, 8, device=DEV) * 0.02, torch.randn(cout, device=DEV)
@@ -33,4 +34,4 @@ for c, cout, t, s in ((600, 800, 1000, 1), (800, 1000, 1000, 2), (1000, 1200, 50
     cv_a = timeit(lambda: hip.dense_conv1d_fused_packed(normed, t, packed, cout, 8, bias, (), y, s, scheme='f16x2', x_absmax=amax))
     ln_b = timeit(lambda: hip.layernorm_split_image(x, g, be, stats, bound, image, t, 1e-3))
     cv_b = timeit(lambda: hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, x.shape[2], packed, cout, 8, bias, y, s))
-    print(f'{c}->{cout} T={t} s={s}: LN {ln_a:6.1f} + conv {cv_a:7.1f} = {ln_a + cv_a:7.1f} us   |   LN-split {ln_b:6.1f} + conv-img {cv_b:7.1f} = {ln_b + cv_b:7.1f} us', flush=True)
+    print(f'B={b} {c}->{cout} T={t} s={s}: LN {ln_a:6.1f} + conv {cv_a:7.1f} = {ln_a + cv_a:7.1f} us   |   LN-split {ln_b:6.1f} + conv-img {cv_b:7.1f} = {ln_b + cv_b:7.1f} us', flush=True)
