@@ -141,6 +141,17 @@ int nbasr_layernorm_split_image(const float* x, const float* gamma, const float*
 int nbasr_dense_conv1d_fused_packed_f16_img(const void* x_image, const float* x_absmax, const void* packed_w,
                                             const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
                                             int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
+/* The same with a choice of the GEMM's row tile: row_tile = 128 (as above) or 160 output channels per workgroup.  160 pays
+ * where 128 leaves a mostly empty last row tile (c_out = 800: 7 tiles, the last a quarter full, vs 5 full ones) or a partial
+ * last round of workgroups (c_out = 1200 at 64 utterances x 250 frames: 640 workgroups on 256 CUs vs 512).  Weights must be
+ * packed with the same row_tile (the packed sizes can coincide, the layouts do not); results are bit-identical between the two. */
+size_t nbasr_packed_dense_weights_bytes_f16_rows(int c_out, int c_in, int kernel, int row_tile);
+int nbasr_pack_dense_weights_f16_rows(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
+                                      nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_f16_img_rows(const void* x_image, const float* x_absmax, const void* packed_w,
+                                                 const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
+                                                 int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                                 nbasr_stream_t stream);
 
 /* nn.LSTM(input_size=c_in, hidden_size=hidden, batch_first) forward with zero initial state
  * (reference model.py:100 and 118-121): gates i,f,g,o; biases b_ih + b_hh.

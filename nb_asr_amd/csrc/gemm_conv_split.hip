@@ -47,7 +47,10 @@ namespace nbasr {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int PB_M = 128, PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // tile, channels per group, conv taps
+constexpr int PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // frames per tile, channels per group, conv taps
+// rows per tile = 32 * MI: MI = 4 (128 rows; every kernel) or 5 (160 rows; the image-path fp16 kernel only, for layers whose
+// 128-row tiling leaves a mostly empty last row tile or a partial last round of workgroups -- C_out = 800 and 1200)
+constexpr int pb_rows(int mi) { return 32 * mi; }
 constexpr int PB_THREADS = 512;                                              // 8 waves: 2 (rows) x 4 (frames), 64 x 64 each
 
 // ---- the two operand-splitting schemes ---------------------------------------------------------------------------
@@ -90,13 +93,14 @@ struct SplitF16x2 {
     static constexpr const char* NAME = "nbasr_dense_conv1d_fused_packed_f16";
 };
 
-template <class P> constexpr int pb_group_bytes() { return P::NS * PB_TAPS * PB_M * PB_CI * 2; }   // packed weights of one (row tile, channel group)
+template <class P> constexpr size_t pb_group_bytes(int mi) { return static_cast<size_t>(P::NS) * PB_TAPS * pb_rows(mi) * PB_CI * 2; }   // packed weights of one (row tile, channel group)
 
-template <class P, int S>
+template <class P, int S, int MI = 4>
 struct GeoP {
+    static constexpr int PBM = pb_rows(MI);                      // rows per tile; a wave owns 16 * MI of them
     static constexpr int TP = P::taps_per_step(S);               // taps per K-step
     static constexpr int QSTEPS = PB_TAPS / TP;                  // K-steps per channel group
-    static constexpr int A_STEP_BYTES = P::NS * TP * PB_M * PB_CI * 2;
+    static constexpr int A_STEP_BYTES = P::NS * TP * PBM * PB_CI * 2;
     static constexpr int XR = (PB_N - 1) * S + PB_TAPS;          // input frames needed per channel
     static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
     static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
@@ -141,9 +145,9 @@ __device__ __forceinline__ unsigned pack2(unsigned short a, unsigned short b) {
 }
 
 // ---- one-time weight split + re-layout -------------------------------------------------------------------------
-// packed element (mt, g, q, split, tp, half = ci_l/8, co_l, ci_l%8) <- W[mt*128 + co_l][g*16 + ci_l][q*TP + tp]  (zero outside);
+// packed element (mt, g, q, split, tp, half = ci_l/8, co_l, ci_l%8) <- W[mt*PB_M + co_l][g*16 + ci_l][q*TP + tp]  (zero outside);
 // TP = taps per K-step of the kernel that will consume the image
-// SCALED schemes: scales[co] = 2^kw[co], scales[rows + co] = 2^-kw[co]   (rows = n_mt * 128; rows beyond c_out: 1)
+// SCALED schemes: scales[co] = 2^kw[co], scales[rows + co] = 2^-kw[co]   (rows = n_mt * PB_M; rows beyond c_out: 1)
 __global__ __launch_bounds__(256) void weight_row_scales_kernel(const float* __restrict__ w, float* __restrict__ scales,
                                                                 int c_out, int row_elems, int rows)
 {
@@ -167,7 +171,7 @@ __global__ __launch_bounds__(256) void weight_row_scales_kernel(const float* __r
 template <class P>
 __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ wp,
                                                                  const float* __restrict__ row_scale,
-                                                                 int c_out, int c_in, int n_mt, int n_groups, int PB_TP)
+                                                                 int c_out, int c_in, int n_mt, int n_groups, int PB_TP, int PB_M)
 {
     const int PB_QSTEPS = PB_TAPS / PB_TP;
     const long long total = static_cast<long long>(n_mt) * n_groups * PB_QSTEPS * PB_TP * PB_M * PB_CI;
@@ -196,11 +200,13 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
 // XIMG: x is not the fp32 activation but its pre-split fp16 image written by the normalise-and-split LayerNorm kernel
 // (layernorm.hip): [b][16-channel group][split][8-channel half][1 + ld_in rows][8 ch], row 0 all zero, frame t at row t + 1,
 // already scaled by 2^kx[b].  The input tile then needs no vector work at all: it is gathered by LDS-DMA like the weights.
-template <class P, int S, bool LNX, bool XIMG = false>
+template <class P, int S, bool LNX, bool XIMG = false, int MI = 4>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const PackedConvArgs a)
 {
     static_assert(!(XIMG && LNX) && !(XIMG && !P::SCALED), "the image path is the scaled fp16 scheme without LayerNorm on load");
-    using G = GeoP<P, S>;
+    static_assert(MI == 4 || (MI == 5 && XIMG), "160-row tiles exist for the image path only (register budget)");
+    using G = GeoP<P, S, MI>;
+    constexpr int PB_M = G::PBM, WROWS = 16 * MI;                // rows per tile, rows per wave
     using vec8 = typename P::vec8;
     constexpr int TP = G::TP, QS = G::QSTEPS, ASTEP = G::A_STEP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -232,16 +238,16 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * S - a.lpad;
     const float* __restrict__ xstats = LNX ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
-    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * pb_group_bytes<P>();
+    const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * pb_group_bytes<P>(MI);
 
-    // a wave whose whole 64 x 64 tile is out of range issues no MFMAs
-    const bool wave_active = (m0 + wm * 64) < a.c_out && (n0 + wn * 64) < a.ld_out;
+    // a wave whose whole tile is out of range issues no MFMAs
+    const bool wave_active = (m0 + wm * WROWS) < a.c_out && (n0 + wn * 64) < a.ld_out;
 
     // two accumulator sets: `big` only ever receives hi*hi (ONE rounding of the large running sum per 32 k, the
     // accumulation-chain length of a blocked fp32 sum); the small cross terms go to `small`
-    floatx4 big[4][4], small[4][4];                   // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
+    floatx4 big[MI][4], small[MI][4];                 // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     // pair, channel half kq & 1.  Both LDS images are [..][tap][half][row][8 channels] with 16-byte rows, so the 16 lanes
     // of a quarter read 256 contiguous bytes (all 64 banks) and a fragment is one ds_read_b128.
     const int l15 = lane & 15, kq = lane >> 4;
-    const int a_lane = (((kq >> 1) * 2 + (kq & 1)) * PB_M + wm * 64 + l15) * 16;
+    const int a_lane = (((kq >> 1) * 2 + (kq & 1)) * PB_M + wm * WROWS + l15) * 16;
     const int x_lane = (kq & 1) * G::ROWS * 16;
 
     // PIPE (where the registers allow): the fragment reads are software-pipelined IN PLACE over the fully unrolled step --
@@ -387,9 +393,9 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 #pragma unroll
             for (int pp = 0; pp < TP / 2; ++pp) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int cur = (pp * 4 + i) & 1;
-                    const bool more_a = i < 3 || pp + 1 < TP / 2;
+                for (int i = 0; i < MI; ++i) {
+                    const int cur = (pp * MI + i) & 1;
+                    const bool more_a = i < MI - 1 || pp + 1 < TP / 2;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -397,8 +403,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                         __builtin_amdgcn_sched_barrier(0);
                         // hipcc waits for ALL outstanding LDS reads before the first MFMA of a row block (lgkmcnt(0), not a
                         // counted wait), so the next reads are issued BEHIND that first block: they then have 9 MFMAs to land
-                        if (j == 0 && more_a) read_a(i < 3 ? pp : pp + 1, (i + 1) & 3, af[cur ^ 1]);
-                        if (i == 3 && pp + 1 < TP / 2) read_b(pp + 1, j, bfr[j]);
+                        if (j == 0 && more_a) read_a(i < MI - 1 ? pp : pp + 1, (i + 1) % MI, af[cur ^ 1]);
+                        if (i == MI - 1 && pp + 1 < TP / 2) read_b(pp + 1, j, bfr[j]);
                     }
                 }
             }
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 #pragma unroll
                 for (int j = 0; j < 4; ++j) read_b(pp, j, bfr[j]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MI; ++i) {
                     vec8 af[P::NS];
                     read_a(pp, i, af);
 #pragma unroll
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     // ---- epilogue: bias + ReLU + min(20) (+ skips); a store covers 4 rows x 16 consecutive frames -----------------
     if (!wave_active) return;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < MI; ++i) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + l15;
@@ -488,7 +494,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             const bool live = n < a.frames_out;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + kq * 4 + r;
+                const int m = m0 + wm * WROWS + i * 16 + kq * 4 + r;
                 if (m >= a.c_out) continue;
                 float acc = big[i][j][r] + small[i][j][r] * P::SMALL_SCALE;
                 if constexpr (P::SCALED) acc = acc * x_inv * a.w_inv_scale[m];  // exact: powers of two, applied one after the other
@@ -504,10 +510,35 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     }
 }
 
+// 160-row tiles: image-path fp16 kernel only
+template <class P, int S>
+static int launch_packed_rows160(PackedConvArgs a, hipStream_t stream)
+{
+    if constexpr (P::SCALED) {
+        using G = GeoP<P, S, 5>;
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true, 5>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (attr != hipSuccess) {
+            set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr));
+            return static_cast<int>(attr);
+        }
+        a.n_mt = (a.c_out + G::PBM - 1) / G::PBM;
+        a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
+        const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
+        NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
+        hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, 5>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+        return launch_status(P::NAME);
+    } else {
+        set_error("%s: 160-row tiles exist for the fp16 image path only", P::NAME);
+        return NBASR_EINVAL;
+    }
+}
+
 template <class P, int S>
 static int launch_packed(PackedConvArgs a, hipStream_t stream)
 {
     using G = GeoP<P, S>;
+    constexpr int PB_M = G::PBM;
     constexpr bool HAS_LNX = !P::SCALED;      // the scaled scheme needs the range of the normalised tensor: no LayerNorm on load
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -542,18 +573,24 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     return launch_status(P::NAME);
 }
 
+static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : 0); }
+
 template <class P>
-static size_t packed_bytes(int c_out, int c_in, int kernel)
+static size_t packed_bytes(int c_out, int c_in, int kernel, int row_tile = 128)
 {
-    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS) return 0;
-    const size_t n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
-    return n_mt * n_groups * pb_group_bytes<P>() + (P::SCALED ? 2 * n_mt * PB_M * sizeof(float) : 0);   // + row scales and inverses
+    const int mi = rows_to_mi(row_tile);
+    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS || mi == 0 || (mi == 5 && !P::SCALED)) return 0;
+    const size_t PB_M = pb_rows(mi), n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
+    return n_mt * n_groups * pb_group_bytes<P>(mi) + (P::SCALED ? 2 * n_mt * PB_M * sizeof(float) : 0);   // + row scales and inverses
 }
 
 template <class P>
-static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, nbasr_stream_t stream)
+static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, nbasr_stream_t stream, int row_tile = 128)
 {
     clear_error();
+    const int mi = rows_to_mi(row_tile);
+    NBASR_REQUIRE(mi != 0 && (mi == 4 || P::SCALED), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 160 for the fp16 scheme)", row_tile);
+    const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
                   "nbasr_pack_dense_weights: (kernel=%d, stride=%d) unsupported (the downsample convs have k=8, s in {1,2})", kernel, stride);
@@ -562,12 +599,12 @@ static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kern
     const int n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
     float* scales = nullptr;
     if (P::SCALED) {
-        scales = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + static_cast<size_t>(n_mt) * n_groups * pb_group_bytes<P>());
+        scales = reinterpret_cast<float*>(static_cast<unsigned char*>(packed) + static_cast<size_t>(n_mt) * n_groups * pb_group_bytes<P>(mi));
         hipLaunchKernelGGL(weight_row_scales_kernel, dim3(n_mt * PB_M), dim3(256), 0, as_stream(stream), w, scales, c_out,
                            c_in * PB_TAPS, n_mt * PB_M);
     }
     hipLaunchKernelGGL(pack_dense_weights_kernel<P>, dim3(2048), dim3(256), 0, as_stream(stream), w,
-                       static_cast<unsigned short*>(packed), scales, c_out, c_in, n_mt, n_groups, P::taps_per_step(stride));
+                       static_cast<unsigned short*>(packed), scales, c_out, c_in, n_mt, n_groups, P::taps_per_step(stride), PB_M);
     return launch_status("nbasr_pack_dense_weights");
 }
 
@@ -575,9 +612,14 @@ template <class P>
 static int dense_packed_impl(const float* x, const void* packed_w, const float* bias, const float* skip0,
                              const float* skip1, const float* skip2, float* y, int batch, int c_in,
                              int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                             const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream, bool x_is_image = false)
+                             const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream, bool x_is_image = false,
+                             int row_tile = 128)
 {
     clear_error();
+    const int mi = rows_to_mi(row_tile);
+    NBASR_REQUIRE(mi == 4 || (mi == 5 && x_is_image && P::SCALED), NBASR_EINVAL,
+                  "%s: row_tile=%d unsupported (128; 160 for the fp16 image path)", P::NAME, row_tile);
+    const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
                   "%s: (kernel=%d, stride=%d) unsupported; packed path covers k=8, s in {1,2}", P::NAME, kernel, stride);
@@ -599,9 +641,10 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
         NBASR_REQUIRE(x_absmax, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
         a.x_absmax = x_absmax;
         a.x_is_image = x_is_image ? 1 : 0;
-        a.w_inv_scale = reinterpret_cast<const float*>(a.wp + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * a.n_groups * pb_group_bytes<P>())
+        a.w_inv_scale = reinterpret_cast<const float*>(a.wp + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * a.n_groups * pb_group_bytes<P>(mi))
                         + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * PB_M;
     }
+    if (mi == 5) return stride == 1 ? launch_packed_rows160<P, 1>(a, as_stream(stream)) : launch_packed_rows160<P, 2>(a, as_stream(stream));
     return stride == 1 ? launch_packed<P, 1>(a, as_stream(stream)) : launch_packed<P, 2>(a, as_stream(stream));
 }
 
@@ -662,4 +705,24 @@ extern "C" int nbasr_dense_conv1d_fused_packed_f16_img(const void* x_image, cons
 {
     return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
                                          frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, x_absmax, stream, true);
+}
+
+extern "C" size_t nbasr_packed_dense_weights_bytes_f16_rows(int c_out, int c_in, int kernel, int row_tile)
+{
+    return packed_bytes<SplitF16x2>(c_out, c_in, kernel, row_tile);
+}
+
+extern "C" int nbasr_pack_dense_weights_f16_rows(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
+                                                 nbasr_stream_t stream)
+{
+    return pack_impl<SplitF16x2>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed_f16_img_rows(const void* x_image, const float* x_absmax, const void* packed_w,
+                                                            const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
+                                                            int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                                            nbasr_stream_t stream)
+{
+    return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
+                                         frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, x_absmax, stream, true, row_tile);
 }

@@ -104,6 +104,10 @@ class ForwardPlan:
         self._pw_ws = None           # scratch of the pre-split activation image, grown on demand
         # LayerNorm -> dense conv hand-off as a pre-split fp16 image (NBASR_IMAGE_MODE=0: fp32 tensor + in-GEMM staging)
         self.image_mode = os.environ.get('NBASR_IMAGE_MODE', '1') != '0'
+        # row tile of the image-path GEMM: auto (per layer, see _row_tile) | 128 | 160
+        self.row_tile_mode = os.environ.get('NBASR_ROW_TILE', 'auto')
+        if self.row_tile_mode not in ('auto', '128', '160'):
+            raise ValueError(f'NBASR_ROW_TILE must be auto, 128 or 160, got {self.row_tile_mode!r}')
         self._image = None
         self._act_image = None
         self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
@@ -148,15 +152,28 @@ class ForwardPlan:
         self.timer.append((kind, meta, start, stop))
         return out
 
-    def _packed_weights(self, layer, scheme):
+    def _packed_weights(self, layer, scheme, row_tile=128):
         """Split/re-laid-out copy of a downsample conv's weights, rebuilt whenever the parameter changes."""
         w = layer.conv.weight
         key = (w.data_ptr(), w._version)
-        hit = self._packed.get((id(layer), scheme))
+        hit = self._packed.get((id(layer), scheme, row_tile))
         if hit is None or hit[0] != key:
-            hit = (key, hip.pack_dense_weights(w.detach(), layer.strides, scheme))
-            self._packed[(id(layer), scheme)] = hit
+            hit = (key, hip.pack_dense_weights(w.detach(), layer.strides, scheme, row_tile))
+            self._packed[(id(layer), scheme, row_tile)] = hit
         return hit[1]
+
+    def _row_tile(self, c_out, frames_out):
+        """Rows per workgroup of the image-path GEMM: 128, or 160 where that means less work in whole rounds of workgroups
+        (a tile's cost is proportional to its rows; 256 CUs run one workgroup each).  At the benchmark shape: 160 for
+        C_out = 800 (5 full row tiles instead of 7 with the last a quarter full) and 1200 (512 workgroups instead of 640)."""
+        if self.row_tile_mode != 'auto':
+            return int(self.row_tile_mode)
+        n_nt = (hip.round_up4(frames_out) + 255) // 256
+
+        def cost(rows):
+            wgs = -(-c_out // rows) * n_nt * self.batch
+            return -(-wgs // 256) * rows
+        return 160 if cost(160) < cost(128) else 128
 
     def _packed_linear(self, linear):
         """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""
@@ -189,9 +206,10 @@ class ForwardPlan:
         if image is not None:
             self.dense_schemes[blk] = 'f16x2-image'
             b, c, ld = act.shape
-            return hip.dense_conv1d_fused_packed_f16_img(image[0], image[1], b, c, act_frames, ld, self._packed_weights(layer, 'f16x2'),
-                                                         layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out,
-                                                         layer.strides)
+            rows = self._row_tile(layer.conv.out_channels, (act_frames + layer.strides - 1) // layer.strides)
+            return hip.dense_conv1d_fused_packed_f16_img(image[0], image[1], b, c, act_frames, ld,
+                                                         self._packed_weights(layer, 'f16x2', rows), layer.conv.out_channels,
+                                                         layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, rows)
         if self.dense_mode != 'f32' and layer.kernel_size == 8:
             scheme = 'f16x2' if self.dense_mode == 'auto' and absmax is not None and ln is None else 'bf16x3'
             self.dense_schemes[blk] = scheme

@@ -38,6 +38,9 @@ SIGNATURES = {
     'nbasr_split_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_layernorm_split_image': (_c_int, [_c_float_p] * 6 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused_packed_f16_img': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_packed_dense_weights_bytes_f16_rows': (ctypes.c_size_t, [_c_int] * 4),
+    'nbasr_pack_dense_weights_f16_rows': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_dense_conv1d_fused_packed_f16_img_rows': (_c_int, [_c_float_p] * 5 + [_c_int] * 9 + [_c_stream]),
     'nbasr_absmax': (_c_int, [_c_float_p] * 2 + [_c_int, ctypes.c_longlong, _c_stream]),
     'nbasr_layernorm_channels_absmax': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
@@ -265,15 +268,18 @@ def layernorm_split_image(x, gamma, beta, stats, bound, image, frames, eps):
     return image
 
 
-def dense_conv1d_fused_packed_f16_img(image, bound, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride):
+def dense_conv1d_fused_packed_f16_img(image, bound, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride,
+                                      row_tile=128):
     lib = load_library()
-    if packed.numel() != lib.nbasr_packed_dense_weights_bytes_f16(c_out, c_in, kernel):
-        raise HipError(f'packed weights are not an f16x2 image of a ({c_out}, {c_in}, {kernel}) weight')
+    if packed.numel() != lib.nbasr_packed_dense_weights_bytes_f16_rows(c_out, c_in, kernel, row_tile) or \
+            getattr(packed, 'nbasr_row_tile', 128) != row_tile:
+        raise HipError(f'packed weights are not an f16x2 image of a ({c_out}, {c_in}, {kernel}) weight for row_tile={row_tile}')
     if image.numel() < lib.nbasr_split_image_bytes(batch, c_in, ld_in):
         raise HipError('image buffer too small for (batch, c_in, ld_in)')
-    _check(lib.nbasr_dense_conv1d_fused_packed_f16_img(image.data_ptr(), _dev(bound, 'bound'), packed.data_ptr(), _dev(bias, 'bias'),
-                                                       _dev(y, 'y'), batch, c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride,
-                                                       _stream(y)), 'nbasr_dense_conv1d_fused_packed_f16_img')
+    _check(lib.nbasr_dense_conv1d_fused_packed_f16_img_rows(image.data_ptr(), _dev(bound, 'bound'), packed.data_ptr(),
+                                                            _dev(bias, 'bias'), _dev(y, 'y'), batch, c_in, frames_in, ld_in, c_out,
+                                                            y.shape[2], kernel, stride, row_tile, _stream(y)),
+           'nbasr_dense_conv1d_fused_packed_f16_img_rows')
     return y
 
 
@@ -296,20 +302,31 @@ def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln
     return y
 
 
-def pack_dense_weights(weight, stride, scheme='bf16x3'):
+def pack_dense_weights(weight, stride, scheme='bf16x3', row_tile=128):
     """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its split (3 x bf16, or 2 x fp16 for
-    ``scheme='f16x2'``) in the LDS layout of the stride-`stride` kernel that will consume it."""
+    ``scheme='f16x2'``) in the LDS layout of the stride-`stride` kernel that will consume it.  ``row_tile`` = 160 packs for
+    the 160-row tiles of the fp16 image-path kernel (``dense_conv1d_fused_packed_f16_img(..., row_tile=160)``)."""
     sfx = _scheme_suffix(scheme)
     lib = load_library()
     c_out, c_in, kernel = weight.shape
-    nbytes = getattr(lib, 'nbasr_packed_dense_weights_bytes' + sfx)(c_out, c_in, kernel)
+    if row_tile != 128 and scheme != 'f16x2':
+        raise HipError('row_tile other than 128 exists for the f16x2 scheme only')
+    if row_tile == 128:
+        nbytes = getattr(lib, 'nbasr_packed_dense_weights_bytes' + sfx)(c_out, c_in, kernel)
+    else:
+        nbytes = lib.nbasr_packed_dense_weights_bytes_f16_rows(c_out, c_in, kernel, row_tile)
     if nbytes == 0:
-        raise HipError(f'packed dense path does not cover weight shape {tuple(weight.shape)}')
+        raise HipError(f'packed dense path does not cover weight shape {tuple(weight.shape)} with row_tile={row_tile}')
     if not weight.is_cuda:
         raise HipError('weight must be on a HIP device')
     packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _check(getattr(lib, 'nbasr_pack_dense_weights' + sfx)(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel,
-                                                          stride, _stream(weight)), 'nbasr_pack_dense_weights' + sfx)
+    if row_tile == 128:
+        _check(getattr(lib, 'nbasr_pack_dense_weights' + sfx)(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel,
+                                                              stride, _stream(weight)), 'nbasr_pack_dense_weights' + sfx)
+    else:
+        _check(lib.nbasr_pack_dense_weights_f16_rows(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride, row_tile,
+                                                     _stream(weight)), 'nbasr_pack_dense_weights_f16_rows')
+    packed.nbasr_row_tile = row_tile           # the packed sizes of the two tilings can coincide (c_out = 1200): remember which
     return packed
 
 

@@ -573,7 +573,7 @@ def test_fused_cell_limits():
 
 
 @pytest.mark.parametrize('c,cout,t,stride,b', [(40, 72, 150, 1, 2), (40, 72, 151, 2, 2), (600, 136, 300, 1, 1), (136, 200, 515, 2, 3), (24, 40, 1, 1, 2),
-                                               (1000, 136, 260, 2, 1)])
+                                               (1000, 136, 260, 2, 1), (72, 800, 300, 1, 1), (40, 1200, 130, 2, 2), (24, 161, 20, 1, 1)])
 def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     """LayerNorm written as the convolution's pre-split operand image + image-gathering convolution == materialised LayerNorm +
     fp16-split convolution, to fp32 resolution (the per-utterance scale comes from a bound instead of the exact maximum)."""
@@ -604,3 +604,10 @@ def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     e_img = float(((got[:, :, :t_out].cpu().double() - truth) / scale).abs().max())
     e_ref = float(((want[:, :, :t_out].cpu().double() - truth) / scale).abs().max())
     assert e_img <= max(2.0 * e_ref, 2e-6), (e_img, e_ref)
+    # 160-row tiles: another tiling of the same sums, the K order of every output is unchanged -> bit-identical
+    got160 = torch.full_like(want, float('nan'))
+    packed160 = hip.pack_dense_weights(w, stride, 'f16x2', row_tile=160)
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed160, cout, 8, bias, got160, stride, row_tile=160)
+    assert torch.equal(got160, got)
+    with pytest.raises(hip.HipError, match='row_tile=128'):
+        hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed160, cout, 8, bias, got160, stride)

@@ -34,4 +34,6 @@ for c, cout, t, s in ((600, 800, 1000, 1), (800, 1000, 1000, 2), (1000, 1200, 50
     cv_a = timeit(lambda: hip.dense_conv1d_fused_packed(normed, t, packed, cout, 8, bias, (), y, s, scheme='f16x2', x_absmax=amax))
     ln_b = timeit(lambda: hip.layernorm_split_image(x, g, be, stats, bound, image, t, 1e-3))
     cv_b = timeit(lambda: hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, x.shape[2], packed, cout, 8, bias, y, s))
-    print(f'B={b} {c}->{cout} T={t} s={s}: LN {ln_a:6.1f} + conv {cv_a:7.1f} = {ln_a + cv_a:7.1f} us   |   LN-split {ln_b:6.1f} + conv-img {cv_b:7.1f} = {ln_b + cv_b:7.1f} us', flush=True)
+    packed160 = hip.pack_dense_weights(w, s, 'f16x2', row_tile=160)
+    cv_c = timeit(lambda: hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, x.shape[2], packed160, cout, 8, bias, y, s, row_tile=160))
+    print(f'B={b} {c}->{cout} T={t} s={s}: LN {ln_a:6.1f} + conv {cv_a:7.1f} = {ln_a + cv_a:7.1f} us   |   LN-split {ln_b:6.1f} + conv-img {cv_b:7.1f} = {ln_b + cv_b:7.1f} us   |   conv-img, 160-row tiles {cv_c:7.1f} us', flush=True)
