@@ -113,6 +113,7 @@ class ForwardPlan:
         self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
         self.absmax_in = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|model input| per utterance
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
+        self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
         # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
         # 'materialize' = the stand-alone LayerNorm kernel writes the normalised tensor
         self.ln_mode = os.environ.get('NBASR_LN_MODE', 'deferred')
@@ -206,7 +207,7 @@ class ForwardPlan:
         if image is not None:
             self.dense_schemes[blk] = 'f16x2-image'
             b, c, ld = act.shape
-            rows = self._row_tile(layer.conv.out_channels, (act_frames + layer.strides - 1) // layer.strides)
+            rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, (act_frames + layer.strides - 1) // layer.strides)
             return hip.dense_conv1d_fused_packed_f16_img(image[0], image[1], b, c, act_frames, ld,
                                                          self._packed_weights(layer, 'f16x2', rows), layer.conv.out_channels,
                                                          layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, rows)

@@ -130,3 +130,18 @@ def test_keyed_generators_are_platform_stable(known):
     x = keyed_input(2, 37, seed=0)
     assert hashlib.sha256(x.numpy().tobytes()).hexdigest() == known['keyed_input_digest']
     assert x.dtype == torch.float32 and tuple(x.shape) == (2, 80, 37)
+
+
+def test_row_tile_rule_counts_rounds_of_workgroups():
+    """Image-path GEMM: 160-row tiles exactly where they mean fewer (rows x rounds of 256 workgroups) than 128-row tiles."""
+    import types
+    from nb_asr_amd.executor import ForwardPlan
+    plan = types.SimpleNamespace(row_tile_mode='auto', batch=64)
+    pick = lambda c, t: ForwardPlan._row_tile(plan, c, t)                      # noqa: E731
+    assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 160]     # the benchmark shape: convs 1 and 3
+    plan.batch = 32
+    assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 160]
+    plan.batch = 2
+    assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [128, 128, 128]     # a single round either way: shorter tiles
+    plan.row_tile_mode = '160'
+    assert pick(1000, 500) == 160

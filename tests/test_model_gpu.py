@@ -245,6 +245,8 @@ def test_dense_scheme_selection():
         y0 = model(x)
     plan = next(iter(model._plans.values()))
     assert plan.dense_schemes == {0: 'f16x2', 1: 'f16x2-image', 2: 'f16x2-image', 3: 'f16x2-image'}
+    assert set(plan.dense_row_tiles) == {1, 2, 3} and set(plan.dense_row_tiles.values()) <= {128, 160}
+    assert plan._row_tile(800, 1000) == 128 and plan._row_tile(1200, 250) == 128          # 2 utterances: one round either way
     os.environ['NBASR_DENSE_MODE'] = 'bf16x3'
     try:
         model._plans.clear()
