@@ -201,15 +201,28 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
     if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
     const int nquads = (groups + 3) / 4;
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    for (int k = 0; k < nquads; ++k) {
-        const float nb = static_cast<float>(cg * min(4, groups - 4 * k));
-        const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld;
-        const float pm = prow[t], pq = prow[ld + t];
-        const float tot = cnt + nb;
-        const float delta = pm - mean;
-        mean += delta * (nb / tot);
-        m2 += pq + delta * delta * (cnt * nb / tot);
-        cnt = tot;
+    // the partials are loaded five at a time BEFORE they are merged: the merge is a serial chain, the loads need not be
+    // (25 partials per frame at 100 groups: 5 round trips to memory instead of 25; same merge order, same result)
+    for (int k0 = 0; k0 < nquads; k0 += 5) {
+        float pm[5], pq[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = min(k0 + u, nquads - 1);
+            const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld;
+            pm[u] = prow[t];
+            pq[u] = prow[ld + t];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = k0 + u;
+            if (k >= nquads) break;
+            const float nb = static_cast<float>(cg * min(4, groups - 4 * k));
+            const float tot = cnt + nb;
+            const float delta = pm[u] - mean;
+            mean += delta * (nb / tot);
+            m2 += pq[u] + delta * delta * (cnt * nb / tot);
+            cnt = tot;
+        }
     }
     srow[t] = mean;
     srow[ld + t] = 1.0f / sqrtf(m2 / cnt + eps);
