@@ -84,6 +84,12 @@ def main():
             med, mn = timeit(lambda: hip.layernorm_channels(x, g, be, x, tt, 1e-3), a.iters)
             by = 8.0 * b * c * tt
             print(f'layernorm C={c:5d} T={tt:5d}: {med * 1e3:8.1f} us (min {mn * 1e3:8.1f})  {by / med / 1e6:7.0f} GB/s (1R+1W algorithmic)')
+            stats = torch.empty(b, 2, r4(tt), device=DEV)
+            med, mn = timeit(lambda: hip.channel_stats(x, stats, tt, 1e-3), a.iters)
+            print(f'channel_stats C={c:5d} T={tt:5d}: {med * 1e3:8.1f} us (min {mn * 1e3:8.1f})  {by / 2 / med / 1e6:7.0f} GB/s (1R)')
+            bound, image = torch.empty(b, device=DEV), hip.split_image(b, c, r4(tt), DEV)
+            med, mn = timeit(lambda: hip.layernorm_split_image(x, g, be, stats, bound, image, tt, 1e-3), a.iters)
+            print(f'layernorm_split_image (stats+bound, normalise+split) C={c:5d} T={tt:5d}: {med * 1e3:8.1f} us (min {mn * 1e3:8.1f})')
 
     if a.what in ('lstm', 'all'):
         hid, cin = 500, 1200
