@@ -291,6 +291,15 @@ int nbasr_ctc_postprocess(const float* logits, const int* lengths, float* log_pr
  *   A label outside [0, classes) gives NaN for that utterance. */
 int nbasr_ctc_loss(const float* log_probs, const int* lengths, const int* targets, const int* target_lengths, float* losses,
                    int batch, int frames, int classes, int ld_targets, int blank, int divide_by_length, nbasr_stream_t stream);
+/* nbasr_ctc_loss_grad: the loss of nbasr_ctc_loss (divided by the lengths) AND the gradient of its batch mean with respect to the
+ *   LOGITS that log_probs = log_softmax(logits) came from -- what the reference's `loss.backward()` (trainer.py:220-223, without
+ *   the weight-norm term) hands to the model: grad_logits(batch, frames, classes), zero beyond each utterance's length and for
+ *   utterances whose loss is infinite (zero_infinity).  The first step of the backward pass; nothing in
+ *   this library consumes it yet.  ws: nbasr_ctc_grad_workspace_bytes (alpha of every frame), no state between calls. */
+size_t nbasr_ctc_grad_workspace_bytes(int batch, int frames, int ld_targets);
+int nbasr_ctc_loss_grad(const float* log_probs, const int* lengths, const int* targets, const int* target_lengths, void* ws,
+                        float* losses, float* grad_logits, int batch, int frames, int classes, int ld_targets, int blank,
+                        nbasr_stream_t stream);
 size_t nbasr_ctc_beam_workspace_bytes(int batch, int frames, int classes, int beam_width);
 int nbasr_ctc_beam_search(const float* log_probs, const int* lengths, void* ws, int* beams, float* scores, int* beam_lens,
                           int batch, int frames, int classes, int beam_width, int blank, int cutoff_top_n,

@@ -371,6 +371,117 @@ __global__ __launch_bounds__(64) void ctc_loss_kernel(const float* __restrict__ 
     }
 }
 
+// ---- CTC loss gradient (first step of the backward pass) -------------------------------------------------
+// d L / d logits for L = mean_b( nll_b / len_b ), log_probs = log_softmax(logits)  (reference trainer.py:36-42, 217-222: this is
+// what `_regu_loss.backward()` propagates into the model, without the weight-norm term).  With alpha as above and beta the
+// mirrored recursion from the last frame,
+//     grad[b][t][c] = ( exp(lp[t][c]) - exp( log sum_{s: l'_s = c} exp(alpha_t(s) + beta_t(s)) + nll - lp[t][c] ) ) / (B len_b)
+// for t < len_b, 0 beyond (ATen's ctc_loss backward composed with log_softmax's; Graves et al. 2006, eq. 16); 0 for utterances
+// whose loss is infinite (zero_infinity).  One wavefront per utterance: alpha of every frame goes to a global workspace in
+// the forward sweep, the backward sweep keeps beta in LDS and turns each frame into its gradient row: lane c sums, in a fixed
+// order, the positions that carry class c (deterministic; classes <= 64).
+__global__ __launch_bounds__(64) void ctc_grad_kernel(const float* __restrict__ log_probs, const int* __restrict__ lengths,
+                                                      const int* __restrict__ targets, const int* __restrict__ target_lengths,
+                                                      float* __restrict__ alpha_ws, float* __restrict__ losses, float* __restrict__ grad,
+                                                      int batch, int frames, int classes, int ld_targets, int blank)
+{
+    __shared__ float s_beta[2][2 * CTC_MAX_LABELS + 1];
+    __shared__ float s_ab[2 * CTC_MAX_LABELS + 1];
+    __shared__ int s_label[2 * CTC_MAX_LABELS + 1];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int len = min(max(lengths[b], 0), frames);
+    const int n_lab = min(max(target_lengths[b], 0), ld_targets);
+    const int n_pos = 2 * n_lab + 1;
+    const float ninf = -INFINITY;
+    const float* __restrict__ lp_b = log_probs + static_cast<size_t>(b) * frames * classes;
+    float* __restrict__ g_b = grad + static_cast<size_t>(b) * frames * classes;
+    float* __restrict__ al = alpha_ws + static_cast<size_t>(b) * frames * (2 * static_cast<size_t>(ld_targets) + 1);
+    const int pitch = 2 * ld_targets + 1;
+    bool bad = false;
+    for (int s = lane; s < n_pos; s += 64) {
+        int lab = blank;
+        if (s & 1) {
+            lab = targets[static_cast<size_t>(b) * ld_targets + (s >> 1)];
+            if (lab < 0 || lab >= classes) { bad = true; lab = blank; }
+        }
+        s_label[s] = lab;
+    }
+    wave_sync();
+    const bool any_bad = __any(bad);
+    // ---- forward sweep: alpha_t for every frame --------------------------------------------------------------------
+    float nll = INFINITY;
+    if (len > 0) {
+        for (int s = lane; s < n_pos; s += 64) al[s] = s < 2 ? lp_b[s_label[s]] : ninf;
+        __threadfence_block();
+        for (int t = 1; t < len; ++t) {
+            const float* __restrict__ row = lp_b + static_cast<size_t>(t) * classes;
+            const float* prev = al + static_cast<size_t>(t - 1) * pitch;
+            float* next = al + static_cast<size_t>(t) * pitch;
+            __syncthreads();                                           // previous row (global memory) written by other lanes
+            for (int s = lane; s < n_pos; s += 64) {
+                const int lab = s_label[s];
+                const float a = prev[s];
+                const float a1 = s > 0 ? prev[s - 1] : ninf;
+                const float a2 = (s > 1 && lab != blank && lab != s_label[s - 2]) ? prev[s - 2] : ninf;
+                const float m = fmaxf(a, fmaxf(a1, a2));
+                next[s] = m == ninf ? ninf : logf(expf(a - m) + expf(a1 - m) + expf(a2 - m)) + m + row[lab];
+            }
+        }
+        __syncthreads();
+        const float* last = al + static_cast<size_t>(len - 1) * pitch;
+        const float l1 = last[n_pos - 1], l2 = n_pos > 1 ? last[n_pos - 2] : ninf;
+        const float m = fmaxf(l1, l2);
+        nll = m == ninf ? INFINITY : -(logf(expf(l1 - m) + expf(l2 - m)) + m);
+    } else if (n_lab == 0) {
+        nll = 0.f;
+    }
+    const bool finite = nll != INFINITY && !any_bad && len > 0;
+    if (lane == 0) losses[b] = any_bad ? NAN : (nll == INFINITY ? 0.f : nll / static_cast<float>(lengths[b]));
+    const float scale = finite ? 1.0f / (static_cast<float>(batch) * static_cast<float>(lengths[b])) : 0.f;
+    // ---- backward sweep: beta in LDS, one gradient row per frame --------------------------------------------------------
+    int cur = 0;
+    for (int t = frames - 1; t >= 0; --t) {
+        float* grow = g_b + static_cast<size_t>(t) * classes;
+        if (t >= len || !finite) {                                      // beyond the utterance, or no gradient at all
+            if (lane < classes) grow[lane] = 0.f;
+            for (int c = 64 + lane; c < classes; c += 64) grow[c] = 0.f;
+            continue;
+        }
+        const float* __restrict__ row = lp_b + static_cast<size_t>(t) * classes;
+        const float* arow = al + static_cast<size_t>(t) * pitch;
+        float* beta = s_beta[cur];
+        const float* bnext = s_beta[cur ^ 1];
+        for (int s = lane; s < n_pos; s += 64) {
+            const int lab = s_label[s];
+            float bt;
+            if (t == len - 1) {
+                bt = (s >= n_pos - 2) ? row[lab] : ninf;               // only the last blank and the last label can end the path
+            } else {
+                const float b0 = bnext[s];
+                const float b1 = s + 1 < n_pos ? bnext[s + 1] : ninf;
+                const float b2 = (s + 2 < n_pos && s_label[s + 2] != blank && s_label[s + 2] != lab) ? bnext[s + 2] : ninf;
+                const float m = fmaxf(b0, fmaxf(b1, b2));
+                bt = m == ninf ? ninf : logf(expf(b0 - m) + expf(b1 - m) + expf(b2 - m)) + m + row[lab];
+            }
+            beta[s] = bt;
+            s_ab[s] = arow[s] + bt;                                     // alpha and beta both contain lp[t][l'_s]: divided out below
+        }
+        wave_sync();
+        for (int c = lane; c < classes; c += 64) {
+            float m = ninf;
+            for (int s = (c == blank ? 0 : 1); s < n_pos; s += 2) if (s_label[s] == c) m = fmaxf(m, s_ab[s]);      // blanks sit at even positions
+            float sum = 0.f;
+            if (m != ninf)
+                for (int s = (c == blank ? 0 : 1); s < n_pos; s += 2) if (s_label[s] == c) sum += expf(s_ab[s] - m);
+            const float lp = row[c];
+            const float lcab = m == ninf ? ninf : logf(sum) + m;
+            grow[c] = (expf(lp) - (lcab == ninf ? 0.f : expf(lcab + nll - lp))) * scale;
+        }
+        cur ^= 1;
+        wave_sync();
+    }
+}
+
 // ---- label table + blank removal + Levenshtein distance, one workgroup per utterance -------------------------------------
 // D[i][j] over anti-diagonals d = i + j: the cells of a diagonal are independent, three diagonals rotate through LDS
 // (indexed by i).  Integer arithmetic: exact.
@@ -496,6 +607,28 @@ extern "C" int nbasr_ctc_loss(const float* log_probs, const int* lengths, const 
     hipLaunchKernelGGL(ctc_loss_kernel, dim3(batch), dim3(64), 0, as_stream(stream), log_probs, lengths, targets, target_lengths, losses,
                        frames, classes, ld_targets, blank, divide_by_length);
     return launch_status("nbasr_ctc_loss");
+}
+
+extern "C" size_t nbasr_ctc_grad_workspace_bytes(int batch, int frames, int ld_targets)
+{
+    if (batch <= 0 || frames <= 0 || ld_targets < 0) return 0;
+    return static_cast<size_t>(batch) * frames * (2 * static_cast<size_t>(ld_targets) + 1) * sizeof(float);
+}
+
+extern "C" int nbasr_ctc_loss_grad(const float* log_probs, const int* lengths, const int* targets, const int* target_lengths, void* ws,
+                                   float* losses, float* grad_logits, int batch, int frames, int classes, int ld_targets, int blank,
+                                   nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && frames >= 0 && classes > 0 && ld_targets >= 0 && blank >= 0 && blank < classes, NBASR_EINVAL,
+                  "nbasr_ctc_loss_grad: bad sizes (batch=%d frames=%d classes=%d ld_targets=%d blank=%d)", batch, frames, classes, ld_targets, blank);
+    NBASR_REQUIRE(ld_targets <= CTC_MAX_LABELS, NBASR_EINVAL, "nbasr_ctc_loss_grad: at most %d labels per utterance, got ld_targets=%d", CTC_MAX_LABELS, ld_targets);
+    if (batch == 0) return NBASR_OK;
+    NBASR_REQUIRE(lengths && target_lengths && losses && (frames == 0 || (log_probs && grad_logits && ws)) && (ld_targets == 0 || targets), NBASR_ENULL,
+                  "nbasr_ctc_loss_grad: NULL pointer");
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(batch), dim3(64), 0, as_stream(stream), log_probs, lengths, targets, target_lengths,
+                       static_cast<float*>(ws), losses, grad_logits, batch, frames, classes, ld_targets, blank);
+    return launch_status("nbasr_ctc_loss_grad");
 }
 
 extern "C" int nbasr_token_error_counts(const int* hyp, const int* hyp_len, int ld_hyp, const int* ref, const int* ref_len, int ld_ref,

@@ -133,3 +133,14 @@ def evaluate(model, batches, beam_width=12):
         model.train(was_training)
     return loss_avg, per_avg
 
+
+def ctc_loss_and_grad(log_probs, output_len, targets, targets_len, blank=0):
+    """``ctc_loss`` together with the gradient of that scalar with respect to the LOGITS (``log_probs = log_softmax(logits)``):
+    what the reference's ``loss.backward()`` hands to the model (trainer.py:220-223, without its weight-norm term).  The first
+    step of a backward pass; the model itself has none yet.  Returns ``(loss, grad_logits)``."""
+    dev = log_probs.device
+    b = log_probs.shape[0]
+    per, grad = hip.ctc_loss_grad(log_probs.contiguous(), _lengths(output_len, b, dev), targets.to(device=dev, dtype=torch.int32).contiguous(),
+                                  _lengths(targets_len, b, dev), blank)
+    return per.mean(), grad
+

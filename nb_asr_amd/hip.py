@@ -83,6 +83,8 @@ SIGNATURES = {
     'nbasr_linear_head_bct_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_ctc_postprocess': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
     'nbasr_ctc_loss': (_c_int, [_c_float_p] * 5 + [_c_int] * 6 + [_c_stream]),
+    'nbasr_ctc_grad_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_ctc_loss_grad': (_c_int, [_c_float_p] * 7 + [_c_int] * 5 + [_c_stream]),
     'nbasr_ctc_beam_workspace_bytes': (ctypes.c_size_t, [_c_int] * 4),
     'nbasr_ctc_beam_search': (_c_int, [_c_float_p] * 6 + [_c_int] * 6 + [_c_stream]),
     'nbasr_token_error_counts': (_c_int, [_c_float_p, _c_float_p, _c_int, _c_float_p, _c_float_p, _c_int, _c_float_p, _c_int, _c_int,
@@ -608,4 +610,24 @@ def ctc_loss(log_probs, lengths, targets, target_lengths, blank=0, divide_by_len
                                          losses.data_ptr(), b, t, c, targets.shape[1], blank, 1 if divide_by_length else 0,
                                          _stream(log_probs)), 'nbasr_ctc_loss')
     return losses
+
+
+def ctc_loss_grad(log_probs, lengths, targets, target_lengths, blank=0):
+    """-> (per-utterance loss / length (B), d mean(loss / length) / d logits (B, T', C)) for log_probs = log_softmax(logits)."""
+    _dev(log_probs, 'log_probs')
+    b, t, c = log_probs.shape
+    dev = log_probs.device
+    _int_tensor(lengths, 'lengths', dev, (b,))
+    _int_tensor(target_lengths, 'target_lengths', dev, (b,))
+    _int_tensor(targets, 'targets', dev)
+    if targets.dim() != 2 or targets.shape[0] != b:
+        raise HipError(f'targets must be (batch, labels), got {tuple(targets.shape)}')
+    lib = load_library()
+    losses = torch.empty(b, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(log_probs)
+    ws = torch.empty(max(lib.nbasr_ctc_grad_workspace_bytes(b, t, targets.shape[1]) // 4, 1), dtype=torch.float32, device=dev)
+    _check(lib.nbasr_ctc_loss_grad(log_probs.data_ptr(), lengths.data_ptr(), targets.data_ptr(), target_lengths.data_ptr(),
+                                   ws.data_ptr(), losses.data_ptr(), grad.data_ptr(), b, t, c, targets.shape[1], blank,
+                                   _stream(log_probs)), 'nbasr_ctc_loss_grad')
+    return losses, grad
 

@@ -202,3 +202,13 @@ def ctc_loss(log_probs, output_len, targets, targets_len, reduce=True):
     loss = loss / output_len
     return loss.mean() if reduce else loss
 
+
+def ctc_loss_grad(logits, output_len, targets, targets_len):
+    """(loss, d loss / d logits) of ``ctc_loss(log_softmax(logits), ...)`` by torch autograd on CPU: what the reference's
+    ``loss.backward()`` (trainer.py:220-223, without the weight-norm term) hands to the model."""
+    import torch
+    logits = logits.detach().clone().requires_grad_(True)
+    loss = ctc_loss(torch.log_softmax(logits, dim=2), output_len, targets, targets_len)
+    loss.backward()
+    return loss.detach(), logits.grad
+

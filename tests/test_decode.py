@@ -348,3 +348,33 @@ def test_gpu_evaluate_is_the_reference_validation_loop():
     assert loss == pytest.approx(np.mean(want_loss), rel=1e-4)
     assert per == pytest.approx(np.mean(want_per), rel=1e-6)
 
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('b,frames,classes,max_labels', [(6, 40, 49, 12), (3, 250, 49, 70), (2, 7, 5, 4), (4, 130, 49, 200), (2, 30, 80, 9)])
+def test_gpu_ctc_loss_gradient_matches_torch_autograd(b, frames, classes, max_labels):
+    """d mean(nll / len) / d logits: the first step of the backward pass (f4), against ATen's autograd through
+    log_softmax + ctc_loss -- the reference's own `loss.backward()`."""
+    from nb_asr_amd import ctc
+    gen = torch.Generator().manual_seed(frames * 3 + max_labels)
+    logits = torch.randn(b, frames, classes, generator=gen) * 1.5
+    targets = torch.randint(1, classes, (b, max_labels), generator=gen, dtype=torch.int32)
+    targets[:, 1::3] = targets[:, 0:-1:3][:, : targets[:, 1::3].shape[1]]
+    out_len = torch.tensor([frames, frames - 1, max(frames // 2, 1), frames, 3, frames][:b], dtype=torch.int32)
+    tgt_len = torch.tensor([min(max_labels, frames // 3), 0, 1, max_labels, 2, min(max_labels, 5)][:b], dtype=torch.int32)
+    want_loss, want_grad = oracle.ctc_loss_grad(logits, out_len, targets, tgt_len)
+    _, truth = oracle.ctc_loss_grad(logits.double(), out_len, targets, tgt_len)          # the same call in float64
+    dev = 'cuda:0'
+    lp = ctc.log_softmax(logits.to(dev))
+    loss, grad = ctc.ctc_loss_and_grad(lp, out_len, targets.to(dev), tgt_len)
+    assert float(loss) == pytest.approx(float(want_loss), rel=2e-5)
+    # the alpha-beta products of 250 frames carry fp32 rounding of ~1e-4 relative in either implementation: measure both
+    # against the float64 evaluation and ask for the reference's own accuracy
+    scale = float(truth.abs().max())
+    err_ref = float((want_grad.double() - truth).abs().max())
+    err_hip = float((grad.cpu().double() - truth).abs().max())
+    assert err_hip <= max(2.0 * err_ref, 2e-6 * scale), (err_hip, err_ref, scale)
+    for i in range(b):                                          # nothing flows beyond an utterance's own frames
+        assert torch.all(grad[i, int(out_len[i]):] == 0)
+    if b > 3 and max_labels > frames:
+        assert torch.all(grad[3] == 0)                          # infeasible utterance: zero_infinity zeroes its gradient too
+
