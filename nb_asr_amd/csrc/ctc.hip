@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void ctc_postprocess_kernel(
         s_scan[threadIdx.x] = keep;
         __syncthreads();
         for (int off = 1; off < 256; off <<= 1) {
-            const int add = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+            const int add = static_cast<int>(threadIdx.x) >= off ? s_scan[threadIdx.x - off] : 0;
             __syncthreads();
             s_scan[threadIdx.x] += add;
             __syncthreads();

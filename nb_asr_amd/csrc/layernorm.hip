@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void channel_stats_bound_kernel(const float* _
 __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ bound, unsigned char* __restrict__ image,
-                                                              int channels, int frames, int ld)
+                                                              int channels, int /* frames: rstd is 0 beyond them */, int ld)
 {
     typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
     // 16 frame quads x 16 channel octets per pass; a thread turns 8 channels x 4 frames into 4 + 4 image rows of 16 bytes
