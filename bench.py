@@ -15,6 +15,13 @@ back-to-back steps issued through model.forward_async (the latency-bound LSTM ta
 i+1 on a second HIP stream; every step is a complete forward, all K complete inside the timed region);
 `value_sequential` / `p50_forward_ms` are the same K steps as plain model(x) calls (no overlap).
 
+`value` is FP32-EMULATED arithmetic on the 16-bit matrix cores for the GEMM-shaped 82 % of the FLOPs (config.dense_scheme /
+config.linear_scheme say how: two fp16 terms per fp32 operand, three MFMAs per product, fp32 accumulate -- error vs fp64 at
+the level of an exact fp32 evaluation, tests/); `value_strict_f32` / `ms_per_step_strict_f32` are the same K steps in the
+same process with every GEMM on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: NBASR_DENSE_MODE=f32 NBASR_LINEAR_MODE=f32).
+With N > 1 `value` is the weak-scaling number (64 utterances per GPU) and `value_strong` the strong-scaling one (the SAME 64
+utterances split over the N ranks): north_star's ">= 6x on (B=64, T=1000)" reads as the latter.
+
 One JSON line on stdout (rank 0).  Besides the driver's contract fields it carries
   roofline      fused grouped Conv1d kernel (the graded, HBM-bound kernel of SURVEY.md 8(d)): algorithmic bytes of
                 its 54 launches / their HIP-event time, vs 8 TB/s
@@ -63,6 +70,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='time plain back-to-back model(x) calls only')
+    ap.add_argument('--no-strict', action='store_true', help='skip the exact-fp32-MFMA leg (value_strict_f32)')
+    ap.add_argument('--no-strong', action='store_true', help='with N > 1: skip the strong-scaling leg (value_strong)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -95,9 +104,11 @@ def main():
     model = model.to(device).eval()
     x = keyed_input(args.batch, args.frames, seed=rank).to(device)           # resident in HBM before timing
 
+    cur = {'x': x}
+
     def step():
         with torch.no_grad():
-            return runner.forward(model, x)                                   # forward + all-gather of logits (N > 1)
+            return runner.forward(model, cur['x'])                            # forward + all-gather of logits (N > 1)
 
     def timed(run_steps):
         runner.barrier()
@@ -119,7 +130,7 @@ def main():
         # encoder of step i+1 (model.forward_async); every step is a complete forward and all K finish before the
         # closing synchronize
         with torch.no_grad():
-            handles = [model.forward_async(x) for _ in range(args.steps)]
+            handles = [model.forward_async(cur['x']) for _ in range(args.steps)]
             out = None
             for h in handles:
                 out = runner.gather_logits(h.result())
@@ -149,6 +160,54 @@ def main():
         lat.append(e0.elapsed_time(e1))
     p50 = statistics.median(lat)
 
+    plan = model._plans.values()[-1]
+    dense_schemes = dict(plan.dense_schemes)
+
+    # the same K steps with every GEMM on the exact-fp32 MFMA (no operand splitting): the strict-fp32 number
+    strict = None
+    if not args.no_strict and plan.dense_mode != 'f32':
+        saved = {k: os.environ.get(k) for k in ('NBASR_DENSE_MODE', 'NBASR_LINEAR_MODE')}
+        os.environ['NBASR_DENSE_MODE'] = os.environ['NBASR_LINEAR_MODE'] = 'f32'
+        try:
+            model._plans.clear()                          # the modes are read when a plan is built
+            for _ in range(2):
+                step()
+            with torch.no_grad():
+                model.forward_async(x).result()
+            elapsed_strict, out_s = timed(sequential if args.no_pipeline else pipelined)
+            worst = float(((out_s.double() - out.double()).abs() / (1e-5 + 1e-4 * out.double().abs())).max())
+            strict = {'value': args.batch * world * args.steps / elapsed_strict, 'ms_per_step': 1e3 * elapsed_strict / args.steps,
+                      'worst_err_over_tol_vs_default_path': worst}
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            model._plans.clear()
+            for _ in range(2):
+                step()                                    # rebuild the default plan for the legs below
+            with torch.no_grad():
+                model.forward_async(x).result()
+        plan = model._plans.values()[-1]
+
+    # strong scaling (N > 1): the SAME global batch of --batch utterances split over the ranks
+    strong = None
+    if world > 1 and args.scaling == 'weak' and not args.no_strong and args.batch % world == 0:
+        from nb_asr_amd.parallel import shard_bounds
+        lo, hi = shard_bounds(args.batch, world, rank)
+        cur['x'] = keyed_input(args.batch, args.frames, seed=0).to(device)[lo:hi].contiguous()
+        for _ in range(3):
+            step()
+        with torch.no_grad():
+            model.forward_async(cur['x']).result()
+        elapsed_strong, out_g = timed(sequential if args.no_pipeline else pipelined)
+        assert out_g.shape[0] == args.batch
+        strong = {'value': args.batch * args.steps / elapsed_strong, 'ms_per_step': 1e3 * elapsed_strong / args.steps,
+                  'per_gpu_batch': hi - lo, 'global_batch': args.batch}
+        cur['x'] = x
+
+    from nb_asr_amd import hip as nb_hip
     result = {
         'metric': 'utterances_per_sec',
         'value': args.batch * world * args.steps / elapsed,
@@ -164,12 +223,27 @@ def main():
         'scaling': args.scaling,
         'vs_baseline': None,
         'dtype': 'f32',
+        'value_strict_f32': strict['value'] if strict else None,
+        'ms_per_step_strict_f32': strict['ms_per_step'] if strict else None,
+        'strict_f32_vs_default_worst_err_over_tol': strict['worst_err_over_tol_vs_default_path'] if strict else None,
+        'value_strong': strong['value'] if strong else (args.batch * world * args.steps / elapsed if world == 1 or args.scaling == 'strong' else None),
+        'ms_per_step_strong': strong['ms_per_step'] if strong else (1e3 * elapsed / args.steps if world == 1 or args.scaling == 'strong' else None),
+        'strong': strong,
+        'build_id': nb_hip.build_id(),
         'data': 'synthetic N(0,1) filterbanks (B,80,T) from a keyed generator; random-init He-uniform weights (keyed)',
         'config': {'workload': ('BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True fp32, HIP conv + HIP LSTM'
                                 if args.arch == 'conv5' else f'arch_vec {arch} (BASELINE configs[3] architecture) use_rnn=True, in fp32'),
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames, 'features': FEATURES,
                    'parallelism': f'batch-sharded x{world}, one RCCL all-gather of logits' if world > 1 else 'single GPU',
-                   'pipelined': not args.no_pipeline},
+                   'pipelined': not args.no_pipeline,
+                   'arithmetic': 'fp32 storage and accumulation; `value`: GEMM operands split into 16-bit terms on the 16-bit matrix '
+                                 'cores (fp32-emulated, see dense_scheme / linear_scheme); `value_strict_f32`: exact-fp32 MFMA',
+                   'dense_scheme': {f'conv_{k}': v for k, v in sorted(dense_schemes.items())},
+                   'dense_scheme_legend': 'f16x2 = 2 fp16 terms per operand, 3 v_mfma_f32_16x16x32_f16 per fp32 product; '
+                                          'f16x2-image = the same with the LayerNorm writing the pre-split operand; '
+                                          'bf16x3 = 3 bf16 terms, 6 MFMAs; f32 = v_mfma_f32_32x32x2_f32',
+                   'linear_scheme': plan.linear_mode, 'ln_mode': plan.ln_mode,
+                   'nbasr_env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('NBASR_')}},
     }
 
     if rank == 0 and not args.no_roofline:
@@ -189,18 +263,36 @@ def main():
         print(json.dumps(result), flush=True)
 
 
+def kernel_source_hash():
+    """Hash of the graded kernel's sources (grouped_conv.hip, grouped_cell.hip, common.h): ties a PMC summary to a build."""
+    import hashlib
+    here = os.path.dirname(os.path.abspath(__file__))
+    h = hashlib.sha256()
+    for name in ('grouped_conv.hip', 'grouped_cell.hip', 'common.h'):
+        with open(os.path.join(here, 'nb_asr_amd', 'csrc', name), 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic_per_launch(kernel_prefix):
     """HBM bytes per launch of a kernel family from the newest committed PMC summary (profiles/rNN_pmc_hbm_traffic.csv:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied by tools/summarize_pmc.py).
     Launch-weighted mean over the family's template instances; None when no summary is committed."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r*_pmc_hbm_traffic.csv')))
+    here = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(here, 'profiles', 'r*_pmc_hbm_traffic.csv')))
     if not files:
         return None, None
+    # the counters describe ONE build of the kernel: the summary's first line records the hash of the kernel's sources
+    # (tools/summarize_pmc.py); a summary taken on other sources is stale and must not sit next to a fresh `achieved`
+    with open(files[-1]) as f:
+        first = f.readline().strip()
+    if not first.startswith('# grouped_conv_src=') or first.split('=', 1)[1] != kernel_source_hash():
+        return None, f'{os.path.basename(files[-1])} is stale for this build (kernel sources changed since the PMC capture)'
     tot = n = 0.0
     with open(files[-1], newline='') as f:
-        for row in csv.DictReader(f):
+        for row in csv.DictReader(line for line in f if not line.startswith('#')):
             if row['kernel'].startswith(kernel_prefix):
                 tot += float(row['hbm_total_MB']) * 1e6 * int(row['launches'])
                 n += int(row['launches'])
@@ -209,7 +301,7 @@ def pmc_traffic_per_launch(kernel_prefix):
 
 def roofline_leg(model, x, args):
     """Re-run `steps` forwards with HIP events around every launch of the graded kernels (same stream)."""
-    plan = next(iter(model._plans.values()))
+    plan = model._plans.values()[-1]
     plan.timer = []
     with torch.no_grad():
         for _ in range(args.steps):
@@ -245,8 +337,8 @@ def roofline_leg(model, x, args):
         e['n'] += n
     if launches:
         traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_kernel')
-        if args.batch != BATCH or args.frames != FRAMES:
-            traffic, traffic_src = None, None          # the committed counters are for the default workload only
+        if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or any(k.startswith('NBASR_') for k in os.environ):
+            traffic, traffic_src = None, None          # the committed counters are for the default workload and modes only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
         out['roofline'] = {
             'kernel': 'grouped_cell_kernel<CG> / grouped_conv_kernel<CG,K,D,..> (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
@@ -304,20 +396,29 @@ def cpu_baseline_leg(model, args):
     """The CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample of the same workload."""
     from oracle import asr_oracle as oracle
     from nb_asr_amd.weights import keyed_input
-    sample_b = min(8, args.batch)
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    xs = keyed_input(sample_b, args.frames, seed=0)
+    warm_b = min(8, args.batch)
     with torch.no_grad():
-        oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)                  # warm-up
-        times = []
-        for _ in range(3):
+        xs = keyed_input(warm_b, args.frames, seed=0)
+        oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)                  # warm-up (thread pool, allocator)
+        t0 = time.perf_counter()
+        oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)
+        small = time.perf_counter() - t0
+        # the metric's own batch (ONE forward: 10-30 s of CPU work on the GPU box's host) unless that would take minutes
+        full = small * args.batch / warm_b < 60.0
+        sample_b = args.batch if full else warm_b
+        if full and sample_b != warm_b:
+            xs = keyed_input(sample_b, args.frames, seed=0)
             t0 = time.perf_counter()
             oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)
-            times.append(time.perf_counter() - t0)
-    med = statistics.median(times)
-    return {'value': sample_b / med, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'B={sample_b}, T={args.frames}, median of 3 forwards of oracle/asr_oracle.py (torch CPU ops), '
-                      f'os.cpu_count()={os.cpu_count()}', 'seconds_per_forward': med}
+            secs = time.perf_counter() - t0
+        else:
+            secs = small
+    return {'value': sample_b / secs, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'batch': sample_b, 'frames': args.frames, 'forwards_timed': 1,
+            'sample': f'one forward of B={sample_b}, T={args.frames} through oracle/asr_oracle.py (torch CPU ops, the reference\'s op '
+                      f'sequence) after a B={warm_b} warm-up forward; os.cpu_count()={os.cpu_count()}',
+            'seconds_per_forward': secs, 'value_small_batch': warm_b / small, 'small_batch': warm_b}
 
 
 if __name__ == '__main__':

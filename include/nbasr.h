@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NBASR_ABI_VERSION 1
+#define NBASR_ABI_VERSION 2
 
 #define NBASR_OK 0
 #define NBASR_EINVAL (-1)   /* bad size / unsupported shape */
@@ -39,6 +39,11 @@ typedef void* nbasr_stream_t;
 
 /* ABI version of the loaded library (== NBASR_ABI_VERSION it was built with). */
 int nbasr_version(void);
+
+/* Identifies the sources this library was compiled from: the first 16 hex digits of a SHA-256 over csrc and include files and the
+ * compiler flags (nb_asr_amd/build.py:source_hash computes the same value from a checkout), "unknown" for a build that
+ * bypassed build.py.  Static storage; never NULL. */
+const char* nbasr_build_id(void);
 
 /* Message for the most recent failing call on this thread ("" if none). */
 const char* nbasr_last_error(void);

@@ -9,7 +9,13 @@ two consecutive pickles in one file -- a header dict, then a list of rows.
     rows   = [[model_hash, latency_seconds, ...], ...]        # hash from get_model_hash(arch, ops=header ops)
 
 ``from_folder`` (``dataset.py:477-555``) picks the file up by its name ``nb-asr-bench-{device}.pickle``.
+
+The header holds ONLY the keys the reference's files have: its loader pops ``device`` and then requires the remaining
+header of every file it is given to be equal (``dataset.py:37-42``), so run metadata (batch, frames, dtype, number of
+GPUs, build id, timing protocol) goes to a side-car ``nb-asr-bench-{device}.meta.json`` that ``from_folder``'s file-name
+patterns ignore -- a 1-GPU and an 8-GPU sweep, or this file and an upstream device file, load together.
 """
+import json
 import pickle
 import re
 import statistics
@@ -21,7 +27,7 @@ DATASET_VERSION = 1
 _DEVICE_RE = re.compile(r'[a-zA-Z0-9-]+')
 
 
-def make_header(device, columns=('model_hash', 'latency'), ops=None, nodes=None, extra=None):
+def make_header(device, columns=('model_hash', 'latency'), ops=None, nodes=None):
     if not _DEVICE_RE.fullmatch(device):
         raise ValueError(f'device name {device!r} must match [a-zA-Z0-9-]+ (it becomes part of the file name)')
     columns = list(columns)
@@ -32,8 +38,6 @@ def make_header(device, columns=('model_hash', 'latency'), ops=None, nodes=None,
     header = {'dataset_type': 'benchmarking', 'device': device, 'version': DATASET_VERSION,
               'search_space': {'shape': search_space.get_search_space(ops, nodes), 'ops': ops, 'nodes': nodes},
               'columns': columns}
-    if extra:
-        header.update(extra)
     return header
 
 
@@ -41,16 +45,29 @@ def file_name(device):
     return f'nb-asr-bench-{device}.pickle'
 
 
-def write_benchmarking_dataset(path, device, rows, columns=('model_hash', 'latency'), extra_header=None):
-    """rows: iterable of [model_hash, latency, ...] (one per unique architecture)."""
-    header = make_header(device, columns, extra=extra_header)
+def meta_name(device):
+    return f'nb-asr-bench-{device}.meta.json'
+
+
+def write_benchmarking_dataset(path, device, rows, columns=('model_hash', 'latency'), meta=None):
+    """rows: iterable of [model_hash, latency, ...] (one per unique architecture).  ``meta`` (a dict of run metadata) is
+    written next to the pickle as ``nb-asr-bench-{device}.meta.json``, never into the header."""
+    header = make_header(device, columns)
     rows = [list(r) for r in rows]
+    seen = set()
     for r in rows:
         if len(r) != len(header['columns']) or not isinstance(r[0], str):
             raise ValueError(f'row {r!r} does not match columns {header["columns"]}')
+        if r[0] in seen:
+            raise ValueError(f'model hash {r[0]} appears twice: one row per unique architecture')
+        seen.add(r[0])
     with open(path, 'wb') as f:
         pickle.dump(header, f)
         pickle.dump(rows, f)
+    if meta is not None:
+        import pathlib
+        side = pathlib.Path(path).with_name(meta_name(device))
+        side.write_text(json.dumps(dict(meta, device=device, rows=len(rows)), indent=1, sort_keys=True) + '\n')
     return header
 
 
@@ -75,17 +92,54 @@ def sweep_work_list(limit=None, rank=0, world_size=1):
     return items[rank::world_size]
 
 
-def build_for_timing(arch_vec, device, use_rnn=True):
-    """Model on `device` with cheap constant weights (latency does not depend on weight values; skips the ~1 s
-    Xavier initialisation of 26 M parameters that dominates a per-architecture sweep)."""
-    import torch
-    from .model import ASRModel
-    with torch.device(device):
-        model = ASRModel(search_space.arch_vec_to_names(arch_vec), use_rnn=use_rnn, dropout_rate=0.0)
-    with torch.no_grad():
-        for p in model.parameters():
-            p.fill_(0.01)
-    return model.eval()
+class WeightBank:
+    """ONE set of device parameters that every architecture of a sweep borrows from.
+
+    Building 8 242 models one after the other spends its time allocating and initialising 26 M parameters and re-packing
+    the same four dense convolutions and the LSTM for the matrix cores, not measuring.  Latency does not depend on weight
+    values, so the bank holds, per state_dict key and shape, one constant-filled ``nn.Parameter``; ``build`` constructs the
+    module tree on the ``meta`` device (no allocation, no initialisation) and plugs the bank's parameters in.  All models
+    share one ``PlanPool``: workspaces are allocated once, and because the dense / LSTM / head parameters are the SAME
+    tensor objects for every architecture, their packed copies are built once for the whole sweep (a `linear` node op's
+    weight is shared per (position, shape), too)."""
+
+    def __init__(self, device, use_rnn=True, fill=0.01):
+        import torch
+        from .executor import PlanPool
+        self.device, self.use_rnn, self.fill = torch.device(device), use_rnn, fill
+        self._params = {}
+        self.pool = PlanPool()
+
+    def _param(self, key, meta_param):
+        import torch
+        k = (key, tuple(meta_param.shape))
+        p = self._params.get(k)
+        if p is None:
+            value = 1.0 if (key.endswith('weight') and meta_param.dim() == 1) else self.fill       # LayerNorm gamma = 1
+            p = self._params[k] = torch.nn.Parameter(torch.full(tuple(meta_param.shape), value, device=self.device,
+                                                                dtype=torch.float32), requires_grad=False)
+        return p
+
+    def build(self, arch_vec):
+        import torch
+        from .model import ASRModel
+        with torch.device('meta'):
+            model = ASRModel(search_space.arch_vec_to_names(arch_vec), use_rnn=self.use_rnn, dropout_rate=0.0)
+        for mod_name, mod in model.named_modules():
+            for name in list(mod._parameters):
+                if mod._parameters[name] is not None:
+                    mod._parameters[name] = self._param(f'{mod_name}.{name}' if mod_name else name, mod._parameters[name])
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.LSTM):
+                mod._flat_weights = [getattr(mod, n) for n in mod._flat_weights_names]
+        model._plans = self.pool
+        return model.eval()
+
+
+def build_for_timing(arch_vec, device, use_rnn=True, bank=None):
+    """Model on `device` with cheap constant weights (latency does not depend on weight values).  With a ``WeightBank``
+    the parameters, workspaces and packed weights are shared with every other model built from it."""
+    return (bank or WeightBank(device, use_rnn)).build(arch_vec)
 
 
 def measure_latency(model, x, warmup=2, iters=5):
@@ -107,14 +161,32 @@ def measure_latency(model, x, warmup=2, iters=5):
 
 
 def latency_sweep(work, device, batch=32, frames=1000, warmup=2, iters=5, progress=None):
-    """[[hash, latency_s], ...] for the (hash, arch) pairs in `work`, one model at a time on `device`."""
+    """[[hash, latency_s], ...] for the (hash, arch) pairs in `work`, one model at a time on `device` (BASELINE config 5:
+    one architecture per GPU at a time; all models of the sweep borrow their parameters from one WeightBank)."""
     import torch
     x = torch.randn(batch, 80, frames, device=device)
+    bank = WeightBank(device)
     rows, t0 = [], time.time()
     for i, (h, arch) in enumerate(work):
-        model = build_for_timing(arch, device)
+        model = bank.build(arch)
         rows.append([h, measure_latency(model, x, warmup, iters)])
         del model
         if progress and (i + 1) % progress == 0:
             print(f'  {i + 1}/{len(work)} architectures, {time.time() - t0:.0f} s', flush=True)
+    bank.pool.clear()
     return rows
+
+
+def summarize(rows, by_hash=None):
+    """min / median / max latency (seconds) and, when ``by_hash`` maps hash -> arch_vec, the median per main-op family
+    (an architecture counts towards every op it uses in one of its three nodes)."""
+    lat = sorted(r[1] for r in rows)
+    out = {'architectures': len(rows), 'latency_min_s': lat[0], 'latency_median_s': statistics.median(lat), 'latency_max_s': lat[-1]}
+    if by_hash:
+        fam = {}
+        for h, latency, *_ in rows:
+            for op in {search_space.all_ops[node[0]] for node in by_hash[h]}:
+                fam.setdefault(op, []).append(latency)
+        out['median_s_by_op_used'] = {op: statistics.median(v) for op, v in sorted(fam.items())}
+        out['count_by_op_used'] = {op: len(v) for op, v in sorted(fam.items())}
+    return out

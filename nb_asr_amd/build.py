@@ -5,6 +5,7 @@ without a GPU present.  Objects go to ``nb_asr_amd/csrc/build/`` and the library
 ``nb_asr_amd/lib/libnbasr_hip.so`` (both git-ignored; the .so travels with gpurun snapshots).
 """
 import concurrent.futures
+import hashlib
 import os
 import pathlib
 import shutil
@@ -30,6 +31,18 @@ def _hipcc():
     return exe
 
 
+def source_hash():
+    """Build id: SHA-256 over every source the library is compiled from (names and contents, sorted), first 16 hex digits.
+    Compiled into the library (``nbasr_build_id()``), so a loaded .so can be tied to the sources of a checkout --
+    ``tests/test_abi.py`` asserts they match, and ``bench.py`` prints the id next to its numbers."""
+    h = hashlib.sha256()
+    files = sorted(CSRC_DIR.glob('*.hip')) + sorted(CSRC_DIR.glob('*.cpp')) + sorted(CSRC_DIR.glob('*.h')) + sorted(INCLUDE_DIR.glob('*.h'))
+    for f in files:
+        h.update(f.name.encode() + b'\0' + f.read_bytes() + b'\0')
+    h.update(' '.join(CXXFLAGS).encode())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not target.exists():
         return True
@@ -37,10 +50,15 @@ def _newer(target, deps):
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def _compile(src, obj, headers, verbose):
-    if not _newer(obj, [src] + headers):
-        return False
-    cmd = [_hipcc(), *CXXFLAGS, f'-I{INCLUDE_DIR}', f'-I{CSRC_DIR}', '-x', 'hip', '-c', str(src), '-o', str(obj)]
+def _compile(src, obj, headers, verbose, build_id=None):
+    stamp = obj.with_suffix('.id')
+    if build_id is None:
+        if not _newer(obj, [src] + headers):
+            return False
+    elif obj.exists() and stamp.exists() and stamp.read_text() == build_id:
+        return False                                  # api.cpp carries the build id: rebuilt whenever ANY source changed
+    extra = [f'-DNBASR_BUILD_ID="{build_id}"'] if build_id is not None else []
+    cmd = [_hipcc(), *CXXFLAGS, *extra, f'-I{INCLUDE_DIR}', f'-I{CSRC_DIR}', '-x', 'hip', '-c', str(src), '-o', str(obj)]
     if verbose:
         print(' '.join(cmd), flush=True)
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -48,6 +66,8 @@ def _compile(src, obj, headers, verbose):
         raise RuntimeError(f'hipcc failed on {src.name}:\n{res.stdout}\n{res.stderr}')
     if verbose and res.stderr.strip():
         print(res.stderr, file=sys.stderr)
+    if build_id is not None:
+        stamp.write_text(build_id)
     return True
 
 
@@ -60,8 +80,9 @@ def build_library(force=False, verbose=False, jobs=4):
     if force:
         for _, obj in pairs:
             obj.unlink(missing_ok=True)
+    build_id = source_hash()
     with concurrent.futures.ThreadPoolExecutor(max_workers=jobs) as pool:
-        rebuilt = list(pool.map(lambda p: _compile(p[0], p[1], headers, verbose), pairs))
+        rebuilt = list(pool.map(lambda p: _compile(p[0], p[1], headers, verbose, build_id if p[0].name == 'api.cpp' else None), pairs))
     objs = [obj for _, obj in pairs]
     if any(rebuilt) or _newer(LIB_PATH, objs):
         cmd = [_hipcc(), '-shared', '-fPIC', f'--offload-arch={ARCH}', '-o', str(LIB_PATH)] + [str(o) for o in objs]

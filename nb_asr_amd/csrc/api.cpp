@@ -20,6 +20,11 @@ void clear_error() { g_error[0] = '\0'; }
 
 extern "C" int nbasr_version(void) { return NBASR_ABI_VERSION; }
 
+#ifndef NBASR_BUILD_ID
+#define NBASR_BUILD_ID "unknown"
+#endif
+extern "C" const char* nbasr_build_id(void) { return NBASR_BUILD_ID; }
+
 extern "C" const char* nbasr_last_error(void) { return nbasr::g_error; }
 
 extern "C" int nbasr_pad_amounts(int kernel, int dilation, int stride, int* left, int* right) {

@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
         for (int r = 0; r < 4; ++r) {
             o[r] = (o[r] - mu[r]) * rs[r] * g + bt;
             if (t0 + r >= frames) o[r] = 0.f;
-            if (ABSMAX) amax = fmaxf(amax, fabsf(o[r]));
+            if (ABSMAX) amax = fmaxf(amax, finite_abs(o[r]));
         }
         *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -258,14 +258,14 @@ __global__ __launch_bounds__(256) void channel_stats_bound_kernel(const float* _
             srow[t] = live ? s_mu[threadIdx.x] : 0.f;
             srow[ld + t] = live ? s_rstd[threadIdx.x] : 0.f;
             // max_c |x_c - mean| = max(hi - mean, mean - lo): no second pass over the tile
-            if (live) dev = fmaxf(s_hi[0][threadIdx.x] - s_mu[threadIdx.x], s_mu[threadIdx.x] - s_lo[0][threadIdx.x]) * s_rstd[threadIdx.x];
+            if (live) dev = finite_abs(fmaxf(s_hi[0][threadIdx.x] - s_mu[threadIdx.x], s_mu[threadIdx.x] - s_lo[0][threadIdx.x]) * s_rstd[threadIdx.x]);
         }
     }
     if (threadIdx.x < 64) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) dev = fmaxf(dev, __shfl_xor(dev, d));
         // a little headroom for the rounding of the bound itself and of the normalisation it bounds
-        if (threadIdx.x == 0) atomicMax(bound + b, __float_as_uint((dev * gm + bm) * 1.0001f));
+        if (threadIdx.x == 0) atomicMax(bound + b, __float_as_uint(finite_abs((dev * gm + bm) * 1.0001f)));
     }
 }
 
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     float m = 0.f;
     for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
         const float4 v = xb[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        m = fmaxf(fmaxf(m, fmaxf(finite_abs(v.x), finite_abs(v.y))), fmaxf(finite_abs(v.z), finite_abs(v.w)));
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));

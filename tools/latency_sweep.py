@@ -27,6 +27,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--frames', type=int, default=1000)
     ap.add_argument('--iters', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--summary', default=None, help='also write the min / median / max + per-op-family summary here (JSON)')
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
     device = torch.device('cuda', local)
@@ -34,8 +36,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group('nccl', device_id=device)
-    work = bench_dataset.sweep_work_list(a.limit, rank, world)
-    rows = bench_dataset.latency_sweep(work, device, a.batch, a.frames, iters=a.iters, progress=50 if rank == 0 else None)
+    import time
+    t0 = time.time()
+    everything = bench_dataset.sweep_work_list(a.limit)
+    work = everything[rank::world]
+    rows = bench_dataset.latency_sweep(work, device, a.batch, a.frames, warmup=a.warmup, iters=a.iters, progress=500 if rank == 0 else None)
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
@@ -45,11 +50,18 @@ def main():
         out = pathlib.Path(a.out)
         out.mkdir(parents=True, exist_ok=True)
         path = out / bench_dataset.file_name(a.device_name)
-        bench_dataset.write_benchmarking_dataset(path, a.device_name, sorted(rows), extra_header={
-            'batch_size': a.batch, 'frames': a.frames, 'dtype': 'fp32', 'n_gpus': world})
-        lat = sorted(r[1] for r in rows)
-        print(f'wrote {path}: {len(rows)} architectures, latency min {lat[0] * 1e3:.2f} ms  median {lat[len(lat) // 2] * 1e3:.2f} ms  '
-              f'max {lat[-1] * 1e3:.2f} ms')
+        from nb_asr_amd import hip
+        meta = {'batch_size': a.batch, 'frames': a.frames, 'features': 80, 'dtype': 'fp32', 'n_gpus': world, 'use_rnn': True,
+                'protocol': f'{a.warmup} warm-up + median of {a.iters} forwards, HIP events on the launch stream, one architecture '
+                            f'per GPU at a time', 'build_id': hip.build_id(), 'sweep_seconds': time.time() - t0,
+                'gpu': torch.cuda.get_device_name(device)}
+        bench_dataset.write_benchmarking_dataset(path, a.device_name, sorted(rows), meta=meta)
+        summary = dict(bench_dataset.summarize(rows, dict(everything)), **meta, file=path.name)
+        if a.summary:
+            import json
+            pathlib.Path(a.summary).write_text(json.dumps(summary, indent=1, sort_keys=True) + '\n')
+        print(f'wrote {path}: {len(rows)} architectures in {meta["sweep_seconds"]:.0f} s, latency min {summary["latency_min_s"] * 1e3:.2f} ms  '
+              f'median {summary["latency_median_s"] * 1e3:.2f} ms  max {summary["latency_max_s"] * 1e3:.2f} ms')
 
 
 if __name__ == '__main__':

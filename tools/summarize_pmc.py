@@ -29,6 +29,11 @@ def per_kernel(path, counter):
 def main():
     fetch = per_kernel(sys.argv[1], 'FETCH_SIZE')
     write = per_kernel(sys.argv[2], 'WRITE_SIZE')
+    # first line: hash of the graded kernel's sources, so bench.py can tell a stale summary from a current one
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from bench import kernel_source_hash
+    print(f'# grouped_conv_src={kernel_source_hash()}')
     out = csv.writer(sys.stdout, lineterminator='\n')
     out.writerow(['kernel', 'launches', 'FETCH_SIZE_KiB_mean', 'WRITE_SIZE_KiB_mean', 'hbm_read_MB_corrected_x2', 'hbm_write_MB',
                   'hbm_total_MB'])
