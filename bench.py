@@ -46,10 +46,10 @@ FP32_MFMA_PEAK_TFLOPS = 157.3    # ibid.: v_mfma_f32_32x32x2_f32 dense peak
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # ibid.: bf16 MFMA dense peak
 
 
-def grouped_conv_bytes(batch, channels, frames, kernel, n_skips, groups=100):
+def grouped_conv_bytes(batch, channels, frames, kernel, n_skips, groups=100, elem=4):
     """Algorithmic HBM bytes of one fused grouped-conv launch: read x, write y, read each
-    fused skip input, read weights + bias once."""
-    return 4.0 * (batch * channels * frames * (2 + n_skips) + channels * (channels // groups) * kernel + channels)
+    fused skip input (`elem` bytes per activation: 4 fp32, 2 bf16), read the fp32 weights + bias once."""
+    return float(elem) * batch * channels * frames * (2 + n_skips) + 4.0 * (channels * (channels // groups) * kernel + channels)
 
 
 def dense_conv_flops(batch, c_in, c_out, kernel, frames_out):
@@ -67,6 +67,9 @@ def main():
                     help='weak: --batch utterances per GPU (default); strong: --batch utterances in total, split over the ranks')
     ap.add_argument('--arch', choices=sorted(ARCHS), default='conv5',
                     help="conv5: the benchmark architecture (default); dense-skip: BASELINE configs[3]'s architecture, run in fp32")
+    ap.add_argument('--dtype', choices=('f32', 'bf16'), default='f32',
+                    help='f32 (default); bf16: BASELINE configs[3] -- activations and GEMM operands stored as bfloat16 '
+                         '(model.to(torch.bfloat16)), fp32 accumulation')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-pipeline', action='store_true', help='time plain back-to-back model(x) calls only')
@@ -103,6 +106,9 @@ def main():
     keyed_fill_(model, seed=1235, mode='lively')
     model = model.to(device).eval()
     x = keyed_input(args.batch, args.frames, seed=rank).to(device)           # resident in HBM before timing
+    if args.dtype == 'bf16':
+        model, x = model.to(torch.bfloat16), x.to(torch.bfloat16)
+        args.no_strict = True
 
     cur = {'x': x}
 
@@ -142,7 +148,7 @@ def main():
         for _ in range(2):
             model.forward_async(x).result()
     elapsed_seq, out = timed(sequential)
-    assert out.shape == (args.batch * world, (((args.frames + 1) // 2) + 1) // 2, 49) and bool(torch.isfinite(out).all())
+    assert out.shape == (args.batch * world, (((args.frames + 1) // 2) + 1) // 2, 49) and bool(torch.isfinite(out.float()).all())
     if args.no_pipeline:
         elapsed = elapsed_seq
     else:
@@ -196,7 +202,7 @@ def main():
     if world > 1 and args.scaling == 'weak' and not args.no_strong and args.batch % world == 0:
         from nb_asr_amd.parallel import shard_bounds
         lo, hi = shard_bounds(args.batch, world, rank)
-        cur['x'] = keyed_input(args.batch, args.frames, seed=0).to(device)[lo:hi].contiguous()
+        cur['x'] = keyed_input(args.batch, args.frames, seed=0).to(device)[lo:hi].contiguous().to(x.dtype)
         for _ in range(3):
             step()
         with torch.no_grad():
@@ -222,7 +228,7 @@ def main():
         'higher_is_better': True,
         'scaling': args.scaling,
         'vs_baseline': None,
-        'dtype': 'f32',
+        'dtype': args.dtype,
         'value_strict_f32': strict['value'] if strict else None,
         'ms_per_step_strict_f32': strict['ms_per_step'] if strict else None,
         'strict_f32_vs_default_worst_err_over_tol': strict['worst_err_over_tol_vs_default_path'] if strict else None,
@@ -231,13 +237,17 @@ def main():
         'strong': strong,
         'build_id': nb_hip.build_id(),
         'data': 'synthetic N(0,1) filterbanks (B,80,T) from a keyed generator; random-init He-uniform weights (keyed)',
-        'config': {'workload': ('BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True fp32, HIP conv + HIP LSTM'
-                                if args.arch == 'conv5' else f'arch_vec {arch} (BASELINE configs[3] architecture) use_rnn=True, in fp32'),
+        'config': {'workload': ('BASELINE configs[1]/[2]: arch_vec [[1,0],[1,0,0],[1,0,0,0]] use_rnn=True, HIP conv + HIP LSTM'
+                                if args.arch == 'conv5' else f'arch_vec {arch} (BASELINE configs[3] architecture) use_rnn=True')
+                               + (' -- bf16 storage (activations, GEMM operands), fp32 accumulation' if args.dtype == 'bf16' else ' -- fp32'),
                    'per_gpu_batch': args.batch, 'global_batch': args.batch * world, 'frames': args.frames, 'features': FEATURES,
                    'parallelism': f'batch-sharded x{world}, one RCCL all-gather of logits' if world > 1 else 'single GPU',
                    'pipelined': not args.no_pipeline,
-                   'arithmetic': 'fp32 storage and accumulation; `value`: GEMM operands split into 16-bit terms on the 16-bit matrix '
-                                 'cores (fp32-emulated, see dense_scheme / linear_scheme); `value_strict_f32`: exact-fp32 MFMA',
+                   'arithmetic': ('fp32 storage and accumulation; `value`: GEMM operands split into 16-bit terms on the 16-bit matrix '
+                                  'cores (fp32-emulated, see dense_scheme / linear_scheme); `value_strict_f32`: exact-fp32 MFMA')
+                                 if args.dtype == 'f32' else
+                                 ('bf16 storage of activations and dense-conv operands (one bf16 MFMA per product), fp32 accumulation, '
+                                  'LayerNorm statistics, LSTM and head in fp32; logits returned as bf16'),
                    'dense_scheme': {f'conv_{k}': v for k, v in sorted(dense_schemes.items())},
                    'dense_scheme_legend': 'f16x2 = 2 fp16 terms per operand, 3 v_mfma_f32_16x16x32_f16 per fp32 product; '
                                           'f16x2-image = the same with the LayerNorm writing the pre-split operand; '
@@ -320,7 +330,7 @@ def roofline_leg(model, x, args):
     for (kind, meta), (ms, n) in agg.items():
         if kind == 'grouped_conv':
             blk, c, _, k, frames, n_skips = meta
-            b = grouped_conv_bytes(args.batch, c, frames, k, n_skips)
+            b = grouped_conv_bytes(args.batch, c, frames, k, n_skips, elem=2 if args.dtype == 'bf16' else 4)
         elif kind == 'grouped_cell':
             # one launch = the three node operations of a cell: credited with the algorithmic bytes of those three ops
             # (SURVEY.md 8(d) per-op figure x the ops one launch processes); the intermediates never leave the CU
@@ -337,7 +347,7 @@ def roofline_leg(model, x, args):
         e['n'] += n
     if launches:
         traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_kernel')
-        if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or any(k.startswith('NBASR_') for k in os.environ):
+        if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or args.dtype != 'f32' or any(k.startswith('NBASR_') for k in os.environ):
             traffic, traffic_src = None, None          # the committed counters are for the default workload and modes only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
         out['roofline'] = {
@@ -373,7 +383,7 @@ def roofline_leg(model, x, args):
                     per_layer[f'conv_{meta[0]}_{meta[1]}x{meta[2]}_T{meta[4]}']['scheme'] = scheme
                     if meta[0] in plan.dense_row_tiles:
                         per_layer[f'conv_{meta[0]}_{meta[1]}x{meta[2]}_T{meta[4]}']['row_tile'] = plan.dense_row_tiles[meta[0]]
-                    issued_flops += (3.0 if scheme.startswith('f16x2') else 6.0) * dense_conv_flops(args.batch, meta[1], meta[2], meta[3], meta[4]) * n
+                    issued_flops += (1.0 if scheme == 'bf16' else 3.0 if scheme.startswith('f16x2') else 6.0) * dense_conv_flops(args.batch, meta[1], meta[2], meta[3], meta[4]) * n
             issued = issued_flops / (tot_ms * 1e-3) / 1e12
             out['roofline_mfma'] = {'kernel': 'gemm_conv_split_kernel<P,S> (dense k=8 conv on v_mfma_f32_16x16x32_{f16,bf16}: 3 fp16 or 6 bf16 products per fp32 product)',
                                     'bound': 'mfma', 'achieved': issued, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (16-bit MFMA issued)',
@@ -398,11 +408,13 @@ def cpu_baseline_leg(model, args):
     from nb_asr_amd.weights import keyed_input
     params = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     warm_b = min(8, args.batch)
+    dt = torch.bfloat16 if args.dtype == 'bf16' else torch.float32      # bf16: the reference's model.to(torch.bfloat16) forward
+    fwd = lambda inp: oracle.asr_forward(params, ARCHS[args.arch], inp, use_rnn=True, dtype=dt)      # noqa: E731
     with torch.no_grad():
         xs = keyed_input(warm_b, args.frames, seed=0)
-        oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)                  # warm-up (thread pool, allocator)
+        fwd(xs)                                                                         # warm-up (thread pool, allocator)
         t0 = time.perf_counter()
-        oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)
+        fwd(xs)
         small = time.perf_counter() - t0
         # the metric's own batch (ONE forward: 10-30 s of CPU work on the GPU box's host) unless that would take minutes
         full = small * args.batch / warm_b < 60.0
@@ -410,7 +422,7 @@ def cpu_baseline_leg(model, args):
         if full and sample_b != warm_b:
             xs = keyed_input(sample_b, args.frames, seed=0)
             t0 = time.perf_counter()
-            oracle.asr_forward(params, ARCHS[args.arch], xs, use_rnn=True)
+            fwd(xs)
             secs = time.perf_counter() - t0
         else:
             secs = small

@@ -37,6 +37,13 @@ extern "C" {
 
 typedef void* nbasr_stream_t;
 
+/* Storage type of an activation tensor for the entry points that exist for both precisions (`dtype` argument).
+ * NBASR_BF16 = bfloat16 storage (BASELINE config 4): values are converted to fp32 when loaded, every product, sum,
+ * LayerNorm statistic and recurrent state is fp32, and a tensor is rounded to bf16 ONCE when it is written back.
+ * bf16 rows are pitched to multiples of 8 frames (16 bytes), like fp32 rows to multiples of 4. */
+#define NBASR_F32 0
+#define NBASR_BF16 1
+
 /* ABI version of the loaded library (== NBASR_ABI_VERSION it was built with). */
 int nbasr_version(void);
 
@@ -234,6 +241,21 @@ int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float
                                      int groups, int kernel, int dilation,
                                      const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
                                      float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream);
+/* The node operation for either storage type and in the kernel variants kept for measurement (one C symbol instead of
+ * one per combination).  Arguments as nbasr_grouped_conv1d_fused_stats without stats_out / eps (merge the partials with
+ * nbasr_grouped_stats_finalize); x, skips, y are `dtype` tensors, everything else fp32.
+ * variant: 0 = 4 frames per lane, weights as torch stores them; NBASR_GC_FPL8 = 8 frames per lane (fp32: ld % 8 == 0);
+ * NBASR_GC_WPERM = `w` is the [group][ci][tap][co] copy made by nbasr_pack_grouped_weights (channels * channels/groups *
+ * kernel floats), whose per-input-channel weights are contiguous for the scalar loads.  Results do not depend on the variant. */
+#define NBASR_GC_FPL8 1
+#define NBASR_GC_WPERM 2
+int nbasr_grouped_conv1d_node(const void* x, const float* w, const float* bias,
+                              const void* skip0, const void* skip1, const void* skip2, void* y,
+                              int batch, int channels, int frames, int ld, int groups, int kernel, int dilation,
+                              const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, float* stats_ws,
+                              int dtype, int variant, nbasr_stream_t stream);
+int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int groups, int kernel, nbasr_stream_t stream);
+
 /* A whole SearchCell whose three node operations are grouped convolutions, in one launch (reference model.py:49-59 over
  * model.py:13-22 and ops.py:24-30): x1 = op0(x0) + s00 x0; x2 = op1(x1) + s10 x0 + s11 x1; x3 = op2(x2) + s20 x0 + s21 x1 + s22 x2.
  * The intermediates stay in LDS; the result is bit-identical to three nbasr_grouped_conv1d_fused launches.
@@ -353,6 +375,40 @@ int nbasr_power_spectrum(const float* spec, float* power, int batch, int bins, i
                          nbasr_stream_t stream);
 int nbasr_log_normalize(const float* mel, const int* lengths, const float* mean, const float* inv_scale, float* feats,
                         int batch, int samples, int hop, int n_mels, int ld, nbasr_stream_t stream);
+
+/* ---- bf16 path (BASELINE config 4: activations and GEMM operands stored as bfloat16) ------------------------------------------
+ * Mirrors `model.to(torch.bfloat16)(x.bfloat16())` of the reference (ops.py:24-30, model.py:116-131 run on bf16 tensors).
+ * Storage is bf16, arithmetic is fp32, a tensor is rounded once when it is written; the `_v` entry points below are the
+ * fp32 ones with a storage-type argument (x / y / skips are `dtype` tensors, everything else -- weights of the node op,
+ * bias, gamma, beta, statistics -- stays fp32).  bf16 rows: ld % 8 == 0, 16-byte aligned, pitch columns zero. */
+int nbasr_skip_sum_v(const void* skip0, const void* skip1, const void* skip2, void* y, int batch, int channels, int frames,
+                     int ld, const nbasr_deferred_ln* ln, int ln_on_skip0, int dtype, nbasr_stream_t stream);
+int nbasr_repitch_v(const void* src, void* dst, int rows, int frames, int ld_src, int ld_dst, int dtype, nbasr_stream_t stream);
+int nbasr_channel_stats_v(const void* x, float* stats, int batch, int channels, int frames, int ld, float eps, int dtype,
+                          nbasr_stream_t stream);
+/* LayerNorm over channels, x of in_dtype -> y of out_dtype: f32 -> f32, bf16 -> bf16, or bf16 -> f32 (the encoder output
+ * handed to the fp32 LSTM).  In place only when the two types are equal. */
+int nbasr_layernorm_channels_v(const void* x, const float* gamma, const float* beta, void* y, int batch, int channels, int frames,
+                               int ld, float eps, int in_dtype, int out_dtype, nbasr_stream_t stream);
+/* Element-wise conversion between the two storage types (n % 8 == 0, both pointers 16-byte aligned): the bridge to the
+ * operators that exist in fp32 only. */
+int nbasr_convert(const void* x, void* y, long long n, int in_dtype, int out_dtype, nbasr_stream_t stream);
+/* Operand image of the bf16 dense convolution: [batch][16-channel group][8-channel half][1 + ld rows][8 ch] bfloat16, row 0
+ * zero, frame t at row t + 1 (nbasr_bf16_image_bytes bytes).  gamma != NULL: image of LayerNorm(x) -- `stats`
+ * (batch, 2, ld) receives the per-frame statistics on the way; gamma == NULL: plain re-layout of x (the model input,
+ * cells without LayerNorm).  x is a `dtype` tensor (batch, channels, ld). */
+size_t nbasr_bf16_image_bytes(int batch, int channels, int ld);
+int nbasr_bf16_image(const void* x, const float* gamma, const float* beta, float* stats, void* image, int batch, int channels,
+                     int frames, int ld, float eps, int dtype, nbasr_stream_t stream);
+/* Dense PadConvRelu k = 8 (reference model.py:82-89) on bf16 operands: ONE v_mfma_f32_16x16x32_bf16 per 32 products, fp32
+ * accumulation, bias + relu + min(20) in fp32, one rounding to the bf16 output (batch, c_out, ld_out), ld_out % 8 == 0.
+ * Weights: the fp32 values of the bf16 parameter, packed once per version (row_tile 128 or 160). */
+size_t nbasr_packed_dense_weights_bytes_bf16(int c_out, int c_in, int kernel, int row_tile);
+int nbasr_pack_dense_weights_bf16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
+                                  nbasr_stream_t stream);
+int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
+                                int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                nbasr_stream_t stream);
 
 #ifdef __cplusplus
 }

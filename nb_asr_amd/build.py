@@ -20,8 +20,9 @@ LIB_PATH = PKG_DIR / 'lib' / 'libnbasr_hip.so'
 INCLUDE_DIR = REPO_DIR / 'include'
 ARCH = 'gfx950'
 
-SOURCES = ['api.cpp', 'grouped_conv.hip', 'grouped_cell.hip', 'layernorm.hip', 'gemm_conv.hip', 'gemm_conv_split.hip', 'gemm_pointwise_split.hip', 'lstm.hip', 'ctc.hip', 'ctc_decode.hip', 'frontend.hip']
+SOURCES = ['api.cpp', 'grouped_conv.hip', 'grouped_conv_alt.hip', 'grouped_conv_bf16.hip', 'grouped_cell.hip', 'layernorm.hip', 'gemm_conv.hip', 'gemm_conv_split.hip', 'gemm_pointwise_split.hip', 'lstm.hip', 'ctc.hip', 'ctc_decode.hip', 'frontend.hip']
 CXXFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
+CXXFLAGS += os.environ.get('NBASR_EXTRA_CXXFLAGS', '').split()      # diagnostics (A/B builds); part of the build id
 
 
 def _hipcc():
@@ -71,7 +72,7 @@ def _compile(src, obj, headers, verbose, build_id=None):
     return True
 
 
-def build_library(force=False, verbose=False, jobs=4):
+def build_library(force=False, verbose=False, jobs=8):
     """Compile every source for gfx950 and link the shared library.  Returns its path."""
     OBJ_DIR.mkdir(parents=True, exist_ok=True)
     LIB_PATH.parent.mkdir(parents=True, exist_ok=True)

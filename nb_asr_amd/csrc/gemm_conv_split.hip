@@ -39,7 +39,7 @@
 //    a step in opposite order (stage-then-multiply / multiply-then-stage) so a wave's memory phase sits beside its SIMD
 //    partner's MFMAs, and the multiply-first half runs at s_setprio 1 so that it really finishes first;
 //  * the hi*hi products accumulate in their own register set, so the large running sum is rounded once per 32 k.
-#include "common.h"
+#include "storage.h"
 
 #include <type_traits>
 
@@ -93,6 +93,26 @@ struct SplitF16x2 {
     static constexpr const char* NAME = "nbasr_dense_conv1d_fused_packed_f16";
 };
 
+// bf16 path (BASELINE config 4): operands ARE bfloat16 -- one term, one MFMA per product, no scaling (bf16 has fp32's exponent
+// range).  Image path only: the producer (LayerNorm, or the re-layout of the model input) writes the operand image; the
+// result is rounded once to bf16 and leaves through an LDS transpose as whole 128-byte row segments.
+struct PlainBf16 {
+    static constexpr int NS = 1;
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    static constexpr float SMALL_SCALE = 0.f;
+    static constexpr bool SCALED = false;
+    __host__ __device__ static constexpr int taps_per_step(int) { return 8; }      // all 8 taps of a channel group per K-step
+    __device__ static __forceinline__ void split(float v, unsigned short (&s)[NS]) {
+        s[0] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+    }
+    __device__ static __forceinline__ floatx4 mfma(vec8 a, vec8 b, floatx4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    static constexpr const char* NAME = "nbasr_dense_conv1d_bf16_img";
+};
+
+template <class P> constexpr bool has_image_path() { return P::SCALED || P::NS == 1; }
+
 template <class P> constexpr size_t pb_group_bytes(int mi) { return static_cast<size_t>(P::NS) * PB_TAPS * pb_rows(mi) * PB_CI * 2; }   // packed weights of one (row tile, channel group)
 
 template <class P, int S, int MI = 4>
@@ -109,7 +129,7 @@ struct GeoP {
     // misalignment of the tile's first frame; an item = (quad, channel pair), 8 consecutive quads x 8 pairs per wave
     static constexpr int NQUADS = ((XR + 3 + 3) / 4 + 7) / 8 * 8;
     static constexpr int XITEMS = NQUADS * (PB_CI / 2);
-    static constexpr int NCHUNK = QSTEPS - 1;                    // the next group's tile is staged in QSTEPS-1 chunks
+    static constexpr int NCHUNK = QSTEPS > 1 ? QSTEPS - 1 : 1;   // the next group's tile is staged in QSTEPS-1 chunks (register staging path)
     static constexpr int XI = (XITEMS + PB_THREADS * NCHUNK - 1) / (PB_THREADS * NCHUNK);   // items per thread per chunk
     static constexpr int LDS_BYTES = 2 * A_STEP_BYTES + 2 * X_BYTES;   // weights and input tile both double-buffered
     __device__ static constexpr int rowmap(int row) { return (S == 1) ? row : (row & 1) * XRH + (row >> 1); }
@@ -203,7 +223,8 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
 template <class P, int S, bool LNX, bool XIMG = false, int MI = 4>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const PackedConvArgs a)
 {
-    static_assert(!(XIMG && LNX) && !(XIMG && !P::SCALED), "the image path is the scaled fp16 scheme without LayerNorm on load");
+    static_assert(!(XIMG && LNX) && !(XIMG && !has_image_path<P>()), "the image path: scaled fp16 scheme or plain bf16, no LayerNorm on load");
+    static_assert(XIMG || P::NS > 1, "plain bf16 operands exist as an image only");
     static_assert(MI == 4 || (MI == 5 && XIMG), "160-row tiles exist for the image path only (register budget)");
     using G = GeoP<P, S, MI>;
     constexpr int PB_M = G::PBM, WROWS = 16 * MI;                // rows per tile, rows per wave
@@ -272,7 +293,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     auto dma_x = [&](int g, int xbuf, int q) {
         constexpr int NP = (G::X_BYTES + 1023) / 1024;
         const unsigned char* img = reinterpret_cast<const unsigned char*>(a.x) +
-                                   (static_cast<size_t>(b) * a.n_groups + g) * 4 * static_cast<size_t>(a.ld_in + 1) * 16;
+                                   (static_cast<size_t>(b) * a.n_groups + g) * (2 * P::NS) * static_cast<size_t>(a.ld_in + 1) * 16;
 #pragma unroll 1
         for (int i = wave * QS + q; i < NP; i += 8 * QS) {
             const int o = i * 1024 + lane * 16;
@@ -374,16 +395,22 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             for (int k = 0; k < P::NS; ++k) f[k] = *reinterpret_cast<const vec8*>(A + ((k * TP + 2 * pp) * 2 * PB_M + i * 16) * 16);
         };
         auto block = [&](int i, int j, const vec8 (&af)[P::NS], const vec8 (&bf)[P::NS]) {
+            if constexpr (P::NS == 1) {
+                big[i][j] = P::mfma(af[0], bf[0], big[i][j]);
+                return;
+            }
             floatx4 c = small[i][j];
             if constexpr (P::NS == 3) {
                 c = P::mfma(af[2], bf[0], c);   // lo * hi
                 c = P::mfma(af[0], bf[2], c);   // hi * lo
                 c = P::mfma(af[1], bf[1], c);   // mid * mid
             }
-            c = P::mfma(af[1], bf[0], c);       // mid * hi   (fp16: lo' * hi)
-            c = P::mfma(af[0], bf[1], c);       // hi * mid   (fp16: hi * lo')
-            small[i][j] = c;
-            big[i][j] = P::mfma(af[0], bf[0], big[i][j]);   // hi * hi
+            if constexpr (P::NS > 1) {
+                c = P::mfma(af[1], bf[0], c);       // mid * hi   (fp16: lo' * hi)
+                c = P::mfma(af[0], bf[1], c);       // hi * mid   (fp16: hi * lo')
+                small[i][j] = c;
+                big[i][j] = P::mfma(af[0], bf[0], big[i][j]);   // hi * hi
+            }
         };
         if constexpr (PIPE) {
             vec8 bfr[4][P::NS], af[2][P::NS];
@@ -483,6 +510,40 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         }
     }
 
+    if constexpr (P::NS == 1) {
+        // ---- bf16 output: bias + ReLU + min(20), ONE rounding, then out through LDS so that a store instruction writes whole
+        // 128-byte row segments (64 frames) instead of 32-byte ones.  Each wave owns WROWS x 64 bf16 = WROWS x 128 bytes of
+        // the staging buffers, which nobody reads any more (the last K-step ended with a barrier).
+        unsigned short* const T = reinterpret_cast<unsigned short*>(smem) + wave * (WROWS * 64);
+        static_assert(8 * WROWS * 128 <= G::LDS_BYTES, "output staging must fit the operand buffers");
+        if (wave_active) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = n0 + wn * 64 + j * 16 + l15 < a.frames_out;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int ml = i * 16 + kq * 4 + r, m = m0 + wm * WROWS + ml;
+                        const float v = (live && m < a.c_out) ? relu_clamp(big[i][j][r] + a.bias[m]) : 0.f;
+                        T[ml * 64 + j * 16 + l15] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+                    }
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done (wave-private tile); also keeps
+                                                                 // the compiler from moving the differently-typed reads above them
+            bf16_t* const yb = reinterpret_cast<bf16_t*>(a.y);
+            const int n = n0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+            for (int it = 0; it < WROWS / 8; ++it) {
+                const int ml = it * 8 + (lane >> 3), m = m0 + wm * WROWS + ml;
+                if (m < a.c_out && n < a.ld_out) {
+                    const u4v t = *reinterpret_cast<const u4v*>(T + ml * 64 + (lane & 7) * 8);
+                    *reinterpret_cast<u4v*>(yb + (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n) = t;
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias + ReLU + min(20) (+ skips); a store covers 4 rows x 16 consecutive frames -----------------
     if (!wave_active) return;
 #pragma unroll
@@ -514,7 +575,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 template <class P, int S>
 static int launch_packed_rows160(PackedConvArgs a, hipStream_t stream)
 {
-    if constexpr (P::SCALED) {
+    if constexpr (has_image_path<P>()) {
         using G = GeoP<P, S, 5>;
         static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true, 5>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -529,7 +590,7 @@ static int launch_packed_rows160(PackedConvArgs a, hipStream_t stream)
         hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, 5>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
         return launch_status(P::NAME);
     } else {
-        set_error("%s: 160-row tiles exist for the fp16 image path only", P::NAME);
+        set_error("%s: 160-row tiles exist for the image path only", P::NAME);
         return NBASR_EINVAL;
     }
 }
@@ -575,11 +636,30 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
 
 static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : 0); }
 
+// image-path kernel of scheme P at a given row tile (the only kernel the plain-bf16 scheme has)
+template <class P, int S, int MI>
+static int launch_image(PackedConvArgs a, hipStream_t stream)
+{
+    using G = GeoP<P, S, MI>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true, MI>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (attr != hipSuccess) {
+        set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr));
+        return static_cast<int>(attr);
+    }
+    a.n_mt = (a.c_out + G::PBM - 1) / G::PBM;
+    a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
+    const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
+    NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
+    hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, MI>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+    return launch_status(P::NAME);
+}
+
 template <class P>
 static size_t packed_bytes(int c_out, int c_in, int kernel, int row_tile = 128)
 {
     const int mi = rows_to_mi(row_tile);
-    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS || mi == 0 || (mi == 5 && !P::SCALED)) return 0;
+    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS || mi == 0 || (mi == 5 && !has_image_path<P>())) return 0;
     const size_t PB_M = pb_rows(mi), n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
     return n_mt * n_groups * pb_group_bytes<P>(mi) + (P::SCALED ? 2 * n_mt * PB_M * sizeof(float) : 0);   // + row scales and inverses
 }
@@ -589,7 +669,7 @@ static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kern
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
-    NBASR_REQUIRE(mi != 0 && (mi == 4 || P::SCALED), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 160 for the fp16 scheme)", row_tile);
+    NBASR_REQUIRE(mi != 0 && (mi == 4 || has_image_path<P>()), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 160 for the image-path schemes)", row_tile);
     const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
@@ -725,4 +805,46 @@ extern "C" int nbasr_dense_conv1d_fused_packed_f16_img_rows(const void* x_image,
 {
     return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
                                          frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, x_absmax, stream, true, row_tile);
+}
+
+// ---- bf16 path ------------------------------------------------------------------------------------------------------------
+extern "C" size_t nbasr_packed_dense_weights_bytes_bf16(int c_out, int c_in, int kernel, int row_tile)
+{
+    return packed_bytes<PlainBf16>(c_out, c_in, kernel, row_tile);
+}
+
+extern "C" int nbasr_pack_dense_weights_bf16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
+                                             nbasr_stream_t stream)
+{
+    return pack_impl<PlainBf16>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
+}
+
+extern "C" int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
+                                           int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                           nbasr_stream_t stream)
+{
+    using P = PlainBf16;
+    clear_error();
+    const int mi = rows_to_mi(row_tile);
+    NBASR_REQUIRE(mi != 0, NBASR_EINVAL, "%s: row_tile=%d unsupported (128 or 160)", P::NAME, row_tile);
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
+    NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
+                  "%s: (kernel=%d, stride=%d) unsupported; the downsample convs have k=8, s in {1,2}", P::NAME, kernel, stride);
+    const int frames_out = (frames_in + stride - 1) / stride;
+    NBASR_REQUIRE(ld_in >= frames_in, NBASR_EINVAL, "%s: ld_in=%d < frames_in=%d", P::NAME, ld_in, frames_in);
+    NBASR_REQUIRE(ld_out >= frames_out && ld_out % 8 == 0, NBASR_EALIGN,
+                  "%s: ld_out=%d must be >= %d output frames and a multiple of 8", P::NAME, ld_out, frames_out);
+    if (batch == 0 || frames_out == 0) return NBASR_OK;
+    NBASR_REQUIRE(x_image && packed_w && bias && y, NBASR_ENULL, "%s: x_image, packed_w, bias, y must be non-NULL", P::NAME);
+    NBASR_REQUIRE(aligned16(packed_w) && aligned16(x_image) && aligned16(y), NBASR_EALIGN, "%s: pointers must be 16-byte aligned", P::NAME);
+    PackedConvArgs a{};
+    a.x = static_cast<const float*>(x_image); a.wp = static_cast<const unsigned char*>(packed_w); a.bias = bias;
+    a.y = static_cast<float*>(y);
+    a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
+    a.lpad = pad_left(kernel, 1, stride); a.n_groups = (c_in + PB_CI - 1) / PB_CI; a.batch = batch;
+    a.ln_x = LnRef{nullptr, nullptr, nullptr};
+    a.x_is_image = 1;
+    hipStream_t s = as_stream(stream);
+    if (mi == 5) return stride == 1 ? launch_image<P, 1, 5>(a, s) : launch_image<P, 2, 5>(a, s);
+    return stride == 1 ? launch_image<P, 1, 4>(a, s) : launch_image<P, 2, 4>(a, s);
 }

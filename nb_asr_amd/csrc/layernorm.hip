@@ -10,35 +10,36 @@
 // single pass is cancellation-safe), the 16 row partials are merged with Chan's parallel-variance
 // formula through LDS, pass 2 re-reads the tile (L2 / Infinity-Cache warm) and writes the result.
 // HBM-bound: 2 reads + 1 write of the tensor (algorithmic minimum 1 read + 1 write).
-#include "common.h"
+#include "storage.h"
 
 namespace nbasr {
 
 constexpr int LN_ROWS = 16;   // channel rows in flight per workgroup
-constexpr int LN_QS = 16;     // 16-byte chunks (4 frames each) per row segment
+constexpr int LN_QS = 16;     // 16-byte chunks (4 fp32 / 8 bf16 frames each) per row segment
 
 // Statistics of one 64-frame tile: fills s_mu / s_rstd (LDS) for the tile's frame columns.  Called by all 256 threads.
 // MINMAX: also the per-frame extrema of x over the channels (s_lo / s_hi: [LN_ROWS][64] partials in, merged into row 0).
-template <bool MINMAX = false>
-__device__ __forceinline__ void tile_statistics(const float* x, int channels, int ld, float eps, size_t base, bool active,
-                                                int row, int ql, float (*s_mean)[LN_QS * 4], float (*s_m2)[LN_QS * 4],
+template <typename T, bool MINMAX = false, int FR = Chunk<T>::FR>
+__device__ __forceinline__ void tile_statistics(const T* x, int channels, int ld, float eps, size_t base, bool active,
+                                                int row, int ql, float (*s_mean)[LN_QS * FR], float (*s_m2)[LN_QS * FR],
                                                 float* s_cnt, float* s_mu, float* s_rstd,
-                                                float (*s_lo)[LN_QS * 4] = nullptr, float (*s_hi)[LN_QS * 4] = nullptr)
+                                                float (*s_lo)[LN_QS * FR] = nullptr, float (*s_hi)[LN_QS * FR] = nullptr)
 {
     // per-lane shifted sums over this lane's channel subset
-    float shift[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-    float lo[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f}, hi[4] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};
+    float shift[FR], s1[FR], s2[FR], lo[FR], hi[FR];
+#pragma unroll
+    for (int r = 0; r < FR; ++r) { shift[r] = 0.f; s1[r] = 0.f; s2[r] = 0.f; lo[r] = 3.0e38f; hi[r] = -3.0e38f; }
     int n = 0;
     if (active) {
         for (int c = row; c < channels; c += LN_ROWS) {
-            const float4 v = *reinterpret_cast<const float4*>(x + base + static_cast<size_t>(c) * ld);
-            const float e[4] = {v.x, v.y, v.z, v.w};
+            float e[FR];
+            load_frames<FR>(x + base + static_cast<size_t>(c) * ld, e);
             if (n == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) shift[r] = e[r];
+                for (int r = 0; r < FR; ++r) shift[r] = e[r];
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int r = 0; r < FR; ++r) {
                 const float d = e[r] - shift[r];
                 s1[r] += d;
                 s2[r] = __builtin_fmaf(d, d, s2[r]);
@@ -49,17 +50,17 @@ __device__ __forceinline__ void tile_statistics(const float* x, int channels, in
     }
     const float fn = static_cast<float>(n);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int r = 0; r < FR; ++r) {
         const float dm = n ? s1[r] / fn : 0.f;
-        s_mean[row][ql * 4 + r] = shift[r] + dm;
-        s_m2[row][ql * 4 + r] = n ? fmaxf(s2[r] - dm * s1[r], 0.f) : 0.f;
-        if (MINMAX) { s_lo[row][ql * 4 + r] = lo[r]; s_hi[row][ql * 4 + r] = hi[r]; }
+        s_mean[row][ql * FR + r] = shift[r] + dm;
+        s_m2[row][ql * FR + r] = n ? fmaxf(s2[r] - dm * s1[r], 0.f) : 0.f;
+        if (MINMAX) { s_lo[row][ql * FR + r] = lo[r]; s_hi[row][ql * FR + r] = hi[r]; }
     }
     if (ql == 0) s_cnt[row] = fn;
     __syncthreads();
 
     // merge the 16 row partials (Chan's parallel-variance formula), one thread per frame column
-    if (threadIdx.x < LN_QS * 4) {
+    if (threadIdx.x < LN_QS * FR) {
         const int col = threadIdx.x;
         float cnt = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
@@ -87,46 +88,48 @@ __device__ __forceinline__ void tile_statistics(const float* x, int channels, in
 
 // ABSMAX: also fold max|y| of each utterance into absmax[b] (float bits, non-negative floats order like unsigned ints);
 // the 2-way fp16 dense conv (gemm_conv_split.hip) scales its input by a power of two derived from it
-template <bool ABSMAX>
+// TI / TO: storage types of x and y (float | bf16_t; bf16 -> float feeds the fp32 LSTM projection of the bf16 path)
+template <typename TI, typename TO, bool ABSMAX>
 __global__ __launch_bounds__(256) void layernorm_channels_kernel(
-    const float* x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* y, int channels, int frames, int ld, float eps, unsigned* __restrict__ absmax)   // x may alias y (in-place)
+    const TI* x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    TO* y, int channels, int frames, int ld, float eps, unsigned* __restrict__ absmax)   // x may alias y (in-place, TI == TO)
 {
-    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
-    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
+    constexpr int FR = Chunk<TI>::FR;
+    __shared__ float s_mean[LN_ROWS][LN_QS * FR];
+    __shared__ float s_m2[LN_ROWS][LN_QS * FR];
     __shared__ float s_cnt[LN_ROWS];
-    __shared__ float s_mu[LN_QS * 4];
-    __shared__ float s_rstd[LN_QS * 4];
+    __shared__ float s_mu[LN_QS * FR];
+    __shared__ float s_rstd[LN_QS * FR];
 
     const int ql = threadIdx.x & (LN_QS - 1);
     const int row = threadIdx.x / LN_QS;
-    const int nq = ld >> 2;
+    const int nq = ld / FR;
     const int q = blockIdx.x * LN_QS + ql;
     const int b = blockIdx.y;
     const bool active = q < nq;
-    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * FR;
 
-    tile_statistics(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
+    tile_statistics<TI>(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
 
     // pass 2: normalise, scale, shift; keep the pitch columns at zero
     if (!active && !ABSMAX) return;
-    float mu[4], rs[4];
+    float mu[FR], rs[FR];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { mu[r] = s_mu[ql * 4 + r]; rs[r] = s_rstd[ql * 4 + r]; }
-    const int t0 = q * 4;
+    for (int r = 0; r < FR; ++r) { mu[r] = s_mu[ql * FR + r]; rs[r] = s_rstd[ql * FR + r]; }
+    const int t0 = q * FR;
     float amax = 0.f;
     for (int c = row; active && c < channels; c += LN_ROWS) {
         const size_t off = base + static_cast<size_t>(c) * ld;
-        const float4 v = *reinterpret_cast<const float4*>(x + off);
+        float o[FR];
+        load_frames<FR>(x + off, o);
         const float g = gamma[c], bt = beta[c];
-        float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < FR; ++r) {
             o[r] = (o[r] - mu[r]) * rs[r] * g + bt;
             if (t0 + r >= frames) o[r] = 0.f;
             if (ABSMAX) amax = fmaxf(amax, finite_abs(o[r]));
         }
-        *reinterpret_cast<float4*>(y + off) = make_float4(o[0], o[1], o[2], o[3]);
+        store_frames<FR, false>(y + off, o);
     }
     if (ABSMAX) {
 #pragma unroll
@@ -136,27 +139,29 @@ __global__ __launch_bounds__(256) void layernorm_channels_kernel(
 }
 
 // deferred LayerNorm: ONE read pass, per-frame (mean, rstd) only; consumers normalise while loading
-__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, float* __restrict__ stats,
+template <typename T>
+__global__ __launch_bounds__(256) void channel_stats_kernel(const T* __restrict__ x, float* __restrict__ stats,
                                                             int channels, int frames, int ld, float eps)
 {
-    __shared__ float s_mean[LN_ROWS][LN_QS * 4];
-    __shared__ float s_m2[LN_ROWS][LN_QS * 4];
+    constexpr int FR = Chunk<T>::FR;
+    __shared__ float s_mean[LN_ROWS][LN_QS * FR];
+    __shared__ float s_m2[LN_ROWS][LN_QS * FR];
     __shared__ float s_cnt[LN_ROWS];
-    __shared__ float s_mu[LN_QS * 4];
-    __shared__ float s_rstd[LN_QS * 4];
+    __shared__ float s_mu[LN_QS * FR];
+    __shared__ float s_rstd[LN_QS * FR];
 
     const int ql = threadIdx.x & (LN_QS - 1);
     const int row = threadIdx.x / LN_QS;
-    const int nq = ld >> 2;
+    const int nq = ld / FR;
     const int q = blockIdx.x * LN_QS + ql;
     const int b = blockIdx.y;
     const bool active = q < nq;
-    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * FR;
 
-    tile_statistics(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
+    tile_statistics<T>(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd);
 
-    if (threadIdx.x < LN_QS * 4) {
-        const int t = blockIdx.x * (LN_QS * 4) + threadIdx.x;
+    if (threadIdx.x < LN_QS * FR) {
+        const int t = blockIdx.x * (LN_QS * FR) + threadIdx.x;
         if (t < ld) {
             const bool live = t < frames;
             float* srow = stats + static_cast<size_t>(b) * 2 * ld;
@@ -170,28 +175,47 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 
 using namespace nbasr;
 
-static int layernorm_impl(const char* what, const float* x, const float* gamma, const float* beta, float* y, float* absmax,
-                          int batch, int channels, int frames, int ld, float eps, nbasr_stream_t stream)
+static int layernorm_impl(const char* what, const void* x, const float* gamma, const float* beta, void* y, float* absmax,
+                          int batch, int channels, int frames, int ld, float eps, nbasr_stream_t stream,
+                          int in_dtype = NBASR_F32, int out_dtype = NBASR_F32)
 {
     clear_error();
+    NBASR_REQUIRE((in_dtype == NBASR_F32 || in_dtype == NBASR_BF16) && (out_dtype == NBASR_F32 || out_dtype == NBASR_BF16) &&
+                  !(in_dtype == NBASR_F32 && out_dtype == NBASR_BF16), NBASR_EINVAL,
+                  "%s: storage types (%d -> %d) unsupported (f32 -> f32, bf16 -> bf16, bf16 -> f32)", what, in_dtype, out_dtype);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "%s: bad sizes", what);
-    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "%s: ld=%d must be >= frames=%d and a multiple of 4", what, ld, frames);
+    const int fr = in_dtype == NBASR_BF16 ? 8 : 4;
+    NBASR_REQUIRE(ld >= frames && ld % fr == 0, NBASR_EALIGN, "%s: ld=%d must be >= frames=%d and a multiple of %d", what, ld, frames, fr);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(x && gamma && beta && y, NBASR_ENULL, "%s: NULL pointer", what);
     NBASR_REQUIRE(aligned16(x) && aligned16(y), NBASR_EALIGN, "%s: x, y must be 16-byte aligned", what);
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "%s: batch %d > 65535", what, batch);
-    const int nq = ld / 4;
+    NBASR_REQUIRE(!absmax || in_dtype == NBASR_F32, NBASR_EINVAL, "%s: the absmax by-product exists for fp32 tensors only", what);
+    const int nq = ld / fr;
     const dim3 grid((nq + LN_QS - 1) / LN_QS, batch);
-    if (absmax) {
+    if (in_dtype == NBASR_BF16) {
+        if (out_dtype == NBASR_BF16)
+            hipLaunchKernelGGL((layernorm_channels_kernel<bf16_t, bf16_t, false>), grid, dim3(256), 0, as_stream(stream),
+                               static_cast<const bf16_t*>(x), gamma, beta, static_cast<bf16_t*>(y), channels, frames, ld, eps, static_cast<unsigned*>(nullptr));
+        else
+            hipLaunchKernelGGL((layernorm_channels_kernel<bf16_t, float, false>), grid, dim3(256), 0, as_stream(stream),
+                               static_cast<const bf16_t*>(x), gamma, beta, static_cast<float*>(y), channels, frames, ld, eps, static_cast<unsigned*>(nullptr));
+    } else if (absmax) {
         const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * batch, as_stream(stream));
         if (e != hipSuccess) { set_error("%s: hipMemsetAsync failed: %s", what, hipGetErrorString(e)); return static_cast<int>(e); }
-        hipLaunchKernelGGL(layernorm_channels_kernel<true>, grid, dim3(256), 0, as_stream(stream),
-                           x, gamma, beta, y, channels, frames, ld, eps, reinterpret_cast<unsigned*>(absmax));
+        hipLaunchKernelGGL((layernorm_channels_kernel<float, float, true>), grid, dim3(256), 0, as_stream(stream),
+                           static_cast<const float*>(x), gamma, beta, static_cast<float*>(y), channels, frames, ld, eps, reinterpret_cast<unsigned*>(absmax));
     } else {
-        hipLaunchKernelGGL(layernorm_channels_kernel<false>, grid, dim3(256), 0, as_stream(stream),
-                           x, gamma, beta, y, channels, frames, ld, eps, static_cast<unsigned*>(nullptr));
+        hipLaunchKernelGGL((layernorm_channels_kernel<float, float, false>), grid, dim3(256), 0, as_stream(stream),
+                           static_cast<const float*>(x), gamma, beta, static_cast<float*>(y), channels, frames, ld, eps, static_cast<unsigned*>(nullptr));
     }
     return launch_status(what);
+}
+
+extern "C" int nbasr_layernorm_channels_v(const void* x, const float* gamma, const float* beta, void* y, int batch, int channels,
+                                          int frames, int ld, float eps, int in_dtype, int out_dtype, nbasr_stream_t stream)
+{
+    return layernorm_impl("nbasr_layernorm_channels_v", x, gamma, beta, y, nullptr, batch, channels, frames, ld, eps, stream, in_dtype, out_dtype);
 }
 
 extern "C" int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y, int batch,
@@ -245,7 +269,7 @@ __global__ __launch_bounds__(256) void channel_stats_bound_kernel(const float* _
     for (int d = 32; d >= 1; d >>= 1) { gm = fmaxf(gm, __shfl_xor(gm, d)); bm = fmaxf(bm, __shfl_xor(bm, d)); }
     if ((threadIdx.x & 63) == 0) { s_gb[threadIdx.x >> 6] = gm; s_gb[4 + (threadIdx.x >> 6)] = bm; }
 
-    tile_statistics<true>(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd, s_lo, s_hi);   // ends with a barrier
+    tile_statistics<float, true>(x, channels, ld, eps, base, active, row, ql, s_mean, s_m2, s_cnt, s_mu, s_rstd, s_lo, s_hi);   // ends with a barrier
     gm = fmaxf(fmaxf(s_gb[0], s_gb[1]), fmaxf(s_gb[2], s_gb[3]));
     bm = fmaxf(fmaxf(s_gb[4], s_gb[5]), fmaxf(s_gb[6], s_gb[7]));
 
@@ -388,18 +412,158 @@ extern "C" int nbasr_absmax(const float* x, float* absmax, int batch, long long 
     return launch_status("nbasr_absmax");
 }
 
-extern "C" int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
-                                   nbasr_stream_t stream)
+extern "C" int nbasr_channel_stats_v(const void* x, float* stats, int batch, int channels, int frames, int ld, float eps, int dtype,
+                                     nbasr_stream_t stream)
 {
     clear_error();
+    NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "nbasr_channel_stats: unknown dtype %d", dtype);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_channel_stats: bad sizes");
-    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_channel_stats: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    const int fr = dtype == NBASR_BF16 ? 8 : 4;
+    NBASR_REQUIRE(ld >= frames && ld % fr == 0, NBASR_EALIGN, "nbasr_channel_stats: ld=%d must be >= frames=%d and a multiple of %d", ld, frames, fr);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(x && stats, NBASR_ENULL, "nbasr_channel_stats: NULL pointer");
     NBASR_REQUIRE(aligned16(x) && aligned16(stats), NBASR_EALIGN, "nbasr_channel_stats: x, stats must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_channel_stats: batch %d > 65535", batch);
-    const int nq = ld / 4;
-    hipLaunchKernelGGL(channel_stats_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
-                       x, stats, channels, frames, ld, eps);
+    const int nq = ld / fr;
+    const dim3 grid((nq + LN_QS - 1) / LN_QS, batch);
+    if (dtype == NBASR_BF16)
+        hipLaunchKernelGGL(channel_stats_kernel<bf16_t>, grid, dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(x), stats, channels, frames, ld, eps);
+    else
+        hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, as_stream(stream), static_cast<const float*>(x), stats, channels, frames, ld, eps);
     return launch_status("nbasr_channel_stats");
+}
+
+extern "C" int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
+                                   nbasr_stream_t stream)
+{
+    return nbasr_channel_stats_v(x, stats, batch, channels, frames, ld, eps, NBASR_F32, stream);
+}
+
+// ---- bf16 path: the dense convolution's operand image in ONE bf16 term --------------------------------------------------
+// image[b][16-channel group][8-channel half][1 + ld rows][8 ch] bfloat16 (row 0 zero, frame t at row t + 1): the layout the
+// fp16-split image has per term, so gemm_conv_split.hip's image kernel gathers it by LDS-DMA in exactly the same way.
+// NORM: y = LayerNorm(x) from precomputed per-frame statistics (the LayerNorm in front of downsample convs 1-3);
+// otherwise a plain re-layout (the model input in front of conv 0; cells without LayerNorm).
+template <typename T, bool NORM>
+__global__ __launch_bounds__(256) void bf16_image_kernel(const T* __restrict__ x, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         unsigned char* __restrict__ image, int channels, int frames, int ld)
+{
+    constexpr int FR = Chunk<T>::FR;
+    // 16 frame chunks x 16 channel octets per pass; a thread turns 8 channels x FR frames into FR image rows of 16 bytes
+    const int ql = threadIdx.x & 15, oct0 = threadIdx.x >> 4;
+    const int nq = ld / FR;
+    const int q = blockIdx.x * 16 + ql;
+    const int b = blockIdx.y;
+    const int n_groups = (channels + 15) >> 4;
+    const size_t rows = static_cast<size_t>(ld) + 1;
+    unsigned char* const img_b = image + static_cast<size_t>(b) * n_groups * 2 * rows * 16;
+    if (blockIdx.x == 0) {            // the zero rows (row 0 of every plane): one workgroup per utterance writes them
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+        for (int pl = threadIdx.x; pl < n_groups * 2; pl += 256) *reinterpret_cast<uint4*>(img_b + static_cast<size_t>(pl) * rows * 16) = z;
+    }
+    if (q >= nq) return;
+    float m[FR], r[FR];
+#pragma unroll
+    for (int e = 0; e < FR; ++e) { m[e] = 0.f; r[e] = 1.f; }
+    if (NORM) {
+        const float* st = stats + static_cast<size_t>(b) * 2 * ld + q * FR;
+        load_frames<FR>(st, m);
+        load_frames<FR>(st + ld, r);
+    }
+    const T* xb = x + static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * FR;
+    const int n_oct = (channels + 7) >> 3;
+    for (int oct = oct0; oct < 2 * n_groups; oct += 16) {
+        float v[8][FR];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ch = oct * 8 + c;
+#pragma unroll
+            for (int e = 0; e < FR; ++e) v[c][e] = 0.f;
+            if (oct < n_oct && ch < channels) {
+                load_frames<FR>(xb + static_cast<size_t>(ch) * ld, v[c]);
+                if (NORM) {
+                    const float g = gamma[ch], be = beta[ch];
+#pragma unroll
+                    for (int e = 0; e < FR; ++e) v[c][e] = ln_apply(v[c][e], m[e], r[e], g, be);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < FR; ++e) if (q * FR + e >= frames) v[c][e] = 0.f;     // pitch columns of a caller's tensor
+                }
+            }
+        }
+        unsigned char* plane = img_b + ((static_cast<size_t>(oct >> 1) * 2 + (oct & 1)) * rows + 1 + static_cast<size_t>(q) * FR) * 16;
+#pragma unroll
+        for (int e = 0; e < FR; ++e) {
+            const u4v row = {pack_bf16x2(v[0][e], v[1][e]), pack_bf16x2(v[2][e], v[3][e]), pack_bf16x2(v[4][e], v[5][e]), pack_bf16x2(v[6][e], v[7][e])};
+            *reinterpret_cast<u4v*>(plane + e * 16) = row;
+        }
+    }
+}
+
+extern "C" size_t nbasr_bf16_image_bytes(int batch, int channels, int ld)
+{
+    if (batch <= 0 || channels <= 0 || ld < 0) return 0;
+    return static_cast<size_t>(batch) * ((channels + 15) / 16) * 2 * (static_cast<size_t>(ld) + 1) * 16;
+}
+
+// stats != NULL: LayerNorm(x) -> image (statistics pass + normalise-and-pack pass; stats (batch, 2, ld) is filled on the way);
+// gamma == NULL: plain re-layout of x
+extern "C" int nbasr_bf16_image(const void* x, const float* gamma, const float* beta, float* stats, void* image, int batch,
+                                int channels, int frames, int ld, float eps, int dtype, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "nbasr_bf16_image: unknown dtype %d", dtype);
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_bf16_image: bad sizes");
+    const int fr = dtype == NBASR_BF16 ? 8 : 4;
+    NBASR_REQUIRE(ld >= frames && ld % fr == 0, NBASR_EALIGN, "nbasr_bf16_image: ld=%d must be >= frames=%d and a multiple of %d", ld, frames, fr);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && image, NBASR_ENULL, "nbasr_bf16_image: NULL pointer");
+    const bool norm = gamma != nullptr;
+    NBASR_REQUIRE(!norm || (beta && stats), NBASR_ENULL, "nbasr_bf16_image: LayerNorm needs gamma, beta and the stats buffer");
+    NBASR_REQUIRE(aligned16(x) && aligned16(stats) && aligned16(image), NBASR_EALIGN, "nbasr_bf16_image: x, stats, image must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_bf16_image: batch %d > 65535", batch);
+    const int nq = ld / fr;
+    if (norm) {
+        const int rc = nbasr_channel_stats_v(x, stats, batch, channels, frames, ld, eps, dtype, stream);
+        if (rc != NBASR_OK) return rc;
+    }
+    const dim3 grid((nq + 15) / 16, batch);
+    unsigned char* img = static_cast<unsigned char*>(image);
+#define NBASR_IMG(T, NORM) hipLaunchKernelGGL((bf16_image_kernel<T, NORM>), grid, dim3(256), 0, as_stream(stream), static_cast<const T*>(x), \
+                                              stats, gamma, beta, img, channels, frames, ld)
+    if (dtype == NBASR_BF16) { if (norm) NBASR_IMG(bf16_t, true); else NBASR_IMG(bf16_t, false); }
+    else                     { if (norm) NBASR_IMG(float, true); else NBASR_IMG(float, false); }
+#undef NBASR_IMG
+    return launch_status("nbasr_bf16_image");
+}
+
+// element-wise storage conversion of a pitched (rows, ld) tensor (ld % 8 == 0): the bridge between the bf16 encoder and the
+// operators that exist in fp32 only
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void convert_kernel(const TI* __restrict__ x, TO* __restrict__ y, size_t n8)
+{
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n8; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
+        float v[8];
+        load_frames<8>(x + i * 8, v);
+        store_frames<8, false>(y + i * 8, v);
+    }
+}
+
+extern "C" int nbasr_convert(const void* x, void* y, long long n, int in_dtype, int out_dtype, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(n >= 0 && n % 8 == 0, NBASR_EINVAL, "nbasr_convert: n=%lld must be a non-negative multiple of 8", n);
+    NBASR_REQUIRE((in_dtype == NBASR_F32 && out_dtype == NBASR_BF16) || (in_dtype == NBASR_BF16 && out_dtype == NBASR_F32), NBASR_EINVAL,
+                  "nbasr_convert: conversions are f32 -> bf16 and bf16 -> f32");
+    if (n == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && y, NBASR_ENULL, "nbasr_convert: NULL pointer");
+    NBASR_REQUIRE(aligned16(x) && aligned16(y), NBASR_EALIGN, "nbasr_convert: pointers must be 16-byte aligned");
+    const size_t n8 = static_cast<size_t>(n / 8);
+    const unsigned blocks = static_cast<unsigned>(n8 / 256 + 1 < 8192 ? n8 / 256 + 1 : 8192);
+    if (in_dtype == NBASR_F32)
+        hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const float*>(x), static_cast<bf16_t*>(y), n8);
+    else
+        hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const bf16_t*>(x), static_cast<float*>(y), n8);
+    return launch_status("nbasr_convert");
 }

@@ -371,10 +371,16 @@ class ForwardPlan:
         from .ops import PadConvRelu
         import torch.nn as nn
 
-        if x.dtype != torch.float32:
-            raise hip.HipError(f'input must be float32 (got {x.dtype})')
         if x.device != self.device:
             raise hip.HipError(f'input on {x.device}, plan on {self.device}')
+        wdtype = next(model.parameters()).dtype
+        if x.dtype != wdtype:
+            raise hip.HipError(f'input is {x.dtype} but the model\'s parameters are {wdtype}: cast one of them '
+                               f'(model.to(torch.bfloat16) / x.bfloat16() for the bf16 path)')
+        if x.dtype == torch.bfloat16:
+            return self._run_bf16(model, x.detach().contiguous(), taps, pipelined, _capturing)
+        if x.dtype != torch.float32:
+            raise hip.HipError(f'input must be float32 or bfloat16 (got {x.dtype})')
         x = x.detach().contiguous()
         pipe = bool(pipelined) and model.use_rnn and taps is None
         if not pipe and not _capturing:
@@ -528,6 +534,228 @@ class ForwardPlan:
             tail_ctx.__exit__(None, None, None)
             self.tail_done[pipe_k] = done
         if idx != n_layers - 1 or logits is None:
+            raise RuntimeError('the model list does not end in the CTC head')
+        if pipelined:
+            return PendingLogits(logits, self.tail_done[pipe_k] if tail_ctx is not None else None)
+        if taps is not None:
+            taps[len(model.model) - 1] = logits.clone()
+        return logits
+
+    # ---- bf16 storage path (BASELINE config 4) ----------------------------------------------------------------------------
+    def _f32(self, param):
+        """fp32 copy of a (bf16) parameter, rebuilt when it changes: the kernels read weights of the node ops, biases,
+        gamma / beta and the LSTM / head matrices as fp32 whatever the storage type of the activations (exact: every bf16
+        value is an fp32 value)."""
+        if param.dtype == torch.float32:
+            return param.detach()
+        return self._cached(param, 'f32', lambda: param.detach().float().contiguous())
+
+    def _view16(self, idx, channels, frames):
+        ld = hip.row_pitch(frames, torch.bfloat16)
+        return self.pool16[idx][: self.batch * channels * ld].view(self.batch, channels, ld)
+
+    def _run_bf16(self, model, x, taps, pipelined, capturing):
+        """The forward with activations and GEMM operands STORED as bfloat16 (what `model.to(torch.bfloat16)(x.bfloat16())`
+        is in the reference): dense convs as one bf16 MFMA per product on a producer-written operand image, node ops /
+        LayerNorm reading and writing bf16 rows (half the HBM bytes) with fp32 arithmetic and ONE rounding per tensor,
+        LayerNorm statistics, LSTM gates / state and the head in fp32; logits returned as bfloat16."""
+        from .model import SearchCell, FILTERS, LSTM_HIDDEN
+        from .ops import PadConvRelu, Linear, Zero, Identity
+        import torch.nn as nn
+        bf16 = torch.bfloat16
+        pipe = bool(pipelined) and model.use_rnn and taps is None
+        if not pipe and not capturing:
+            self.wait_tails()
+        self._set_shape(x.shape[0], x.shape[2], model.use_rnn)
+        B = self.batch
+        lds = [hip.row_pitch(t, bf16) for t in self.block_frames]
+        elems = max(B * c * ld for c, ld in zip(FILTERS, lds))
+        self.pool16 = [self._buf(f'pool16_{i}', elems, bf16) for i in range(4)]
+        variant = int(os.environ.get('NBASR_GC_BF16_VARIANT', str(hip.GC_FPL8 | hip.GC_WPERM)))
+        lib = hip.load_library()
+
+        def image_of(act, frames, norm=None, stats=None, eps=0.0):
+            b, c, ld = act.shape
+            img = self._buf('image16', max(lib.nbasr_bf16_image_bytes(b, c, ld), 16), torch.uint8)
+            return hip.bf16_image(act, img, frames, norm, stats, eps)
+
+        def grouped_weight(op):
+            w = op.conv.weight
+            if variant & hip.GC_WPERM:
+                return self._cached(w, 'gc_wperm', lambda: hip.pack_grouped_weights(self._f32(w).contiguous(), op.groups))
+            return self._f32(w)
+
+        # model input -> pitched bf16 rows (whole 16-byte chunks)
+        act, act_frames, cur = x, self.frames, None
+        if x.shape[-1] % 8 or x.data_ptr() % 16:
+            cur = 2
+            act = hip.repitch_v(x, self._view16(cur, x.shape[1], self.frames), self.frames)
+        pending, image = None, None            # deferred LayerNorm of `act` / operand image holding (the LayerNorm of) `act`
+        self._stat_turn = 0
+        pipe_k, tail_ctx, logits = None, None, None
+        blk, n_layers = -1, len(model.model)
+        act_is_f32 = False                     # set once the encoder output has been handed over to the fp32 tail
+        for idx, layer in enumerate(model.model):
+            nxt = model.model[idx + 1] if idx + 1 < n_layers else None
+            if isinstance(layer, PadConvRelu):
+                blk += 1
+                if pending is not None:
+                    raise RuntimeError('a dense convolution cannot take a deferred LayerNorm in the bf16 path')
+                if image is None:
+                    image = image_of(act, act_frames)
+                dst = 0 if cur != 0 else 1
+                t_out = self.block_frames[blk]
+                out = self._view16(dst, layer.conv.out_channels, t_out)
+                rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out)
+                w = layer.conv.weight
+                packed = self._cached(w, ('bf16', rows, layer.strides),
+                                      lambda: hip.pack_dense_weights_bf16(self._f32(w), layer.strides, rows))
+                bias, src_shape, img_now, frames_now = self._f32(layer.conv.bias), act.shape, image, act_frames
+                self.dense_schemes[blk] = 'bf16'
+                self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
+                            lambda: hip.dense_conv1d_bf16_img(img_now, B, src_shape[1], frames_now, src_shape[2], packed,
+                                                              layer.conv.out_channels, layer.kernel_size, bias, out, layer.strides, rows))
+                act, act_frames, cur, image = out, t_out, dst, None
+                if taps is not None:
+                    taps[idx] = act[:, :, :act_frames].clone()
+            elif isinstance(layer, (nn.LayerNorm, SearchCell)):
+                if isinstance(layer, SearchCell):
+                    free = [i for i in range(4) if i != cur]
+                    if len(layer.nodes) > len(free):
+                        raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
+                    last_op = layer.nodes[-1].op
+                    norm = layer.norm_layer if layer.use_norm else None
+                    epilogue_stats = (self.epilogue_stats and norm is not None and self._cheap_consumer(nxt)
+                                      and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
+                    outs = [act]
+                    for j, (node, dst) in enumerate(zip(layer.nodes, free)):
+                        if len(outs) != len(node.branch_ops):
+                            raise AssertionError('Branch op and input list have different lenghts')
+                        skips = [src for br, src in zip(node.branch_ops, outs) if isinstance(br, Identity)]
+                        n_skips = len(skips)
+                        on_x = pending is not None and len(outs) == 1
+                        on_s0 = pending is not None and isinstance(node.branch_ops[0], Identity)
+                        ln = pending if (on_x or on_s0) else None
+                        view, op, last = self._view16(dst, layer.filters, act_frames), node.op, outs[-1]
+                        meta = (blk, layer.filters, layer.filters, getattr(op, 'kernel_size', 1), act_frames, n_skips)
+                        if isinstance(op, PadConvRelu):
+                            ws = self.stats_ws if (epilogue_stats and j == len(layer.nodes) - 1) else None
+                            wt, bs = grouped_weight(op), self._f32(op.conv.bias)
+                            self._timed('grouped_conv', meta, lambda: hip.grouped_conv1d_node(
+                                last, wt, bs, skips, view, act_frames, op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, ws, variant))
+                        elif isinstance(op, Zero):
+                            self._timed('skip_sum', meta, lambda: hip.skip_sum_v(skips, view, act_frames, ln if on_s0 else None, on_s0))
+                        elif isinstance(op, Linear):
+                            raise NotImplementedError('the `linear` node op has no bf16 kernel yet (BASELINE config 4 does not use it); '
+                                                      'run this architecture in float32')
+                        else:
+                            raise TypeError(f'unsupported node operation {type(op).__name__}')
+                        outs.append(view)
+                    act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
+                else:
+                    norm, epilogue_stats = layer, False
+                    if act.dim() != 3 or pending is not None:
+                        raise RuntimeError('LayerNorm in an unexpected position of the layer list')
+                feeds_tail = isinstance(nxt, (nn.Dropout, nn.LSTM, nn.Linear))
+                meta = (blk, act.shape[1], act.shape[1], 0, act_frames, 0)
+                if feeds_tail:
+                    # hand-over to the fp32 tail (LSTM projection / head): the last LayerNorm writes fp32
+                    b, c, ld = act.shape
+                    if pipe:
+                        pipe_k, enc = self._pipeline_buffers(c, ld)           # fp32 (B, C, ld) double buffer
+                    else:
+                        enc = self._buf('enc32', b * c * ld)[: b * c * ld].view(b, c, ld)
+                    src = act
+                    if norm is not None:
+                        g32, b32 = self._f32(norm.weight), self._f32(norm.bias)
+                        self._timed('layernorm', meta, lambda: hip.layernorm_channels_v(src, g32, b32, enc, act_frames, norm.eps))
+                    else:
+                        hip.convert(src, enc)
+                    act, cur, act_is_f32 = enc, None, True
+                    if taps is not None:
+                        taps[idx] = act[:, :, :act_frames].clone()
+                elif norm is None:
+                    if taps is not None:
+                        taps[idx] = act[:, :, :act_frames].clone()
+                else:
+                    g32, b32 = self._f32(norm.weight), self._f32(norm.bias)
+                    self._stat_turn ^= 1
+                    b, c, ld = act.shape
+                    stats = self.stats[self._stat_turn][: b * 2 * ld].view(b, 2, ld)
+                    src = act
+                    if isinstance(nxt, PadConvRelu):
+                        # the consumer is a dense conv: the LayerNorm writes its operand image (statistics on the way)
+                        self._timed('layernorm', meta, lambda: image_of(src, act_frames, (g32, b32), stats, norm.eps))
+                        image = self._bufs['image16']
+                        if taps is not None:
+                            copy = torch.empty_like(act)
+                            hip.layernorm_channels_v(act, g32, b32, copy, act_frames, norm.eps)
+                            taps[idx] = copy[:, :, :act_frames].clone()
+                    elif self._cheap_consumer(nxt) and self.ln_mode == 'deferred':
+                        if epilogue_stats:
+                            self._timed('stats_finalize', meta, lambda: hip.grouped_stats_finalize(self.stats_ws, stats, c, act_frames,
+                                                                                                 last_op.groups, norm.eps))
+                        else:
+                            self._timed('channel_stats', meta, lambda: hip.channel_stats_v(src, stats, act_frames, norm.eps))
+                        pending = (stats, g32, b32)
+                        if taps is not None:
+                            copy = torch.empty_like(act)
+                            hip.layernorm_channels_v(act, g32, b32, copy, act_frames, norm.eps)
+                            taps[idx] = copy[:, :, :act_frames].clone()
+                    else:
+                        self._timed('layernorm', meta, lambda: hip.layernorm_channels_v(src, g32, b32, src, act_frames, norm.eps))
+                        if taps is not None:
+                            taps[idx] = act[:, :, :act_frames].clone()
+            elif isinstance(layer, nn.Dropout):
+                if taps is not None:
+                    taps[idx] = taps[idx - 1]
+            elif isinstance(layer, nn.LSTM):
+                if not act_is_f32:
+                    raise RuntimeError('the LSTM expects the fp32 hand-over of the encoder output')
+                src, src_frames = act, act_frames
+                b_ih, b_hh = self._f32(layer.bias_ih_l0), self._f32(layer.bias_hh_l0)
+                gates = self.gates_pipe[pipe_k] if pipe else self.gates_ws
+                w_ih32, w_hh32 = self._f32(layer.weight_ih_l0), self._f32(layer.weight_hh_l0)
+                packed_ih = self._cached(layer.weight_ih_l0, 'pointwise', lambda: hip.pack_pointwise_weights(w_ih32))
+                ws = self._pointwise_ws(src.shape[1], src.shape[2])
+                self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                            lambda: hip.lstm_input_projection_packed(src, src_frames, packed_ih, b_ih, b_hh, gates, layer.hidden_size, ws, None))
+                if pipe:
+                    ready = torch.cuda.Event()
+                    ready.record(torch.cuda.current_stream(self.device))
+                    self.side_stream.wait_event(ready)
+                    tail_ctx = torch.cuda.stream(self.side_stream)
+                    tail_ctx.__enter__()
+                packed_hh = self._cached(layer.weight_hh_l0, 'whh', lambda: hip.lstm_pack_whh(w_hh32))
+                self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                            lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
+                act = self.h_out
+                if taps is not None:
+                    taps[idx] = act.permute(0, 2, 1).clone()
+            elif isinstance(layer, nn.Linear):
+                n = B * act_frames * layer.out_features
+                n8 = (n + 7) & ~7
+                logits32 = torch.empty(max(n8, 8), device=self.device, dtype=torch.float32)
+                l32 = logits32[:n].view(B, act_frames, layer.out_features)
+                w32, b32 = self._f32(layer.weight), self._f32(layer.bias)
+                if act is self.h_out:
+                    hip.linear_head(act, w32, b32, l32)
+                else:
+                    hip.linear_head_bct(act, act_frames, w32, b32, l32, None)
+                out16 = torch.empty(max(n8, 8), device=self.device, dtype=bf16)
+                if n8 > n:
+                    logits32[n:].zero_()
+                hip.convert(logits32, out16)
+                logits = out16[:n].view(B, act_frames, layer.out_features)
+                act = logits
+            else:
+                raise TypeError(f'unsupported layer {type(layer).__name__} in the model list')
+        if tail_ctx is not None:
+            done = torch.cuda.Event()
+            done.record(self.side_stream)
+            tail_ctx.__exit__(None, None, None)
+            self.tail_done[pipe_k] = done
+        if logits is None:
             raise RuntimeError('the model list does not end in the CTC head')
         if pipelined:
             return PendingLogits(logits, self.tail_done[pipe_k] if tail_ctx is not None else None)

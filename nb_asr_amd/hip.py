@@ -91,7 +91,23 @@ SIGNATURES = {
     'nbasr_token_error_counts': (_c_int, [_c_float_p, _c_float_p, _c_int, _c_float_p, _c_float_p, _c_int, _c_float_p, _c_int, _c_int,
                                           _c_float_p, _c_int, _c_stream]),
     'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    # storage-type generic / bf16 path
+    'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
+    'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_skip_sum_v': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_repitch_v': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_channel_stats_v': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
+    'nbasr_layernorm_channels_v': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_int, _c_stream]),
+    'nbasr_convert': (_c_int, [_c_float_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_stream]),
+    'nbasr_bf16_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_bf16_image': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
+    'nbasr_packed_dense_weights_bytes_bf16': (ctypes.c_size_t, [_c_int] * 4),
+    'nbasr_pack_dense_weights_bf16': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_dense_conv1d_bf16_img': (_c_int, [_c_float_p] * 4 + [_c_int] * 9 + [_c_stream]),
 }
+
+F32, BF16 = 0, 1                 # NBASR_F32 / NBASR_BF16
+GC_FPL8, GC_WPERM = 1, 2         # NBASR_GC_* variant bits of nbasr_grouped_conv1d_node
 
 
 class HipError(RuntimeError):
@@ -153,6 +169,35 @@ def _dev(t, name):
 
 def _opt(t, name):
     return None if t is None else _dev(t, name)
+
+
+def dtype_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise HipError(f'activations must be float32 or bfloat16 (got {dtype})')
+
+
+def row_pitch(frames, dtype=torch.float32):
+    """Row pitch of an activation tensor: whole 16-byte chunks (4 fp32 / 8 bf16 frames)."""
+    return (frames + 7) & ~7 if dtype == torch.bfloat16 else (frames + 3) & ~3
+
+
+def _act(t, name, dtype=None):
+    """Device pointer of an activation tensor of either storage type (float32 / bfloat16), contiguous."""
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise HipError(f'{name} must be a tensor on a HIP device (got {getattr(t, "device", type(t))}); '
+                       f'this package has no CPU path')
+    if t.dtype not in (torch.float32, torch.bfloat16) or (dtype is not None and t.dtype != dtype):
+        raise HipError(f'{name} must be {dtype or "float32 or bfloat16"} (got {t.dtype})')
+    if not t.is_contiguous():
+        raise HipError(f'{name} must be contiguous')
+    return t.data_ptr()
+
+
+def _act_opt(t, name, dtype):
+    return None if t is None else _act(t, name, dtype)
 
 
 def _ln(ln):
@@ -637,3 +682,113 @@ def ctc_loss_grad(log_probs, lengths, targets, target_lengths, blank=0):
                                    _stream(log_probs)), 'nbasr_ctc_loss_grad')
     return losses, grad
 
+
+# ---------------------------------------------------------------------------------------------
+# storage-type generic entry points (float32 | bfloat16 activations; SURVEY 8 row g1 / BASELINE config 4)
+# ---------------------------------------------------------------------------------------------
+def pack_grouped_weights(weight, groups):
+    """(C, C/groups, k) fp32 weight -> [group][ci][tap][co] copy for the GC_WPERM kernel variants."""
+    c, cg, k = weight.shape
+    packed = torch.empty_like(weight)
+    _check(load_library().nbasr_pack_grouped_weights(_dev(weight, 'weight'), _dev(packed, 'packed'), c, groups, k, _stream(weight)),
+           'nbasr_pack_grouped_weights')
+    return packed
+
+
+def grouped_conv1d_node(x, weight, bias, skips, y, frames, groups, kernel, dilation, ln=None, ln_on_x=False, ln_on_skip0=False,
+                        stats_ws=None, variant=0):
+    """The grouped-conv node op for float32 or bfloat16 activations; ``weight`` / ``bias`` are float32 (``weight`` in the
+    layout the variant wants: torch's, or pack_grouped_weights' for GC_WPERM)."""
+    b, c, ld = x.shape
+    dt = x.dtype
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_grouped_conv1d_node(
+        _act(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _act_opt(s[0], 'skip0', dt), _act_opt(s[1], 'skip1', dt),
+        _act_opt(s[2], 'skip2', dt), _act(y, 'y', dt), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
+        int(ln_on_skip0), _opt(stats_ws, 'stats_ws'), dtype_code(dt), variant, _stream(x)), 'nbasr_grouped_conv1d_node')
+    return y
+
+
+def skip_sum_v(skips, y, frames, ln=None, ln_on_skip0=False):
+    b, c, ld = y.shape
+    dt = y.dtype
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_skip_sum_v(_act_opt(s[0], 'skip0', dt), _act_opt(s[1], 'skip1', dt), _act_opt(s[2], 'skip2', dt),
+                                           _act(y, 'y'), b, c, frames, ld, _ln(ln), int(ln_on_skip0), dtype_code(dt), _stream(y)),
+           'nbasr_skip_sum_v')
+    return y
+
+
+def repitch_v(src, dst, frames):
+    rows = src.numel() // src.shape[-1]
+    _check(load_library().nbasr_repitch_v(_act(src, 'src'), _act(dst, 'dst', src.dtype), rows, frames, src.shape[-1], dst.shape[-1],
+                                          dtype_code(src.dtype), _stream(src)), 'nbasr_repitch_v')
+    return dst
+
+
+def channel_stats_v(x, stats, frames, eps):
+    b, c, ld = x.shape
+    _check(load_library().nbasr_channel_stats_v(_act(x, 'x'), _dev(stats, 'stats'), b, c, frames, ld, float(eps), dtype_code(x.dtype),
+                                                _stream(x)), 'nbasr_channel_stats_v')
+    return stats
+
+
+def layernorm_channels_v(x, gamma, beta, y, frames, eps):
+    """LayerNorm over channels; y may be float32 for a bfloat16 x (the hand-off to the fp32 LSTM)."""
+    b, c, ld = x.shape
+    _check(load_library().nbasr_layernorm_channels_v(_act(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'), _act(y, 'y'), b, c, frames,
+                                                     ld, float(eps), dtype_code(x.dtype), dtype_code(y.dtype), _stream(x)),
+           'nbasr_layernorm_channels_v')
+    return y
+
+
+def convert(x, y):
+    """Storage conversion float32 <-> bfloat16 of equally shaped contiguous tensors (numel % 8 == 0)."""
+    if x.shape != y.shape:
+        raise HipError('convert: shapes differ')
+    _check(load_library().nbasr_convert(_act(x, 'x'), _act(y, 'y'), x.numel(), dtype_code(x.dtype), dtype_code(y.dtype), _stream(x)),
+           'nbasr_convert')
+    return y
+
+
+def bf16_image_bytes(batch, channels, ld):
+    return load_library().nbasr_bf16_image_bytes(batch, channels, ld)
+
+
+def bf16_image(x, image, frames, norm=None, stats=None, eps=0.0):
+    """Operand image of the bf16 dense conv from x (B, C, ld); ``norm`` = (gamma, beta): image of LayerNorm(x), ``stats`` filled."""
+    b, c, ld = x.shape
+    if image.dtype != torch.uint8 or image.numel() < bf16_image_bytes(b, c, ld):
+        raise HipError('image buffer too small: needs bf16_image_bytes(batch, channels, ld) bytes of uint8')
+    gamma, beta = norm if norm is not None else (None, None)
+    _check(load_library().nbasr_bf16_image(_act(x, 'x'), _opt(gamma, 'gamma'), _opt(beta, 'beta'), _opt(stats, 'stats'),
+                                           image.data_ptr(), b, c, frames, ld, float(eps), dtype_code(x.dtype), _stream(x)),
+           'nbasr_bf16_image')
+    return image
+
+
+def pack_dense_weights_bf16(weight, stride, row_tile=128):
+    """(c_out, c_in, 8) fp32 weight (the values of a bf16 parameter) -> packed one-term bf16 image of the stride-`stride` kernel."""
+    lib = load_library()
+    c_out, c_in, kernel = weight.shape
+    nbytes = lib.nbasr_packed_dense_weights_bytes_bf16(c_out, c_in, kernel, row_tile)
+    if nbytes == 0:
+        raise HipError(f'bf16 dense path does not cover weight shape {tuple(weight.shape)} with row_tile={row_tile}')
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _check(lib.nbasr_pack_dense_weights_bf16(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride, row_tile,
+                                             _stream(weight)), 'nbasr_pack_dense_weights_bf16')
+    packed.nbasr_row_tile = row_tile
+    return packed
+
+
+def dense_conv1d_bf16_img(image, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride, row_tile=128):
+    lib = load_library()
+    if packed.numel() != lib.nbasr_packed_dense_weights_bytes_bf16(c_out, c_in, kernel, row_tile) or \
+            getattr(packed, 'nbasr_row_tile', 128) != row_tile:
+        raise HipError(f'packed weights are not a bf16 image of a ({c_out}, {c_in}, {kernel}) weight for row_tile={row_tile}')
+    if image.numel() < lib.nbasr_bf16_image_bytes(batch, c_in, ld_in):
+        raise HipError('image buffer too small for (batch, c_in, ld_in)')
+    _check(lib.nbasr_dense_conv1d_bf16_img(image.data_ptr(), packed.data_ptr(), _dev(bias, 'bias'), _act(y, 'y', torch.bfloat16), batch,
+                                           c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride, row_tile, _stream(y)),
+           'nbasr_dense_conv1d_bf16_img')
+    return y

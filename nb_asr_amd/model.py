@@ -118,7 +118,7 @@ class ASRModel(nn.Module):
                          dropout_rate=self.dropout_rate)
         clone.load_state_dict(self.state_dict(), strict=False)
         ref = next(self.parameters())
-        clone.to(ref.device)
+        clone.to(device=ref.device, dtype=ref.dtype)
         clone.train()
         return clone
 

@@ -4,9 +4,12 @@ Nothing in the product package (``nb_asr_amd``) imports this file: it is the che
 ``tests/``, by ``__graft_entry__.smoke()`` and by the ``cpu_baseline`` leg of ``bench.py``.
 
 It restates, as plain functions over a ``state_dict``-like mapping of tensors, the arithmetic
-of the reference's PyTorch model (floating point, so the restatement is written with torch CPU
-ops in a caller-chosen dtype: float32 reproduces the reference's own op sequence, float64 gives
-a "truth" to measure both against):
+of the reference's PyTorch model.  The arithmetic of this path lives in ATen, so
+the restatement issues THE SAME ATen calls the reference's modules make -- ``F.pad`` + ``F.conv1d``,
+``F.linear``, ``F.layer_norm`` on the permuted tensor, the fused ``lstm`` op behind ``nn.LSTM`` --
+in a caller-chosen dtype: float32 reproduces the reference's outputs (bit for bit for every op
+but the multi-threaded reductions), bfloat16 reproduces ``model.to(torch.bfloat16)``, float64
+gives a "truth" to measure both against:
 
 * ``pad_amounts``        -- reference ``nasbench_asr/model/torch/ops.py:12-17``
 * ``pad_conv_relu``      -- ``ops.py:24-30``   (zero pad -> conv1d -> relu -> min(.,20))
@@ -69,16 +72,15 @@ def pad_conv_relu(x, weight, bias, dilation, stride, groups):
 
 
 def linear_relu(x, weight, bias):
-    """x: (B, C, T); the same (C_out, C_in) matrix applied to every frame."""
-    y = torch.einsum('oc,bct->bot', weight, x) + bias.view(1, -1, 1)
-    return torch.clamp(torch.relu(y), max=CLAMP)
+    """x: (B, C, T); the same (C_out, C_in) matrix applied to every frame: permute -> nn.Linear -> relu -> clamp -> permute
+    (ops.py:42-50)."""
+    y = F.linear(x.permute(0, 2, 1), weight, bias)
+    return torch.clamp(torch.relu(y), max=CLAMP).permute(0, 2, 1)
 
 
 def layer_norm_channels(x, gamma, beta, eps=LN_EPS):
-    """LayerNorm over the channel dim of (B, C, T), biased variance."""
-    mean = x.mean(dim=1, keepdim=True)
-    var = ((x - mean) ** 2).mean(dim=1, keepdim=True)
-    return (x - mean) / torch.sqrt(var + eps) * gamma.view(1, -1, 1) + beta.view(1, -1, 1)
+    """LayerNorm over the channel dim of (B, C, T): permute -> nn.LayerNorm(C) -> permute (model.py:55-58, 125-128)."""
+    return F.layer_norm(x.permute(0, 2, 1), (x.shape[1],), gamma, beta, eps).permute(0, 2, 1)
 
 
 def node_forward(inputs, op_name, flags, params, prefix):
@@ -111,7 +113,19 @@ def cell_forward(x, arch_names, params, prefix, use_norm=True):
 
 
 def lstm_forward(x, w_ih, w_hh, b_ih, b_hh):
-    """x: (B, T, I) -> (B, T, H); single layer, zero initial state, gate order i, f, g, o."""
+    """x: (B, T, I) -> (B, T, H); single layer, zero initial state, gate order i, f, g, o: the ATen op nn.LSTM(batch_first=True)
+    calls (model.py:100, 118-121)."""
+    bsz, _, _ = x.shape
+    hidden = w_hh.shape[1]
+    if bsz == 0 or x.shape[1] == 0:
+        return x.new_zeros(bsz, x.shape[1], hidden)
+    zeros = x.new_zeros(1, bsz, hidden)
+    out, _, _ = torch._VF.lstm(x.contiguous(), (zeros, zeros), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, False, False, True)
+    return out
+
+
+def lstm_forward_loop(x, w_ih, w_hh, b_ih, b_hh):
+    """The same recurrence written out frame by frame (documents what the fused op computes; tests compare the two)."""
     bsz, steps, _ = x.shape
     hidden = w_hh.shape[1]
     xg = x @ w_ih.t() + (b_ih + b_hh)
@@ -124,7 +138,7 @@ def lstm_forward(x, w_ih, w_hh, b_ih, b_hh):
         c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(gg)
         h = torch.sigmoid(o) * torch.tanh(c)
         ys.append(h)
-    return torch.stack(ys, dim=1)
+    return torch.stack(ys, dim=1) if ys else x.new_zeros(bsz, 0, hidden)
 
 
 def arch_names(arch_vec):
@@ -169,7 +183,7 @@ def asr_forward(params, arch_vec, x, use_rnn=True, use_norm=True, dtype=torch.fl
             h = lstm_forward(h.permute(0, 2, 1), p[pre + 'weight_ih_l0'], p[pre + 'weight_hh_l0'],
                              p[pre + 'bias_ih_l0'], p[pre + 'bias_hh_l0']).permute(0, 2, 1)
         elif kind == 'head':
-            h = h.permute(0, 2, 1) @ p[pre + 'weight'].t() + p[pre + 'bias']
+            h = F.linear(h.permute(0, 2, 1), p[pre + 'weight'], p[pre + 'bias'])
         if taps is not None:
             taps[idx] = h
     return h

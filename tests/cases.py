@@ -23,7 +23,15 @@ MODEL_CASES = [
     ('M_lively_b2_t40_nornn', ARCH_M, False, 'lively', 2, 40),
     ('M_lively_b1_t90', ARCH_M, True, 'lively', 1, 90),
 ]
-N_SAMPLES = 16
+N_SAMPLES = 256
+
+BF16_CASES = [
+    # tag, arch, use_rnn, init mode, batch, frames  (tests/golden/bf16_fixtures.npz)
+    ('D_lively_b2_t200', ARCH_D, True, 'lively', 2, 200),
+    ('D_xavier_b1_t131', ARCH_D, True, 'xavier', 1, 131),
+    ('A_lively_b1_t160', ARCH_A, True, 'lively', 1, 160),
+    ('Z_lively_b2_t90_nornn', [[1, 1], [5, 1, 0], [4, 0, 1, 1]], False, 'lively', 2, 90),
+]
 
 GCONV_CASES = [(cg, k, d) for cg in (6, 8, 10, 12) for k, d in ((5, 1), (5, 2), (7, 1), (7, 2))]
 GCONV100_CASES = [('conv5', 600, 5, 1), ('conv5d2', 800, 5, 2), ('conv7', 1000, 7, 1), ('conv7d2', 1200, 7, 2)]
@@ -86,3 +94,47 @@ def worst_ratio(got, want, rtol, atol):
     want = torch.as_tensor(want).double().cpu()
     err = (got - want).abs()
     return float((err / (atol + rtol * want.abs())).max()) if err.numel() else 0.0
+
+
+# ---- the parity rule ("tighten parity to what can honestly be claimed") ---------------------------------------------
+# north star: logits within rtol 1e-4 / atol 1e-5 of the reference's CPU forward.  fp32 arithmetic itself is that noisy for
+# some fixtures (the reference's OWN distance to an fp64 evaluation of the same weights reaches 0.96 of the bound for the
+# 18-cell no-skip He-init model), so the rule has two legs and no free multiplier:
+#   quiet fixtures (reference-vs-fp64 < 0.4 of the bound): the north-star bound, un-relaxed;
+#   noisy fixtures: the HIP path must be no further from the fp64 evaluation than the reference is --
+#     RMS error <= 1.25 x the reference's, worst element <= 1.5 x the reference's worst (the maximum of ~10^4 heavy-tailed
+#     errors is itself only reproducible to a few tens of per cent; the RMS is the stable statistic).
+QUIET = 0.4
+
+
+def _rms(v):
+    v = torch.as_tensor(v).double()
+    return float(v.pow(2).mean().sqrt()) if v.numel() else 0.0
+
+
+def assert_parity(got, want, truth, what='', rtol=1e-4, atol=1e-5):
+    """`want` = the reference's (or the fp32 oracle's) output, `truth` = the fp64 evaluation of the same weights."""
+    got, want, truth = (torch.as_tensor(t).double().cpu() for t in (got, want, truth))
+    noise = worst_ratio(want, truth, rtol, atol)
+    ratio = worst_ratio(got, want, rtol, atol)
+    if noise < QUIET:
+        assert ratio <= 1.0, f'{what}: worst err/tol {ratio:.3f} vs the reference (its own fp32 noise floor: {noise:.3f})'
+        return ratio, noise
+    e_ref, e_got = want - truth, got - truth
+    assert _rms(e_got) <= 1.25 * _rms(e_ref), f'{what}: rms error vs fp64 {_rms(e_got):.3e}, reference {_rms(e_ref):.3e}'
+    worst = worst_ratio(got, truth, rtol, atol)
+    assert worst <= 1.5 * noise, f'{what}: worst err/tol vs fp64 {worst:.3f}, reference {noise:.3f}'
+    return ratio, noise
+
+
+def assert_layer_parity(got, ref, f64, scale, what='', tol=1e-4):
+    """Sampled values of one layer: within `tol` of the layer's scale of the reference where the reference itself is that
+    close to fp64; otherwise no further from fp64 than the reference (same two legs as assert_parity)."""
+    got, ref, f64 = (torch.as_tensor(t).double().cpu() for t in (got, ref, f64))
+    e_ref, e_got = (ref - f64).abs(), (got - f64).abs()
+    if float(e_ref.max()) < QUIET * tol * scale:
+        d = float((got - ref).abs().max())
+        assert d <= tol * scale, f'{what}: sample err {d:.3e} vs scale {scale:.3e}'
+    else:
+        assert _rms(e_got) <= 1.25 * _rms(e_ref) and float(e_got.max()) <= 1.5 * float(e_ref.max()), \
+            f'{what}: err vs fp64 rms {_rms(e_got):.3e} max {float(e_got.max()):.3e}; reference rms {_rms(e_ref):.3e} max {float(e_ref.max()):.3e}'

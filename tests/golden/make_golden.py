@@ -10,7 +10,9 @@ ONLY inputs-by-recipe + expected outputs are stored (no reference source text):
                             state_dict key digests, weight-generator digests
   ops_fixtures.npz          expected outputs of the reference's op / node / cell / LayerNorm / LSTM
                             modules on keyed inputs
-  model_fixtures.npz        full-model logits + per-layer statistics / samples
+  model_fixtures.npz        full-model logits + per-layer statistics / samples (reference fp32 AND an fp64 evaluation)
+  bf16_fixtures.npz         the reference model .to(torch.bfloat16) on bf16 inputs: logits + per-layer samples, next to an
+                            fp64 evaluation of the same bf16-rounded parameters (BASELINE config 4's arithmetic)
 
 While generating, the CPU oracle (oracle/asr_oracle.py) is checked against every reference output;
 the script aborts if the oracle deviates.  Usage:  python tests/golden/make_golden.py
@@ -249,7 +251,7 @@ MODEL_CASES = [
     ('M_lively_b2_t40_nornn', ARCH_M, False, 'lively', 2, 40),  # linear + zero ops, no LSTM
     ('M_lively_b1_t90', ARCH_M, True, 'lively', 1, 90),
 ]
-N_SAMPLES = 16
+N_SAMPLES = 256
 
 
 def sample_indices(tag, idx, numel):
@@ -276,18 +278,21 @@ def model_fixtures():
             h.remove()
         # normalise tap layouts to the oracle's: encoder layers (B,C,T); the model permutes around
         # LayerNorm / LSTM / Linear, so their raw hook outputs are (B,T,C)
-        otaps = {}
+        otaps, ttaps = {}, {}
         want = oracle.asr_forward(dict(m.state_dict()), arch, x, use_rnn=use_rnn, taps=otaps)
-        truth = oracle.asr_forward(dict(m.state_dict()), arch, x, use_rnn=use_rnn, dtype=torch.float64)
+        truth = oracle.asr_forward(dict(m.state_dict()), arch, x, use_rnn=use_rnn, dtype=torch.float64, taps=ttaps)
         # fp32 noise floor: how far the REFERENCE itself is from an fp64 evaluation of the same model,
         # in units of the north-star tolerance (rtol 1e-4 / atol 1e-5).  Stored with the fixture.
         _, ref_noise = err_ratio(logits, truth, 1e-4, 1e-5)
         print(f'  reference vs fp64 truth: worst err/tol {ref_noise:.3f}')
-        check(f'{tag}/logits', want, logits, rtol=1e-4, atol=1e-5, slack=max(1.0, 2.5 * ref_noise))
+        # the oracle issues the reference's own ATen calls: it must reproduce the reference to a small fraction of the
+        # tolerance (bit for bit except where multi-threaded reductions re-associate), with NO noise allowance
+        check(f'{tag}/logits', want, logits, rtol=1e-4, atol=1e-5, slack=0.05)
         fx[f'{tag}/logits_f64'] = truth.numpy()
         fx[f'{tag}/ref_noise_ratio'] = np.float64(ref_noise)
         stats = np.zeros((len(m.model), 3), dtype=np.float64)
         samples = np.zeros((len(m.model), N_SAMPLES), dtype=np.float32)
+        samples64 = np.zeros((len(m.model), N_SAMPLES), dtype=np.float64)
         for idx, layer in enumerate(m.model):
             ref_t = taps[idx]
             if isinstance(layer, (torch.nn.LayerNorm, torch.nn.LSTM)):
@@ -296,13 +301,80 @@ def model_fixtures():
                 ref_t = otaps[idx]
             ref_t = ref_t.contiguous()
             scale = float(ref_t.abs().max()) + 1e-30
-            check(f'{tag}/layer{idx}', otaps[idx] / scale, ref_t / scale, rtol=0.0, atol=1e-4)
+            check(f'{tag}/layer{idx}', otaps[idx] / scale, ref_t / scale, rtol=0.0, atol=1e-6)
             d = ref_t.double()
             stats[idx] = (float(d.mean()), float(d.std(unbiased=False)), float(d.abs().max()))
-            samples[idx] = ref_t.flatten()[torch.from_numpy(sample_indices(tag, idx, ref_t.numel()))].numpy()
+            sel = torch.from_numpy(sample_indices(tag, idx, ref_t.numel()))
+            samples[idx] = ref_t.flatten()[sel].numpy()
+            samples64[idx] = ttaps[idx].contiguous().flatten()[sel].numpy()
         fx[f'{tag}/logits'] = logits.numpy().astype(np.float32)
         fx[f'{tag}/layer_stats'] = stats
         fx[f'{tag}/layer_samples'] = samples
+        fx[f'{tag}/layer_samples_f64'] = samples64
+    return fx
+
+
+# ------------------------------------------------------------------------------------------------
+BF16_CASES = [
+    # tag, arch, use_rnn, init mode, batch, frames  (BASELINE config 4: the dense-skip architecture in bf16)
+    ('D_lively_b2_t200', ARCH_D, True, 'lively', 2, 200),
+    ('D_xavier_b1_t131', ARCH_D, True, 'xavier', 1, 131),       # odd frame count
+    ('A_lively_b1_t160', ARCH_A, True, 'lively', 1, 160),
+    ('Z_lively_b2_t90_nornn', [[1, 1], [5, 1, 0], [4, 0, 1, 1]], False, 'lively', 2, 90),   # conv5, zero, conv7d2; no LSTM
+]
+
+
+def bf16_fixtures():
+    """The reference model cast with ``.to(torch.bfloat16)`` on a bf16 input, against an fp64 evaluation of the SAME
+    (bf16-rounded) parameters and input: what the reference's bf16 arithmetic costs in accuracy, layer by layer."""
+    fx = {}
+    for tag, arch, use_rnn, mode, b, t in BF16_CASES:
+        print(f' bf16 case {tag}')
+        m = ref_nb.get_model(arch, use_rnn=use_rnn, dropout_rate=0.0, backend='torch').eval()
+        keyed_fill_(m, seed=1235, mode=mode)
+        m = m.to(torch.bfloat16)
+        x = keyed_input(b, t, seed=0).to(torch.bfloat16)
+        taps, hooks = {}, []
+        for idx, layer in enumerate(m.model):
+            def hook(_mod, _inp, out, idx=idx):
+                o = out[0] if isinstance(out, tuple) else out
+                taps[idx] = o.detach()
+            hooks.append(layer.register_forward_hook(hook))
+        logits = m(x)
+        for h in hooks:
+            h.remove()
+        assert logits.dtype == torch.bfloat16
+        params = dict(m.state_dict())                                   # bf16 tensors
+        otaps, ttaps = {}, {}
+        want = oracle.asr_forward(params, arch, x, use_rnn=use_rnn, dtype=torch.bfloat16, taps=otaps)
+        truth = oracle.asr_forward({k: v.double() for k, v in params.items()}, arch, x.double(), use_rnn=use_rnn, dtype=torch.float64,
+                                   taps=ttaps)
+        check(f'bf16/{tag}/logits (oracle in bf16 vs reference in bf16)', want.float(), logits.float(), rtol=0.0, atol=1e-9)
+        err = (logits.double() - truth)
+        rms = lambda v: float(v.double().pow(2).mean().sqrt())           # noqa: E731
+        print(f'  reference bf16 vs fp64: logits rms err {rms(err):.4e} of rms {rms(truth):.4e}, max {float(err.abs().max()):.4e}')
+        n_layers = len(m.model)
+        ref_s = np.zeros((n_layers, N_SAMPLES), dtype=np.float32)
+        tru_s = np.zeros((n_layers, N_SAMPLES), dtype=np.float64)
+        rel = np.zeros((n_layers, 2), dtype=np.float64)                  # rms(ref - truth), rms(truth) over the whole layer
+        for idx, layer in enumerate(m.model):
+            ref_t = taps[idx]
+            if isinstance(layer, (torch.nn.LayerNorm, torch.nn.LSTM)):
+                ref_t = ref_t.permute(0, 2, 1)
+            if isinstance(layer, torch.nn.Dropout):
+                ref_t = otaps[idx]
+            ref_t = ref_t.contiguous()
+            assert torch.equal(ref_t.float(), otaps[idx].contiguous().float()), f'bf16 oracle deviates from the reference at layer {idx}'
+            tr = ttaps[idx].contiguous()
+            sel = torch.from_numpy(sample_indices('bf16/' + tag, idx, ref_t.numel()))
+            ref_s[idx] = ref_t.float().flatten()[sel].numpy()
+            tru_s[idx] = tr.flatten()[sel].numpy()
+            rel[idx] = (rms(ref_t.double() - tr), rms(tr))
+        fx[f'{tag}/logits'] = logits.float().numpy()
+        fx[f'{tag}/logits_f64'] = truth.numpy()
+        fx[f'{tag}/layer_ref_samples'] = ref_s
+        fx[f'{tag}/layer_f64_samples'] = tru_s
+        fx[f'{tag}/layer_rms'] = rel
     return fx
 
 
@@ -314,5 +386,7 @@ if __name__ == '__main__':
     np.savez_compressed(HERE / 'ops_fixtures.npz', **op_fixtures())
     print('model fixtures ...')
     np.savez_compressed(HERE / 'model_fixtures.npz', **model_fixtures())
+    print('bf16 fixtures ...')
+    np.savez_compressed(HERE / 'bf16_fixtures.npz', **bf16_fixtures())
     for f in sorted(HERE.glob('*.*')):
         print(f'{f.name:32s} {f.stat().st_size:9d} bytes')

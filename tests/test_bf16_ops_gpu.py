@@ -1,0 +1,183 @@
+"""Storage-type generic kernels (fp32 | bf16 activations) and the kernel variants of the grouped-conv node op, through the C ABI.
+
+* every variant of `nbasr_grouped_conv1d_node` (4 / 8 frames per lane, torch / re-laid-out weights) gives BIT-IDENTICAL results
+  for a storage type: a variant is a launch geometry, never an arithmetic;
+* bf16 kernels = the fp32 arithmetic on bf16-rounded inputs, rounded once: checked against the fp32 oracle evaluated on the
+  same bf16-valued inputs, to one bf16 ulp (2^-8 relative) plus the fp32 tolerance.
+"""
+import pytest
+import torch
+
+from nb_asr_amd import hip
+from oracle import asr_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+BF = torch.bfloat16
+
+
+def pitched(t, dtype):
+    b, c, n = t.shape
+    ld = hip.row_pitch(n, dtype)
+    out = torch.zeros(b, c, ld, dtype=dtype, device=DEV)
+    out[:, :, :n] = t.to(dtype)
+    return out
+
+
+def node(x, w, bias, skips, k, d, groups, dtype, variant, ln=None, on_x=False, on_s0=False, frames=None):
+    frames = x.shape[2] if frames is None else frames
+    xp = pitched(x, dtype)
+    sp = [pitched(s, dtype) for s in skips]
+    y = torch.full_like(xp, 7.0)
+    wd = w.to(DEV).contiguous()
+    if variant & hip.GC_WPERM:
+        wd = hip.pack_grouped_weights(wd, groups)
+    hip.grouped_conv1d_node(xp, wd, bias.to(DEV), sp, y, frames, groups, k, d, ln, on_x, on_s0, None, variant)
+    torch.cuda.synchronize()
+    assert torch.all(y[:, :, frames:] == 0)
+    return y[:, :, :frames]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, BF])
+@pytest.mark.parametrize('cg', [6, 8, 10, 12])
+@pytest.mark.parametrize('k,d', [(5, 1), (5, 2), (7, 1), (7, 2)])
+def test_node_variants_are_bit_identical_and_match_the_oracle(dtype, cg, k, d):
+    torch.manual_seed(cg * 100 + k * 10 + d)
+    groups, b, t = 4, 3, 203
+    c = cg * groups
+    x = torch.randn(b, c, t).to(dtype).float()                 # bf16-representable inputs for both storage types
+    skips = [torch.randn(b, c, t).to(dtype).float() for _ in range(3)]
+    w = (torch.randn(c, cg, k) * 0.3).to(dtype).float()
+    bias = (torch.randn(c) * 0.2).to(dtype).float()
+    want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + skips[0] + skips[1] + skips[2]
+    outs = [node(x, w, bias, skips, k, d, groups, dtype, v) for v in range(4)]
+    for v in range(1, 4):
+        assert torch.equal(outs[v], outs[0]), f'variant {v} differs from variant 0'
+    got = outs[0].float().cpu()
+    tol = (2.0 ** -8 if dtype == BF else 0.0) * want.abs() + 2e-5 + 1e-5 * want.abs()
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, BF])
+@pytest.mark.parametrize('t', [1, 2, 7, 8, 9, 63, 64, 65, 255, 256, 257, 400, 1027])
+def test_node_ragged_lengths_and_flattened_lanes(dtype, t):
+    """Lanes are dealt over the flattened (utterance, chunk) index: utterance boundaries fall inside waves."""
+    torch.manual_seed(t)
+    groups, b, cg, k, d = 4, 5, 10, 7, 2
+    c = cg * groups
+    x = torch.randn(b, c, t).to(dtype).float()
+    w, bias = (torch.randn(c, cg, k) * 0.3).to(dtype).float(), torch.randn(c).to(dtype).float() * 0.2
+    want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + x
+    for v in (0, 3):
+        got = node(x, w, bias, [x], k, d, groups, dtype, v).float().cpu()
+        tol = (2.0 ** -8 if dtype == BF else 0.0) * want.abs() + 2e-5 + 1e-5 * want.abs()
+        assert bool(((got - want).abs() <= tol).all()), (v, float(((got - want).abs() / tol).max()))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, BF])
+def test_node_deferred_layernorm_and_epilogue_statistics(dtype):
+    """LayerNorm on load (main input and skip0) and the statistics by-product, for both storage types and every variant."""
+    torch.manual_seed(5)
+    groups, b, t, cg, k, d = 100, 2, 77, 6, 5, 1
+    c = cg * groups
+    x = (torch.randn(b, c, t) * 1.5 + 0.3).to(dtype).float()
+    gamma, beta = torch.rand(c) * 0.4 + 0.8, torch.randn(c) * 0.1
+    w, bias = (torch.randn(c, cg, k) * 0.3).to(dtype).float(), torch.randn(c).to(dtype).float() * 0.2
+    xn = oracle.layer_norm_channels(x, gamma, beta)
+    want = oracle.pad_conv_relu(xn, w, bias, d, 1, groups) + xn
+    xp = pitched(x, dtype)
+    ld = xp.shape[2]
+    stats = torch.empty(b, 2, ld, device=DEV)
+    hip.channel_stats_v(xp, stats, t, 1e-3)
+    ln = (stats, gamma.to(DEV), beta.to(DEV))
+    results = []
+    for v in range(4):
+        y = torch.empty_like(xp)
+        ws = hip.grouped_stats_workspace(b, ld, groups, DEV)
+        wd = w.to(DEV).contiguous()
+        if v & hip.GC_WPERM:
+            wd = hip.pack_grouped_weights(wd, groups)
+        hip.grouped_conv1d_node(xp, wd, bias.to(DEV), [xp], y, t, groups, k, d, ln, True, True, ws, v)
+        out_stats = torch.empty(b, 2, ld, device=DEV)
+        hip.grouped_stats_finalize(ws, out_stats, c, t, groups, 1e-3)
+        results.append((y[:, :, :t].clone(), out_stats[:, :, :t].clone()))
+    for y, st in results[1:]:
+        assert torch.equal(y, results[0][0]) and torch.allclose(st, results[0][1], rtol=1e-6, atol=1e-7)
+    got = results[0][0].float().cpu()
+    tol = (2.0 ** -8 if dtype == BF else 0.0) * want.abs() + 1e-4 + 1e-4 * want.abs()
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+    mean = want.mean(dim=1)
+    rstd = 1.0 / torch.sqrt(want.var(dim=1, unbiased=False) + 1e-3)
+    st = results[0][1].cpu()
+    assert torch.allclose(st[:, 0], mean, rtol=0, atol=(3e-3 if dtype == BF else 2e-5) * float(want.abs().max()))
+    assert torch.allclose(st[:, 1], rstd, rtol=2e-2 if dtype == BF else 1e-4, atol=0)
+
+
+@pytest.mark.parametrize('c,t', [(600, 19), (1200, 7), (24, 37), (800, 130)])
+def test_layernorm_bf16_storage(c, t):
+    torch.manual_seed(c + t)
+    x = (torch.randn(2, c, t) * 2 + 0.5).to(BF).float()
+    gamma, beta = torch.rand(c) * 0.6 + 0.7, torch.randn(c) * 0.2
+    want = oracle.layer_norm_channels(x, gamma, beta)
+    xp = pitched(x, BF)
+    y16, y32 = torch.full_like(xp, 3.0), torch.full(xp.shape, 3.0, device=DEV)
+    hip.layernorm_channels_v(xp, gamma.to(DEV), beta.to(DEV), y16, t, 1e-3)
+    hip.layernorm_channels_v(xp, gamma.to(DEV), beta.to(DEV), y32, t, 1e-3)
+    assert torch.all(y16[:, :, t:] == 0) and torch.all(y32[:, :, t:] == 0)
+    assert torch.allclose(y32[:, :, :t].cpu(), want, rtol=1e-5, atol=2e-5)                   # fp32 out: exact LayerNorm of the bf16 input
+    assert torch.equal(y16[:, :, :t].cpu(), y32[:, :, :t].cpu().to(BF))                      # bf16 out: the same, rounded once
+    stats = torch.empty(2, 2, xp.shape[2], device=DEV)
+    hip.channel_stats_v(xp, stats, t, 1e-3)
+    assert torch.allclose(stats[:, 0, :t].cpu(), x.mean(dim=1), atol=1e-5)
+    assert torch.all(stats[:, :, t:] == 0)
+
+
+@pytest.mark.parametrize('c_in,c_out,t,stride,rows', [(80, 600, 50, 1, 128), (600, 800, 300, 1, 160), (136, 200, 131, 2, 128),
+                                                       (800, 1000, 257, 2, 128), (1000, 1200, 64, 2, 160), (24, 40, 37, 1, 128)])
+@pytest.mark.parametrize('with_norm', [False, True])
+def test_dense_conv_bf16_image_path(c_in, c_out, t, stride, rows, with_norm):
+    """image (plain re-layout, or LayerNorm written as the operand) -> one-term bf16 MFMA GEMM -> bf16 rows."""
+    torch.manual_seed(c_in + t)
+    b = 2
+    x = torch.randn(b, c_in, t).to(BF).float()
+    w = (torch.randn(c_out, c_in, 8) * (2.0 / (c_in * 8)) ** 0.5).to(BF).float()
+    bias = (torch.randn(c_out) * 0.2).to(BF).float()
+    gamma, beta = torch.rand(c_in) * 0.4 + 0.8, torch.randn(c_in) * 0.1
+    xin = oracle.layer_norm_channels(x, gamma, beta) if with_norm else x
+    xin16 = xin.to(BF).float()                                   # the operand is rounded to bf16 when the image is written
+    want = oracle.pad_conv_relu(xin16, w, bias, 1, stride, 1)
+    xp = pitched(x, BF)
+    ld = xp.shape[2]
+    image = torch.empty(hip.bf16_image_bytes(b, c_in, ld), dtype=torch.uint8, device=DEV)
+    stats = torch.empty(b, 2, ld, device=DEV)
+    hip.bf16_image(xp, image, t, (gamma.to(DEV), beta.to(DEV)) if with_norm else None, stats if with_norm else None, 1e-3)
+    t_out = (t + stride - 1) // stride
+    y = torch.full((b, c_out, hip.row_pitch(t_out, BF)), 5.0, dtype=BF, device=DEV)
+    packed = hip.pack_dense_weights_bf16(w.to(DEV), stride, rows)
+    hip.dense_conv1d_bf16_img(image, b, c_in, t, ld, packed, c_out, 8, bias.to(DEV), y, stride, rows)
+    torch.cuda.synchronize()
+    assert torch.all(y[:, :, t_out:] == 0)
+    got = y[:, :, :t_out].float().cpu()
+    # the LayerNorm'd operand can round differently by one bf16 ulp where the fp32 value sits on a rounding boundary
+    tol = 2.0 ** -8 * want.abs() + (3e-2 if with_norm else 1e-4)
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+    assert float((got - want).abs().mean()) <= 2.0 ** -9 * float(want.abs().mean()) + (2e-3 if with_norm else 1e-5)
+
+
+def test_convert_and_skip_sum_and_repitch_bf16():
+    torch.manual_seed(0)
+    x = torch.randn(3, 24, 40, device=DEV)
+    y = torch.empty(3, 24, 40, dtype=BF, device=DEV)
+    hip.convert(x, y)
+    assert torch.equal(y, x.to(BF))
+    back = torch.empty_like(x)
+    hip.convert(y, back)
+    assert torch.equal(back, y.float())
+    s = [torch.randn(2, 16, 24, device=DEV).to(BF) for _ in range(3)]
+    out = torch.empty_like(s[0])
+    hip.skip_sum_v(s, out, 24)
+    assert torch.equal(out, (s[0].float() + s[1].float() + s[2].float()).to(BF))
+    src = torch.randn(2, 5, 13, device=DEV).to(BF)
+    dst = torch.full((2, 5, 16), 9.0, dtype=BF, device=DEV)
+    hip.repitch_v(src, dst, 13)
+    assert torch.equal(dst[:, :, :13], src) and torch.all(dst[:, :, 13:] == 0)
