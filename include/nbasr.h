@@ -376,6 +376,22 @@ int nbasr_power_spectrum(const float* spec, float* power, int batch, int bins, i
 int nbasr_log_normalize(const float* mel, const int* lengths, const float* mean, const float* inv_scale, float* feats,
                         int batch, int samples, int hop, int n_mels, int ld, nbasr_stream_t stream);
 
+/* ---- the model input: range summary and per-utterance routing ---------------------------------------------------------------
+ * The first dense convolution takes caller data, whose range this library does not control.  nbasr_input_range writes, per
+ * utterance, range[4 b] = { max finite |x|, the quietest non-silent frame's max |x| over channels, non-zero if any sample is
+ * Inf / NaN, unused } (x: (batch, channels, ld) fp32, any ld >= frames).  An utterance is EXTREME when it holds a non-finite
+ * sample or a frame more than 2^20 below its loudest sample: the scaled fp16 scheme would then lose precision in (or, for Inf,
+ * flush) the quiet part.  The two `_ranged` convolutions are launched back to back on the same output: the fp16 one computes
+ * the ordinary utterances (scale from range[4 b]) and skips the extreme ones, the 3-way bf16 one (fp32's exponent range, no
+ * scaling, NaN / Inf propagate like in the reference) computes exactly those.  No host synchronisation. */
+int nbasr_input_range(const float* x, float* range, int batch, int channels, int frames, int ld, nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_f16_ranged(const float* x, const float* x_range, const void* packed_w_f16, const float* bias,
+                                               float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
+                                               int kernel, int stride, nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_ranged(const float* x, const float* x_range, const void* packed_w_bf16x3, const float* bias,
+                                           float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
+                                           int kernel, int stride, nbasr_stream_t stream);
+
 /* ---- bf16 path (BASELINE config 4: activations and GEMM operands stored as bfloat16) ------------------------------------------
  * Mirrors `model.to(torch.bfloat16)(x.bfloat16())` of the reference (ops.py:24-30, model.py:116-131 run on bf16 tensors).
  * Storage is bf16, arithmetic is fp32, a tensor is rounded once when it is written; the `_v` entry points below are the

@@ -145,7 +145,14 @@ struct PackedConvArgs {
     const float* x_absmax;       // SCALED schemes: (batch) upper bounds of max|x[b]|
     const float* w_inv_scale;    // SCALED schemes: (n_mt * 128) 2^-kw[co], tail of the packed buffer
     int x_is_image;              // x points to the pre-split fp16 image (XIMG kernels)
+    // per-utterance routing on the device (the model input, nbasr_input_range): range[4 b] = {max|x|, quietest frame's max,
+    // non-finite flag, -}; a workgroup whose utterance is (not) extreme exits at once when sel_want is 0 (1); -1: no routing
+    const float* x_range;
+    int sel_want;
 };
+
+// an utterance the scaled fp16 scheme must not take: non-finite samples, or a frame > 2^20 below the loudest sample
+__device__ __forceinline__ bool range_is_extreme(const float* r) { return r[2] != 0.f || r[1] < r[0] * 9.5367431640625e-07f; }
 
 // 2^k that moves a magnitude with biased exponent field e to [2^target, 2^(target+1)), and its inverse; (1, 1) for zero
 __host__ __device__ inline void pow2_normaliser(float absmax, int target, float& scale, float& inv)
@@ -244,6 +251,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     const int b = rem / a.n_nt;
     const int nt_i = rem - b * a.n_nt;
     const int m0 = mt_i * PB_M, n0 = nt_i * PB_N;
+    if (a.x_range && a.sel_want >= 0 && static_cast<int>(range_is_extreme(a.x_range + 4 * b)) != a.sel_want) return;   // whole workgroup
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     // pitch columns frames_in..ld_in-1 are zero by the layout contract (nbasr.h) and their rstd is 0.
     const int a0 = tin0 & ~3, xoff = tin0 - a0;
     float x_scale = 1.f, x_inv = 1.f;                 // SCALED schemes: 2^kx[b] and its inverse (uniform over the workgroup)
-    if constexpr (P::SCALED) pow2_normaliser(a.x_absmax[b], 14, x_scale, x_inv);
+    if constexpr (P::SCALED) pow2_normaliser(a.x_range ? a.x_range[4 * b] : a.x_absmax[b], 14, x_scale, x_inv);
     auto load_x = [&](int g, int c) {
 #pragma unroll
         for (int i = 0; i < G::XI; ++i) {
@@ -693,7 +701,7 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
                              const float* skip1, const float* skip2, float* y, int batch, int c_in,
                              int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
                              const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream, bool x_is_image = false,
-                             int row_tile = 128)
+                             int row_tile = 128, const float* x_range = nullptr, int sel_want = -1)
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
@@ -717,8 +725,10 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
     a.lpad = pad_left(kernel, 1, stride); a.n_groups = (c_in + PB_CI - 1) / PB_CI; a.batch = batch;
     NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "%s: deferred LayerNorm needs stats, gamma and beta", P::NAME);
     a.ln_x = ln_ref(ln, true);
+    a.x_range = x_range;
+    a.sel_want = x_range ? sel_want : -1;
     if (P::SCALED) {
-        NBASR_REQUIRE(x_absmax, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
+        NBASR_REQUIRE(x_absmax || x_range, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
         a.x_absmax = x_absmax;
         a.x_is_image = x_is_image ? 1 : 0;
         a.w_inv_scale = reinterpret_cast<const float*>(a.wp + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * a.n_groups * pb_group_bytes<P>(mi))
@@ -847,4 +857,23 @@ extern "C" int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* pack
     hipStream_t s = as_stream(stream);
     if (mi == 5) return stride == 1 ? launch_image<P, 1, 5>(a, s) : launch_image<P, 2, 5>(a, s);
     return stride == 1 ? launch_image<P, 1, 4>(a, s) : launch_image<P, 2, 4>(a, s);
+}
+
+// ---- the model input: per-utterance routing between the two fp32-accurate schemes (nbasr_input_range) -------------------------
+extern "C" int nbasr_dense_conv1d_fused_packed_f16_ranged(const float* x, const float* x_range, const void* packed_w, const float* bias,
+                                                          float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
+                                                          int kernel, int stride, nbasr_stream_t stream)
+{
+    NBASR_REQUIRE(x_range, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_f16_ranged: x_range is NULL");
+    return dense_packed_impl<SplitF16x2>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                         kernel, stride, nullptr, nullptr, stream, false, 128, x_range, 0);
+}
+
+extern "C" int nbasr_dense_conv1d_fused_packed_ranged(const float* x, const float* x_range, const void* packed_w, const float* bias,
+                                                      float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
+                                                      int kernel, int stride, nbasr_stream_t stream)
+{
+    NBASR_REQUIRE(x_range, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_ranged: x_range is NULL");
+    return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                          kernel, stride, nullptr, nullptr, stream, false, 128, x_range, 1);
 }

@@ -394,6 +394,64 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if ((threadIdx.x & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
 }
 
+// Range summary of a caller-supplied tensor (the MODEL INPUT, the one activation whose range this library does not control):
+// range[b] = { max finite |x[b]|,  min over frames of (max over channels of |x[b, :, t]|) among frames where that is > 0,
+//              non-zero if x[b] holds an Inf or NaN,  unused }.
+// The scaled fp16 convolution keeps full fp32 precision for elements down to 2^-29 of the utterance's maximum; an utterance
+// whose quietest frame lies more than 2^20 below its loudest sample (or that holds non-finite values) is EXTREME and is
+// routed to the range-free 3-way bf16 split instead (nbasr_dense_conv1d_fused_packed_ranged), per utterance, on the device.
+__global__ __launch_bounds__(256) void input_range_kernel(const float* __restrict__ x, unsigned* __restrict__ range,
+                                                          int channels, int frames, int ld)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    float fmax_ = 0.f;
+    unsigned bad = 0u;
+    if (t < frames) {
+        const float* col = x + static_cast<size_t>(b) * channels * ld + t;
+        for (int c = 0; c < channels; ++c) {
+            const float v = col[static_cast<size_t>(c) * ld];
+            const float a = fabsf(v);
+            if (!(a <= 3.4028234664e38f)) bad = 1u;          // Inf or NaN
+            else fmax_ = fmaxf(fmax_, a);
+        }
+    }
+    float hi = fmax_, lo = (t < frames && fmax_ > 0.f) ? fmax_ : __uint_as_float(0x7f800000u);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        hi = fmaxf(hi, __shfl_xor(hi, d));
+        lo = fminf(lo, __shfl_xor(lo, d));
+        bad |= __shfl_xor(bad, d);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(range + 4 * b, __float_as_uint(hi));        // non-negative floats order like unsigned integers
+        atomicMin(range + 4 * b + 1, __float_as_uint(lo));
+        if (bad) atomicOr(range + 4 * b + 2, 0x3f800000u);     // 1.0f
+    }
+}
+
+__global__ void input_range_init_kernel(unsigned* __restrict__ range, int batch)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < batch) { range[4 * b] = 0u; range[4 * b + 1] = 0x7f800000u; range[4 * b + 2] = 0u; range[4 * b + 3] = 0u; }
+}
+
+extern "C" int nbasr_input_range(const float* x, float* range, int batch, int channels, int frames, int ld, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && ld >= frames, NBASR_EINVAL, "nbasr_input_range: bad sizes");
+    if (batch == 0) return NBASR_OK;
+    NBASR_REQUIRE(range, NBASR_ENULL, "nbasr_input_range: range is NULL");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_input_range: batch %d > 65535", batch);
+    hipLaunchKernelGGL(input_range_init_kernel, dim3((batch + 255) / 256), dim3(256), 0, as_stream(stream), reinterpret_cast<unsigned*>(range), batch);
+    if (frames > 0) {
+        NBASR_REQUIRE(x, NBASR_ENULL, "nbasr_input_range: x is NULL");
+        hipLaunchKernelGGL(input_range_kernel, dim3((frames + 255) / 256, batch), dim3(256), 0, as_stream(stream), x,
+                           reinterpret_cast<unsigned*>(range), channels, frames, ld);
+    }
+    return launch_status("nbasr_input_range");
+}
+
 extern "C" int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_stream_t stream)
 {
     clear_error();

@@ -167,9 +167,10 @@ class ForwardPlan:
             t = (t + s - 1) // s
             self.block_frames.append(t)
         self.out_frames = self.block_frames[-1]
-        stat_elems = max(batch * 2 * hip.round_up4(t) for t in self.block_frames)
+        pitch8 = lambda t: (t + 7) & ~7                  # noqa: E731  (bf16 rows are pitched to 8 frames: size for either storage type)
+        stat_elems = max(batch * 2 * pitch8(t) for t in self.block_frames)
         self.stats = [self._buf(f'stats{i}', stat_elems) for i in range(2)]
-        ws_bytes = hip.load_library().nbasr_grouped_stats_workspace_bytes(max(batch, 1), max(max(hip.round_up4(t) for t in self.block_frames), 4), 100)
+        ws_bytes = hip.load_library().nbasr_grouped_stats_workspace_bytes(max(batch, 1), max(max(pitch8(t) for t in self.block_frames), 8), 100)
         self.stats_ws = self._buf('stats_ws', ws_bytes // 4)
         elems = max(batch * c * hip.round_up4(t) for c, t in zip(FILTERS, self.block_frames))
         self.pool = [self._buf(f'pool{i}', elems) for i in range(4)]
@@ -373,7 +374,7 @@ class ForwardPlan:
 
         if x.device != self.device:
             raise hip.HipError(f'input on {x.device}, plan on {self.device}')
-        wdtype = next(model.parameters()).dtype
+        wdtype = model.model[0].conv.weight.dtype          # (not model.parameters(): a DataParallel replica has none)
         if x.dtype != wdtype:
             raise hip.HipError(f'input is {x.dtype} but the model\'s parameters are {wdtype}: cast one of them '
                                f'(model.to(torch.bfloat16) / x.bfloat16() for the bf16 path)')
@@ -395,9 +396,11 @@ class ForwardPlan:
         pending = None                                   # (stats, gamma, beta) when `act` still awaits its LayerNorm
         self._act_absmax = None                          # set by _norm when it wrote `act` together with max|act[b]|
         self._act_image = None                           # set by _norm when it wrote the LayerNorm of `act` as the conv's image
+        input_range = None
         if self.dense_mode == 'auto' and act.shape[0] > 0:
-            # the model input is unbounded: one small reduction gives the first conv its range, too
-            self._act_absmax = hip.absmax(act, self.absmax_in[: act.shape[0]])
+            # the model input is caller data: one small reduction gives the first conv its range AND decides, per utterance
+            # and on the device, whether that range is tame enough for the scaled fp16 scheme (nbasr.h: nbasr_input_range)
+            input_range = hip.input_range(act, act_frames, self._buf('input_range', 4 * act.shape[0])[: 4 * act.shape[0]])
         pipe_k, tail_ctx = None, None
         self._stat_turn = 0
         lin_ctx = (self._packed_linear, self._pointwise_ws) if self.linear_mode == 'f16x2' else None
@@ -411,8 +414,16 @@ class ForwardPlan:
                 t_out = self.block_frames[blk]
                 out = self._view(dst, layer.conv.out_channels, t_out)
                 ln, src, src_frames, amax, blk_now, img = pending, act, act_frames, self._act_absmax, blk, self._act_image
-                self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
-                            lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now, img))
+                meta = (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0)
+                if input_range is not None and layer.kernel_size == 8 and ln is None and img is None:
+                    rng, input_range = input_range, None
+                    self.dense_schemes[blk] = 'f16x2'       # with per-utterance fall-back to bf16x3 (extreme / non-finite input)
+                    self._timed('dense_conv', meta, lambda: hip.dense_conv1d_first_ranged(
+                        src, src_frames, rng, self._packed_weights(layer, 'f16x2'), self._packed_weights(layer, 'bf16x3'),
+                        layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out, layer.strides))
+                else:
+                    input_range = None
+                    self._timed('dense_conv', meta, lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now, img))
                 act, act_frames, cur, pending, self._act_absmax, self._act_image = out, t_out, dst, None, None, None
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)

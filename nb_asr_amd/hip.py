@@ -91,6 +91,9 @@ SIGNATURES = {
     'nbasr_token_error_counts': (_c_int, [_c_float_p, _c_float_p, _c_int, _c_float_p, _c_float_p, _c_int, _c_float_p, _c_int, _c_int,
                                           _c_float_p, _c_int, _c_stream]),
     'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_dense_conv1d_fused_packed_f16_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_dense_conv1d_fused_packed_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
     # storage-type generic / bf16 path
     'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
     'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
@@ -341,6 +344,31 @@ def absmax(x, out):
     b = x.shape[0]
     _check(load_library().nbasr_absmax(_dev(x, 'x'), _dev(out, 'absmax'), b, x.numel() // max(b, 1), _stream(x)), 'nbasr_absmax')
     return out
+
+
+def input_range(x, frames, out):
+    """out (B, 4) float32 <- per utterance (max finite |x|, quietest non-silent frame's max, non-finite flag, -); see nbasr.h."""
+    b, c, ld = x.shape
+    if out.numel() < 4 * b:
+        raise HipError('input_range: out needs 4 floats per utterance')
+    _check(load_library().nbasr_input_range(_dev(x, 'x'), _dev(out, 'range'), b, c, frames, ld, _stream(x)), 'nbasr_input_range')
+    return out
+
+
+def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride):
+    """The model's first dense conv with per-utterance routing on the device: ordinary utterances on the 2-way fp16 split,
+    extreme ones (non-finite samples, > 2^20 dynamic range between frames) on the 3-way bf16 split; same output tensor."""
+    lib = load_library()
+    b, c_in, ld_in = x.shape
+    if packed_f16.numel() != lib.nbasr_packed_dense_weights_bytes_f16(c_out, c_in, kernel) or \
+            packed_bf16x3.numel() != lib.nbasr_packed_dense_weights_bytes(c_out, c_in, kernel):
+        raise HipError('packed weights do not match the (c_out, c_in, kernel) of this convolution')
+    args = (_dev(bias, 'bias'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride, _stream(x))
+    _check(lib.nbasr_dense_conv1d_fused_packed_f16_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_f16.data_ptr(), *args),
+           'nbasr_dense_conv1d_fused_packed_f16_ranged')
+    _check(lib.nbasr_dense_conv1d_fused_packed_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_bf16x3.data_ptr(), *args),
+           'nbasr_dense_conv1d_fused_packed_ranged')
+    return y
 
 
 def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln_on_x=False, ln_on_skip0=False):

@@ -18,7 +18,7 @@ BF = torch.bfloat16
 
 def pitched(t, dtype):
     b, c, n = t.shape
-    ld = hip.row_pitch(n, dtype)
+    ld = hip.row_pitch(n, BF)                 # multiple of 8: the pitch every variant of either storage type accepts
     out = torch.zeros(b, c, ld, dtype=dtype, device=DEV)
     out[:, :, :n] = t.to(dtype)
     return out
