@@ -249,6 +249,8 @@ int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float
  * kernel floats), whose per-input-channel weights are contiguous for the scalar loads.  Results do not depend on the variant. */
 #define NBASR_GC_FPL8 1
 #define NBASR_GC_WPERM 2
+#define NBASR_GC_FPL2 4   /* fp32 only, not combinable with FPL8 / WPERM: 2 frames per lane (twice as many, half as heavy waves) */
+#define NBASR_GC_KEEP 8   /* any variant: plain instead of streaming (non-temporal) stores of y -- tensors that fit the last-level cache */
 int nbasr_grouped_conv1d_node(const void* x, const float* w, const float* bias,
                               const void* skip0, const void* skip1, const void* skip2, void* y,
                               int batch, int channels, int frames, int ld, int groups, int kernel, int dilation,

@@ -147,17 +147,20 @@ extern "C" size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int gro
 static int grouped_node_impl(const char* what, const void* x, const float* w, const float* bias, const void* skip0, const void* skip1,
                              const void* skip2, void* y, int batch, int channels, int frames, int ld, int groups, int kernel,
                              int dilation, const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, float* stats_ws, int dtype,
-                             int variant, nbasr_stream_t stream)
+                             int variant /* by value: the KEEP bit is peeled off below */, nbasr_stream_t stream)
 {
     NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "%s: dtype %d is neither NBASR_F32 nor NBASR_BF16", what, dtype);
-    NBASR_REQUIRE(variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM), NBASR_EINVAL, "%s: unknown variant %d", what, variant);
+    const int keep = (variant & NBASR_GC_KEEP) ? 1 : 0;
+    variant &= ~NBASR_GC_KEEP;
+    NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || (variant == NBASR_GC_FPL2 && dtype == NBASR_F32), NBASR_EINVAL,
+                  "%s: unknown variant %d", what, variant);
     NBASR_REQUIRE(aligned16(stats_ws), NBASR_EALIGN, "%s: statistics buffers must be 16-byte aligned", what);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "%s: bad sizes batch=%d channels=%d frames=%d groups=%d", what, batch, channels, frames, groups);
     if (batch == 0 || ld == 0) return NBASR_OK;      // empty batch: nothing to do (empty tensors have NULL storage)
     NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "%s: x, w, bias, y must be non-NULL", what);
     // a lane moves 16 bytes: 4 fp32 or 8 bf16 frames (8 fp32 frames as two accesses); rows are pitched to whole lanes
-    const int pitch = (dtype == NBASR_BF16 || (variant & NBASR_GC_FPL8)) ? 8 : 4;
+    const int pitch = (dtype == NBASR_BF16 || (variant != NBASR_GC_FPL2 && (variant & NBASR_GC_FPL8))) ? 8 : 4;
     NBASR_REQUIRE(ld >= frames && ld % pitch == 0, NBASR_EALIGN, "%s: ld=%d must be >= frames=%d and a multiple of %d", what, ld, frames, pitch);
     NBASR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
                   "%s: activation pointers must be 16-byte aligned", what);
@@ -169,11 +172,12 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
     hipStream_t s = as_stream(stream);
     if (dtype == NBASR_F32) {
         GroupedArgs<float> a{static_cast<const float*>(x), w, bias, static_cast<const float*>(skip0), static_cast<const float*>(skip1),
-                             static_cast<const float*>(skip2), static_cast<float*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws};
+                             static_cast<const float*>(skip2), static_cast<float*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws, keep};
+        if (variant == NBASR_GC_FPL2) return grouped_conv_f32_fpl2(a, kernel, dilation, s);
         return variant == 0 ? grouped_conv_f32_base(a, kernel, dilation, s) : grouped_conv_f32_alt(variant, a, kernel, dilation, s);
     }
     GroupedArgs<bf16_t> a{static_cast<const bf16_t*>(x), w, bias, static_cast<const bf16_t*>(skip0), static_cast<const bf16_t*>(skip1),
-                          static_cast<const bf16_t*>(skip2), static_cast<bf16_t*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws};
+                          static_cast<const bf16_t*>(skip2), static_cast<bf16_t*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws, keep};
     return grouped_conv_bf16(variant, a, kernel, dilation, s);
 }
 

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
     const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const T* __restrict__ s0, const T* __restrict__ s1, const T* __restrict__ s2,
     T* __restrict__ y, int batch, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0,
-    float* __restrict__ part)
+    float* __restrict__ part, int keep_in_cache)
 {
     constexpr int LPAD = pad_left(K, D, 1);
     constexpr int SPAN = (K - 1) * D;                   // taps reach frames [t - LPAD, t - LPAD + SPAN]
@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
 #pragma unroll
             for (int r = 0; r < FPL; ++r) if (t0 + r >= frames) o[r] = 0.f;
         }
-        store_frames<FPL, true>(y + off, o);
+        // streaming (non-temporal) stores by default: the next kernel reads y from HBM anyway when the tensor is larger than
+        // the 256 MiB last-level cache; `keep_in_cache` (small tensors: the narrow blocks) leaves it there for that reader
+        if (keep_in_cache) store_frames<FPL, false>(y + off, o); else store_frames<FPL, true>(y + off, o);
         if (STATS) {
 #pragma unroll
             for (int r = 0; r < FPL; ++r) acc[co][r] = o[r];         // keep the final values for the statistics
@@ -217,6 +219,7 @@ struct GroupedArgs {
     int batch, channels, frames, ld, groups;
     LnRef ln_x, ln_s0;
     float* part;                 // partial-statistics workspace (nullptr: no statistics)
+    int keep_in_cache;           // plain instead of non-temporal output stores
 };
 
 template <typename T, int FPL, bool WPERM, int CG, int K, int D>
@@ -226,7 +229,7 @@ static int launch_grouped(const GroupedArgs<T>& a, hipStream_t stream)
     dim3 grid(static_cast<unsigned>((items + 63) / 64), (a.groups + 3) / 4);
 #define NBASR_LAUNCH_GROUPED(LNX, STATS)                                                                                    \
     hipLaunchKernelGGL((grouped_conv_kernel<T, CG, K, D, LNX, STATS, FPL, WPERM>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, \
-                       a.s0, a.s1, a.s2, a.y, a.batch, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part)
+                       a.s0, a.s1, a.s2, a.y, a.batch, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part, a.keep_in_cache)
     if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
     else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
 #undef NBASR_LAUNCH_GROUPED
@@ -262,6 +265,7 @@ int grouped_conv_variant(const GroupedArgs<T>& a, int kernel, int dilation, hipS
 // defined one per translation unit (explicit variants)
 int grouped_conv_f32_base(const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);     // FPL 4, torch weight layout
 int grouped_conv_f32_alt(int variant, const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);
+int grouped_conv_f32_fpl2(const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);
 int grouped_conv_bf16(int variant, const GroupedArgs<bf16_t>& a, int kernel, int dilation, hipStream_t stream);
 
 }  // namespace nbasr

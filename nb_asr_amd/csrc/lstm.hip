@@ -235,14 +235,20 @@ __global__ __launch_bounds__(256) void head_kernel(
     const int r0 = (blockIdx.x * 4 + wave) * 16;
     if (r0 >= rows) return;
 
-    floatx4 acc[4];
+    // blocked accumulation: 128 products go into `part`, which is then folded into `acc` -- the rounding error of a 1 200-term dot
+    // product then grows like that of the blocked / vectorised sums of a CPU GEMM instead of one long sequential chain
+    floatx4 acc[4], part[4];
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n) { acc[n] = floatx4{0.f, 0.f, 0.f, 0.f}; part[n] = floatx4{0.f, 0.f, 0.f, 0.f}; }
 
     const int row = r0 + i16;
     const bool row_ok = row < rows;
     const int kchunks = (features + 15) / 16;
     for (int c = 0; c < kchunks; ++c) {
+        if ((c & 7) == 0 && c) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) { acc[n] += part[n]; part[n] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+        }
         const int k = c * 16 + kq * 4;
         const bool kok = k < features;                        // features % 4 == 0
         float av[4] = {0.f, 0.f, 0.f, 0.f};
@@ -268,12 +274,14 @@ __global__ __launch_bounds__(256) void head_kernel(
             const int cls = n * 16 + i16;
             float4 wv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (cls < classes && kok) wv = *reinterpret_cast<const float4*>(w + static_cast<size_t>(cls) * features + k);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wv.x, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wv.y, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wv.z, acc[n], 0, 0, 0);
-            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wv.w, acc[n], 0, 0, 0);
+            part[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], wv.x, part[n], 0, 0, 0);
+            part[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], wv.y, part[n], 0, 0, 0);
+            part[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], wv.z, part[n], 0, 0, 0);
+            part[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], wv.w, part[n], 0, 0, 0);
         }
     }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] += part[n];
     // D[m = row][n = class]: col = lane & 15 (class), row = (lane >> 4) * 4 + reg
 #pragma unroll
     for (int n = 0; n < 4; ++n) {

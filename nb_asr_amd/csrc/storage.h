@@ -30,7 +30,12 @@ __device__ __forceinline__ float bf16_hi(unsigned d) { return __uint_as_float(d 
 // N consecutive frames (N = 4 or 8) of a row -> fp32 registers.  The pointer must be aligned to the access it implies:
 // fp32 16 B per 4 frames; bf16 8 B per 4 frames, 16 B per 8 frames.
 template <int N> __device__ __forceinline__ void load_frames(const float* __restrict__ p, float (&v)[N]) {
-    static_assert(N == 4 || N == 8, "4 or 8 frames per access");
+    static_assert(N == 2 || N == 4 || N == 8, "2, 4 or 8 frames per access");
+    if constexpr (N == 2) {
+        const f2v t = *reinterpret_cast<const f2v*>(p);
+        v[0] = t.x; v[1] = t.y;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < N / 4; ++h) {
         const f4v t = *reinterpret_cast<const f4v*>(p + 4 * h);
@@ -55,6 +60,12 @@ template <int N, typename T> __device__ __forceinline__ void zero_frames(float (
 
 // NT: non-temporal (streaming) store -- the output of a node is read next by another kernel, not by this one
 template <int N, bool NT> __device__ __forceinline__ void store_frames(float* __restrict__ p, const float (&v)[N]) {
+    if constexpr (N == 2) {
+        const f2v t = {v[0], v[1]};
+        if (NT) __builtin_nontemporal_store(t, reinterpret_cast<f2v*>(p));
+        else *reinterpret_cast<f2v*>(p) = t;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < N / 4; ++h) {
         const f4v t = {v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]};

@@ -24,7 +24,7 @@ import torch
 from . import hip
 
 
-def node_into(node, inputs, frames, out, ln0=None, stats=None, linear_ctx=None):
+def node_into(node, inputs, frames, out, ln0=None, stats=None, linear_ctx=None, gc_variant=0):
     """Enqueue one cell node: ``out = op(inputs[-1]) + sum(flagged inputs)`` (left-to-right).
 
     ``ln0`` = (stats, gamma, beta): ``inputs[0]`` (the cell input) is stored un-normalised with a pending LayerNorm that
@@ -42,9 +42,9 @@ def node_into(node, inputs, frames, out, ln0=None, stats=None, linear_ctx=None):
     ln = ln0 if (on_x or on_s0) else None
     if isinstance(op, PadConvRelu):
         # with `stats` the epilogue writes partial statistics to the workspace; the caller merges them (finalize)
-        hip.grouped_conv1d_fused(last, op.conv.weight.detach(), op.conv.bias.detach(), skips, out, frames,
-                                 op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, None,
-                                 stats[1] if stats is not None else None, 0.0)
+        hip.grouped_conv1d_node(last, op.conv.weight.detach(), op.conv.bias.detach(), skips, out, frames,
+                                op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0,
+                                stats[1] if stats is not None else None, gc_variant)
     elif isinstance(op, Linear):
         if stats is not None:
             raise ValueError('statistics from the epilogue are only available for grouped-conv nodes')
@@ -305,6 +305,15 @@ class ForwardPlan:
             taps[tap_idx] = copy[:, :, :act_frames].clone()
         return (stats, norm.weight.detach(), norm.bias.detach())
 
+    def _gc_variant(self, view):
+        """Kernel variant of the fp32 grouped-conv node op for an output of this size (speed only: results are bit-identical).
+        NBASR_GC_F32_VARIANT=<int> forces one; NBASR_GC_KEEP_MB=<float> moves the streaming / cache-resident store threshold."""
+        forced = os.environ.get('NBASR_GC_F32_VARIANT')
+        if forced is not None:
+            return int(forced)
+        mb = view.numel() * 4 / 1e6
+        return hip.GC_KEEP if mb <= float(os.environ.get('NBASR_GC_KEEP_MB', '0')) else 0
+
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)
         return self.pool[idx][: self.batch * channels * ld].view(self.batch, channels, ld)
@@ -473,7 +482,7 @@ class ForwardPlan:
                         ld = view.shape[2]
                         new_stats = self.stats[self._stat_turn][: self.batch * 2 * ld].view(self.batch, 2, ld)
                         st = (new_stats, self.stats_ws, layer.norm_layer.eps)
-                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx)))
+                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx, self._gc_variant(view))))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 if feeds_tail:
                     pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)
@@ -570,7 +579,7 @@ class ForwardPlan:
         is in the reference): dense convs as one bf16 MFMA per product on a producer-written operand image, node ops /
         LayerNorm reading and writing bf16 rows (half the HBM bytes) with fp32 arithmetic and ONE rounding per tensor,
         LayerNorm statistics, LSTM gates / state and the head in fp32; logits returned as bfloat16."""
-        from .model import SearchCell, FILTERS, LSTM_HIDDEN
+        from .model import SearchCell, FILTERS, LSTM_HIDDEN, LN_EPS
         from .ops import PadConvRelu, Linear, Zero, Identity
         import torch.nn as nn
         bf16 = torch.bfloat16
@@ -582,15 +591,22 @@ class ForwardPlan:
         lds = [hip.row_pitch(t, bf16) for t in self.block_frames]
         elems = max(B * c * ld for c, ld in zip(FILTERS, lds))
         self.pool16 = [self._buf(f'pool16_{i}', elems, bf16) for i in range(4)]
-        variant = int(os.environ.get('NBASR_GC_BF16_VARIANT', str(hip.GC_FPL8 | hip.GC_WPERM)))
+        forced = os.environ.get('NBASR_GC_BF16_VARIANT')
         lib = hip.load_library()
+
+        def variant_for(frames):
+            # 8 frames per lane (16-byte accesses) where rows are long; the narrow blocks run better as more, lighter waves
+            # (tools/bench_gc_variants.py on an MI355X: 40 vs 49 us at 1 600 frames, 39 vs 37 us at 400)
+            if forced is not None:
+                return int(forced)
+            return (hip.GC_FPL8 | hip.GC_WPERM) if frames >= 512 else hip.GC_WPERM
 
         def image_of(act, frames, norm=None, stats=None, eps=0.0):
             b, c, ld = act.shape
             img = self._buf('image16', max(lib.nbasr_bf16_image_bytes(b, c, ld), 16), torch.uint8)
             return hip.bf16_image(act, img, frames, norm, stats, eps)
 
-        def grouped_weight(op):
+        def grouped_weight(op, variant):
             w = op.conv.weight
             if variant & hip.GC_WPERM:
                 return self._cached(w, 'gc_wperm', lambda: hip.pack_grouped_weights(self._f32(w).contiguous(), op.groups))
@@ -651,14 +667,39 @@ class ForwardPlan:
                         meta = (blk, layer.filters, layer.filters, getattr(op, 'kernel_size', 1), act_frames, n_skips)
                         if isinstance(op, PadConvRelu):
                             ws = self.stats_ws if (epilogue_stats and j == len(layer.nodes) - 1) else None
-                            wt, bs = grouped_weight(op), self._f32(op.conv.bias)
+                            variant = variant_for(act_frames)
+                            wt, bs = grouped_weight(op, variant), self._f32(op.conv.bias)
                             self._timed('grouped_conv', meta, lambda: hip.grouped_conv1d_node(
                                 last, wt, bs, skips, view, act_frames, op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, ws, variant))
                         elif isinstance(op, Zero):
                             self._timed('skip_sum', meta, lambda: hip.skip_sum_v(skips, view, act_frames, ln if on_s0 else None, on_s0))
                         elif isinstance(op, Linear):
-                            raise NotImplementedError('the `linear` node op has no bf16 kernel yet (BASELINE config 4 does not use it); '
-                                                      'run this architecture in float32')
+                            # no bf16 GEMM for the per-frame linear map yet (BASELINE config 4 does not use the op): bridge through
+                            # the fp32 one.  x -> fp32 (its pending LayerNorm applied on the way), the fp16-split GEMM, the op's
+                            # output rounded to bf16 as the reference's bf16 module does, then the skip sum in bf16 storage.
+                            b_, c_, ld_ = last.shape
+                            n = b_ * c_ * ld_
+                            x32 = self._buf('bridge_x32', n)[:n].view(b_, c_, ld_)
+                            y32 = self._buf('bridge_y32', n)[:n].view(b_, c_, ld_)
+                            if on_x:
+                                hip.layernorm_channels_v(last, ln[1], ln[2], x32, act_frames, LN_EPS)
+                            else:
+                                hip.convert(last, x32)
+                            wl = op.linear.weight
+                            packed = self._cached(wl, 'pointwise', lambda: hip.pack_pointwise_weights(self._f32(wl)))
+                            self._timed('linear_op', meta, lambda: hip.linear_fused_packed(
+                                x32, act_frames, packed, op.linear.out_features, self._f32(op.linear.bias), (), y32, self._pointwise_ws(c_, ld_)))
+                            if not skips:
+                                hip.convert(y32, view)
+                            else:
+                                op16 = self._buf('bridge_op16', n, bf16)[:n].view(b_, c_, ld_)
+                                hip.convert(y32, op16)
+                                if len(skips) <= 2:
+                                    hip.skip_sum_v(skips + [op16], view, act_frames, ln if on_s0 else None, on_s0)
+                                else:
+                                    part = self._buf('bridge_sum16', n, bf16)[:n].view(b_, c_, ld_)
+                                    hip.skip_sum_v(skips, part, act_frames, ln if on_s0 else None, on_s0)
+                                    hip.skip_sum_v([op16, part], view, act_frames)
                         else:
                             raise TypeError(f'unsupported node operation {type(op).__name__}')
                         outs.append(view)

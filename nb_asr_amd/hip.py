@@ -110,7 +110,7 @@ SIGNATURES = {
 }
 
 F32, BF16 = 0, 1                 # NBASR_F32 / NBASR_BF16
-GC_FPL8, GC_WPERM = 1, 2         # NBASR_GC_* variant bits of nbasr_grouped_conv1d_node
+GC_FPL8, GC_WPERM, GC_FPL2, GC_KEEP = 1, 2, 4, 8         # NBASR_GC_* variants of nbasr_grouped_conv1d_node
 
 
 class HipError(RuntimeError):

@@ -16,7 +16,6 @@ Interface mirror of the reference's ``nasbench_asr/model/torch/model.py``: ``Nod
 ``executor.ForwardPlan``; the nested torch modules are parameter containers.  Inputs must live on
 a HIP device -- there is no CPU path in this package.
 """
-import os
 import warnings
 
 import torch
@@ -111,7 +110,6 @@ class ASRModel(nn.Module):
             layers.append(nn.Linear(FILTERS[-1], num_classes + 1))
         self.model = layers
         self._plans = PlanPool()
-        self._lanes = None                    # graph lanes of forward_async at small batch (see _forward_lanes)
 
     # ------------------------------------------------------------------------------------------
     def get_prunable_copy(self, bn=False, masks=None):
@@ -145,61 +143,7 @@ class ASRModel(nn.Module):
         """Pipelined forward for back-to-back batches: the encoder runs on the current stream, the latency-bound
         LSTM + head on the plan's side stream, so the NEXT call's encoder overlaps with this call's LSTM.  Returns a
         handle; ``handle.result()`` makes the current stream wait for the logits and returns them."""
-        lanes = self._lane_count(input)
-        if lanes:
-            return self._forward_lanes(input, lanes)
         return self.forward(input, _pipelined=True)
-
-    # -- small batches: whole-forward HIP graphs replayed on alternating streams ------------------------------------------------
-    @staticmethod
-    def _lane_count(input):
-        """How many graph lanes forward_async uses for this input (0 = the stream-pipelined path).  At small batch x frames
-        (the per-GPU shard of a strongly scaled batch: 8 utterances of 1 000 frames) a forward is ~350 launches of 2-15 us
-        each, so the host (one ctypes call per launch) and the launch boundaries, not the GPU, set the pace: replaying each
-        forward as ONE captured graph removes the host cost, and two or three forwards in flight on separate streams fill
-        the boundaries and the 250 dependent LSTM steps of one with the encoder of the next.  NBASR_GRAPH_LANES=0|2|3 overrides."""
-        env = os.environ.get('NBASR_GRAPH_LANES')
-        if env is not None:
-            return int(env)
-        if not isinstance(input, torch.Tensor) or input.dim() != 3:
-            return 0
-        return 3 if input.shape[0] * input.shape[2] <= 16 * 1000 and input.shape[0] > 0 else 0
-
-    def _forward_lanes(self, input, n_lanes):
-        from .executor import ForwardPlan, PendingLogits
-        _check_dropout(self)
-        if not input.is_cuda or input.shape[1] != FEATURES:
-            raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor on a HIP device')
-        dev = input.device
-        if self._lanes is None or self._lanes['device'] != dev or len(self._lanes['plans']) != n_lanes:
-            self._drop_lanes()
-            self._lanes = {'device': dev, 'turn': 0, 'plans': [ForwardPlan(dev) for _ in range(n_lanes)],
-                           'streams': [torch.cuda.Stream(device=dev) for _ in range(n_lanes)], 'done': [None] * n_lanes}
-        L = self._lanes
-        k = L['turn'] = (L['turn'] + 1) % n_lanes
-        cur = torch.cuda.current_stream(dev)
-        ready = torch.cuda.Event()
-        ready.record(cur)                                  # the caller's input is ready at this point of ITS stream
-        stream = L['streams'][k]
-        stream.wait_event(ready)
-        x = input.detach().contiguous()
-        x.record_stream(stream)
-        with torch.cuda.stream(stream):
-            y = L['plans'][k].run_graph(self, x).clone()   # the graph's output buffer is overwritten by this lane's next replay
-            done = torch.cuda.Event()
-            done.record(stream)
-        L['done'][k] = done
-        return PendingLogits(y, done)
-
-    def _drop_lanes(self):
-        if self._lanes is not None:
-            for ev in self._lanes['done']:
-                if ev is not None:
-                    torch.cuda.current_stream(self._lanes['device']).wait_event(ev)
-            for plan in self._lanes['plans']:
-                with torch.cuda.device(plan.device):
-                    plan.close()
-            self._lanes = None
 
     def forward(self, input, _taps=None, _pipelined=False):
         """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1)."""
@@ -224,13 +168,10 @@ class ASRModel(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_plans'] = PlanPool()          # never pickle / deepcopy workspaces
-        state['_lanes'] = None
         return state
 
     def _apply(self, fn, *args, **kwargs):
         self._plans.clear()                   # parameters may move: drop cached workspaces (after waiting for their tails)
-        if getattr(self, '_lanes', None) is not None:
-            self._drop_lanes()
         return super()._apply(fn, *args, **kwargs)
 
     @property

@@ -30,7 +30,7 @@ def node(x, w, bias, skips, k, d, groups, dtype, variant, ln=None, on_x=False, o
     sp = [pitched(s, dtype) for s in skips]
     y = torch.full_like(xp, 7.0)
     wd = w.to(DEV).contiguous()
-    if variant & hip.GC_WPERM:
+    if variant & hip.GC_WPERM and variant != hip.GC_FPL2:
         wd = hip.pack_grouped_weights(wd, groups)
     hip.grouped_conv1d_node(xp, wd, bias.to(DEV), sp, y, frames, groups, k, d, ln, on_x, on_s0, None, variant)
     torch.cuda.synchronize()
@@ -50,9 +50,10 @@ def test_node_variants_are_bit_identical_and_match_the_oracle(dtype, cg, k, d):
     w = (torch.randn(c, cg, k) * 0.3).to(dtype).float()
     bias = (torch.randn(c) * 0.2).to(dtype).float()
     want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + skips[0] + skips[1] + skips[2]
-    outs = [node(x, w, bias, skips, k, d, groups, dtype, v) for v in range(4)]
-    for v in range(1, 4):
-        assert torch.equal(outs[v], outs[0]), f'variant {v} differs from variant 0'
+    variants = (0, 1, 2, 3) + ((hip.GC_FPL2,) if dtype == torch.float32 else ())
+    outs = [node(x, w, bias, skips, k, d, groups, dtype, v) for v in variants]
+    for v, out in zip(variants[1:], outs[1:]):
+        assert torch.equal(out, outs[0]), f'variant {v} differs from variant 0'
     got = outs[0].float().cpu()
     tol = (2.0 ** -8 if dtype == BF else 0.0) * want.abs() + 2e-5 + 1e-5 * want.abs()
     assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())

@@ -382,7 +382,8 @@ def test_nan_input_is_not_swallowed():
     assert torch.equal(y[0], clean[0])                          # the other utterance: untouched
     # (900 - 506) / 4 = 98: before the receptive field -- the same values to fp32 accuracy (not bit for bit: an utterance with a
     # non-finite sample is routed to the range-free bf16x3 first conv, the clean run took the fp16 split)
-    assert cases.worst_ratio(y[1, :98], clean[1, :98].cpu(), 1e-4, 1e-5) <= 1.0 and torch.isfinite(y[1, :98]).all()
+    # (two fp32-accurate evaluations of the noisiest fixture architecture: each within ~1x the bound of fp64, hence 2x of each other)
+    assert cases.worst_ratio(y[1, :98], clean[1, :98].cpu(), 1e-4, 1e-5) <= 2.0 and torch.isfinite(y[1, :98]).all()
     assert torch.isnan(y[1, 240:]).all()                        # after it (and the LSTM carries it on)
     want = oracle.asr_forward({k: v.cpu() for k, v in m.state_dict().items()}, cases.ARCH_A, x[1:2], use_rnn=True)
     assert torch.equal(torch.isnan(want[0]).any(dim=1), torch.isnan(y[1].cpu()).any(dim=1))     # the same frames as the oracle
@@ -436,13 +437,31 @@ def test_model_bf16_golden(bf16_fx, tag, arch, use_rnn, mode, b, t):
             f'{tag} layer {idx}: rms err vs fp64 {hip_err:.3e}, reference bf16 {ref_err:.3e}, layer rms {rms[idx, 1]:.3e}'
 
 
-def test_bf16_needs_matching_dtypes_and_rejects_what_it_lacks():
+def test_bf16_needs_matching_dtypes():
     m = build_bf16(cases.ARCH_D, True, 'lively')
     with pytest.raises(nb.hip.HipError, match='parameters are torch.bfloat16'):
         m(keyed_input(1, 40, seed=0).to(DEV))                  # fp32 input into a bf16 model: loud, no silent cast
-    lin = build_bf16(cases.ARCH_M, True, 'lively')             # `linear` node op: no bf16 kernel yet -> says so
-    with pytest.raises(NotImplementedError, match='linear'):
-        lin(keyed_input(1, 40, seed=0).to(torch.bfloat16).to(DEV))
+
+
+@pytest.mark.parametrize('seed', range(6))
+def test_random_architectures_bf16_vs_reference_arithmetic(seed):
+    """Any architecture of the search space runs in bf16 storage (the `linear` op through an fp32 bridge): no further from
+    fp64 than the reference's own bf16 arithmetic (the oracle in bfloat16 IS that arithmetic, tests/test_oracle_golden.py)."""
+    import random
+    rng = random.Random(2000 + seed)
+    arch = nb.get_random_architectures(1, seed=5000 + seed)[0] if seed else cases.ARCH_M
+    use_rnn = bool(seed % 2)
+    b, t = rng.choice([1, 2, 3]), rng.choice([5, 31, 64, 97, 130, 201])
+    m = build_bf16(arch, use_rnn, 'lively', seed=600 + seed)
+    x = keyed_input(b, t, seed=seed).to(torch.bfloat16)
+    params = {k: v.cpu() for k, v in m.state_dict().items()}
+    ref = oracle.asr_forward(params, arch, x, use_rnn=use_rnn, dtype=torch.bfloat16).double()
+    truth = oracle.asr_forward({k: v.double() for k, v in params.items()}, arch, x.double(), use_rnn=use_rnn, dtype=torch.float64)
+    with torch.no_grad():
+        got = m(x.to(DEV)).double().cpu()
+    e_ref, e_hip = cases._rms(ref - truth), cases._rms(got - truth)
+    print(f'arch {arch} b={b} t={t} rnn={use_rnn}: rms err vs fp64: HIP {e_hip:.3e}, reference-arithmetic bf16 {e_ref:.3e}')
+    assert e_hip <= 1.25 * e_ref and float((got - truth).abs().max()) <= 1.5 * float((ref - truth).abs().max())
 
 
 class TestConfig4Bf16:
@@ -549,32 +568,8 @@ def test_inf_input_is_loud_and_confined():
         x[1, 3, 560] = float('inf')
         y = m(x.to(DEV))
     assert torch.equal(y[0], clean[0])
-    assert cases.worst_ratio(y[1, :13], clean[1, :13].cpu(), 1e-4, 1e-5) <= 1.0 and torch.isfinite(y[1, :13]).all()    # (560 - 506) / 4 = 13
+    assert cases.worst_ratio(y[1, :13], clean[1, :13].cpu(), 1e-4, 1e-5) <= 2.0 and torch.isfinite(y[1, :13]).all()    # (560 - 506) / 4 = 13
     assert torch.isnan(y[1, 145:]).all()
-
-
-@pytest.mark.parametrize('lanes', ['0', '2', '3'])
-def test_forward_async_paths_agree(lanes):
-    """forward_async = stream-pipelined eager launches (NBASR_GRAPH_LANES=0; the default at large batch) or whole-forward
-    graphs replayed on alternating streams (2 / 3 lanes; the default at small batch x frames).  Same logits, in order."""
-    m = build(cases.ARCH_D, True, 'lively')
-    xs = [keyed_input(3, 120, seed=s).to(DEV) for s in range(7)]
-    os.environ['NBASR_GRAPH_LANES'] = lanes
-    try:
-        with torch.no_grad():
-            want = [m(x).clone() for x in xs]
-            for _ in range(2):
-                handles = [m.forward_async(x) for x in xs]          # seven forwards in flight, nothing resolved yet
-                got = [h.result() for h in handles]
-                torch.cuda.synchronize()
-                for g, w in zip(got, want):
-                    assert torch.equal(g, w)
-            m.model[28].bias.add_(0.25)                               # a parameter update must reach the captured graphs
-            assert torch.equal(m.forward_async(xs[0]).result(), m(xs[0]))
-            assert not torch.equal(m(xs[0]), want[0])
-    finally:
-        del os.environ['NBASR_GRAPH_LANES']
-    assert (m._lanes is None) == (lanes == '0')
 
 
 @pytest.mark.parametrize('case', ['A_lively_fixture', 'M_nornn_b2_t258', 'random_seed2'])

@@ -56,16 +56,17 @@ def main():
                         'skip3': dict(skips=[s0, s1, s2], ln=None, on_x=False, ws=None)}
             for fname, f in flavours.items():
                 nbytes = elem * a.batch * c * t * (2 + len(f['skips'])) + 4 * (c * (c // 100) * a.kernel + c)
-                times = {v: [] for v in range(4)}
+                variants = (0, 1, 2, 3, 4) if dname == 'f32' else (0, 1, 2, 3)      # 4 = two frames per lane (fp32 only)
+                times = {v: [] for v in variants}
 
                 def run(v):
-                    hip.grouped_conv1d_node(x, wp if v & hip.GC_WPERM else w, bias, f['skips'], y, t, 100, a.kernel, a.dilation,
+                    hip.grouped_conv1d_node(x, wp if (v & hip.GC_WPERM and v != hip.GC_FPL2) else w, bias, f['skips'], y, t, 100, a.kernel, a.dilation,
                                             f['ln'], f['on_x'], False, f['ws'], v)
-                for v in range(4):
+                for v in variants:
                     run(v)
                 torch.cuda.synchronize()
                 for _ in range(a.rounds):
-                    for v in range(4):
+                    for v in variants:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                         e0.record()
                         for _ in range(a.reps):
@@ -74,7 +75,7 @@ def main():
                         e1.synchronize()
                         times[v].append(e0.elapsed_time(e1) * 1e3 / a.reps)
                 row = {'block': blk, 'C': c, 'T': t, 'dtype': dname, 'flavour': fname, 'MB': nbytes / 1e6}
-                for v in range(4):
+                for v in variants:
                     us = statistics.median(times[v])
                     row[f'v{v}_us'] = round(us, 1)
                     row[f'v{v}_TBps'] = round(nbytes / us / 1e6, 2)
