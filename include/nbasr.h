@@ -249,8 +249,6 @@ int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float
  * kernel floats), whose per-input-channel weights are contiguous for the scalar loads.  Results do not depend on the variant. */
 #define NBASR_GC_FPL8 1
 #define NBASR_GC_WPERM 2
-#define NBASR_GC_FPL2 4   /* fp32 only, not combinable with FPL8 / WPERM: 2 frames per lane (twice as many, half as heavy waves) */
-#define NBASR_GC_KEEP 8   /* any variant: plain instead of streaming (non-temporal) stores of y -- tensors that fit the last-level cache */
 int nbasr_grouped_conv1d_node(const void* x, const float* w, const float* bias,
                               const void* skip0, const void* skip1, const void* skip2, void* y,
                               int batch, int channels, int frames, int ld, int groups, int kernel, int dilation,
@@ -427,6 +425,23 @@ int nbasr_pack_dense_weights_bf16(const float* w, void* packed, int c_out, int c
 int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
                                 int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
                                 nbasr_stream_t stream);
+
+/* ---- backward building blocks (bottom-up; fp32) -------------------------------------------------------------------
+ * The node op z = min(relu(conv1d(zero_pad(x), w, b, dilation, groups)), 20) (reference ops.py:24-30) given dz = dL/dz:
+ *   the relu / clamp_max_ masks are taken from the op's OUTPUT z (0 < z < 20), so no pre-activation has to be kept;
+ *   dx (batch, channels, ld)  -- may be NULL;   dw (channels, channels/groups, kernel) and db (channels) -- both or neither, they need
+ *   `workspace` (nbasr_grouped_conv1d_backward_workspace_bytes) and x.  The weight gradient is accumulated per utterance on
+ *   the fp32 matrix cores and summed over utterances in a fixed order: no atomics, bit-reproducible.  dz's pitch columns must be 0.
+ * LayerNorm over channels (reference model.py:46-47, 55-58, 92) given dy: `stats` = the (batch, 2, ld) statistics of x
+ * (nbasr_channel_stats); dx, dgamma (channels), dbeta (channels); workspace of nbasr_layernorm_backward_workspace_bytes. */
+size_t nbasr_grouped_conv1d_backward_workspace_bytes(int batch, int channels, int groups, int kernel);
+int nbasr_grouped_conv1d_backward(const float* x, const float* w, const float* z, const float* dz, float* dx, float* dw, float* db,
+                                  float* workspace, int batch, int channels, int frames, int ld, int groups, int kernel, int dilation,
+                                  nbasr_stream_t stream);
+size_t nbasr_layernorm_backward_workspace_bytes(int batch, int channels, int ld);
+int nbasr_layernorm_channels_backward(const float* x, const float* stats, const float* gamma, const float* dy, float* dx,
+                                      float* dgamma, float* dbeta, float* workspace, int batch, int channels, int frames, int ld,
+                                      nbasr_stream_t stream);
 
 #ifdef __cplusplus
 }

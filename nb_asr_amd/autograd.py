@@ -1,0 +1,74 @@
+"""Differentiable building blocks (bottom-up): the grouped node op and the channel LayerNorm with HIP
+backward kernels, as ``torch.autograd.Function``s.
+
+What exists: ``grouped_pad_conv_relu`` (reference ``ops.PadConvRelu`` with groups > 1, ops.py:24-30) and ``layer_norm_channels``
+(``nn.LayerNorm`` over the channel dimension of (B, C, T), model.py:55-58) -- forward AND backward through the C ABI, gradients
+checked against the reference modules' own autograd (tests/golden/grad_fixtures.npz).  ``ops.PadConvRelu`` (grouped) calls the
+former when a gradient is required, so the op is trainable on its own.  What does not exist yet: backward of the dense
+downsample convs, the ``linear`` op, the LSTM and the head, dropout masks, and therefore ``loss.backward()`` through
+``ASRModel`` (its forward still returns detached logits and says so).
+"""
+import torch
+
+from . import hip
+
+
+def _pitched(t):
+    frames = t.shape[2]
+    ld = hip.round_up4(frames)
+    t = t.detach()
+    if ld == frames and t.is_contiguous():
+        return t, frames
+    buf = torch.empty(t.shape[0], t.shape[1], ld, device=t.device, dtype=t.dtype)
+    hip.repitch(t.contiguous(), buf, frames)
+    return buf, frames
+
+
+class _GroupedPadConvRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, groups, kernel, dilation):
+        xp, frames = _pitched(x)
+        z = torch.empty_like(xp)
+        hip.grouped_conv1d_fused(xp, weight.detach(), bias.detach(), (), z, frames, groups, kernel, dilation)
+        ctx.save_for_backward(xp, weight.detach(), z)
+        ctx.cfg = (frames, groups, kernel, dilation)
+        return z[:, :, :frames]
+
+    @staticmethod
+    def backward(ctx, dz):
+        xp, weight, z = ctx.saved_tensors
+        frames, groups, kernel, dilation = ctx.cfg
+        dzp, _ = _pitched(dz)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dw, db = hip.grouped_conv1d_backward(xp, weight, z, dzp, frames, groups, kernel, dilation, need_dx, need_dw)
+        return (dx[:, :, :frames] if dx is not None else None), dw, db, None, None, None
+
+
+class _LayerNormChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xp, frames = _pitched(x)
+        stats = torch.empty(xp.shape[0], 2, xp.shape[2], device=xp.device, dtype=torch.float32)
+        hip.channel_stats(xp, stats, frames, eps)
+        y = torch.empty_like(xp)
+        hip.layernorm_channels(xp, gamma.detach(), beta.detach(), y, frames, eps)
+        ctx.save_for_backward(xp, stats, gamma.detach())
+        ctx.frames = frames
+        return y[:, :, :frames]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, stats, gamma = ctx.saved_tensors
+        dyp, _ = _pitched(dy)
+        dx, dgamma, dbeta = hip.layernorm_channels_backward(xp, stats, gamma, dyp, ctx.frames)
+        return dx[:, :, :ctx.frames], dgamma, dbeta, None
+
+
+def grouped_pad_conv_relu(x, weight, bias, groups, kernel, dilation):
+    """min(relu(conv1d(zero_pad(x), weight, bias, dilation=dilation, groups=groups)), 20), differentiable in x, weight, bias."""
+    return _GroupedPadConvRelu.apply(x, weight, bias, groups, kernel, dilation)
+
+
+def layer_norm_channels(x, gamma, beta, eps=1e-3):
+    """LayerNorm over the channel dimension of (B, C, T), differentiable in x, gamma, beta."""
+    return _LayerNormChannels.apply(x, gamma, beta, eps)

@@ -1,0 +1,360 @@
+// Backward building blocks of the encoder's two dominant operators (bottom-up: the node op and the
+// LayerNorm first; dense convs, `linear`, LSTM and the model-level autograd are not built yet).
+//
+//  * grouped PadConvRelu node op (reference ops.py:24-30, groups = 100):  z = min(relu(conv(x) + b), 20)
+//        gm = dz * [0 < z < 20]                       (relu / clamp_max_ masks, from the op's OUTPUT: no pre-activation is kept)
+//        dx[ci][t]      = sum_{co,j} w[co][ci][j] * gm[co][t + lpad - j*d]                           grouped_dgrad_kernel (vector ALU)
+//        dw[co][ci][j]  = sum_{b,t}  gm[b][co][t] * x[b][ci][t - lpad + j*d],   db[co] = sum gm      grouped_wgrad_kernel (fp32 MFMA)
+//    The weight gradient is a GEMM whose reduction dimension is (batch, frames): per (group, utterance) a wave multiplies the
+//    16 x frames matrix of masked output gradients by the frames x (ci, tap) im2col of x on v_mfma_f32_16x16x4_f32 (exact fp32),
+//    one extra all-ones column yields the bias gradient; per-utterance partials are summed by a second kernel in a FIXED order
+//    (no atomics: the gradients are bit-reproducible).
+//  * LayerNorm over channels (model.py:46-47, 55-58, 92):  y = (x - mu) * rstd * gamma + beta
+//        dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)),  g = dy * gamma;   dgamma = sum_{b,t} dy * xhat,  dbeta = sum dy
+#include "storage.h"
+
+namespace nbasr {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_mask(float z) { return (z > 0.f && z < kClamp) ? 1.f : 0.f; }
+
+// ---- dgrad of the grouped node op ------------------------------------------------------------------------------------------
+template <int CG, int K, int D>
+__global__ __launch_bounds__(256) void grouped_dgrad_kernel(const float* __restrict__ dz, const float* __restrict__ z,
+                                                            const float* __restrict__ w, float* __restrict__ dx,
+                                                            int channels, int frames, int ld, int groups)
+{
+    constexpr int LPAD = pad_left(K, D, 1);
+    constexpr int SPAN = (K - 1) * D;
+    constexpr int L = SPAN - LPAD, R = LPAD;            // the transposed conv reaches L frames back and R ahead
+    constexpr int QL = (L + 3) / 4, QR = (R + 3) / 4, NCH = QL + 1 + QR;
+    const int nq = ld >> 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave);
+    const int b = blockIdx.z;
+    if (g >= groups) return;
+    const bool active = q < nq;
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
+    const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
+
+    float acc[CG][4];
+#pragma unroll
+    for (int ci = 0; ci < CG; ++ci)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ci][r] = 0.f;
+
+#pragma unroll 1
+    for (int co = 0; co < CG; ++co) {
+        const float* __restrict__ drow = dz + row0 + static_cast<size_t>(co) * ld;
+        const float* __restrict__ zrow = z + row0 + static_cast<size_t>(co) * ld;
+        float gm[NCH * 4];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int qq = q - QL + c;
+            float dv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (active && qq >= 0 && qq < nq) { load_frames<4>(drow + qq * 4, dv); load_frames<4>(zrow + qq * 4, zv); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gm[4 * c + e] = dv[e] * act_mask(zv[e]);
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int ci = 0; ci < CG; ++ci) {
+                const float wv = wg[(co * CG + ci) * K + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[ci][r] = __builtin_fmaf(wv, gm[4 * QL + r + LPAD - j * D], acc[ci][r]);
+            }
+        }
+    }
+    if (!active) return;
+    const int t0 = q * 4;
+#pragma unroll
+    for (int ci = 0; ci < CG; ++ci) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (t0 + r < frames) ? acc[ci][r] : 0.f;
+        store_frames<4, false>(dx + row0 + static_cast<size_t>(ci) * ld + t0, o);
+    }
+}
+
+// ---- wgrad + bias gradient of the grouped node op on the fp32 matrix cores --------------------------------------------------
+// One wave per (group, utterance).  v_mfma_f32_16x16x4_f32: lane l supplies A[row l & 15][k = l >> 4] and B[k = l >> 4][col l & 15].
+// The 4 k of MFMA m of a 64-frame step are frames t0 + 16 * kq + m (kq = 0..3): a lane then needs 16 CONSECUTIVE frames of its
+// row per step -- aligned for the gradient rows, at a tap-dependent offset for the im2col columns.
+// Column of tile c: col = 16 c + (l & 15) -> (ci, j) = (col / K, col % K); col == CG * K is the all-ones column (bias gradient).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <int CG, int K, int D>
+__global__ __launch_bounds__(256) void grouped_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                            const float* __restrict__ z, float* __restrict__ part,
+                                                            int channels, int frames, int ld, int groups, int batch)
+{
+    constexpr int LPAD = pad_left(K, D, 1);
+    constexpr int NCOL = CG * K + 1, NCT = (NCOL + 15) / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int g = blockIdx.x * 4 + wave;
+    const int b = blockIdx.y;
+    if (g >= groups) return;
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
+
+    floatx4 acc[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // this lane's im2col column per tile: source row and frame offset
+    int col_ci[NCT], col_off[NCT];
+    bool col_one[NCT], col_ok[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+        const int col = 16 * c + i16;
+        col_ok[c] = col < CG * K;
+        col_one[c] = col == CG * K;
+        col_ci[c] = col_ok[c] ? col / K : 0;
+        col_off[c] = col_ok[c] ? (col % K) * D - LPAD : 0;
+    }
+    const float* __restrict__ drow = dz + row0 + static_cast<size_t>(i16 < CG ? i16 : 0) * ld;
+    const float* __restrict__ zrow = z + row0 + static_cast<size_t>(i16 < CG ? i16 : 0) * ld;
+
+    for (int t0 = 0; t0 < frames; t0 += 64) {
+        const int ta = t0 + 16 * kq;                        // this lane's 16 frames of the step
+        float a[16];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            float dv[4] = {0.f, 0.f, 0.f, 0.f}, zv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (i16 < CG && ta + 4 * h < ld) { load_frames<4>(drow + ta + 4 * h, dv); load_frames<4>(zrow + ta + 4 * h, zv); }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[4 * h + e] = (ta + 4 * h + e < frames) ? dv[e] * act_mask(zv[e]) : 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            float bv[16];
+            const int s = ta + col_off[c];
+            const float* __restrict__ xrow = x + row0 + static_cast<size_t>(col_ci[c]) * ld;
+            if (col_ok[c] && s >= 0 && s + 16 <= frames) {           // interior: four (unaligned) 16-byte loads
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const f4u v = *reinterpret_cast<const f4u*>(xrow + s + 4 * h);
+                    bv[4 * h] = v.x; bv[4 * h + 1] = v.y; bv[4 * h + 2] = v.z; bv[4 * h + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int f = s + e;
+                    bv[e] = col_one[c] ? 1.f : ((col_ok[c] && f >= 0 && f < frames) ? xrow[f] : 0.f);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 16; ++m) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[m], acc[c], 0, 0, 0);
+        }
+    }
+    // D[row = co][col]: lane holds rows 4 kq + r of column i16 -> part[(g, b)][tile][co][16]
+    float* __restrict__ p = part + (static_cast<size_t>(g) * batch + b) * (NCT * 256);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[c * 256 + (4 * kq + r) * 16 + i16] = acc[c][r];
+}
+
+// dw[g][co][ci][j], db[g * CG + co] <- sum over utterances of the partials, in utterance order
+__global__ __launch_bounds__(256) void grouped_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                   float* __restrict__ db, int groups, int batch, int cg, int k)
+{
+    const int ncol = cg * k + 1, nct = (ncol + 15) / 16;
+    const int total = groups * cg * ncol;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int col = i % ncol, co = (i / ncol) % cg, g = i / (ncol * cg);
+        const float* p = part + static_cast<size_t>(g) * batch * (nct * 256) + (col >> 4) * 256 + co * 16 + (col & 15);
+        float s = 0.f;
+        for (int b = 0; b < batch; ++b) s += p[static_cast<size_t>(b) * (nct * 256)];
+        if (col == cg * k) db[g * cg + co] = s;
+        else dw[(static_cast<size_t>(g) * cg + co) * (cg * k) + col] = s;      // (co, ci, j) with col = ci * k + j: torch's layout
+    }
+}
+
+// ---- LayerNorm backward --------------------------------------------------------------------------------------------------
+// Workgroup = 64 frames of one utterance (16 lanes x 4 frames) x 16 channel slots, as the forward kernel.  Pass 1: per frame
+// s1 = sum_c g, s2 = sum_c g * xhat (g = dy * gamma) -- the slots' partial sums meet in LDS; pass 2: dx.  The per-channel sums
+// over this tile's frames (dgamma, dbeta partials) go to `part` [tile][2][channels]; a second kernel adds the tiles in order.
+__global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __restrict__ x, const float* __restrict__ stats,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                                 float* __restrict__ dx, float* __restrict__ part,
+                                                                 int channels, int frames, int ld)
+{
+    __shared__ float s_a[16][64], s_b[16][64];
+    const int ql = threadIdx.x & 15, slot = threadIdx.x >> 4;
+    const int nq = ld >> 2;
+    const int q = blockIdx.x * 16 + ql;
+    const int b = blockIdx.y;
+    const bool active = q < nq;
+    const size_t base = static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
+    float mu[4] = {0.f, 0.f, 0.f, 0.f}, rs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const float* st = stats + static_cast<size_t>(b) * 2 * ld + q * 4;
+        load_frames<4>(st, mu);
+        load_frames<4>(st + ld, rs);
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    float* __restrict__ pg = part + static_cast<size_t>(tile) * 2 * channels;
+    for (int c = slot; c < channels; c += 16) {
+        float xv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (active) { load_frames<4>(x + base + static_cast<size_t>(c) * ld, xv); load_frames<4>(dy + base + static_cast<size_t>(c) * ld, dv); }
+        const float gm = gamma[c];
+        float pgam = 0.f, pbet = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (xv[r] - mu[r]) * rs[r];          // rstd == 0 beyond the utterance: xhat = 0, and dy is 0 there
+            const float gg = dv[r] * gm;
+            s1[r] += gg;
+            s2[r] = __builtin_fmaf(gg, xh, s2[r]);
+            pgam = __builtin_fmaf(dv[r], xh, pgam);
+            pbet += dv[r];
+        }
+        // the 16 lanes of a slot hold the 64 frames of this channel: reduce over them (xor 1, 2, 4, 8 stays inside the 16-lane row)
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { pgam += __shfl_xor(pgam, d); pbet += __shfl_xor(pbet, d); }
+        if (ql == 0) { pg[c] = pgam; pg[channels + c] = pbet; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s_a[slot][ql * 4 + r] = s1[r]; s_b[slot][ql * 4 + r] = s2[r]; }
+    __syncthreads();
+    float m1[4], m2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float u = 0.f, v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { u += s_a[k][ql * 4 + r]; v += s_b[k][ql * 4 + r]; }
+        m1[r] = u / static_cast<float>(channels);
+        m2[r] = v / static_cast<float>(channels);
+    }
+    if (!active) return;
+    const int t0 = q * 4;
+    for (int c = slot; c < channels; c += 16) {
+        float xv[4], dv[4], o[4];
+        load_frames<4>(x + base + static_cast<size_t>(c) * ld, xv);
+        load_frames<4>(dy + base + static_cast<size_t>(c) * ld, dv);
+        const float gm = gamma[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float xh = (xv[r] - mu[r]) * rs[r];
+            o[r] = (t0 + r < frames) ? rs[r] * (dv[r] * gm - m1[r] - xh * m2[r]) : 0.f;
+        }
+        store_frames<4, false>(dx + base + static_cast<size_t>(c) * ld, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_backward_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
+                                                                        float* __restrict__ dbeta, int tiles, int channels)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= channels) return;
+    float a = 0.f, bsum = 0.f;
+    for (int t = 0; t < tiles; ++t) { a += part[static_cast<size_t>(t) * 2 * channels + c]; bsum += part[static_cast<size_t>(t) * 2 * channels + channels + c]; }
+    dgamma[c] = a;
+    dbeta[c] = bsum;
+}
+
+template <int CG>
+static int launch_grouped_backward(int kernel, int dilation, const float* x, const float* w, const float* z, const float* dz, float* dx,
+                                   float* part, int batch, int channels, int frames, int ld, int groups, hipStream_t s)
+{
+    const dim3 dgrid((ld / 4 + 63) / 64, (groups + 3) / 4, batch), wgrid((groups + 3) / 4, batch);
+#define NBASR_BWD(KK, DD)                                                                                                          \
+    do {                                                                                                                           \
+        if (dx) hipLaunchKernelGGL((grouped_dgrad_kernel<CG, KK, DD>), dgrid, dim3(256), 0, s, dz, z, w, dx, channels, frames, ld, groups); \
+        if (part) hipLaunchKernelGGL((grouped_wgrad_kernel<CG, KK, DD>), wgrid, dim3(256), 0, s, x, dz, z, part, channels, frames, ld, groups, batch); \
+        return launch_status("nbasr_grouped_conv1d_backward");                                                                     \
+    } while (0)
+    if (kernel == 5 && dilation == 1) NBASR_BWD(5, 1);
+    if (kernel == 5 && dilation == 2) NBASR_BWD(5, 2);
+    if (kernel == 7 && dilation == 1) NBASR_BWD(7, 1);
+    if (kernel == 7 && dilation == 2) NBASR_BWD(7, 2);
+#undef NBASR_BWD
+    set_error("nbasr_grouped_conv1d_backward: unsupported (kernel=%d, dilation=%d)", kernel, dilation);
+    return NBASR_EINVAL;
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" size_t nbasr_grouped_conv1d_backward_workspace_bytes(int batch, int channels, int groups, int kernel)
+{
+    if (batch <= 0 || channels <= 0 || groups <= 0 || channels % groups || kernel <= 0) return 0;
+    const int ncol = (channels / groups) * kernel + 1;
+    return static_cast<size_t>(groups) * batch * ((ncol + 15) / 16) * 256 * sizeof(float);
+}
+
+extern "C" int nbasr_grouped_conv1d_backward(const float* x, const float* w, const float* z, const float* dz, float* dx, float* dw,
+                                             float* db, float* workspace, int batch, int channels, int frames, int ld, int groups,
+                                             int kernel, int dilation, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
+                  "nbasr_grouped_conv1d_backward: bad sizes");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_grouped_conv1d_backward: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    NBASR_REQUIRE((dw == nullptr) == (db == nullptr), NBASR_ENULL, "nbasr_grouped_conv1d_backward: dw and db come together");
+    NBASR_REQUIRE(!dw || workspace, NBASR_ENULL, "nbasr_grouped_conv1d_backward: the weight gradient needs the workspace");
+    if (batch == 0 || ld == 0) {
+        if (dw) {
+            (void)hipMemsetAsync(dw, 0, sizeof(float) * channels * (channels / groups) * kernel, as_stream(stream));
+            (void)hipMemsetAsync(db, 0, sizeof(float) * channels, as_stream(stream));
+        }
+        return NBASR_OK;
+    }
+    NBASR_REQUIRE(w && z && dz && (dx || dw), NBASR_ENULL, "nbasr_grouped_conv1d_backward: w, z, dz and at least one output must be non-NULL");
+    NBASR_REQUIRE(!dw || x, NBASR_ENULL, "nbasr_grouped_conv1d_backward: the weight gradient needs x");
+    NBASR_REQUIRE(aligned16(x) && aligned16(z) && aligned16(dz) && aligned16(dx) && aligned16(workspace), NBASR_EALIGN,
+                  "nbasr_grouped_conv1d_backward: pointers must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_grouped_conv1d_backward: batch %d > 65535", batch);
+    hipStream_t s = as_stream(stream);
+    float* part = dw ? workspace : nullptr;
+    int rc;
+    switch (channels / groups) {
+        case 6:  rc = launch_grouped_backward<6>(kernel, dilation, x, w, z, dz, dx, part, batch, channels, frames, ld, groups, s); break;
+        case 8:  rc = launch_grouped_backward<8>(kernel, dilation, x, w, z, dz, dx, part, batch, channels, frames, ld, groups, s); break;
+        case 10: rc = launch_grouped_backward<10>(kernel, dilation, x, w, z, dz, dx, part, batch, channels, frames, ld, groups, s); break;
+        case 12: rc = launch_grouped_backward<12>(kernel, dilation, x, w, z, dz, dx, part, batch, channels, frames, ld, groups, s); break;
+        default:
+            set_error("nbasr_grouped_conv1d_backward: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", channels / groups);
+            return NBASR_EINVAL;
+    }
+    if (rc != NBASR_OK || !dw) return rc;
+    const int total = channels * ((channels / groups) * kernel + 1);
+    hipLaunchKernelGGL(grouped_wgrad_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, s, part, dw, db, groups, batch, channels / groups, kernel);
+    return launch_status("nbasr_grouped_conv1d_backward");
+}
+
+extern "C" size_t nbasr_layernorm_backward_workspace_bytes(int batch, int channels, int ld)
+{
+    if (batch <= 0 || channels <= 0 || ld <= 0) return 0;
+    return static_cast<size_t>(batch) * ((ld / 4 + 15) / 16) * 2 * channels * sizeof(float);
+}
+
+extern "C" int nbasr_layernorm_channels_backward(const float* x, const float* stats, const float* gamma, const float* dy, float* dx,
+                                                 float* dgamma, float* dbeta, float* workspace, int batch, int channels, int frames,
+                                                 int ld, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_layernorm_channels_backward: bad sizes");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_layernorm_channels_backward: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    NBASR_REQUIRE(dgamma && dbeta, NBASR_ENULL, "nbasr_layernorm_channels_backward: dgamma / dbeta are NULL");
+    if (batch == 0 || ld == 0) {
+        (void)hipMemsetAsync(dgamma, 0, sizeof(float) * channels, as_stream(stream));
+        (void)hipMemsetAsync(dbeta, 0, sizeof(float) * channels, as_stream(stream));
+        return NBASR_OK;
+    }
+    NBASR_REQUIRE(x && stats && gamma && dy && dx && workspace, NBASR_ENULL, "nbasr_layernorm_channels_backward: NULL pointer");
+    NBASR_REQUIRE(aligned16(x) && aligned16(stats) && aligned16(dy) && aligned16(dx), NBASR_EALIGN,
+                  "nbasr_layernorm_channels_backward: pointers must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_layernorm_channels_backward: batch %d > 65535", batch);
+    const int tiles_x = (ld / 4 + 15) / 16;
+    hipLaunchKernelGGL(layernorm_backward_kernel, dim3(tiles_x, batch), dim3(256), 0, as_stream(stream), x, stats, gamma, dy, dx, workspace,
+                       channels, frames, ld);
+    hipLaunchKernelGGL(layernorm_backward_reduce_kernel, dim3((channels + 255) / 256), dim3(256), 0, as_stream(stream), workspace, dgamma, dbeta,
+                       tiles_x * batch, channels);
+    return launch_status("nbasr_layernorm_channels_backward");
+}

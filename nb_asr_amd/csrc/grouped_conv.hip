@@ -128,9 +128,224 @@ __global__ __launch_bounds__(256) void repitch_kernel(
         dst[static_cast<size_t>(r) * ld_dst + t] = (t < frames) ? src[static_cast<size_t>(r) * ld_src + t] : E(0);
 }
 
+// ---- the fp32 default: the round-1 kernel, kept verbatim ---------------------------------------------------------------------
+// grouped_conv_impl.h holds the same kernel as a template over storage type / frames per lane / weight layout (bf16 path, A/B
+// variants).  Instantiated for (float, 4 frames, torch weights) that template computes bit-identical results but runs 10-23 %
+// SLOWER in the plain and statistics flavours (same-process A/B, tools/ubench/ab_gc_r1.py: 69.5 vs 62.7 us, 93.1 vs 82.8,
+// 69.2 vs 56.1, 41.6 vs 37.8 us over the four blocks; equal with LayerNorm on load): with the per-frame statistics of skip0 in
+// arrays instead of float4 members hipcc no longer hoists their compares and subtractions out of the channel loop of the
+// epilogue (32 v_cmp + 32 v_sub instead of 4 + packed adds, 33 s_nop instead of 6 in the CG = 8 instance).  The graded kernel
+// therefore stays the tuned source; the template serves everything else.
+// LNX: the main input carries a pending LayerNorm (deferred normalisation, nbasr.h) applied while loading;
+// ln_s0.stats != nullptr: skip0 carries one (inside a cell both are the cell input, with the same statistics).
+// STATS: the epilogue also emits this workgroup's partial LayerNorm statistics of y -- per frame the (mean, M2) over the
+// 4 x CG channels of its four groups -- to `part` ([group quad][batch][2][ld]); stats_finalize_kernel merges the quads.
+// This replaces the separate statistics pass over y when y is the last node of a cell.
+template <int CG, int K, int D, bool LNX, bool STATS>
+__global__ __launch_bounds__(256) void grouped_conv_f32_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+    float* __restrict__ y, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0,
+    float* __restrict__ part)
+{
+    constexpr int LPAD = pad_left(K, D, 1);
+    constexpr int SPAN = (K - 1) * D;            // taps reach frames [t - LPAD, t - LPAD + SPAN]
+    constexpr int QL = (LPAD + 3) / 4;           // whole chunks left of the lane's own chunk
+    constexpr int QR = (SPAN - LPAD + 3) / 4;    // whole chunks right of it
+    constexpr int NCH = QL + 1 + QR;
+    constexpr int BASE = 4 * QL - LPAD;          // window index of (r = 0, tap = 0)
+
+    const int nq = ld >> 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    // wave-uniform group index (scalar registers => s_load for weights and bias)
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave);
+    const int b = blockIdx.z;
+    if (!STATS && g >= groups) return;              // with STATS every wave must reach the workgroup barrier below
+    const bool active = q < nq && g < groups;
+
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
+    const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
+    const float* __restrict__ bg = bias + g * CG;
+
+    float acc[CG][4];
+#pragma unroll
+    for (int co = 0; co < CG; ++co) {
+        const float bv = bg[co];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[co][r] = bv;
+    }
+
+    // per-frame LayerNorm statistics of the window (shared by all input channels), kept as frame PAIRS so that the
+    // normalisation below is packed arithmetic: -mean, rstd and a 0/1 mask (rstd == 0 marks frames outside the utterance,
+    // which must stay exactly 0).  (x + -mean) * rstd, fma(., gamma, beta), * mask rounds exactly like ln_apply.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = LNX ? NCH * 2 : 1;
+    f2 nmw[NP], rw[NP], kw[NP];
+    if (LNX) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_x.stats + static_cast<size_t>(b) * 2 * ld);
+        const float4* __restrict__ rrow = mrow + nq;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int qq = q - QL + c;
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = m;
+            if (active && qq >= 0 && qq < nq) { m = mrow[qq]; r = rrow[qq]; }
+            nmw[(2 * c) % NP] = f2{-m.x, -m.y}; nmw[(2 * c + 1) % NP] = f2{-m.z, -m.w};
+            rw[(2 * c) % NP] = f2{r.x, r.y};    rw[(2 * c + 1) % NP] = f2{r.z, r.w};
+            kw[(2 * c) % NP] = f2{r.x != 0.f ? 1.f : 0.f, r.y != 0.f ? 1.f : 0.f};
+            kw[(2 * c + 1) % NP] = f2{r.z != 0.f ? 1.f : 0.f, r.w != 0.f ? 1.f : 0.f};
+        }
+    }
+
+#pragma unroll 1
+    for (int ci = 0; ci < CG; ++ci) {
+        const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + row0 + static_cast<size_t>(ci) * ld);
+        float xw[NCH * 4];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int qq = q - QL + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active && qq >= 0 && qq < nq) v = xrow[qq];
+            xw[4 * c + 0] = v.x; xw[4 * c + 1] = v.y; xw[4 * c + 2] = v.z; xw[4 * c + 3] = v.w;
+        }
+        if (LNX) {
+            const float gam = ln_x.gamma[g * CG + ci], bet = ln_x.beta[g * CG + ci];     // wave-uniform: scalar loads
+            const f2 gam2 = f2{gam, gam}, bet2 = f2{bet, bet};
+#pragma unroll
+            for (int p = 0; p < NCH * 2; ++p) {
+                f2 v = f2{xw[2 * p], xw[2 * p + 1]};
+                v = (v + nmw[p % NP]) * rw[p % NP];
+                v = __builtin_elementwise_fma(v, gam2, bet2) * kw[p % NP];
+                xw[2 * p] = v.x; xw[2 * p + 1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int co = 0; co < CG; ++co) {
+                const float wv = wg[(co * CG + ci) * K + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[co][r] = __builtin_fmaf(wv, xw[BASE + r + j * D], acc[co][r]);
+            }
+        }
+    }
+
+    if (!STATS && !active) return;
+    const int t0 = q * 4;
+    const bool ragged = __any(active && t0 + 3 >= frames) != 0;   // wave-uniform
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;          // statistics of this lane's own 4 frames (skip0)
+    if (active && s0 && ln_s0.stats) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_s0.stats + static_cast<size_t>(b) * 2 * ld);
+        sm = mrow[q];
+        sr = mrow[nq + q];
+    }
+    if (active) {
+#pragma unroll
+    for (int co = 0; co < CG; ++co) {
+        const size_t off = row0 + static_cast<size_t>(co) * ld + t0;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+        if (s0) {
+            float4 v = *reinterpret_cast<const float4*>(s0 + off);
+            if (ln_s0.stats) {
+                const float gam = ln_s0.gamma[g * CG + co], bet = ln_s0.beta[g * CG + co];
+                v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
+                v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
+            }
+            o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+        }
+        if (s1) { const float4 v = *reinterpret_cast<const float4*>(s1 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        if (s2) { const float4 v = *reinterpret_cast<const float4*>(s2 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        // keep the pitch columns frames..ld-1 at zero (layout invariant, nbasr.h); only the wave that holds the ragged chunk
+        if (ragged) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (t0 + r >= frames) o[r] = 0.f;
+        }
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + off));
+        if (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];           // keep the final values for the statistics
+        }
+    }
+    }
+    if (STATS) {
+        // per-lane (mean, M2) over this group's CG channels, exact two-pass in registers
+        __shared__ float sp[4][8][64];
+        float pm[4], p2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sum = 0.f;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) sum += acc[co][r];
+            pm[r] = sum * (1.0f / CG);
+            float m2 = 0.f;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) { const float d = acc[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
+            p2[r] = m2;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sp[wave][r][lane] = pm[r]; sp[wave][4 + r][lane] = p2[r]; }
+        __syncthreads();
+        if (wave == 0 && q < nq) {
+            const int g0 = blockIdx.y * 4;
+            const int nw = min(4, groups - g0);                      // groups (waves) that hold real data
+            float om[4], o2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mean = 0.f;
+                for (int k = 0; k < nw; ++k) mean += sp[k][r][lane];
+                mean /= static_cast<float>(nw);
+                float m2 = 0.f;
+                for (int k = 0; k < nw; ++k) { const float d = sp[k][r][lane] - mean; m2 += sp[k][4 + r][lane] + CG * d * d; }
+                om[r] = mean; o2[r] = m2;
+            }
+            float* prow = part + (static_cast<size_t>(blockIdx.y) * gridDim.z + b) * 2 * ld + t0;
+            *reinterpret_cast<float4*>(prow) = make_float4(om[0], om[1], om[2], om[3]);
+            *reinterpret_cast<float4*>(prow + ld) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        }
+    }
+}
+
+template <int CG, int K, int D>
+static int launch_grouped_f32(const GroupedArgs<float>& a, hipStream_t stream)
+{
+    const int nq = a.ld / 4;
+    dim3 grid((nq + 63) / 64, (a.groups + 3) / 4, a.batch);
+#define NBASR_LAUNCH_GROUPED(LNX, STATS)                                                                                  \
+    hipLaunchKernelGGL((grouped_conv_f32_kernel<CG, K, D, LNX, STATS>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1, \
+                       a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part)
+    if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
+    else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
+#undef NBASR_LAUNCH_GROUPED
+    return launch_status("nbasr_grouped_conv1d_fused");
+}
+
+template <int CG>
+static int dispatch_kd_f32(int kernel, int dilation, const GroupedArgs<float>& a, hipStream_t stream)
+{
+    if (kernel == 5 && dilation == 1) return launch_grouped_f32<CG, 5, 1>(a, stream);
+    if (kernel == 5 && dilation == 2) return launch_grouped_f32<CG, 5, 2>(a, stream);
+    if (kernel == 7 && dilation == 1) return launch_grouped_f32<CG, 7, 1>(a, stream);
+    if (kernel == 7 && dilation == 2) return launch_grouped_f32<CG, 7, 2>(a, stream);
+    set_error("nbasr_grouped_conv1d_fused: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
+    return NBASR_EINVAL;
+}
+
 int grouped_conv_f32_base(const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream)
 {
-    return grouped_conv_variant<float, 4, false>(a, kernel, dilation, stream);
+    switch (a.channels / a.groups) {
+        case 6:  return dispatch_kd_f32<6>(kernel, dilation, a, stream);
+        case 8:  return dispatch_kd_f32<8>(kernel, dilation, a, stream);
+        case 10: return dispatch_kd_f32<10>(kernel, dilation, a, stream);
+        case 12: return dispatch_kd_f32<12>(kernel, dilation, a, stream);
+        default:
+            set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", a.channels / a.groups);
+            return NBASR_EINVAL;
+    }
 }
 
 }  // namespace nbasr
@@ -147,24 +362,21 @@ extern "C" size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int gro
 static int grouped_node_impl(const char* what, const void* x, const float* w, const float* bias, const void* skip0, const void* skip1,
                              const void* skip2, void* y, int batch, int channels, int frames, int ld, int groups, int kernel,
                              int dilation, const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, float* stats_ws, int dtype,
-                             int variant /* by value: the KEEP bit is peeled off below */, nbasr_stream_t stream)
+                             int variant, nbasr_stream_t stream)
 {
     NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "%s: dtype %d is neither NBASR_F32 nor NBASR_BF16", what, dtype);
-    const int keep = (variant & NBASR_GC_KEEP) ? 1 : 0;
-    variant &= ~NBASR_GC_KEEP;
-    NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || (variant == NBASR_GC_FPL2 && dtype == NBASR_F32), NBASR_EINVAL,
-                  "%s: unknown variant %d", what, variant);
+    NBASR_REQUIRE(variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM), NBASR_EINVAL, "%s: unknown variant %d", what, variant);
     NBASR_REQUIRE(aligned16(stats_ws), NBASR_EALIGN, "%s: statistics buffers must be 16-byte aligned", what);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "%s: bad sizes batch=%d channels=%d frames=%d groups=%d", what, batch, channels, frames, groups);
     if (batch == 0 || ld == 0) return NBASR_OK;      // empty batch: nothing to do (empty tensors have NULL storage)
     NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "%s: x, w, bias, y must be non-NULL", what);
     // a lane moves 16 bytes: 4 fp32 or 8 bf16 frames (8 fp32 frames as two accesses); rows are pitched to whole lanes
-    const int pitch = (dtype == NBASR_BF16 || (variant != NBASR_GC_FPL2 && (variant & NBASR_GC_FPL8))) ? 8 : 4;
+    const int pitch = (dtype == NBASR_BF16 || (variant & NBASR_GC_FPL8)) ? 8 : 4;
     NBASR_REQUIRE(ld >= frames && ld % pitch == 0, NBASR_EALIGN, "%s: ld=%d must be >= frames=%d and a multiple of %d", what, ld, frames, pitch);
     NBASR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
                   "%s: activation pointers must be 16-byte aligned", what);
-    NBASR_REQUIRE(static_cast<long long>(batch) * (ld / 4) < (1ll << 31), NBASR_EINVAL, "%s: batch * ld too large", what);
+    NBASR_REQUIRE(static_cast<long long>(batch) * (ld / 4) < (1ll << 31) && batch <= 65535, NBASR_EINVAL, "%s: batch * ld too large", what);
     const bool any_ln = ln && (ln_on_x || (ln_on_skip0 && skip0));
     NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
                   "%s: deferred LayerNorm needs stats (16-byte aligned), gamma and beta", what);
@@ -172,12 +384,11 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
     hipStream_t s = as_stream(stream);
     if (dtype == NBASR_F32) {
         GroupedArgs<float> a{static_cast<const float*>(x), w, bias, static_cast<const float*>(skip0), static_cast<const float*>(skip1),
-                             static_cast<const float*>(skip2), static_cast<float*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws, keep};
-        if (variant == NBASR_GC_FPL2) return grouped_conv_f32_fpl2(a, kernel, dilation, s);
+                             static_cast<const float*>(skip2), static_cast<float*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws};
         return variant == 0 ? grouped_conv_f32_base(a, kernel, dilation, s) : grouped_conv_f32_alt(variant, a, kernel, dilation, s);
     }
     GroupedArgs<bf16_t> a{static_cast<const bf16_t*>(x), w, bias, static_cast<const bf16_t*>(skip0), static_cast<const bf16_t*>(skip1),
-                          static_cast<const bf16_t*>(skip2), static_cast<bf16_t*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws, keep};
+                          static_cast<const bf16_t*>(skip2), static_cast<bf16_t*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws};
     return grouped_conv_bf16(variant, a, kernel, dilation, s);
 }
 

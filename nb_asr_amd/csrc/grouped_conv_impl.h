@@ -16,14 +16,15 @@ namespace nbasr {
 // statistics, gamma / beta are fp32 either way).  FPL: frames per lane (4 or 8): one 16-byte access per 4 fp32 / 8 bf16
 // frames.  WPERM: the weights were re-laid-out as [group][ci][tap][co] (pack_grouped_weights_kernel), so the CG * K weights
 // of one input channel are one contiguous run for the scalar loads.
-// Lanes are dealt over the FLATTENED (utterance, chunk) index: a wave is full whatever the number of frames (250-frame
-// rows used to leave 6 of 64 lanes idle, 400-frame bf16 rows would leave 14).
-template <typename T, int CG, int K, int D, bool LNX, bool STATS, int FPL, bool WPERM>
+// FLAT: lanes are dealt over the FLATTENED (utterance, chunk) index, so a wave is full whatever the number of frames (400-frame
+// bf16 rows = 50 chunks would leave 14 of 64 lanes idle); otherwise the utterance is blockIdx.z and wave-uniform (scalar
+// address arithmetic: the fp32 default, whose 250-chunk rows fill 250 of 256 lanes anyway).
+template <typename T, int CG, int K, int D, bool LNX, bool STATS, int FPL, bool WPERM, bool FLAT>
 __global__ __launch_bounds__(256) void grouped_conv_kernel(
     const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
     const T* __restrict__ s0, const T* __restrict__ s1, const T* __restrict__ s2,
     T* __restrict__ y, int batch, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0,
-    float* __restrict__ part, int keep_in_cache)
+    float* __restrict__ part)
 {
     constexpr int LPAD = pad_left(K, D, 1);
     constexpr int SPAN = (K - 1) * D;                   // taps reach frames [t - LPAD, t - LPAD + SPAN]
@@ -35,13 +36,14 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
     const int nq = ld / FPL;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int item = blockIdx.x * 64 + lane;            // flattened (utterance, chunk)
+    const int item = blockIdx.x * 64 + lane;            // FLAT: flattened (utterance, chunk); else the chunk
     // wave-uniform group index (scalar registers => s_load for weights and bias)
     const int g = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave);
     if (!STATS && g >= groups) return;              // with STATS every wave must reach the workgroup barrier below
-    const bool active = item < batch * nq && g < groups;
-    const int b = active ? item / nq : 0;
-    const int q = item - b * nq;
+    const bool in_range = FLAT ? item < batch * nq : item < nq;
+    const bool active = in_range && g < groups;
+    const int b = FLAT ? (active ? item / nq : 0) : static_cast<int>(blockIdx.z);
+    const int q = FLAT ? item - b * nq : item;
 
     const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
     const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
@@ -124,10 +126,17 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
     float sm[FPL], sr[FPL];                                            // statistics of this lane's own frames (skip0)
 #pragma unroll
     for (int e = 0; e < FPL; ++e) { sm[e] = 0.f; sr[e] = 0.f; }
+    float sk[FPL];                                                     // 0 / 1: frames beyond the utterance (rstd == 0) stay exactly 0
+#pragma unroll
+    for (int e = 0; e < FPL; ++e) sk[e] = 0.f;
     if (active && s0 && ln_s0.stats) {
         const float* __restrict__ mrow = ln_s0.stats + static_cast<size_t>(b) * 2 * ld;
         load_frames<FPL>(mrow + t0, sm);
         load_frames<FPL>(mrow + ld + t0, sr);
+        // the mask is computed ONCE here: written as `rstd != 0 ? ... : 0` per element (ln_apply) hipcc re-evaluates the compare
+        // and the subtraction for every channel of the epilogue (see grouped_conv.hip on the fp32 default)
+#pragma unroll
+        for (int e = 0; e < FPL; ++e) { sk[e] = sr[e] != 0.f ? 1.f : 0.f; sm[e] = -sm[e]; }
     }
     if (active) {
 #pragma unroll
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
             if (ln_s0.stats) {
                 const float gam = ln_s0.gamma[g * CG + co], bet = ln_s0.beta[g * CG + co];
 #pragma unroll
-                for (int r = 0; r < FPL; ++r) v[r] = ln_apply(v[r], sm[r], sr[r], gam, bet);
+                for (int r = 0; r < FPL; ++r) v[r] = __builtin_fmaf((v[r] + sm[r]) * sr[r], gam, bet) * sk[r];    // == ln_apply for finite values
             }
 #pragma unroll
             for (int r = 0; r < FPL; ++r) o[r] += v[r];
@@ -164,9 +173,10 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
 #pragma unroll
             for (int r = 0; r < FPL; ++r) if (t0 + r >= frames) o[r] = 0.f;
         }
-        // streaming (non-temporal) stores by default: the next kernel reads y from HBM anyway when the tensor is larger than
-        // the 256 MiB last-level cache; `keep_in_cache` (small tensors: the narrow blocks) leaves it there for that reader
-        if (keep_in_cache) store_frames<FPL, false>(y + off, o); else store_frames<FPL, true>(y + off, o);
+        // streaming (non-temporal) stores: worth 2 % of the forward over plain ones (round 1).  Measured and rejected in round 2: a
+        // RUN-TIME choice between the two store flavours (plain for tensors that fit the 256 MiB last-level cache) -- no gain
+        // from the plain stores, and the second store path alone made this kernel 30 % slower in the widest-row block
+        store_frames<FPL, true>(y + off, o);
         if (STATS) {
 #pragma unroll
             for (int r = 0; r < FPL; ++r) acc[co][r] = o[r];         // keep the final values for the statistics
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
 #pragma unroll
         for (int r = 0; r < FPL; ++r) { sp[wave][r][lane] = pm[r]; sp[wave][FPL + r][lane] = p2[r]; }
         __syncthreads();
-        if (wave == 0 && item < batch * nq) {
+        if (wave == 0 && in_range) {
             const int g0 = blockIdx.y * 4;
             const int nw = min(4, groups - g0);                      // groups (waves) that hold real data
             float om[FPL], o2[FPL];
@@ -219,17 +229,22 @@ struct GroupedArgs {
     int batch, channels, frames, ld, groups;
     LnRef ln_x, ln_s0;
     float* part;                 // partial-statistics workspace (nullptr: no statistics)
-    int keep_in_cache;           // plain instead of non-temporal output stores
 };
+
+#ifndef NBASR_GC_FLAT_F32
+#define NBASR_GC_FLAT_F32 0      /* fp32 kernels: utterance per blockIdx.z (1) or flattened lanes (0/1 A/B at build time) */
+#endif
+template <typename T> constexpr bool gc_flat() { return sizeof(T) == 2 || NBASR_GC_FLAT_F32 != 0; }
 
 template <typename T, int FPL, bool WPERM, int CG, int K, int D>
 static int launch_grouped(const GroupedArgs<T>& a, hipStream_t stream)
 {
-    const long long items = static_cast<long long>(a.batch) * (a.ld / FPL);
-    dim3 grid(static_cast<unsigned>((items + 63) / 64), (a.groups + 3) / 4);
+    constexpr bool FLAT = gc_flat<T>();
+    const long long items = static_cast<long long>(FLAT ? a.batch : 1) * (a.ld / FPL);
+    dim3 grid(static_cast<unsigned>((items + 63) / 64), (a.groups + 3) / 4, FLAT ? 1 : a.batch);
 #define NBASR_LAUNCH_GROUPED(LNX, STATS)                                                                                    \
-    hipLaunchKernelGGL((grouped_conv_kernel<T, CG, K, D, LNX, STATS, FPL, WPERM>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, \
-                       a.s0, a.s1, a.s2, a.y, a.batch, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part, a.keep_in_cache)
+    hipLaunchKernelGGL((grouped_conv_kernel<T, CG, K, D, LNX, STATS, FPL, WPERM, FLAT>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, \
+                       a.s0, a.s1, a.s2, a.y, a.batch, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part)
     if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
     else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
 #undef NBASR_LAUNCH_GROUPED
@@ -265,7 +280,6 @@ int grouped_conv_variant(const GroupedArgs<T>& a, int kernel, int dilation, hipS
 // defined one per translation unit (explicit variants)
 int grouped_conv_f32_base(const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);     // FPL 4, torch weight layout
 int grouped_conv_f32_alt(int variant, const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);
-int grouped_conv_f32_fpl2(const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);
 int grouped_conv_bf16(int variant, const GroupedArgs<bf16_t>& a, int kernel, int dilation, hipStream_t stream);
 
 }  // namespace nbasr

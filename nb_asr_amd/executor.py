@@ -307,12 +307,9 @@ class ForwardPlan:
 
     def _gc_variant(self, view):
         """Kernel variant of the fp32 grouped-conv node op for an output of this size (speed only: results are bit-identical).
-        NBASR_GC_F32_VARIANT=<int> forces one; NBASR_GC_KEEP_MB=<float> moves the streaming / cache-resident store threshold."""
+        NBASR_GC_F32_VARIANT=<int> forces one (diagnostics; needs ld % 8 == 0 for the 8-frame variants)."""
         forced = os.environ.get('NBASR_GC_F32_VARIANT')
-        if forced is not None:
-            return int(forced)
-        mb = view.numel() * 4 / 1e6
-        return hip.GC_KEEP if mb <= float(os.environ.get('NBASR_GC_KEEP_MB', '0')) else 0
+        return int(forced) if forced is not None else 0
 
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)

@@ -94,6 +94,10 @@ SIGNATURES = {
     'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_f16_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_grouped_conv1d_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 4),
+    'nbasr_grouped_conv1d_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 7 + [_c_stream]),
+    'nbasr_layernorm_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_layernorm_channels_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 4 + [_c_stream]),
     # storage-type generic / bf16 path
     'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
     'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
@@ -110,7 +114,7 @@ SIGNATURES = {
 }
 
 F32, BF16 = 0, 1                 # NBASR_F32 / NBASR_BF16
-GC_FPL8, GC_WPERM, GC_FPL2, GC_KEEP = 1, 2, 4, 8         # NBASR_GC_* variants of nbasr_grouped_conv1d_node
+GC_FPL8, GC_WPERM = 1, 2         # NBASR_GC_* variant bits of nbasr_grouped_conv1d_node
 
 
 class HipError(RuntimeError):
@@ -820,3 +824,38 @@ def dense_conv1d_bf16_img(image, batch, c_in, frames_in, ld_in, packed, c_out, k
                                            c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride, row_tile, _stream(y)),
            'nbasr_dense_conv1d_bf16_img')
     return y
+
+
+# ---------------------------------------------------------------------------------------------
+# backward building blocks
+# ---------------------------------------------------------------------------------------------
+def grouped_conv1d_backward(x, weight, z, dz, frames, groups, kernel, dilation, need_dx=True, need_dw=True):
+    """Gradients of z = min(relu(grouped_conv(x, weight) + bias), 20) given dz: (dx or None, dw or None, db or None).
+    x, z, dz: (B, C, ld) float32 pitched tensors (z = the op's output; dz's pitch columns zero)."""
+    b, c, ld = z.shape
+    lib = load_library()
+    dx = torch.empty_like(z) if need_dx else None
+    dw = torch.empty_like(weight) if need_dw else None
+    db = torch.empty(c, dtype=torch.float32, device=z.device) if need_dw else None
+    ws = None
+    if need_dw:
+        ws = torch.empty(max(lib.nbasr_grouped_conv1d_backward_workspace_bytes(max(b, 1), c, groups, kernel) // 4, 4), dtype=torch.float32,
+                         device=z.device)
+    _check(lib.nbasr_grouped_conv1d_backward(_opt(x, 'x'), _dev(weight, 'weight'), _dev(z, 'z'), _dev(dz, 'dz'), _opt(dx, 'dx'), _opt(dw, 'dw'),
+                                             _opt(db, 'db'), _opt(ws, 'workspace'), b, c, frames, ld, groups, kernel, dilation, _stream(z)),
+           'nbasr_grouped_conv1d_backward')
+    return dx, dw, db
+
+
+def layernorm_channels_backward(x, stats, gamma, dy, frames):
+    """(dx, dgamma, dbeta) of y = LayerNorm_channels(x) given dy; stats = channel_stats(x)."""
+    b, c, ld = x.shape
+    lib = load_library()
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(lib.nbasr_layernorm_backward_workspace_bytes(max(b, 1), c, max(ld, 4)) // 4, 4), dtype=torch.float32, device=x.device)
+    _check(lib.nbasr_layernorm_channels_backward(_dev(x, 'x'), _dev(stats, 'stats'), _dev(gamma, 'gamma'), _dev(dy, 'dy'), _dev(dx, 'dx'),
+                                                 _dev(dgamma, 'dgamma'), _dev(dbeta, 'dbeta'), _dev(ws, 'workspace'), b, c, frames, ld, _stream(x)),
+           'nbasr_layernorm_channels_backward')
+    return dx, dgamma, dbeta

@@ -75,6 +75,9 @@ class PadConvRelu(nn.Module):
         else:
             if self.strides != 1:
                 raise NotImplementedError('grouped PadConvRelu only exists with stride 1 in the search space')
+            if torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad) and x.dtype == torch.float32:
+                from .autograd import grouped_pad_conv_relu          # the node op is trainable on its own (first block)
+                return grouped_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.groups, self.kernel_size, self.dilation)
             hip.grouped_conv1d_fused(xp, self.conv.weight.detach(), self.conv.bias.detach(), (), y, frames,
                                      self.groups, self.kernel_size, self.dilation)
         return y[:, :, :t_out]

@@ -11,6 +11,7 @@ ONLY inputs-by-recipe + expected outputs are stored (no reference source text):
   ops_fixtures.npz          expected outputs of the reference's op / node / cell / LayerNorm / LSTM
                             modules on keyed inputs
   model_fixtures.npz        full-model logits + per-layer statistics / samples (reference fp32 AND an fp64 evaluation)
+  grad_fixtures.npz         gradients of the grouped PadConvRelu and the channel LayerNorm from the reference modules' own autograd
   bf16_fixtures.npz         the reference model .to(torch.bfloat16) on bf16 inputs: logits + per-layer samples, next to an
                             fp64 evaluation of the same bf16-rounded parameters (BASELINE config 4's arithmetic)
 
@@ -378,6 +379,70 @@ def bf16_fixtures():
     return fx
 
 
+# ------------------------------------------------------------------------------------------------
+GRAD_GCONV_CASES = [(6, 5, 1), (8, 5, 2), (10, 7, 1), (12, 7, 2), (12, 5, 1)]      # (group width, kernel, dilation); C = 4 groups
+GRAD_GCONV100_CASES = [('conv5', 600), ('conv7d2', 1200)]
+GRAD_LN_CASES = [(600, 19), (24, 37), (1200, 7)]
+
+
+def grad_fixtures():
+    """Gradient fixtures: d(sum(y * r)) / d(x, weight, bias) for the grouped PadConvRelu (ops.py:24-30) and
+    d / d(x, gamma, beta) for the channel LayerNorm (model.py:55-58), r keyed.
+
+    The LayerNorm gradients come from the reference's own module (nn.LayerNorm on the permuted tensor).  The reference's
+    ``PadConvRelu.forward`` cannot be differentiated under this torch: its in-place ``torch.clamp_max_`` (ops.py:28) overwrites
+    the ReLU output that ReluBackward saved ("modified by an inplace operation").  Its gradients are therefore taken through
+    ATen's autograd of the SAME op sequence written out of place (oracle.pad_conv_relu), after checking that this restatement
+    reproduces the reference module's forward bit for bit on the same inputs."""
+    fx = {}
+
+    def run_conv(tag, m, x, k, d, groups):
+        with torch.no_grad():
+            assert torch.equal(m(x), oracle.pad_conv_relu(x, m.conv.weight, m.conv.bias, d, 1, groups)), tag
+        torch.set_grad_enabled(True)
+        try:
+            xg = x.clone().requires_grad_(True)
+            w = m.conv.weight.detach().clone().requires_grad_(True)
+            bias = m.conv.bias.detach().clone().requires_grad_(True)
+            y = oracle.pad_conv_relu(xg, w, bias, d, 1, groups)
+            r = torch.from_numpy(keyed_normal(tag + '/r', 5, tuple(y.shape)))
+            (y * r).sum().backward()
+        finally:
+            torch.set_grad_enabled(False)
+        fx[tag + '/dx'] = xg.grad.numpy().astype(np.float32)
+        fx[tag + '/dw'] = w.grad.numpy().astype(np.float32)
+        fx[tag + '/db'] = bias.grad.numpy().astype(np.float32)
+        print(f'  {tag}: {float(((y > 0) & (y < 20)).float().mean()):.2f} of the outputs pass a gradient, '
+              f'{float((y >= 20).float().mean()):.3f} clamped')
+
+    for cg, k, d in GRAD_GCONV_CASES:
+        c, groups, b, t = cg * 4, 4, 2, 37
+        tag = f'grad/gconv/cg{cg}_k{k}_d{d}'
+        m = fill_module_(ref_ops.PadConvRelu(c, c, k, d, 1, groups=groups), tag).eval()
+        run_conv(tag, m, torch.from_numpy(keyed_normal(tag + '/x', 3, (b, c, t))) * 8.0, k, d, groups)     # some outputs reach the clamp
+    for name, c in GRAD_GCONV100_CASES:
+        tag = f'grad/gconv100/{name}_c{c}'
+        m = fill_module_(ref_ops._ops[name](c, c), tag).eval()
+        k, d = oracle.CONV_OPS[name]
+        run_conv(tag, m, torch.from_numpy(keyed_normal(tag + '/x', 3, (1, c, 70))) * 2.0, k, d, 100)
+    torch.set_grad_enabled(True)
+    try:
+        for c, t in GRAD_LN_CASES:
+            tag = f'grad/layernorm/c{c}_t{t}'
+            with torch.no_grad():
+                ln = fill_module_(torch.nn.LayerNorm(c, eps=0.001), tag).eval()
+            x = torch.from_numpy(keyed_normal(tag + '/x', 3, (2, c, t))).requires_grad_(True)
+            y = ln(x.permute(0, 2, 1)).permute(0, 2, 1)
+            r = torch.from_numpy(keyed_normal(tag + '/r', 5, tuple(y.shape)))
+            (y * r).sum().backward()
+            fx[tag + '/dx'] = x.grad.numpy().astype(np.float32)
+            fx[tag + '/dgamma'] = ln.weight.grad.numpy().astype(np.float32)
+            fx[tag + '/dbeta'] = ln.bias.grad.numpy().astype(np.float32)
+    finally:
+        torch.set_grad_enabled(False)
+    return fx
+
+
 if __name__ == '__main__':
     print('host known answers ...')
     known = host_known_answers()
@@ -386,6 +451,8 @@ if __name__ == '__main__':
     np.savez_compressed(HERE / 'ops_fixtures.npz', **op_fixtures())
     print('model fixtures ...')
     np.savez_compressed(HERE / 'model_fixtures.npz', **model_fixtures())
+    print('gradient fixtures ...')
+    np.savez_compressed(HERE / 'grad_fixtures.npz', **grad_fixtures())
     print('bf16 fixtures ...')
     np.savez_compressed(HERE / 'bf16_fixtures.npz', **bf16_fixtures())
     for f in sorted(HERE.glob('*.*')):

@@ -1,0 +1,128 @@
+"""Backward building blocks (bottom-up): the grouped node op and the channel LayerNorm, HIP backward kernels
+through the C ABI vs gradient fixtures (tests/golden/grad_fixtures.npz: ATen autograd of the reference's op sequence -- the
+reference's own PadConvRelu.forward cannot be differentiated under this torch, its in-place clamp_max_ breaks ReluBackward;
+LayerNorm gradients from the reference's nn.LayerNorm module)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from conftest import GOLDEN
+from nb_asr_amd import autograd as nb_autograd, hip, ops
+from nb_asr_amd.utils import keyed_normal
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def grad_fx():
+    with np.load(GOLDEN / 'grad_fixtures.npz') as z:
+        return {k: z[k] for k in z.files}
+
+
+def close(got, want, what, rtol=1e-4):
+    got, want = got.detach().double().cpu(), torch.from_numpy(want).double()
+    assert tuple(got.shape) == tuple(want.shape), what
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got - want).abs().max())
+    assert err <= rtol * scale, f'{what}: max err {err:.3e} vs scale {scale:.3e}'
+
+
+def conv_case(tag, c, cg, k, shape, scale):
+    p = cases.keyed_params({'conv.weight': (c, cg, k), 'conv.bias': (c,)}, tag)
+    x = torch.from_numpy(keyed_normal(tag + '/x', 3, shape)) * scale
+    r = torch.from_numpy(keyed_normal(tag + '/r', 5, shape))
+    return x, p['conv.weight'], p['conv.bias'], r
+
+
+def run_conv_grad(x, w, bias, r, groups, k, d):
+    xg = x.to(DEV).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)
+    bg = bias.to(DEV).requires_grad_(True)
+    y = nb_autograd.grouped_pad_conv_relu(xg, wg, bg, groups, k, d)
+    (y * r.to(DEV)).sum().backward()
+    return y, xg.grad, wg.grad, bg.grad
+
+
+@pytest.mark.parametrize('cg,k,d', cases.GRAD_GCONV_CASES)
+def test_grouped_node_op_gradients(grad_fx, cg, k, d):
+    tag = f'grad/gconv/cg{cg}_k{k}_d{d}'
+    x, w, bias, r = conv_case(tag, cg * 4, cg, k, (2, cg * 4, 37), 8.0)
+    y, dx, dw, db = run_conv_grad(x, w, bias, r, 4, k, d)
+    assert float(y.max()) == 20.0                                   # the clamp is active: its mask is part of what is tested
+    close(dx, grad_fx[tag + '/dx'], tag + ' dx')
+    close(dw, grad_fx[tag + '/dw'], tag + ' dw')
+    close(db, grad_fx[tag + '/db'], tag + ' db')
+    y2, dx2, dw2, db2 = run_conv_grad(x, w, bias, r, 4, k, d)          # no atomics anywhere: bit-reproducible
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize('name,c,k,d', cases.GRAD_GCONV100_CASES)
+def test_grouped_node_op_gradients_production_width(grad_fx, name, c, k, d):
+    tag = f'grad/gconv100/{name}_c{c}'
+    x, w, bias, r = conv_case(tag, c, c // 100, k, (1, c, 70), 2.0)
+    _, dx, dw, db = run_conv_grad(x, w, bias, r, 100, k, d)
+    close(dx, grad_fx[tag + '/dx'], tag + ' dx')
+    close(dw, grad_fx[tag + '/dw'], tag + ' dw')
+    close(db, grad_fx[tag + '/db'], tag + ' db')
+
+
+@pytest.mark.parametrize('t', [1, 3, 63, 64, 65, 130, 257])
+def test_grouped_node_op_gradients_ragged_lengths_vs_torch_autograd(t):
+    """Frame counts around the 64-frame step of the weight-gradient GEMM and the 4-frame lanes, three utterances."""
+    from oracle import asr_oracle as oracle
+    torch.manual_seed(t)
+    c, groups, k, d, b = 40, 4, 7, 2, 3
+    x, w, bias = torch.randn(b, c, t) * 3, torch.randn(c, c // groups, k) * 0.3, torch.randn(c) * 0.2
+    r = torch.randn(b, c, t)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    (oracle.pad_conv_relu(xr, wr, br, d, 1, groups) * r).sum().backward()
+    _, dx, dw, db = run_conv_grad(x, w, bias, r, groups, k, d)
+    close(dx, xr.grad.numpy(), 'dx')
+    close(dw, wr.grad.numpy(), 'dw')
+    close(db, br.grad.numpy(), 'db')
+
+
+@pytest.mark.parametrize('c,t', cases.GRAD_LN_CASES)
+def test_layernorm_gradients(grad_fx, c, t):
+    tag = f'grad/layernorm/c{c}_t{t}'
+    p = cases.keyed_params({'weight': (c,), 'bias': (c,)}, tag)
+    x = torch.from_numpy(keyed_normal(tag + '/x', 3, (2, c, t))).to(DEV).requires_grad_(True)
+    gamma, beta = p['weight'].to(DEV).requires_grad_(True), p['bias'].to(DEV).requires_grad_(True)
+    r = torch.from_numpy(keyed_normal(tag + '/r', 5, (2, c, t))).to(DEV)
+    y = nb_autograd.layer_norm_channels(x, gamma, beta, 1e-3)
+    (y * r).sum().backward()
+    close(x.grad, grad_fx[tag + '/dx'], tag + ' dx', rtol=2e-4)
+    close(gamma.grad, grad_fx[tag + '/dgamma'], tag + ' dgamma')
+    close(beta.grad, grad_fx[tag + '/dbeta'], tag + ' dbeta')
+
+
+def test_grouped_module_is_trainable_on_its_own():
+    """ops.PadConvRelu with groups > 1 routes through the autograd function when a gradient is required: one SGD step on
+    its own parameters lowers a loss; without grad the ordinary fused launch runs."""
+    torch.manual_seed(0)
+    m = ops._ops['conv5'](600, 600).to(DEV)
+    x = torch.randn(2, 600, 50, device=DEV)
+    target = torch.rand(2, 600, 50, device=DEV)
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = ((m(x) - target) ** 2).mean()
+        loss.backward()
+        assert m.conv.weight.grad is not None and torch.isfinite(m.conv.weight.grad).all()
+        opt.step()
+        losses.append(float(loss))
+    assert losses[-1] < losses[0]
+    with torch.no_grad():
+        assert m(x).grad_fn is None
+
+
+def test_backward_argument_errors():
+    lib = hip.load_library()
+    rc = lib.nbasr_grouped_conv1d_backward(16, 16, 16, 16, 16, 16, None, 16, 1, 600, 16, 16, 100, 5, 1, None)
+    assert rc == -3 and b'come together' in lib.nbasr_last_error()
+    rc = lib.nbasr_grouped_conv1d_backward(16, 16, 16, 16, 16, None, None, None, 1, 600, 10, 10, 100, 5, 1, None)
+    assert rc == -2
+    assert lib.nbasr_grouped_conv1d_backward_workspace_bytes(64, 1200, 100, 5) == 100 * 64 * 4 * 256 * 4

@@ -123,3 +123,18 @@ def test_reference_loader_reads_the_file(tmp_path):
         sys.path.remove(str(REF))
         for name in [m for m in sys.modules if m.startswith('nasbench_asr')]:
             del sys.modules[name]
+
+
+def test_committed_full_sweep_covers_the_search_space():
+    """profiles/r02_sweep/nb-asr-bench-mi355x-fp32.pickle: BASELINE config 5's artefact, produced on one MI355X by
+    tools/latency_sweep.py (8 242 architectures, B=32, T=1000).  One row per unique model hash of the search space, positive
+    finite latencies, the reference's header keys only."""
+    import math
+    path = pathlib.Path(__file__).resolve().parent.parent / 'profiles' / 'r02_sweep' / bench_dataset.file_name('mi355x-fp32')
+    header, device, db = bench_dataset.read_benchmarking_dataset(path)
+    assert device == 'mi355x-fp32' and sorted(header) == ['columns', 'dataset_type', 'search_space', 'version']
+    unique = search_space.get_unique_architectures()
+    assert len(db) == len(unique) == 8242 and set(db) == set(unique)
+    lat = [v[0] for v in db.values()]
+    assert all(math.isfinite(v) and 1e-3 < v < 0.1 for v in lat)
+    assert db[search_space.get_model_hash(ARCH)][0] < db[search_space.get_model_hash([[0, 0], [0, 0, 0], [0, 0, 0, 0]])][0]

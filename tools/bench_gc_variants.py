@@ -56,11 +56,11 @@ def main():
                         'skip3': dict(skips=[s0, s1, s2], ln=None, on_x=False, ws=None)}
             for fname, f in flavours.items():
                 nbytes = elem * a.batch * c * t * (2 + len(f['skips'])) + 4 * (c * (c // 100) * a.kernel + c)
-                variants = (0, 1, 2, 3, 4) if dname == 'f32' else (0, 1, 2, 3)      # 4 = two frames per lane (fp32 only)
+                variants = (0, 1, 2, 3)
                 times = {v: [] for v in variants}
 
                 def run(v):
-                    hip.grouped_conv1d_node(x, wp if (v & hip.GC_WPERM and v != hip.GC_FPL2) else w, bias, f['skips'], y, t, 100, a.kernel, a.dilation,
+                    hip.grouped_conv1d_node(x, wp if v & hip.GC_WPERM else w, bias, f['skips'], y, t, 100, a.kernel, a.dilation,
                                             f['ln'], f['on_x'], False, f['ws'], v)
                 for v in variants:
                     run(v)

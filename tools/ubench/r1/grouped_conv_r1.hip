@@ -1,0 +1,420 @@
+// Fused node operation for the grouped convolutions of the search space:
+//     y = min(relu(conv1d(zero_pad(x), w, bias, dilation, groups)), 20) + skip0 + skip1 + skip2
+// replacing reference ops.py:24-30 (ZeroPad2d -> Conv1d -> ReLU -> clamp_max_) and the python `sum`
+// of Node.forward (model.py:13-22).  No padded copy, no zeros_like tensors, one pass over HBM.
+//
+// Mapping (gfx950, wave64): one lane owns 4 consecutive frames (one 16-byte chunk) of ALL channels
+// of one channel group; a wave covers 256 consecutive frames of one (utterance, group), so every
+// global access is a fully coalesced 1 KiB wave transaction, and the group's weights / bias are
+// wave-uniform and come through the scalar cache (s_load), never through VGPRs or LDS.
+// The k-tap sliding window of an input channel lives in registers: NCH aligned 16-byte chunks per
+// lane (neighbour lanes re-read the halo chunks from L1/L2, HBM sees every byte once).
+//
+// HBM-bound (7.5-21 flop/byte); algorithmic bytes per launch
+//     4 * (B*C*T * (2 + n_skips) + C*(C/groups)*k + C).
+#include "common.h"
+
+namespace nbasr {
+
+// LNX: the main input carries a pending LayerNorm (deferred normalisation, nbasr.h) applied while loading;
+// ln_s0.stats != nullptr: skip0 carries one (inside a cell both are the cell input, with the same statistics).
+// STATS: the epilogue also emits this workgroup's partial LayerNorm statistics of y -- per frame the (mean, M2) over the
+// 4 x CG channels of its four groups -- to `part` ([group quad][batch][2][ld]); stats_finalize_kernel merges the quads.
+// This replaces the separate statistics pass over y when y is the last node of a cell.
+template <int CG, int K, int D, bool LNX, bool STATS>
+__global__ __launch_bounds__(256) void grouped_conv_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+    float* __restrict__ y, int channels, int frames, int ld, int groups, const LnRef ln_x, const LnRef ln_s0,
+    float* __restrict__ part)
+{
+    constexpr int LPAD = pad_left(K, D, 1);
+    constexpr int SPAN = (K - 1) * D;            // taps reach frames [t - LPAD, t - LPAD + SPAN]
+    constexpr int QL = (LPAD + 3) / 4;           // whole chunks left of the lane's own chunk
+    constexpr int QR = (SPAN - LPAD + 3) / 4;    // whole chunks right of it
+    constexpr int NCH = QL + 1 + QR;
+    constexpr int BASE = 4 * QL - LPAD;          // window index of (r = 0, tap = 0)
+
+    const int nq = ld >> 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 64 + lane;
+    // wave-uniform group index (scalar registers => s_load for weights and bias)
+    const int g = __builtin_amdgcn_readfirstlane(blockIdx.y * 4 + wave);
+    const int b = blockIdx.z;
+    if (!STATS && g >= groups) return;              // with STATS every wave must reach the workgroup barrier below
+    const bool active = q < nq && g < groups;
+
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
+    const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
+    const float* __restrict__ bg = bias + g * CG;
+
+    float acc[CG][4];
+#pragma unroll
+    for (int co = 0; co < CG; ++co) {
+        const float bv = bg[co];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[co][r] = bv;
+    }
+
+    // per-frame LayerNorm statistics of the window (shared by all input channels), kept as frame PAIRS so that the
+    // normalisation below is packed arithmetic: -mean, rstd and a 0/1 mask (rstd == 0 marks frames outside the utterance,
+    // which must stay exactly 0).  (x + -mean) * rstd, fma(., gamma, beta), * mask rounds exactly like ln_apply.
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int NP = LNX ? NCH * 2 : 1;
+    f2 nmw[NP], rw[NP], kw[NP];
+    if (LNX) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_x.stats + static_cast<size_t>(b) * 2 * ld);
+        const float4* __restrict__ rrow = mrow + nq;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int qq = q - QL + c;
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = m;
+            if (active && qq >= 0 && qq < nq) { m = mrow[qq]; r = rrow[qq]; }
+            nmw[(2 * c) % NP] = f2{-m.x, -m.y}; nmw[(2 * c + 1) % NP] = f2{-m.z, -m.w};
+            rw[(2 * c) % NP] = f2{r.x, r.y};    rw[(2 * c + 1) % NP] = f2{r.z, r.w};
+            kw[(2 * c) % NP] = f2{r.x != 0.f ? 1.f : 0.f, r.y != 0.f ? 1.f : 0.f};
+            kw[(2 * c + 1) % NP] = f2{r.z != 0.f ? 1.f : 0.f, r.w != 0.f ? 1.f : 0.f};
+        }
+    }
+
+#pragma unroll 1
+    for (int ci = 0; ci < CG; ++ci) {
+        const float4* __restrict__ xrow = reinterpret_cast<const float4*>(x + row0 + static_cast<size_t>(ci) * ld);
+        float xw[NCH * 4];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int qq = q - QL + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (active && qq >= 0 && qq < nq) v = xrow[qq];
+            xw[4 * c + 0] = v.x; xw[4 * c + 1] = v.y; xw[4 * c + 2] = v.z; xw[4 * c + 3] = v.w;
+        }
+        if (LNX) {
+            const float gam = ln_x.gamma[g * CG + ci], bet = ln_x.beta[g * CG + ci];     // wave-uniform: scalar loads
+            const f2 gam2 = f2{gam, gam}, bet2 = f2{bet, bet};
+#pragma unroll
+            for (int p = 0; p < NCH * 2; ++p) {
+                f2 v = f2{xw[2 * p], xw[2 * p + 1]};
+                v = (v + nmw[p % NP]) * rw[p % NP];
+                v = __builtin_elementwise_fma(v, gam2, bet2) * kw[p % NP];
+                xw[2 * p] = v.x; xw[2 * p + 1] = v.y;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+#pragma unroll
+            for (int co = 0; co < CG; ++co) {
+                const float wv = wg[(co * CG + ci) * K + j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[co][r] = __builtin_fmaf(wv, xw[BASE + r + j * D], acc[co][r]);
+            }
+        }
+    }
+
+    if (!STATS && !active) return;
+    const int t0 = q * 4;
+    const bool ragged = __any(active && t0 + 3 >= frames) != 0;   // wave-uniform
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;          // statistics of this lane's own 4 frames (skip0)
+    if (active && s0 && ln_s0.stats) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_s0.stats + static_cast<size_t>(b) * 2 * ld);
+        sm = mrow[q];
+        sr = mrow[nq + q];
+    }
+    if (active) {
+#pragma unroll
+    for (int co = 0; co < CG; ++co) {
+        const size_t off = row0 + static_cast<size_t>(co) * ld + t0;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+        if (s0) {
+            float4 v = *reinterpret_cast<const float4*>(s0 + off);
+            if (ln_s0.stats) {
+                const float gam = ln_s0.gamma[g * CG + co], bet = ln_s0.beta[g * CG + co];
+                v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
+                v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
+            }
+            o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+        }
+        if (s1) { const float4 v = *reinterpret_cast<const float4*>(s1 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        if (s2) { const float4 v = *reinterpret_cast<const float4*>(s2 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        // keep the pitch columns frames..ld-1 at zero (layout invariant, nbasr.h); only the wave that holds the ragged chunk
+        if (ragged) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (t0 + r >= frames) o[r] = 0.f;
+        }
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + off));
+        if (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];           // keep the final values for the statistics
+        }
+    }
+    }
+    if (STATS) {
+        // per-lane (mean, M2) over this group's CG channels, exact two-pass in registers
+        __shared__ float sp[4][8][64];
+        float pm[4], p2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float sum = 0.f;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) sum += acc[co][r];
+            pm[r] = sum * (1.0f / CG);
+            float m2 = 0.f;
+#pragma unroll
+            for (int co = 0; co < CG; ++co) { const float d = acc[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
+            p2[r] = m2;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sp[wave][r][lane] = pm[r]; sp[wave][4 + r][lane] = p2[r]; }
+        __syncthreads();
+        if (wave == 0 && q < nq) {
+            const int g0 = blockIdx.y * 4;
+            const int nw = min(4, groups - g0);                      // groups (waves) that hold real data
+            float om[4], o2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float mean = 0.f;
+                for (int k = 0; k < nw; ++k) mean += sp[k][r][lane];
+                mean /= static_cast<float>(nw);
+                float m2 = 0.f;
+                for (int k = 0; k < nw; ++k) { const float d = sp[k][r][lane] - mean; m2 += sp[k][4 + r][lane] + CG * d * d; }
+                om[r] = mean; o2[r] = m2;
+            }
+            float* prow = part + (static_cast<size_t>(blockIdx.y) * gridDim.z + b) * 2 * ld + t0;
+            *reinterpret_cast<float4*>(prow) = make_float4(om[0], om[1], om[2], om[3]);
+            *reinterpret_cast<float4*>(prow + ld) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        }
+    }
+}
+
+// merge the per-quad partial statistics: stats (batch, 2, ld) <- (mean, rstd) per frame, 0 in the pitch columns
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                             int batch, int frames, int ld, int groups, int cg, float eps)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= ld) return;
+    float* srow = stats + static_cast<size_t>(b) * 2 * ld;
+    if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
+    const int nquads = (groups + 3) / 4;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    // the partials are loaded five at a time BEFORE they are merged: the merge is a serial chain, the loads need not be
+    // (25 partials per frame at 100 groups: 5 round trips to memory instead of 25; same merge order, same result)
+    for (int k0 = 0; k0 < nquads; k0 += 5) {
+        float pm[5], pq[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = min(k0 + u, nquads - 1);
+            const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld;
+            pm[u] = prow[t];
+            pq[u] = prow[ld + t];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int k = k0 + u;
+            if (k >= nquads) break;
+            const float nb = static_cast<float>(cg * min(4, groups - 4 * k));
+            const float tot = cnt + nb;
+            const float delta = pm[u] - mean;
+            mean += delta * (nb / tot);
+            m2 += pq[u] + delta * delta * (cnt * nb / tot);
+            cnt = tot;
+        }
+    }
+    srow[t] = mean;
+    srow[ld + t] = 1.0f / sqrtf(m2 / cnt + eps);
+}
+
+// y = 0 + skip0 + skip1 + skip2 for a node whose main op is `zero` (reference ops.py:67-68); skip0 may carry a pending
+// LayerNorm, in which case the materialised (normalised) value is what gets summed and stored
+__global__ __launch_bounds__(256) void skip_sum_kernel(
+    const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+    float* __restrict__ y, size_t n4, int channels, int nq, const LnRef ln_s0)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (s0) {
+            float4 v = reinterpret_cast<const float4*>(s0)[i];
+            if (ln_s0.stats) {
+                const size_t row = i / nq;
+                const int q = static_cast<int>(i - row * nq);
+                const int c = static_cast<int>(row % channels);
+                const size_t b = row / channels;
+                const float4* mrow = reinterpret_cast<const float4*>(ln_s0.stats + b * 2 * (static_cast<size_t>(nq) * 4));
+                const float4 m = mrow[q], r = mrow[nq + q];
+                const float gam = ln_s0.gamma[c], bet = ln_s0.beta[c];
+                v.x = ln_apply(v.x, m.x, r.x, gam, bet); v.y = ln_apply(v.y, m.y, r.y, gam, bet);
+                v.z = ln_apply(v.z, m.z, r.z, gam, bet); v.w = ln_apply(v.w, m.w, r.w, gam, bet);
+            }
+            o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+        }
+        if (s1) { const float4 v = reinterpret_cast<const float4*>(s1)[i]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        if (s2) { const float4 v = reinterpret_cast<const float4*>(s2)[i]; o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w; }
+        reinterpret_cast<float4*>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void repitch_kernel(
+    const float* __restrict__ src, float* __restrict__ dst, int rows, int frames, int ld_src, int ld_dst)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ld_dst) return;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        dst[static_cast<size_t>(r) * ld_dst + t] = (t < frames) ? src[static_cast<size_t>(r) * ld_src + t] : 0.f;
+}
+
+struct GroupedArgs {
+    const float* x; const float* w; const float* bias; const float* s0; const float* s1; const float* s2; float* y;
+    int batch, channels, frames, ld, groups;
+    LnRef ln_x, ln_s0;
+    float* part;                 // partial-statistics workspace (nullptr: no statistics)
+};
+
+template <int CG, int K, int D>
+static int launch_grouped(const GroupedArgs& a, hipStream_t stream)
+{
+    const int nq = a.ld / 4;
+    dim3 grid((nq + 63) / 64, (a.groups + 3) / 4, a.batch);
+#define NBASR_LAUNCH_GROUPED(LNX, STATS)                                                                                  \
+    hipLaunchKernelGGL((grouped_conv_kernel<CG, K, D, LNX, STATS>), grid, dim3(256), 0, stream, a.x, a.w, a.bias, a.s0, a.s1, \
+                       a.s2, a.y, a.channels, a.frames, a.ld, a.groups, a.ln_x, a.ln_s0, a.part)
+    if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
+    else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
+#undef NBASR_LAUNCH_GROUPED
+    return launch_status("nbasr_grouped_conv1d_fused");
+}
+
+template <int CG>
+static int dispatch_kd(int kernel, int dilation, const GroupedArgs& a, hipStream_t stream)
+{
+    if (kernel == 5 && dilation == 1) return launch_grouped<CG, 5, 1>(a, stream);
+    if (kernel == 5 && dilation == 2) return launch_grouped<CG, 5, 2>(a, stream);
+    if (kernel == 7 && dilation == 1) return launch_grouped<CG, 7, 1>(a, stream);
+    if (kernel == 7 && dilation == 2) return launch_grouped<CG, 7, 2>(a, stream);
+    set_error("nbasr_grouped_conv1d_fused: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
+    return NBASR_EINVAL;
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups)
+{
+    if (batch <= 0 || ld <= 0 || groups <= 0) return 0;
+    return static_cast<size_t>((groups + 3) / 4) * batch * 2 * ld * sizeof(float);
+}
+
+extern "C" int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias, const float* skip0,
+                                                const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                                int frames, int ld, int groups, int kernel, int dilation,
+                                                const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
+                                                float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(!stats_out || stats_ws, NBASR_ENULL,
+                  "nbasr_grouped_conv1d_fused_stats: stats_out needs the partial-statistics workspace stats_ws");
+    NBASR_REQUIRE(aligned16(stats_out) && aligned16(stats_ws), NBASR_EALIGN,
+                  "nbasr_grouped_conv1d_fused_stats: statistics buffers must be 16-byte aligned");
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
+                  "nbasr_grouped_conv1d_fused: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
+    if (batch == 0 || ld == 0) return NBASR_OK;      // empty batch: nothing to do (empty tensors have NULL storage)
+    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_grouped_conv1d_fused: x, w, bias, y must be non-NULL");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_grouped_conv1d_fused: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    NBASR_REQUIRE(aligned16(x) && aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
+                  "nbasr_grouped_conv1d_fused: activation pointers must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_grouped_conv1d_fused: batch %d > 65535", batch);
+    const bool any_ln = ln && (ln_on_x || (ln_on_skip0 && skip0));
+    NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
+                  "nbasr_grouped_conv1d_fused_ln: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
+    GroupedArgs a{x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups,
+                  ln_ref(ln, ln_on_x != 0), ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr), stats_ws};
+    hipStream_t s = as_stream(stream);
+    int rc;
+    switch (channels / groups) {
+        case 6:  rc = dispatch_kd<6>(kernel, dilation, a, s); break;
+        case 8:  rc = dispatch_kd<8>(kernel, dilation, a, s); break;
+        case 10: rc = dispatch_kd<10>(kernel, dilation, a, s); break;
+        case 12: rc = dispatch_kd<12>(kernel, dilation, a, s); break;
+        default:
+            set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", channels / groups);
+            return NBASR_EINVAL;
+    }
+    if (rc != NBASR_OK || !stats_out) return rc;       // stats_ws alone: partials only, merge later with nbasr_grouped_stats_finalize
+    return nbasr_grouped_stats_finalize(stats_ws, stats_out, batch, channels, frames, ld, groups, eps, stream);
+}
+
+extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                            int groups, float eps, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && groups > 0 && channels % groups == 0 && frames >= 0 && ld >= frames, NBASR_EINVAL,
+                  "nbasr_grouped_stats_finalize: bad sizes");
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, as_stream(stream), stats_ws, stats_out,
+                       batch, frames, ld, groups, channels / groups, eps);
+    return launch_status("nbasr_grouped_stats_finalize");
+}
+
+extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
+                                             const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                             int frames, int ld, int groups, int kernel, int dilation,
+                                             const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
+{
+    return nbasr_grouped_conv1d_fused_stats(x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, kernel,
+                                            dilation, ln, ln_on_x, ln_on_skip0, nullptr, nullptr, 0.f, stream);
+}
+
+extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
+                                          const float* skip1, const float* skip2, float* y, int batch, int channels,
+                                          int frames, int ld, int groups, int kernel, int dilation,
+                                          nbasr_stream_t stream)
+{
+    return nbasr_grouped_conv1d_fused_ln(x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, kernel,
+                                         dilation, nullptr, 0, 0, stream);
+}
+
+extern "C" int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
+                                 int channels, int frames, int ld, const nbasr_deferred_ln* ln, int ln_on_skip0,
+                                 nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_skip_sum: bad sizes");
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(y, NBASR_ENULL, "nbasr_skip_sum: y must be non-NULL");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_skip_sum: ld=%d must be >= frames and a multiple of 4", ld);
+    NBASR_REQUIRE(aligned16(y) && aligned16(skip0) && aligned16(skip1) && aligned16(skip2), NBASR_EALIGN,
+                  "nbasr_skip_sum: pointers must be 16-byte aligned");
+    const bool use_ln = ln && ln_on_skip0 && skip0;
+    NBASR_REQUIRE(!use_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
+                  "nbasr_skip_sum_ln: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
+    const size_t n4 = static_cast<size_t>(batch) * channels * ld / 4;
+    const unsigned blocks = static_cast<unsigned>(n4 / 256 + 1 < 4096 ? n4 / 256 + 1 : 4096);
+    hipLaunchKernelGGL(skip_sum_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), skip0, skip1, skip2, y, n4, channels,
+                       ld / 4, ln_ref(ln, use_ln));
+    return launch_status("nbasr_skip_sum");
+}
+
+extern "C" int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
+                              int channels, int frames, int ld, nbasr_stream_t stream)
+{
+    return nbasr_skip_sum_ln(skip0, skip1, skip2, y, batch, channels, frames, ld, nullptr, 0, stream);
+}
+
+extern "C" int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,
+                             nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(rows >= 0 && frames >= 0 && ld_src >= frames && ld_dst >= frames, NBASR_EINVAL, "nbasr_repitch: bad sizes");
+    if (rows == 0 || ld_dst == 0) return NBASR_OK;
+    NBASR_REQUIRE(src && dst, NBASR_ENULL, "nbasr_repitch: NULL pointer");
+    if (rows == 0 || ld_dst == 0) return NBASR_OK;
+    hipLaunchKernelGGL(repitch_kernel, dim3((ld_dst + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, as_stream(stream),
+                       src, dst, rows, frames, ld_src, ld_dst);
+    return launch_status("nbasr_repitch");
+}
