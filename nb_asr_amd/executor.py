@@ -589,6 +589,8 @@ class ForwardPlan:
         elems = max(B * c * ld for c, ld in zip(FILTERS, lds))
         self.pool16 = [self._buf(f'pool16_{i}', elems, bf16) for i in range(4)]
         forced = os.environ.get('NBASR_GC_BF16_VARIANT')
+        # node ops on the matrix cores (grouped_conv_mfma.hip); NBASR_GC_BF16_MFMA=0 keeps them on the vector ALU
+        use_mfma = os.environ.get('NBASR_GC_BF16_MFMA', '1') != '0'
         lib = hip.load_library()
 
         def variant_for(frames):
@@ -649,7 +651,7 @@ class ForwardPlan:
                         raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
                     last_op = layer.nodes[-1].op
                     norm = layer.norm_layer if layer.use_norm else None
-                    epilogue_stats = (self.epilogue_stats and norm is not None and self._cheap_consumer(nxt)
+                    epilogue_stats = (self.epilogue_stats and norm is not None and self._cheap_consumer(nxt) and not use_mfma
                                       and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                     outs = [act]
                     for j, (node, dst) in enumerate(zip(layer.nodes, free)):
@@ -662,7 +664,14 @@ class ForwardPlan:
                         ln = pending if (on_x or on_s0) else None
                         view, op, last = self._view16(dst, layer.filters, act_frames), node.op, outs[-1]
                         meta = (blk, layer.filters, layer.filters, getattr(op, 'kernel_size', 1), act_frames, n_skips)
-                        if isinstance(op, PadConvRelu):
+                        if isinstance(op, PadConvRelu) and use_mfma:
+                            wk = op.conv.weight
+                            frag = self._cached(wk, ('gc_mfma', op.dilation),
+                                                lambda: hip.pack_grouped_weights_mfma(self._f32(wk), op.groups, op.dilation))
+                            bs = self._f32(op.conv.bias)
+                            self._timed('grouped_conv', meta, lambda: hip.grouped_conv1d_node_mfma(
+                                last, frag, bs, skips, view, act_frames, op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0))
+                        elif isinstance(op, PadConvRelu):
                             ws = self.stats_ws if (epilogue_stats and j == len(layer.nodes) - 1) else None
                             variant = variant_for(act_frames)
                             wt, bs = grouped_weight(op, variant), self._f32(op.conv.bias)
