@@ -8,9 +8,8 @@
 //     out[co][F] = sum_{ci, j} w[co][ci][j] * x[ci][F - lpad + j d]      and with u = m - lpad + j d = 8 c + e:
 //                = sum_{ci, c, e} W_m[(c, ci, e)][co] * x[ci][F0 + 8 (i + c) + e],     W_m[(c, ci, e)][co] = w[co][ci][(8 c + e - m + lpad) / d]
 // (zero where that is not a tap).  So the A operand of every MFMA is ALIGNED 8-frame chunks of the input rows -- the same chunks
-// for all eight m -- and the eight output phases m differ only in the weight matrix: eight accumulators of a lane are then
-// frames F0 + 32 kq + 8 r + m, i.e. 32 CONSECUTIVE frames of one output channel (four 16-byte stores), and dilation is just another
-// placement of the weights.  k-slots (8 k each) are (chunk c, input channel ci), chunk-major; a K-block of 32 k is four slots; a
+// for all eight m -- and the eight output phases m differ only in the weight matrix: the eight accumulators of a lane are then 8
+// CONSECUTIVE frames of one output channel per register (one 16-byte store), and dilation is just another placement of the weights.  k-slots (8 k each) are (chunk c, input channel ci), chunk-major; a K-block of 32 k is four slots; a
 // (phase m, K-block) pair whose slots hold no tap is skipped: 36-60 MFMAs per 128 frames x group (15-30 % of the matrix pipe's
 // work is real) = ~1 000 cycles per tile against ~9 KB of HBM traffic: the kernel is HBM-bound with 4 x headroom.
 //  * weights: the fragments B[(m, kb)][lane][8] are built once per weight version (pack_grouped_mfma_kernel) and copied into LDS
@@ -18,11 +17,14 @@
 //  * input: a wave stages its tile's rows (CG channels x (16 + 1 or 2) chunks) through a wave-private LDS buffer -- each chunk is
 //    fetched once (the pending LayerNorm of the cell input is applied once per element on the way), then every A fragment is one
 //    conflict-free ds_read_b128; the next tile's chunks are prefetched into registers under the MFMAs;
-//  * epilogue: bias + relu + clamp + skips (LayerNorm on load for skip0) in fp32, one rounding, streaming stores.
+//  * epilogue: bias + relu + clamp in fp32, rounded to bf16 like the reference's op output, transposed through the staging buffer
+//    so that skips are loaded and y is stored as whole 256-byte row segments; skip sum (LayerNorm on load for skip0) in fp32,
+//    second rounding, streaming stores.
 // The LayerNorm statistics of the output are NOT produced here (the four waves of a workgroup do not hold four groups of the same
 // frames): the executor runs the statistics pass over the tensor instead (one extra read of 12).
 #include "storage.h"
 
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -104,8 +106,13 @@ struct MfmaArgs {
     LnRef ln_x, ln_s0;
 };
 
+// MW waves per workgroup share one copy of the group's weight fragments: 16 waves (one workgroup per CU at the widest group) keep
+// four waves per SIMD in flight -- a tile is a chain of dependent round trips (stage -> fragments -> MFMAs -> skips -> store), and
+// with 4 waves per workgroup (8-12 per CU, limited by the fragments' LDS) the first version ran at 9 us per tile and wave.
+constexpr int MW = 16;
+
 template <int CG, int K, int D, bool LNX>
-__global__ __launch_bounds__(256) void grouped_conv_mfma_kernel(const MfmaArgs a)
+__global__ __launch_bounds__(MW * 64) void grouped_conv_mfma_kernel(const MfmaArgs a)
 {
     using G = MGeo<CG, K, D>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,19 +121,24 @@ __global__ __launch_bounds__(256) void grouped_conv_mfma_kernel(const MfmaArgs a
     unsigned char* const stage = smem + G::FRAG_BYTES + wave * G::STAGE_BYTES;    // wave-private: [CG][NCHK][16 B]
     const int g = blockIdx.x / a.splits, split = blockIdx.x - g * a.splits;
     const int i16 = lane & 15, kq = lane >> 4;
+    // Tile row i computes the 8-frame chunk perm(i) = 4 (i & 3) + (i >> 2) of the tile (a 4 x 4 transpose of the row index): the
+    // accumulator register r of lane (co, kq) -- tile row 4 kq + r -- is then chunk 4 r + kq, so ONE store / skip-load instruction
+    // touches 64 contiguous bytes per channel row (the four kq lanes side by side) instead of four 16-byte pieces 64 bytes apart
+    // (first version: every epilogue instruction was 48 separate quarter-sector requests: 2.3 TB/s at twice the vector kernel's time)
+    const int prow = ((i16 & 3) << 2) | (i16 >> 2);
 
     // the group's weight fragments -> LDS (once per workgroup)
     {
         const u4v* __restrict__ src = reinterpret_cast<const u4v*>(a.wp + static_cast<size_t>(g) * G::FRAG_BYTES);
         u4v* dst = reinterpret_cast<u4v*>(frags);
-        for (int i = threadIdx.x; i < G::FRAG_BYTES / 16; i += 256) dst[i] = src[i];
+        for (int i = threadIdx.x; i < G::FRAG_BYTES / 16; i += MW * 64) dst[i] = src[i];
     }
     __syncthreads();
 
     const int nq = a.ld >> 3;                            // 8-frame chunks per row
     const int tiles_per_row = (a.ld + 127) >> 7;
     const int n_tiles = a.batch * tiles_per_row;
-    const int stride = a.splits * 4;
+    const int stride = a.splits * MW;
     constexpr int NLOAD = (CG * G::NCHK + 63) / 64;      // staged chunks per lane
     const float bias_v = i16 < CG ? a.bias[g * CG + i16] : 0.f;
 
@@ -169,61 +181,79 @@ __global__ __launch_bounds__(256) void grouped_conv_mfma_kernel(const MfmaArgs a
         }
     };
 
-    int tile = split * 4 + wave;
+    int tile = split * MW + wave;
     u4v raw[NLOAD];
     fetch(tile, raw);
     for (; tile < n_tiles; tile += stride) {
         commit(tile, raw);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the wave's own staging writes have landed (wave-private buffer)
-        // A fragments: slot s = 4 kb + kq -> (chunk offset index, input channel); the 16 lanes of a quarter read 256 contiguous bytes
-        bf16x8 af[G::NKB];
-#pragma unroll
-        for (int kb = 0; kb < G::NKB; ++kb) {
-            const int s = 4 * kb + kq;
-            const int cidx = s / CG, ci = s - cidx * CG;
-            u4v t = {0u, 0u, 0u, 0u};
-            if (s < G::NS) t = *reinterpret_cast<const u4v*>(stage + (ci * G::NCHK + i16 + cidx) * 16);
-            af[kb] = __builtin_bit_cast(bf16x8, t);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // fragments are in registers: the stage may be overwritten
         const int next = tile + stride;
         fetch(next, raw);                                               // in flight under the MFMAs and the epilogue
 
+        // K-block outer, phase inner: one A fragment (slot s = 4 kb + kq -> (chunk offset index, input channel); the 16 lanes of a
+        // quarter read 256 contiguous bytes) is live at a time, the eight accumulators take turns -- independent MFMAs back to back
         floatx4 acc[8];
-        static_for<8>([&](auto m_) {
-            constexpr int m = decltype(m_)::value;
-            acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
-            static_for<G::NKB>([&](auto kb_) {
-                constexpr int kb = decltype(kb_)::value;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc[m] = floatx4{0.f, 0.f, 0.f, 0.f};
+        static_for<G::NKB>([&](auto kb_) {
+            constexpr int kb = decltype(kb_)::value;
+            const int s = 4 * kb + kq;
+            const int cidx = s / CG, ci = s - cidx * CG;
+            u4v t = {0u, 0u, 0u, 0u};
+            if (s < G::NS) t = *reinterpret_cast<const u4v*>(stage + (ci * G::NCHK + prow + cidx) * 16);
+            const bf16x8 af = __builtin_bit_cast(bf16x8, t);
+            static_for<8>([&](auto m_) {
+                constexpr int m = decltype(m_)::value;
                 if constexpr (G::active(m, kb)) {
                     constexpr int pair = G::pair_index(m, kb);
                     const bf16x8 bf = *reinterpret_cast<const bf16x8*>(frags + (pair * 64 + lane) * 16);
-                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kb], bf, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, acc[m], 0, 0, 0);
                 }
             });
         });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // every fragment read of this tile is done: the stage may be overwritten
 
-        // epilogue: lane (co = i16, kq) holds out[co][F0 + 32 kq + 8 r + m] in acc[m][r]
+        // epilogue, part 1: lane (co = i16, kq) holds the op's output z[co][F0 + 8 (4 r + kq) + m] in acc[m][r]; bias + relu + clamp,
+        // rounded to bf16 (the reference rounds the op's output, too) and transposed through the wave's staging buffer
+        // ([CG][128 frames] bf16 = CG x 256 bytes, no larger than the input stage) ...
+        static_assert(CG * 256 <= G::STAGE_BYTES, "the output tile must fit the staging buffer");
         if (i16 < CG) {
-            const int b = tile / tiles_per_row, tr = tile - b * tiles_per_row;
-            const size_t row = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG + i16) * a.ld;
-            const float gam0 = (a.s0 && a.ln_s0.stats) ? a.ln_s0.gamma[g * CG + i16] : 0.f;
-            const float bet0 = (a.s0 && a.ln_s0.stats) ? a.ln_s0.beta[g * CG + i16] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int f0 = tr * 128 + 32 * kq + 8 * r;
-                if (f0 >= a.ld) continue;
                 float o[8];
 #pragma unroll
                 for (int m = 0; m < 8; ++m) o[m] = relu_clamp(acc[m][r] + bias_v);
+                const u4v t = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                *reinterpret_cast<u4v*>(stage + i16 * 256 + (4 * r + kq) * 16) = t;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // ... part 2, ROW-COALESCED: 16 lanes x 16 bytes = one whole 256-byte row segment of a channel, four channels per
+        // instruction -- skips are loaded, and y is stored, as full cache lines (the accumulator layout itself gives 64-byte pieces:
+        // at 2.3-2.8 TB/s the first versions of this kernel were slower than the vector-ALU one)
+        {
+            const int b = tile / tiles_per_row, tr = tile - b * tiles_per_row;
+            const int f0 = tr * 128 + 8 * i16;
+            const int rsub = lane >> 4;
+            float mu[8], rs[8];
+            const bool ln0 = a.s0 && a.ln_s0.stats;
+            if (ln0 && f0 < a.ld) {
+                const float* st = a.ln_s0.stats + static_cast<size_t>(b) * 2 * a.ld + f0;
+                load_frames<8>(st, mu);
+                load_frames<8>(st + a.ld, rs);
+            }
+#pragma unroll
+            for (int rg = 0; rg < (CG + 3) / 4; ++rg) {
+                const int co = rg * 4 + rsub;
+                if (co >= CG || f0 >= a.ld) continue;
+                const size_t row = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG + co) * a.ld;
+                float o[8];
+                load_frames<8>(reinterpret_cast<const bf16_t*>(stage + co * 256 + i16 * 16), o);
                 if (a.s0) {
                     float v[8];
                     load_frames<8>(a.s0 + row + f0, v);
-                    if (a.ln_s0.stats) {
-                        const float* st = a.ln_s0.stats + static_cast<size_t>(b) * 2 * a.ld + f0;
-                        float mu[8], rs[8];
-                        load_frames<8>(st, mu);
-                        load_frames<8>(st + a.ld, rs);
+                    if (ln0) {
+                        const float gam0 = a.ln_s0.gamma[g * CG + co], bet0 = a.ln_s0.beta[g * CG + co];
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = ln_apply(v[e], mu[e], rs[e], gam0, bet0);
                     }
@@ -247,6 +277,7 @@ __global__ __launch_bounds__(256) void grouped_conv_mfma_kernel(const MfmaArgs a
                 store_frames<8, true>(a.y + row + f0, o);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the output tile has been read back: the stage is free for the next input
     }
 }
 
@@ -254,7 +285,7 @@ template <int CG, int K, int D>
 static int launch_mfma(const MfmaArgs& a, hipStream_t stream)
 {
     using G = MGeo<CG, K, D>;
-    constexpr int LDS = G::FRAG_BYTES + 4 * G::STAGE_BYTES;
+    constexpr int LDS = G::FRAG_BYTES + MW * G::STAGE_BYTES;
     static_assert(LDS <= 160 * 1024, "weight fragments + staging must fit the LDS");
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv_mfma_kernel<CG, K, D, false>),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -265,8 +296,8 @@ static int launch_mfma(const MfmaArgs& a, hipStream_t stream)
         return static_cast<int>(attr0 != hipSuccess ? attr0 : attr1);
     }
     const dim3 grid(a.groups * a.splits);
-    if (a.ln_x.stats) hipLaunchKernelGGL((grouped_conv_mfma_kernel<CG, K, D, true>), grid, dim3(256), LDS, stream, a);
-    else hipLaunchKernelGGL((grouped_conv_mfma_kernel<CG, K, D, false>), grid, dim3(256), LDS, stream, a);
+    if (a.ln_x.stats) hipLaunchKernelGGL((grouped_conv_mfma_kernel<CG, K, D, true>), grid, dim3(MW * 64), LDS, stream, a);
+    else hipLaunchKernelGGL((grouped_conv_mfma_kernel<CG, K, D, false>), grid, dim3(MW * 64), LDS, stream, a);
     return launch_status("nbasr_grouped_conv1d_node_mfma");
 }
 
@@ -347,11 +378,14 @@ extern "C" int nbasr_grouped_conv1d_node_mfma(const void* x, const void* packed_
     a.y = static_cast<bf16_t*>(y);
     a.batch = batch; a.channels = channels; a.frames = frames; a.ld = ld; a.groups = groups;
     a.ln_x = ln_ref(ln, ln_on_x != 0); a.ln_s0 = ln_ref(ln, ln_on_skip0 != 0 && skip0 != nullptr);
-    // workgroups: `splits` per group, each wave strides over the (utterance, 128-frame tile) list; ~4 workgroups per CU in all,
-    // never more waves than tiles
+    // workgroups: `splits` per group, each of its 16 waves strides over the (utterance, 128-frame tile) list; ~2 workgroups per CU
+    // in all (one resident at a time at the widest group: its fragments take 60 of the 160 KiB), never more waves than tiles
     const long long tiles = static_cast<long long>(batch) * ((ld + 127) / 128);
-    int splits = (1024 + groups - 1) / groups;
-    if (static_cast<long long>(splits) * 4 > tiles) splits = static_cast<int>((tiles + 3) / 4);
+    // whole rounds matter: one workgroup per CU is resident, and 600 workgroups (2.3 rounds of 256) ran 10 % slower than 500 (1.95)
+    int splits = 512 / groups;
+    if (splits < 1) splits = 1;
+    if (const char* env = getenv("NBASR_MFMA_SPLITS")) { const int v = atoi(env); if (v > 0) splits = v; }      // diagnostics
+    if (static_cast<long long>(splits) * MW > tiles) splits = static_cast<int>((tiles + MW - 1) / MW);
     a.splits = splits < 1 ? 1 : splits;
     return launch_rt(channels / groups, kernel, dilation, a, as_stream(stream));
 }

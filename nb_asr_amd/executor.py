@@ -589,8 +589,9 @@ class ForwardPlan:
         elems = max(B * c * ld for c, ld in zip(FILTERS, lds))
         self.pool16 = [self._buf(f'pool16_{i}', elems, bf16) for i in range(4)]
         forced = os.environ.get('NBASR_GC_BF16_VARIANT')
-        # node ops on the matrix cores (grouped_conv_mfma.hip); NBASR_GC_BF16_MFMA=0 keeps them on the vector ALU
-        use_mfma = os.environ.get('NBASR_GC_BF16_MFMA', '1') != '0'
+        # node ops on the matrix cores (grouped_conv_mfma.hip): opt-in (NBASR_GC_BF16_MFMA=1).  Measured at 32 x 1600: node ops 3.82 ms
+        # against 3.93 ms on the vector ALU, but the LayerNorm statistics then need their own pass (+0.43 ms): 6.85 vs 6.47 ms per step
+        use_mfma = os.environ.get('NBASR_GC_BF16_MFMA', '0') == '1'
         lib = hip.load_library()
 
         def variant_for(frames):

@@ -1,11 +1,13 @@
-import csv,sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-steps=int(sys.argv[2])
-tot=0
-out=[]
-for r in rows:
-    t=float(r['TotalDurationNs']); c=int(r['Calls']); tot+=t
-    out.append((t/steps/1e3, c/steps, float(r['AverageNs'])/1e3, r['Name'][:70]))
-out.sort(reverse=True)
-for o in out[:22]: print('%9.1f us/step %7.1f calls/step  avg %8.2f us  %s'%o)
-print('total us/step', tot/steps/1e3)
+#!/usr/bin/env python3
+"""Trim a rocprofv3 --kernel-trace --stats kernel_stats.csv to the rows that matter (this library's kernels and anything above
+0.01 % of the total), same columns.  usage: tools/summarize_kernels.py <kernel_stats.csv>  > profiles/rNN_kernel_stats.csv"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1], newline='')))
+total = sum(float(r['TotalDurationNs']) for r in rows) or 1.0
+w = csv.DictWriter(sys.stdout, fieldnames=list(rows[0].keys()), lineterminator='\n')
+w.writeheader()
+for r in sorted(rows, key=lambda r: -float(r['TotalDurationNs'])):
+    if 'nbasr::' in r['Name'] or float(r['TotalDurationNs']) / total >= 1e-4:
+        w.writerow(r)
