@@ -346,12 +346,12 @@ def roofline_leg(model, x, args):
         e['ms'] += ms
         e['n'] += n
     if launches:
-        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_kernel')
+        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_f32_kernel')
         if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or args.dtype != 'f32' or any(k.startswith('NBASR_') for k in os.environ):
             traffic, traffic_src = None, None          # the committed counters are for the default workload and modes only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
         out['roofline'] = {
-            'kernel': 'grouped_cell_kernel<CG> / grouped_conv_kernel<CG,K,D,..> (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
+            'kernel': 'grouped_conv_f32_kernel<CG,K,D,..> (bf16: grouped_conv_kernel<bf16_t,..>; opt-in whole-cell: grouped_cell_kernel<CG>) (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
                       ' [+LayerNorm on load]; a cell launch runs its three node ops with the intermediates in LDS)',
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,

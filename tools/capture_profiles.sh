@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" --
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/mfma" -- python3 "$REPO/bench.py" --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/mfma.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d "$OUT/valu" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/valu.log" 2>&1
 # BASELINE configs[3] per GPU in bf16: bench line + kernel stats
-python3 bench.py --arch dense-skip --batch 32 --frames 1600 --dtype bf16 > "$OUT/${TAG}_bench_cfg3_bf16.json" 2> "$OUT/bench_bf16.err"
+python3 "$REPO/bench.py" --arch dense-skip --batch 32 --frames 1600 --dtype bf16 > "$OUT/${TAG}_bench_cfg3_bf16.json" 2> "$OUT/bench_bf16.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_bf16" -- python3 "$REPO/bench.py" --arch dense-skip --batch 32 --frames 1600 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_bf16.log" 2>&1
 cd "$REPO"
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
@@ -26,6 +26,8 @@ S16=$(find "$OUT/stats_bf16" -name '*kernel_stats.csv' | head -1)
 V=$(find "$OUT/valu" -name '*counter_collection.csv' | head -1)
 python3 tools/summarize_pmc.py "$F" "$W" > "$OUT/${TAG}_pmc_hbm_traffic.csv"
 python3 tools/summarize_mfma.py "$M" > "$OUT/${TAG}_pmc_mfma_utilisation.csv" 2> "$OUT/mfma_sum.err"
+cp "$OUT/${TAG}_pmc_hbm_traffic.csv" "$REPO/profiles/${TAG}_pmc_hbm_traffic.csv"      # bench.py reads the newest committed summary
+python3 "$REPO/bench.py" > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/bench.err"               # the line with traffic from this capture
 cp "$S" "$OUT/${TAG}_kernel_stats_full.csv"
 cp "$S16" "$OUT/${TAG}_kernel_stats_cfg3_bf16_full.csv"
 python3 tools/summarize_valu.py "$V" > "$OUT/${TAG}_pmc_valu_issue.csv" 2> "$OUT/valu_sum.err"
