@@ -392,6 +392,18 @@ int nbasr_dense_conv1d_fused_packed_ranged(const float* x, const float* x_range,
                                            float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
                                            int kernel, int stride, nbasr_stream_t stream);
 
+/* Image-path form of the fp16 leg (conv 0 then runs like convs 1-3: the GEMM copies pre-split operands by LDS-DMA instead of
+ * splitting the input in its own prologue).  nbasr_split_image_ranged writes x (batch, channels, ld) -- the model input -- as
+ * the fp16 image of nbasr_split_image_bytes, every utterance scaled by the power of two that its x_range[4 b] (the maximum
+ * written by nbasr_input_range) implies; the _img_ranged convolution computes the utterances that are NOT extreme, the bf16
+ * `_ranged` convolution above the others, on the same output. */
+int nbasr_split_image_ranged(const float* x, const float* x_range, void* image, int batch, int channels, int frames, int ld,
+                             nbasr_stream_t stream);
+int nbasr_dense_conv1d_fused_packed_f16_img_ranged(const void* x_image, const float* x_range, const void* packed_w_f16,
+                                                   const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
+                                                   int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                                   nbasr_stream_t stream);
+
 /* ---- bf16 path (BASELINE config 4: activations and GEMM operands stored as bfloat16) ------------------------------------------
  * Mirrors `model.to(torch.bfloat16)(x.bfloat16())` of the reference (ops.py:24-30, model.py:116-131 run on bf16 tensors).
  * Storage is bf16, arithmetic is fp32, a tensor is rounded once when it is written; the `_v` entry points below are the

@@ -877,3 +877,15 @@ extern "C" int nbasr_dense_conv1d_fused_packed_ranged(const float* x, const floa
     return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
                                           kernel, stride, nullptr, nullptr, stream, false, 128, x_range, 1);
 }
+
+// image-path form of the fp16 leg: x_image = nbasr_split_image_ranged(x, x_range) (the GEMM only copies operands by LDS-DMA)
+extern "C" int nbasr_dense_conv1d_fused_packed_f16_img_ranged(const void* x_image, const float* x_range, const void* packed_w,
+                                                              const float* bias, float* y, int batch, int c_in, int frames_in,
+                                                              int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                                              nbasr_stream_t stream)
+{
+    NBASR_REQUIRE(x_range, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_f16_img_ranged: x_range is NULL");
+    return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
+                                         frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, nullptr, stream, true, row_tile,
+                                         x_range, 0);
+}

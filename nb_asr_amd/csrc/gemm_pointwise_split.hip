@@ -98,18 +98,65 @@ __global__ __launch_bounds__(256) void pw_pack_weights_kernel(const float* __res
 }
 
 // ---- activation pre-split -----------------------------------------------------------------------------------------------
-// grid (frame tiles, batch), 1024 threads = 256 frames x 4 channel slices; pass 1: largest |x| of the tile; pass 2: scale,
-// split, write the image rows (16 B per lane, lanes along frames: 1 KiB contiguous per wave store; slice s takes the
-// K-steps s, s + 4, ...).  inv_scale[b * n_nt + nt] = 2^-k of the tile.
+// Two launches with one 256-thread workgroup per (frame tile, K-step, utterance) each -- thousands of light workgroups whose
+// loads are all issued up front, instead of one 1024-thread workgroup per tile that walked the channels in a latency-bound
+// loop (116 us for the LSTM projection's 77 MB at 64 x 250 frames, the same 103 us at 8 x 250):
+//   pw_tile_max_kernel  partial[(b * n_nt + nt) * n_ks + ks] = max |x| over the 32 channels x 256 frames of the K-step
+//   pw_presplit_kernel  reduces the tile's n_ks partials (exact whatever the order), scales, splits and writes the image
+//                       rows of its K-step (16 B per lane, lanes along frames: 1 KiB contiguous per wave store);
+//                       inv_scale[b * n_nt + nt] = 2^-k of the tile.
 template <bool LNX>
-__global__ __launch_bounds__(1024) void pw_presplit_kernel(const float* __restrict__ x, unsigned char* __restrict__ image,
-                                                           float* __restrict__ inv_scale, int c_in, int frames, int ld,
-                                                           int n_ks, const LnRef ln)
+__device__ __forceinline__ void pw_fetch32(const float* __restrict__ xb, int ci0, int c_in, int ld, bool live, float mean, float rstd,
+                                           const LnRef& ln, float (&v)[PW_K])
 {
-    __shared__ float s_max[16];
-    const int nt = blockIdx.x, b = blockIdx.y;
-    const int lane_t = threadIdx.x & (PW_N - 1);             // frame within the tile
-    const int slice = threadIdx.x >> 8;                      // wave-uniform
+#pragma unroll
+    for (int c = 0; c < PW_K; ++c) {
+        const int ci = ci0 + c;                                  // wave-uniform
+        v[c] = (live && ci < c_in) ? xb[static_cast<size_t>(ci) * ld] : 0.f;
+    }
+    if (LNX) {
+#pragma unroll
+        for (int c = 0; c < PW_K; ++c) {
+            const int ci = ci0 + c;
+            if (live && ci < c_in) v[c] = ln_apply(v[c], mean, rstd, ln.gamma[ci], ln.beta[ci]);
+        }
+    }
+}
+
+template <bool LNX>
+__global__ __launch_bounds__(256) void pw_tile_max_kernel(const float* __restrict__ x, float* __restrict__ partial, int c_in,
+                                                          int frames, int ld, int n_ks, const LnRef ln)
+{
+    __shared__ float s_max[4];
+    const int nt = blockIdx.x, ks = blockIdx.y, b = blockIdx.z;
+    const int t = nt * PW_N + threadIdx.x;
+    const bool live = t < frames;
+    const float* __restrict__ xb = x + static_cast<size_t>(b) * c_in * ld + t;
+    float mean = 0.f, rstd = 0.f;
+    if (LNX && live) {
+        const float* st = ln.stats + static_cast<size_t>(b) * 2 * ld;
+        mean = st[t]; rstd = st[ld + t];
+    }
+    float v[PW_K];
+    pw_fetch32<LNX>(xb, ks * PW_K, c_in, ld, live, mean, rstd, ln, v);
+    float m = 0.f;
+#pragma unroll
+    for (int c = 0; c < PW_K; ++c) m = fmaxf(m, fabsf(v[c]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partial[(static_cast<size_t>(b) * gridDim.x + nt) * n_ks + ks] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+}
+
+template <bool LNX>
+__global__ __launch_bounds__(256) void pw_presplit_kernel(const float* __restrict__ x, unsigned char* __restrict__ image,
+                                                          float* __restrict__ inv_scale, const float* __restrict__ partial,
+                                                          int c_in, int frames, int ld, int n_ks, const LnRef ln)
+{
+    const int nt = blockIdx.x, ks = blockIdx.y, b = blockIdx.z;
+    const int lane_t = threadIdx.x;                          // frame within the tile
     const int t = nt * PW_N + lane_t;
     const bool live = t < frames;
     const float* __restrict__ xb = x + static_cast<size_t>(b) * c_in * ld + t;
@@ -118,40 +165,28 @@ __global__ __launch_bounds__(1024) void pw_presplit_kernel(const float* __restri
         const float* st = ln.stats + static_cast<size_t>(b) * 2 * ld;
         mean = st[t]; rstd = st[ld + t];
     }
-    auto fetch = [&](int ci) {
-        float v = (live && ci < c_in) ? xb[static_cast<size_t>(ci) * ld] : 0.f;
-        if (LNX && live && ci < c_in) v = ln_apply(v, mean, rstd, ln.gamma[ci], ln.beta[ci]);
-        return v;
-    };
-    // gridDim.z > 1 (few frame tiles: the LSTM projection has one per utterance): every z-slice of workgroups reduces the
-    // WHOLE tile's maximum (the re-reads hit L2) and writes only its own share of the K-steps
-    float m = 0.f;
-    for (int ks = slice; ks < n_ks; ks += 4)
-#pragma unroll 8
-        for (int c = 0; c < PW_K; ++c) m = fmaxf(m, fabsf(fetch(ks * PW_K + c)));
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
-    __syncthreads();
+    float v[PW_K];
+    pw_fetch32<LNX>(xb, ks * PW_K, c_in, ld, live, mean, rstd, ln, v);
+    // the tile's maximum: every wave reduces the n_ks partials on its own (no barrier)
+    const float* __restrict__ pt = partial + (static_cast<size_t>(b) * gridDim.x + nt) * n_ks;
     float tile_max = 0.f;
+    for (int i = threadIdx.x & 63; i < n_ks; i += 64) tile_max = fmaxf(tile_max, pt[i]);
 #pragma unroll
-    for (int w = 0; w < 16; ++w) tile_max = fmaxf(tile_max, s_max[w]);
+    for (int d = 32; d >= 1; d >>= 1) tile_max = fmaxf(tile_max, __shfl_xor(tile_max, d));
     float scale, inv;
     pw_pow2(tile_max, 14, scale, inv);
-    if (threadIdx.x == 0 && blockIdx.z == 0) inv_scale[static_cast<size_t>(b) * gridDim.x + nt] = inv;
-    unsigned char* tile = image + (static_cast<size_t>(b) * gridDim.x + nt) * n_ks * PW_X_STEP;
-    for (int ks = slice + 4 * blockIdx.z; ks < n_ks; ks += 4 * gridDim.z) {
+    if (threadIdx.x == 0 && ks == 0) inv_scale[static_cast<size_t>(b) * gridDim.x + nt] = inv;
+    unsigned char* step = image + ((static_cast<size_t>(b) * gridDim.x + nt) * n_ks + ks) * PW_X_STEP;
 #pragma unroll
-        for (int bh = 0; bh < 4; ++bh) {                     // (16-channel block, 8-channel half)
-            float v[8];
+    for (int bh = 0; bh < 4; ++bh) {                         // (16-channel block, 8-channel half)
+        float v8[8];
 #pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = fetch(ks * PW_K + bh * 8 + c);
-            halfx8 hi, lo;
-            pw_split8(v, scale, hi, lo);
-            unsigned char* row = tile + static_cast<size_t>(ks) * PW_X_STEP + (bh * PW_N + lane_t) * 16;
-            *reinterpret_cast<halfx8*>(row) = hi;
-            *reinterpret_cast<halfx8*>(row + PW_X_STEP / 2) = lo;
-        }
+        for (int c = 0; c < 8; ++c) v8[c] = v[bh * 8 + c];
+        halfx8 hi, lo;
+        pw_split8(v8, scale, hi, lo);
+        unsigned char* row = step + (bh * PW_N + lane_t) * 16;
+        *reinterpret_cast<halfx8*>(row) = hi;
+        *reinterpret_cast<halfx8*>(row + PW_X_STEP / 2) = lo;
     }
 }
 
@@ -323,6 +358,7 @@ static int pw_launch(PointwiseArgs a, hipStream_t stream, const char* what)
 static inline int pw_n_ks(int c_in) { return (c_in + PW_K - 1) / PW_K; }
 static inline int pw_n_mt(int c_out) { return (c_out + PW_M - 1) / PW_M; }
 static inline int pw_n_nt(int ld) { return (ld + PW_N - 1) / PW_N; }
+static inline size_t pw_round4(size_t n) { return (n + 3) & ~static_cast<size_t>(3); }
 static inline size_t pw_image_bytes(int batch, int c_in, int ld) { return static_cast<size_t>(batch) * pw_n_nt(ld) * pw_n_ks(c_in) * PW_X_STEP; }
 
 // presplit x into ws (image, then batch * n_nt inverse scales); `ln` = pending LayerNorm of x (stats == nullptr: none)
@@ -330,9 +366,17 @@ static int pw_presplit(const float* x, void* ws, int batch, int c_in, int frames
 {
     unsigned char* image = static_cast<unsigned char*>(ws);
     float* inv = reinterpret_cast<float*>(image + pw_image_bytes(batch, c_in, ld));
-    const dim3 grid(pw_n_nt(ld), batch, pw_n_nt(ld) * batch < 512 ? 4 : 1);
-    if (ln.stats) hipLaunchKernelGGL(pw_presplit_kernel<true>, grid, dim3(1024), 0, stream, x, image, inv, c_in, frames, ld, pw_n_ks(c_in), ln);
-    else          hipLaunchKernelGGL(pw_presplit_kernel<false>, grid, dim3(1024), 0, stream, x, image, inv, c_in, frames, ld, pw_n_ks(c_in), ln);
+    float* partial = inv + pw_round4(static_cast<size_t>(batch) * pw_n_nt(ld));
+    const int n_ks = pw_n_ks(c_in);
+    // utterances on grid z: nbasr_linear_fused_packed / nbasr_lstm_input_projection_packed check batch <= 65535
+    const dim3 grid(pw_n_nt(ld), n_ks, batch);
+    if (ln.stats) {
+        hipLaunchKernelGGL(pw_tile_max_kernel<true>, grid, dim3(256), 0, stream, x, partial, c_in, frames, ld, n_ks, ln);
+        hipLaunchKernelGGL(pw_presplit_kernel<true>, grid, dim3(256), 0, stream, x, image, inv, partial, c_in, frames, ld, n_ks, ln);
+    } else {
+        hipLaunchKernelGGL(pw_tile_max_kernel<false>, grid, dim3(256), 0, stream, x, partial, c_in, frames, ld, n_ks, ln);
+        hipLaunchKernelGGL(pw_presplit_kernel<false>, grid, dim3(256), 0, stream, x, image, inv, partial, c_in, frames, ld, n_ks, ln);
+    }
     return launch_status(what);
 }
 
@@ -349,7 +393,9 @@ extern "C" size_t nbasr_pointwise_packed_weights_bytes(int c_out, int c_in)
 extern "C" size_t nbasr_pointwise_workspace_bytes(int batch, int c_in, int ld)
 {
     if (batch <= 0 || c_in <= 0 || ld <= 0) return 0;
-    return pw_image_bytes(batch, c_in, ld) + static_cast<size_t>(batch) * pw_n_nt(ld) * sizeof(float);
+    // operand image, one inverse scale per (utterance, frame tile), one partial maximum per (utterance, frame tile, K-step)
+    const size_t tiles = static_cast<size_t>(batch) * pw_n_nt(ld);
+    return pw_image_bytes(batch, c_in, ld) + (pw_round4(tiles) + tiles * pw_n_ks(c_in)) * sizeof(float);
 }
 
 extern "C" int nbasr_pack_pointwise_weights(const float* w, void* packed, int c_out, int c_in, nbasr_stream_t stream)
@@ -371,6 +417,7 @@ static int pw_common_checks(const char* what, const float* x, const void* ws, co
 {
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames >= 0 && ld_in >= frames, NBASR_EINVAL, "%s: bad sizes", what);
     if (batch == 0 || frames == 0) return 1;
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "%s: batch %d > 65535", what, batch);
     NBASR_REQUIRE(x && ws && packed_w && bias && y, NBASR_ENULL, "%s: x, workspace, packed_w, bias, y must be non-NULL", what);
     NBASR_REQUIRE(aligned16(ws) && aligned16(packed_w), NBASR_EALIGN, "%s: workspace and packed weights must be 16-byte aligned", what);
     return NBASR_OK;

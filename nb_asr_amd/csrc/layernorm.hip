@@ -293,10 +293,14 @@ __global__ __launch_bounds__(256) void channel_stats_bound_kernel(const float* _
     }
 }
 
+// NORM = false: no LayerNorm, x itself is scaled and split (the MODEL INPUT in front of conv 0; bound = the per-utterance maximum
+// that nbasr_input_range wrote, one every `bound_stride` floats).
+template <bool NORM>
 __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __restrict__ x, const float* __restrict__ stats,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ bound, unsigned char* __restrict__ image,
-                                                              int channels, int /* frames: rstd is 0 beyond them */, int ld)
+                                                              int channels, int /* frames: rstd is 0 beyond them */, int ld,
+                                                              int bound_stride)
 {
     typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
     // 16 frame quads x 16 channel octets per pass; a thread turns 8 channels x 4 frames into 4 + 4 image rows of 16 bytes
@@ -316,15 +320,19 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     // 2^k that brings the bound into [2^14, 2^15)
     float scale = 1.f;
     {
-        const unsigned bits = __float_as_uint(bound[b]);
+        const unsigned bits = __float_as_uint(bound[static_cast<size_t>(b) * bound_stride]);
         const int e = static_cast<int>((bits >> 23) & 0xffu);
         int k = (bits & 0x7fffffffu) ? (127 + 14) - e : 0;
         k = k > 126 ? 126 : (k < -126 ? -126 : k);
         scale = __uint_as_float(static_cast<unsigned>(127 + k) << 23);
     }
-    const float* st = stats + static_cast<size_t>(b) * 2 * ld + q * 4;
-    const float4 mu = *reinterpret_cast<const float4*>(st), rs = *reinterpret_cast<const float4*>(st + ld);
-    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w};
+    float m4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NORM) {
+        const float* st = stats + static_cast<size_t>(b) * 2 * ld + q * 4;
+        const float4 mu = *reinterpret_cast<const float4*>(st), rs = *reinterpret_cast<const float4*>(st + ld);
+        m4[0] = mu.x; m4[1] = mu.y; m4[2] = mu.z; m4[3] = mu.w;
+        r4[0] = rs.x; r4[1] = rs.y; r4[2] = rs.z; r4[3] = rs.w;
+    }
     const float* xb = x + static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
     const int n_oct = (channels + 7) >> 3;
     for (int oct = oct0; oct < 2 * n_groups; oct += 16) {
@@ -334,10 +342,16 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
             const int ch = oct * 8 + c;
             float4 t4 = make_float4(0.f, 0.f, 0.f, 0.f);
             float g = 0.f, be = 0.f;
-            if (oct < n_oct && ch < channels) { t4 = *reinterpret_cast<const float4*>(xb + static_cast<size_t>(ch) * ld); g = gamma[ch]; be = beta[ch]; }
+            if (oct < n_oct && ch < channels) {
+                t4 = *reinterpret_cast<const float4*>(xb + static_cast<size_t>(ch) * ld);
+                if constexpr (NORM) { g = gamma[ch]; be = beta[ch]; }
+            }
             const float e4[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[c][r] = (ch < channels) ? ln_apply(e4[r], m4[r], r4[r], g, be) * scale : 0.f;
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (NORM) v[c][r] = (ch < channels) ? ln_apply(e4[r], m4[r], r4[r], g, be) * scale : 0.f;
+                else                v[c][r] = e4[r] * scale;
+            }
         }
         // group = oct >> 1, half = oct & 1; planes of a group: [split][half]
         unsigned char* plane_hi = img_b + ((static_cast<size_t>(oct >> 1) * 4 + (oct & 1)) * rows + 1 + static_cast<size_t>(q) * 4) * 16;
@@ -373,8 +387,8 @@ extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, c
     const int nq = ld / 4;
     hipLaunchKernelGGL(channel_stats_bound_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
                        x, gamma, beta, stats, reinterpret_cast<unsigned*>(bound), channels, frames, ld, eps);
-    hipLaunchKernelGGL(normalize_split_kernel, dim3((nq + 15) / 16, batch), dim3(256), 0, as_stream(stream),
-                       x, stats, gamma, beta, bound, static_cast<unsigned char*>(image), channels, frames, ld);
+    hipLaunchKernelGGL(normalize_split_kernel<true>, dim3((nq + 15) / 16, batch), dim3(256), 0, as_stream(stream),
+                       x, stats, gamma, beta, bound, static_cast<unsigned char*>(image), channels, frames, ld, 1);
     return launch_status("nbasr_layernorm_split_image");
 }
 
@@ -400,33 +414,58 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
 // The scaled fp16 convolution keeps full fp32 precision for elements down to 2^-29 of the utterance's maximum; an utterance
 // whose quietest frame lies more than 2^20 below its loudest sample (or that holds non-finite values) is EXTREME and is
 // routed to the range-free 3-way bf16 split instead (nbasr_dense_conv1d_fused_packed_ranged), per utterance, on the device.
+// 64 lanes x 4 frames wide, 4 channel slices deep: 16-byte loads, all of a thread's loads independent
 __global__ __launch_bounds__(256) void input_range_kernel(const float* __restrict__ x, unsigned* __restrict__ range,
                                                           int channels, int frames, int ld)
 {
+    __shared__ float s_max[4][256];
+    __shared__ unsigned s_bad[4];
     const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    float fmax_ = 0.f;
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;             // slice: wave-uniform
+    const int t0 = (blockIdx.x * 64 + lane) * 4;
+    float m[4] = {0.f, 0.f, 0.f, 0.f};
     unsigned bad = 0u;
-    if (t < frames) {
-        const float* col = x + static_cast<size_t>(b) * channels * ld + t;
-        for (int c = 0; c < channels; ++c) {
-            const float v = col[static_cast<size_t>(c) * ld];
-            const float a = fabsf(v);
-            if (!(a <= 3.4028234664e38f)) bad = 1u;          // Inf or NaN
-            else fmax_ = fmaxf(fmax_, a);
+    if (t0 < frames) {
+        const float* col = x + static_cast<size_t>(b) * channels * ld + t0;
+        const bool whole = t0 + 4 <= ld && ld % 4 == 0 && (reinterpret_cast<size_t>(x) & 15) == 0;
+        for (int c = slice; c < channels; c += 4) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (whole) {
+                const float4 q = *reinterpret_cast<const float4*>(col + static_cast<size_t>(c) * ld);
+                v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (t0 + r < frames) v[r] = col[static_cast<size_t>(c) * ld + r];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = fabsf(v[r]);
+                if (t0 + r < frames) {
+                    if (!(a <= 3.4028234664e38f)) bad = 1u;      // Inf or NaN
+                    else m[r] = fmaxf(m[r], a);
+                }
+            }
         }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_max[slice][lane * 4 + r] = m[r];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bad |= __shfl_xor(bad, d);
+    if (lane == 0) s_bad[slice] = bad;
+    __syncthreads();
+    // one frame per thread: its maximum over all channels, then the tile's loudest sample and quietest non-silent frame
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const float fmax_ = fmaxf(fmaxf(s_max[0][threadIdx.x], s_max[1][threadIdx.x]), fmaxf(s_max[2][threadIdx.x], s_max[3][threadIdx.x]));
     float hi = fmax_, lo = (t < frames && fmax_ > 0.f) ? fmax_ : __uint_as_float(0x7f800000u);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         hi = fmaxf(hi, __shfl_xor(hi, d));
         lo = fminf(lo, __shfl_xor(lo, d));
-        bad |= __shfl_xor(bad, d);
     }
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         atomicMax(range + 4 * b, __float_as_uint(hi));        // non-negative floats order like unsigned integers
         atomicMin(range + 4 * b + 1, __float_as_uint(lo));
-        if (bad) atomicOr(range + 4 * b + 2, 0x3f800000u);     // 1.0f
+        if (slice == 0 && (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3])) atomicOr(range + 4 * b + 2, 0x3f800000u);     // 1.0f
     }
 }
 
@@ -450,6 +489,23 @@ extern "C" int nbasr_input_range(const float* x, float* range, int batch, int ch
                            reinterpret_cast<unsigned*>(range), channels, frames, ld);
     }
     return launch_status("nbasr_input_range");
+}
+
+extern "C" int nbasr_split_image_ranged(const float* x, const float* x_range, void* image, int batch, int channels, int frames,
+                                        int ld, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0, NBASR_EINVAL, "nbasr_split_image_ranged: bad sizes");
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0, NBASR_EALIGN, "nbasr_split_image_ranged: ld=%d must be >= frames=%d and a multiple of 4", ld, frames);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && x_range && image, NBASR_ENULL, "nbasr_split_image_ranged: NULL pointer");
+    NBASR_REQUIRE(aligned16(x) && aligned16(image), NBASR_EALIGN, "nbasr_split_image_ranged: x, image must be 16-byte aligned");
+    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_split_image_ranged: batch %d > 65535", batch);
+    const int nq = ld / 4;
+    hipLaunchKernelGGL(normalize_split_kernel<false>, dim3((nq + 15) / 16, batch), dim3(256), 0, as_stream(stream),
+                       x, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
+                       x_range, static_cast<unsigned char*>(image), channels, frames, ld, 4);
+    return launch_status("nbasr_split_image_ranged");
 }
 
 extern "C" int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_stream_t stream)

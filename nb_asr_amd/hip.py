@@ -8,6 +8,7 @@ There is NO fallback: if the library is missing or the tensors are not on a HIP 
 call fails loudly (build with ``python -m nb_asr_amd.build``).
 """
 import ctypes
+import threading
 import pathlib
 
 import torch
@@ -114,7 +115,15 @@ SIGNATURES = {
     'nbasr_packed_dense_weights_bytes_bf16': (ctypes.c_size_t, [_c_int] * 4),
     'nbasr_pack_dense_weights_bf16': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
     'nbasr_dense_conv1d_bf16_img': (_c_int, [_c_float_p] * 4 + [_c_int] * 9 + [_c_stream]),
+    'nbasr_split_image_ranged': (_c_int, [_c_float_p] * 3 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_dense_conv1d_fused_packed_f16_img_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 9 + [_c_stream]),
 }
+
+# entry points that only answer on the host (never recorded on a launch tape); every other one enqueues work on a stream
+_HOST_ONLY = frozenset({'nbasr_version', 'nbasr_build_id', 'nbasr_last_error', 'nbasr_pad_amounts', 'nbasr_output_frames',
+                        'nbasr_grouped_cell_fits'})
+_ENQUEUES = frozenset(name for name in SIGNATURES if name not in _HOST_ONLY and not name.endswith('_bytes')
+                      and '_bytes_' not in name)
 
 F32, BF16 = 0, 1                 # NBASR_F32 / NBASR_BF16
 GC_FPL8, GC_WPERM = 1, 2         # NBASR_GC_* variant bits of nbasr_grouped_conv1d_node
@@ -127,13 +136,47 @@ class HipError(RuntimeError):
 
 
 _lib = None
+_tls = threading.local()
+
+
+class _TapingLibrary:
+    """Stand-in for the loaded library while a ``ForwardPlan`` records a launch tape (executor.LaunchTape): every entry
+    point that takes a stream -- i.e. enqueues work -- is executed AND appended to ``entries`` as ``[function, [args]]``;
+    host-only queries (sizes, error text, version) pass straight through."""
+
+    def __init__(self, lib, entries):
+        self._lib, self._entries = lib, entries
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if name not in _ENQUEUES:
+            return fn
+        entries = self._entries
+
+        def call(*args):
+            entries.append([fn, list(args)])
+            return fn(*args)
+        return call
+
+
+def start_tape(entries):
+    """Record this thread's enqueueing library calls into ``entries`` until ``stop_tape()``."""
+    _tls.taping = _TapingLibrary(load_library(), entries)
+
+
+def stop_tape():
+    _tls.taping = None
 
 
 def load_library(path=None):
     """Load (once) and type the shared library.  Raises if it has not been built."""
     global _lib
-    if _lib is not None and path is None:
-        return _lib
+    if path is None:
+        taping = getattr(_tls, 'taping', None)
+        if taping is not None:
+            return taping
+        if _lib is not None:
+            return _lib
     p = pathlib.Path(path) if path is not None else LIB_PATH
     if not p.exists():
         raise HipError(f'{p} not found: the HIP extension has not been built '
@@ -362,17 +405,29 @@ def input_range(x, frames, out):
     return out
 
 
-def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride):
+def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride, image=None, row_tile=128):
     """The model's first dense conv with per-utterance routing on the device: ordinary utterances on the 2-way fp16 split,
-    extreme ones (non-finite samples, > 2^20 dynamic range between frames) on the 3-way bf16 split; same output tensor."""
+    extreme ones (non-finite samples, > 2^20 dynamic range between frames) on the 3-way bf16 split; same output tensor.
+    ``image``: uint8 workspace of ``nbasr_split_image_bytes`` -- the fp16 leg then runs on the image path (one split pass over
+    x, LDS-DMA-only GEMM; ``packed_f16`` packed for ``row_tile``); None: the input is split in the GEMM's prologue."""
     lib = load_library()
     b, c_in, ld_in = x.shape
-    if packed_f16.numel() != lib.nbasr_packed_dense_weights_bytes_f16(c_out, c_in, kernel) or \
-            packed_bf16x3.numel() != lib.nbasr_packed_dense_weights_bytes(c_out, c_in, kernel):
+    want_f16 = lib.nbasr_packed_dense_weights_bytes_f16(c_out, c_in, kernel) if image is None else \
+        lib.nbasr_packed_dense_weights_bytes_f16_rows(c_out, c_in, kernel, row_tile)
+    if packed_f16.numel() != want_f16 or packed_bf16x3.numel() != lib.nbasr_packed_dense_weights_bytes(c_out, c_in, kernel):
         raise HipError('packed weights do not match the (c_out, c_in, kernel) of this convolution')
     args = (_dev(bias, 'bias'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride, _stream(x))
-    _check(lib.nbasr_dense_conv1d_fused_packed_f16_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_f16.data_ptr(), *args),
-           'nbasr_dense_conv1d_fused_packed_f16_ranged')
+    if image is not None:
+        if image.dtype != torch.uint8 or image.numel() < lib.nbasr_split_image_bytes(b, c_in, ld_in):
+            raise HipError('dense_conv1d_first_ranged: image workspace too small (nbasr_split_image_bytes)')
+        _check(lib.nbasr_split_image_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), image.data_ptr(), b, c_in, frames_in, ld_in, _stream(x)),
+               'nbasr_split_image_ranged')
+        _check(lib.nbasr_dense_conv1d_fused_packed_f16_img_ranged(image.data_ptr(), _dev(x_range, 'x_range'), packed_f16.data_ptr(),
+                                                                  *args[:-1], row_tile, args[-1]),
+               'nbasr_dense_conv1d_fused_packed_f16_img_ranged')
+    else:
+        _check(lib.nbasr_dense_conv1d_fused_packed_f16_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_f16.data_ptr(), *args),
+               'nbasr_dense_conv1d_fused_packed_f16_ranged')
     _check(lib.nbasr_dense_conv1d_fused_packed_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_bf16x3.data_ptr(), *args),
            'nbasr_dense_conv1d_fused_packed_ranged')
     return y

@@ -71,7 +71,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert rc == -1 and b'reflect' in lib.nbasr_last_error()
     rc = lib.nbasr_pointwise_linear(16, 16, 16, 16, 1, 401, 10, 12, 80, 12, None)               # c_in % 4
     assert rc == -2
-    assert lib.nbasr_pointwise_workspace_bytes(64, 1200, 252) == 64 * 38 * 32768 + 64 * 4
+    assert lib.nbasr_pointwise_workspace_bytes(64, 1200, 252) == 64 * 38 * 32768 + 64 * 4 + 64 * 38 * 4     # image, inverse scales, partial maxima
     assert lib.nbasr_pointwise_packed_weights_bytes(2000, 1200) == 16 * 38 * 16384 + 2 * 16 * 128 * 4
     assert lib.nbasr_packed_dense_weights_bytes_f16(800, 600, 8) == 7 * 38 * 2 * 8 * 128 * 16 * 2 + 2 * 7 * 128 * 4
 

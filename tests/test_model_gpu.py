@@ -78,7 +78,7 @@ def test_prunable_copy_without_cell_norms():
     print(f'prunable copy: worst err/tol {ratio:.3f}, cpu fp32 noise floor {noise:.3f}')
     # no cell LayerNorm -> no range information reaches convs 1-3: they fall back to the range-free 3-way bf16 split
     plan = next(iter(pruned._plans.values()))
-    assert plan.dense_schemes == {0: 'f16x2', 1: 'bf16x3', 2: 'bf16x3', 3: 'bf16x3'}
+    assert plan.dense_schemes == {0: 'f16x2-image', 1: 'bf16x3', 2: 'bf16x3', 3: 'bf16x3'}
 
 
 def test_reference_style_usage():
@@ -235,8 +235,8 @@ def test_dense_scheme_selection():
     with torch.no_grad():
         y0 = model(x)
     plan = next(iter(model._plans.values()))
-    assert plan.dense_schemes == {0: 'f16x2', 1: 'f16x2-image', 2: 'f16x2-image', 3: 'f16x2-image'}
-    assert set(plan.dense_row_tiles) == {1, 2, 3} and set(plan.dense_row_tiles.values()) <= {128, 160}
+    assert plan.dense_schemes == {0: 'f16x2-image', 1: 'f16x2-image', 2: 'f16x2-image', 3: 'f16x2-image'}
+    assert set(plan.dense_row_tiles) == {0, 1, 2, 3} and set(plan.dense_row_tiles.values()) <= {128, 160}
     assert plan._row_tile(800, 1000) == 128 and plan._row_tile(1200, 250) == 128          # 2 utterances: one round either way
     os.environ['NBASR_DENSE_MODE'] = 'bf16x3'
     try:

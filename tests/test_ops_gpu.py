@@ -611,3 +611,32 @@ def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     assert torch.equal(got160, got)
     with pytest.raises(hip.HipError, match='row_tile=128'):
         hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed160, cout, 8, bias, got160, stride)
+
+
+@pytest.mark.parametrize('c,cout,t,b,rows', [(80, 600, 300, 4, 128), (80, 600, 1000, 2, 160), (40, 72, 7, 3, 128), (24, 161, 64, 2, 128)])
+def test_first_conv_image_leg_equals_the_in_kernel_split(c, cout, t, b, rows):
+    """Conv 0 on the image path (one split pass over the model input, GEMM copies operands by LDS-DMA) == conv 0 splitting the
+    input in its own prologue: the same scale, the same two fp16 terms, the same K order -> bit-identical, including the
+    per-utterance routing of an extreme utterance to the 3-way bf16 kernel."""
+    torch.manual_seed(c * t)
+    t4 = hip.round_up4(t)
+    x = torch.zeros(b, c, t4)
+    x[:, :, :t] = torch.randn(b, c, t) * 3.0
+    x[1, :, t // 2:t] *= 2.0 ** -30                          # extreme: routed
+    x[b - 1] *= 2.0 ** -35                                   # uniformly tiny: ordinary
+    x = x.to(DEV)
+    w, bias = torch.randn(cout, c, 8, device=DEV) * (2.0 / (c * 8)) ** 0.5, torch.randn(cout, device=DEV) * 0.1
+    rng = hip.input_range(x, t, torch.empty(4 * b, device=DEV))
+    p16, p16r, pb = hip.pack_dense_weights(w, 1, 'f16x2'), hip.pack_dense_weights(w, 1, 'f16x2', row_tile=rows), hip.pack_dense_weights(w, 1, 'bf16x3')
+    want = torch.full((b, cout, t4), float('nan'), device=DEV)
+    got = torch.full_like(want, float('nan'))
+    hip.dense_conv1d_first_ranged(x, t, rng, p16, pb, cout, 8, bias, want, 1)
+    image = hip.split_image(b, c, t4, DEV)
+    image.fill_(0x7f)
+    hip.dense_conv1d_first_ranged(x, t, rng, p16r, pb, cout, 8, bias, got, 1, image, rows)
+    assert torch.equal(got, want)
+    truth = oracle.pad_conv_relu(x[:, :, :t].cpu().double(), w.cpu().double(), bias.cpu().double(), 1, 1, 1)
+    pre = oracle.pad_conv_relu(x[:, :, :t].cpu().double().abs(), w.cpu().double().abs(), bias.cpu().double().abs(), 1, 1, 1)
+    assert float(((got[:, :, :t].cpu().double() - truth).abs() / (pre + 1e-300)).max()) <= 2e-6
+    with pytest.raises(hip.HipError, match='image workspace too small'):
+        hip.dense_conv1d_first_ranged(x, t, rng, p16r, pb, cout, 8, bias, got, 1, image[:16], rows)
