@@ -78,6 +78,19 @@ class PendingLogits:
         return self._logits
 
 
+# Any submodule or parameter (re-)registered on any module bumps this counter: a launch tape recorded before is not replayed
+# afterwards (a layer swapped inside a model that has already run must be seen by the next forward).
+_structure_epoch = [0]
+
+
+def _bump_structure_epoch(*_args):
+    _structure_epoch[0] += 1
+
+
+torch.nn.modules.module.register_module_module_registration_hook(_bump_structure_epoch)
+torch.nn.modules.module.register_module_parameter_registration_hook(_bump_structure_epoch)
+
+
 class LaunchTape:
     """The enqueueing C-ABI calls of ONE forward, recorded once and replayed for every later batch with the same key
     (shape, dtype, streams, parameter addresses and versions): the plan's workspaces and the derived weight copies sit
@@ -481,14 +494,15 @@ class ForwardPlan:
         """Everything the recorded launch sequence depends on; None: this call cannot use a tape."""
         if getattr(model, '_is_replica', False) or x.numel() == 0:    # DataParallel replica: its weights are fresh tensors every step
             return None
-        slots = self._param_slots
-        if slots is None or slots[0]() is not model:
+        slots, epoch = self._param_slots, _structure_epoch[0]
+        if slots is None or slots[0]() is not model or slots[2] != epoch:
             found = [(m._parameters, n) for m in model.modules() for n, p in m._parameters.items() if p is not None]
-            slots = self._param_slots = (weakref.ref(model), found)
+            slots = self._param_slots = (weakref.ref(model), found, epoch)
         params = tuple([(d[n].data_ptr(), d[n]._version) for d, n in slots[1]])
         pipe = bool(pipelined) and model.use_rnn
         return (x.dtype, tuple(x.shape), x.data_ptr() % 16 == 0, bool(pipelined), (self._turn ^ 1) if pipe else -1,
-                torch.cuda.current_stream(self.device).cuda_stream, tuple(os.environ.get(k) for k in self._TAPE_ENV), params)
+                torch.cuda.current_stream(self.device).cuda_stream, tuple(os.environ.get(k) for k in self._TAPE_ENV),
+                epoch, tuple(map(id, model.model)), params)
 
     def run(self, model, x, taps=None, pipelined=False, _capturing=False):
         """Enqueue one forward of ``model`` (its parameters are read now, so a DataParallel replica runs with its own).

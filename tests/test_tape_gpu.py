@@ -129,3 +129,25 @@ def test_other_stream_and_misaligned_input(monkeypatch):
         odd.copy_(xs[3])
         for _ in range(3):
             assert torch.equal(m(odd), want[3])
+
+
+def test_swapped_modules_are_seen(monkeypatch):
+    """A layer replaced inside a model that has already run (fine-tuning a new head, a re-initialised node op) must reach the
+    next forward: module / parameter registration anywhere invalidates the recorded tapes."""
+    import torch.nn as nn
+    m = build(cases.ARCH_D, True)
+    x = keyed_input(2, 80, seed=4).to(DEV)
+    with torch.no_grad():
+        for _ in range(3):
+            y0 = m(x)
+        (plan,) = plans(m)
+        assert plan.tape_replays == 1
+        torch.manual_seed(3)
+        m.model[-1] = nn.Linear(500, 49).to(DEV)                        # a new head
+        y1 = m(x)
+        op = m.model[2].nodes[0].op                                     # a node op deep inside a cell
+        op.conv = nn.Conv1d(op.conv.in_channels, op.conv.out_channels, op.kernel_size, dilation=op.dilation, groups=op.groups).to(DEV)
+        ys = [m(x) for _ in range(3)]
+    assert not torch.equal(y1, y0) and not torch.equal(ys[0], y1)
+    want = untaped(m, [x], monkeypatch)[0]
+    assert all(torch.equal(y, want) for y in ys)
