@@ -187,6 +187,7 @@ class ForwardPlan:
         # B=64/T=1000 it is VALU/latency-bound (45-50 TFLOP/s at 2-3 waves per SIMD): 139/263/210/164 us per cell vs
         # 177/264/159/117 us for three HBM-bound launches -- a win only in block 0, so it is off by default
         self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '0') == '1'
+        self.osplit_mode = os.environ.get('NBASR_GC_OSPLIT', '1') != '0'      # output-split node kernel where it wins (_gc_variant)
         self._bufs = {}              # name -> flat tensor; grow-only (see _buf)
         self.grow_count = 0          # number of (re)allocations so far (tests: a smaller batch must not allocate)
         # pipelined mode (forward_async): the latency-bound LSTM + head of batch i run on a side stream while the main
@@ -384,11 +385,32 @@ class ForwardPlan:
             taps[tap_idx] = copy[:, :, :act_frames].clone()
         return (stats, norm.weight.detach(), norm.bias.detach())
 
-    def _gc_variant(self, view):
-        """Kernel variant of the fp32 grouped-conv node op for an output of this size (speed only: results are bit-identical).
-        NBASR_GC_F32_VARIANT=<int> forces one (diagnostics; needs ld % 8 == 0 for the 8-frame variants)."""
+    def _gc_variant(self, view, node=None, ln0=None, stats=None, n_inputs=0):
+        """Kernel variant of the fp32 grouped-conv node op for this launch (speed only: results are bit-identical).
+        NBASR_GC_F32_VARIANT=<int> forces one (diagnostics; needs ld % 8 == 0 for the 8-frame variants; the output-split one is never
+        forced onto a statistics launch, which it does not have).
+
+        Output split (a wave owns half of a group's output channels, grouped_conv_osplit.hip) where rows are short and the group is
+        wide: measured on an MI355X as a producer -> consumer chain (tools/ubench/ab_gc_osplit.py, profiles/r02_ab_gc_osplit.txt) it
+        wins 12-18 % at C = 1200 x 250 frames x 64 utterances when the node has a skip input or a LayerNorm on load (nothing without),
+        14-17 % at 8 utterances in blocks 2-3, and LOSES 10-20 % at 6-8 channels per group or long rows."""
         forced = os.environ.get('NBASR_GC_F32_VARIANT')
-        return int(forced) if forced is not None else 0
+        if forced is not None:
+            v = int(forced)
+            return 0 if (v == hip.GC_OSPLIT and (stats is not None or node is None)) else v
+        if node is None or stats is not None or not self.osplit_mode:
+            return 0
+        op = node.op
+        cg = getattr(op, 'groups', 0) and view.shape[1] // op.groups
+        if cg < 10:
+            return 0
+        b, _, ld = view.shape
+        waves_per_simd = b * op.groups * (-(-(ld // 4) // 64)) / 1024.0
+        flagged = [type(br).__name__ == 'Identity' for br in node.branch_ops]
+        has_epilogue_loads = any(flagged) or (ln0 is not None and n_inputs == 1)       # skip inputs, or LayerNorm on load of the main input
+        if waves_per_simd < 2.0 or (waves_per_simd < 8.0 and has_epilogue_loads):
+            return hip.GC_OSPLIT
+        return 0
 
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)
@@ -651,7 +673,7 @@ class ForwardPlan:
                         ld = view.shape[2]
                         new_stats = self.stats[self._stat_turn][: self.batch * 2 * ld].view(self.batch, 2, ld)
                         st = (new_stats, self.stats_ws, layer.norm_layer.eps)
-                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx, self._gc_variant(view))))
+                    outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx, self._gc_variant(view, node, ln0, st, len(outs)))))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 if feeds_tail:
                     pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)

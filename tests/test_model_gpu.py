@@ -602,3 +602,31 @@ def test_exact_fp32_mode_on_the_noisy_cases(model_fx, case):
     ratio, noise = cases.assert_parity(got, want, truth, case, mode='strict')
     print(f'{case}: exact-fp32 mode: worst err/tol vs reference {ratio:.3f}, reference vs fp64 {noise:.3f}, '
           f'rms err vs fp64 {cases._rms(got.double().cpu() - truth):.3e} (reference {cases._rms(want.double() - truth):.3e})')
+
+
+def test_output_split_node_kernel_is_chosen_and_changes_nothing(monkeypatch):
+    """Short rows / few utterances: nodes with >= 10 channels per group run the output-split kernel (executor._gc_variant);
+    NBASR_GC_OSPLIT=0 keeps the default kernel everywhere.  Same sums in the same order: bit-identical logits."""
+    from nb_asr_amd import hip
+    from nb_asr_amd.executor import ForwardPlan
+    m = build(cases.ARCH_D, True, 'lively')
+    x = keyed_input(3, 210, seed=8).to(DEV)
+    chosen = []
+    original = ForwardPlan._gc_variant
+
+    def spy(self, *a, **k):
+        v = original(self, *a, **k)
+        chosen.append(v)
+        return v
+    monkeypatch.setattr(ForwardPlan, '_gc_variant', spy)
+    with torch.no_grad():
+        y1 = m(x).clone()
+    assert hip.GC_OSPLIT in chosen and 0 in chosen           # blocks 2-3 split, blocks 0-1 and the statistics launches do not
+    n_split = chosen.count(hip.GC_OSPLIT)
+    monkeypatch.setenv('NBASR_GC_OSPLIT', '0')
+    m._plans.clear()
+    chosen.clear()
+    with torch.no_grad():
+        y0 = m(x).clone()
+    assert set(chosen) == {0} and n_split > 0
+    assert torch.equal(y0, y1)
