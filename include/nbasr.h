@@ -250,6 +250,7 @@ int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float
 #define NBASR_GC_FPL8 1
 #define NBASR_GC_WPERM 2
 #define NBASR_GC_OSPLIT 4       /* fp32, on its own, no stats_ws: a wave owns half of a group's output channels (short rows / small batches) */
+#define NBASR_GC_PIPE 8         /* fp32, alone (stats_ws allowed) or with NBASR_GC_OSPLIT (no stats_ws): software-pipelined window loads (buffer loads, zero fill by the bounds check) */
 int nbasr_grouped_conv1d_node(const void* x, const float* w, const float* bias,
                               const void* skip0, const void* skip1, const void* skip2, void* y,
                               int batch, int channels, int frames, int ld, int groups, int kernel, int dilation,

@@ -365,8 +365,9 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
                              int variant, nbasr_stream_t stream)
 {
     NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "%s: dtype %d is neither NBASR_F32 nor NBASR_BF16", what, dtype);
-    NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || (variant == NBASR_GC_OSPLIT && dtype == NBASR_F32), NBASR_EINVAL,
-                  "%s: unknown variant %d (NBASR_GC_OSPLIT: fp32 only, alone)", what, variant);
+    const bool alt2 = variant > 0 && (variant & ~(NBASR_GC_OSPLIT | NBASR_GC_PIPE)) == 0;       // output split and / or pipelined loads
+    NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || (alt2 && dtype == NBASR_F32), NBASR_EINVAL,
+                  "%s: unknown variant %d (NBASR_GC_OSPLIT / NBASR_GC_PIPE: fp32 only, not with the other bits)", what, variant);
     NBASR_REQUIRE(aligned16(stats_ws), NBASR_EALIGN, "%s: statistics buffers must be 16-byte aligned", what);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "%s: bad sizes batch=%d channels=%d frames=%d groups=%d", what, batch, channels, frames, groups);
@@ -386,7 +387,7 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
     if (dtype == NBASR_F32) {
         GroupedArgs<float> a{static_cast<const float*>(x), w, bias, static_cast<const float*>(skip0), static_cast<const float*>(skip1),
                              static_cast<const float*>(skip2), static_cast<float*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws};
-        if (variant == NBASR_GC_OSPLIT) return grouped_conv_f32_osplit(a, kernel, dilation, s);
+        if (alt2) return grouped_conv_f32_osplit(variant, a, kernel, dilation, s);
         return variant == 0 ? grouped_conv_f32_base(a, kernel, dilation, s) : grouped_conv_f32_alt(variant, a, kernel, dilation, s);
     }
     GroupedArgs<bf16_t> a{static_cast<const bf16_t*>(x), w, bias, static_cast<const bf16_t*>(skip0), static_cast<const bf16_t*>(skip1),

@@ -78,6 +78,16 @@ class PendingLogits:
         return self._logits
 
 
+def _load_gc_table():
+    import json
+    import pathlib
+    path = pathlib.Path(__file__).with_name('gc_variant_table.json')
+    return json.loads(path.read_text()) if path.exists() else {}
+
+
+_GC_TABLE = _load_gc_table()
+
+
 # Any submodule or parameter (re-)registered on any module bumps this counter: a launch tape recorded before is not replayed
 # afterwards (a layer swapped inside a model that has already run must be seen by the next forward).
 _structure_epoch = [0]
@@ -187,7 +197,8 @@ class ForwardPlan:
         # B=64/T=1000 it is VALU/latency-bound (45-50 TFLOP/s at 2-3 waves per SIMD): 139/263/210/164 us per cell vs
         # 177/264/159/117 us for three HBM-bound launches -- a win only in block 0, so it is off by default
         self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '0') == '1'
-        self.osplit_mode = os.environ.get('NBASR_GC_OSPLIT', '1') != '0'      # output-split node kernel where it wins (_gc_variant)
+        # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_TABLE=0: the default kernel everywhere
+        self.gc_table = _GC_TABLE if os.environ.get('NBASR_GC_TABLE', '1') != '0' else {}
         self._bufs = {}              # name -> flat tensor; grow-only (see _buf)
         self.grow_count = 0          # number of (re)allocations so far (tests: a smaller batch must not allocate)
         # pipelined mode (forward_async): the latency-bound LSTM + head of batch i run on a side stream while the main
@@ -386,31 +397,31 @@ class ForwardPlan:
         return (stats, norm.weight.detach(), norm.bias.detach())
 
     def _gc_variant(self, view, node=None, ln0=None, stats=None, n_inputs=0):
-        """Kernel variant of the fp32 grouped-conv node op for this launch (speed only: results are bit-identical).
-        NBASR_GC_F32_VARIANT=<int> forces one (diagnostics; needs ld % 8 == 0 for the 8-frame variants; the output-split one is never
-        forced onto a statistics launch, which it does not have).
+        """Kernel variant of the fp32 grouped-conv node op for this launch (speed only: every variant computes the same sums in the
+        same order, results are bit-identical).  NBASR_GC_F32_VARIANT=<int> forces one (diagnostics; needs ld % 8 == 0 for the
+        8-frame variants; the output-split ones are never forced onto a statistics launch, which they do not have).
 
-        Output split (a wave owns half of a group's output channels, grouped_conv_osplit.hip) where rows are short and the group is
-        wide: measured on an MI355X as a producer -> consumer chain (tools/ubench/ab_gc_osplit.py, profiles/r02_ab_gc_osplit.txt) it
-        wins 12-18 % at C = 1200 x 250 frames x 64 utterances when the node has a skip input or a LayerNorm on load (nothing without),
-        14-17 % at 8 utterances in blocks 2-3, and LOSES 10-20 % at 6-8 channels per group or long rows."""
+        Default: looked up in gc_variant_table.json, which tools/make_gc_variant_table.py derives from same-process A/B timings of
+        the four variants {default, output split, pipelined buffer loads, both} per (taps, dilation, channels per group, flavour,
+        size class) on an MI355X (profiles/r02_gc_variants2/): the pipelined + split kernel wins almost everywhere for k5 and for
+        >= 10 channels per group, the default kernel keeps the wide-window, narrow-group, skip-free cases."""
         forced = os.environ.get('NBASR_GC_F32_VARIANT')
         if forced is not None:
             v = int(forced)
-            return 0 if (v == hip.GC_OSPLIT and (stats is not None or node is None)) else v
-        if node is None or stats is not None or not self.osplit_mode:
+            return (v & ~hip.GC_OSPLIT if v & hip.GC_PIPE else 0) if (v & hip.GC_OSPLIT and (stats is not None or node is None)) else v
+        if node is None or not self.gc_table:
             return 0
         op = node.op
-        cg = getattr(op, 'groups', 0) and view.shape[1] // op.groups
-        if cg < 10:
+        groups = getattr(op, 'groups', 0)
+        if not groups:
             return 0
-        b, _, ld = view.shape
-        waves_per_simd = b * op.groups * (-(-(ld // 4) // 64)) / 1024.0
-        flagged = [type(br).__name__ == 'Identity' for br in node.branch_ops]
-        has_epilogue_loads = any(flagged) or (ln0 is not None and n_inputs == 1)       # skip inputs, or LayerNorm on load of the main input
-        if waves_per_simd < 2.0 or (waves_per_simd < 8.0 and has_epilogue_loads):
-            return hip.GC_OSPLIT
-        return 0
+        b, c, ld = view.shape
+        waves_per_simd = b * groups * (-(-(ld // 4) // 64)) / 1024.0
+        on_x = ln0 is not None and n_inputs == 1
+        has_skips = any(type(br).__name__ == 'Identity' for br in node.branch_ops)
+        key = f"{op.kernel_size},{op.dilation},{c // groups},{'lnx' if on_x else 'skip' if has_skips else 'plain'}," \
+              f"{'small' if waves_per_simd < 4.0 else 'large'}{',stats' if stats is not None else ''}"
+        return self.gc_table.get(key, 0)
 
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)

@@ -50,7 +50,7 @@ def test_node_variants_are_bit_identical_and_match_the_oracle(dtype, cg, k, d):
     w = (torch.randn(c, cg, k) * 0.3).to(dtype).float()
     bias = (torch.randn(c) * 0.2).to(dtype).float()
     want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + skips[0] + skips[1] + skips[2]
-    variants = (0, 1, 2, 3) + ((hip.GC_OSPLIT,) if dtype == torch.float32 else ())      # output-split: fp32 only
+    variants = (0, 1, 2, 3) + ((hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT) if dtype == torch.float32 else ())      # fp32 only
     outs = [node(x, w, bias, skips, k, d, groups, dtype, v) for v in variants]
     for v, out in zip(variants[1:], outs[1:]):
         assert torch.equal(out, outs[0]), f'variant {v} differs from variant 0'
@@ -69,7 +69,7 @@ def test_node_ragged_lengths_and_flattened_lanes(dtype, t):
     x = torch.randn(b, c, t).to(dtype).float()
     w, bias = (torch.randn(c, cg, k) * 0.3).to(dtype).float(), torch.randn(c).to(dtype).float() * 0.2
     want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + x
-    for v in (0, 3) + ((hip.GC_OSPLIT,) if dtype == torch.float32 else ()):
+    for v in (0, 3) + ((hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT) if dtype == torch.float32 else ()):
         got = node(x, w, bias, [x], k, d, groups, dtype, v).float().cpu()
         tol = (2.0 ** -8 if dtype == BF else 0.0) * want.abs() + 2e-5 + 1e-5 * want.abs()
         assert bool(((got - want).abs() <= tol).all()), (v, float(((got - want).abs() / tol).max()))
@@ -92,7 +92,7 @@ def test_node_deferred_layernorm_and_epilogue_statistics(dtype):
     hip.channel_stats_v(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     results = []
-    for v in range(4):
+    for v in tuple(range(4)) + ((hip.GC_PIPE,) if dtype == torch.float32 else ()):
         y = torch.empty_like(xp)
         ws = hip.grouped_stats_workspace(b, ld, groups, DEV)
         wd = w.to(DEV).contiguous()
@@ -279,11 +279,11 @@ def test_output_split_variant_with_deferred_layernorm(cg, k, d):
     hip.channel_stats_v(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     outs = []
-    for v in (0, hip.GC_OSPLIT):
+    for v in (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT):
         y = torch.full_like(xp, float('nan'))
         hip.grouped_conv1d_node(xp, w.to(DEV), bias.to(DEV), [xp, s1, s2], y, t, groups, k, d, ln, True, True, None, v)
         outs.append(y)
-    assert torch.equal(outs[0], outs[1]) and torch.all(outs[1][:, :, t:] == 0)
+    assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.all(outs[1][:, :, t:] == 0)
     ws = hip.grouped_stats_workspace(b, xp.shape[2], groups, DEV)
     with pytest.raises(hip.HipError, match='no statistics epilogue'):
         hip.grouped_conv1d_node(xp, w.to(DEV), bias.to(DEV), [], outs[1], t, groups, k, d, None, False, False, ws, hip.GC_OSPLIT)

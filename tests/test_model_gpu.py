@@ -604,9 +604,9 @@ def test_exact_fp32_mode_on_the_noisy_cases(model_fx, case):
           f'rms err vs fp64 {cases._rms(got.double().cpu() - truth):.3e} (reference {cases._rms(want.double() - truth):.3e})')
 
 
-def test_output_split_node_kernel_is_chosen_and_changes_nothing(monkeypatch):
-    """Short rows / few utterances: nodes with >= 10 channels per group run the output-split kernel (executor._gc_variant);
-    NBASR_GC_OSPLIT=0 keeps the default kernel everywhere.  Same sums in the same order: bit-identical logits."""
+def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
+    """The executor picks the fp32 node kernel's variant per launch from the measured table (output split and / or pipelined
+    buffer loads); NBASR_GC_TABLE=0 keeps the default kernel everywhere.  Same sums in the same order: bit-identical logits."""
     from nb_asr_amd import hip
     from nb_asr_amd.executor import ForwardPlan
     m = build(cases.ARCH_D, True, 'lively')
@@ -616,17 +616,23 @@ def test_output_split_node_kernel_is_chosen_and_changes_nothing(monkeypatch):
 
     def spy(self, *a, **k):
         v = original(self, *a, **k)
-        chosen.append(v)
+        chosen.append((v, a[3] is not None if len(a) > 3 else False))
         return v
     monkeypatch.setattr(ForwardPlan, '_gc_variant', spy)
     with torch.no_grad():
         y1 = m(x).clone()
-    assert hip.GC_OSPLIT in chosen and 0 in chosen           # blocks 2-3 split, blocks 0-1 and the statistics launches do not
-    n_split = chosen.count(hip.GC_OSPLIT)
-    monkeypatch.setenv('NBASR_GC_OSPLIT', '0')
+    picked = {v for v, _ in chosen}
+    assert picked & {hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT}
+    assert all(not (v & hip.GC_OSPLIT) for v, with_stats in chosen if with_stats)      # statistics launches: default or pipelined only
+    monkeypatch.setenv('NBASR_GC_TABLE', '0')
     m._plans.clear()
     chosen.clear()
     with torch.no_grad():
         y0 = m(x).clone()
-    assert set(chosen) == {0} and n_split > 0
+    assert {v for v, _ in chosen} == {0}
     assert torch.equal(y0, y1)
+    for forced in (hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_OSPLIT):
+        monkeypatch.setenv('NBASR_GC_F32_VARIANT', str(forced))
+        m._plans.clear()
+        with torch.no_grad():
+            assert torch.equal(m(x), y0), forced

@@ -18,6 +18,7 @@ from nb_asr_amd import hip  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='+', default=[64, 8])
 ap.add_argument('--kernel', type=int, default=5)
+ap.add_argument('--dilation', type=int, default=1)
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 for B in args.batches:
@@ -41,11 +42,12 @@ for B in args.batches:
             def run(i, variant):
                 src, dst = bufs[i % nbuf], bufs[(i + 1) % nbuf]
                 skips = [bufs[(i + 2) % nbuf]] if n_skips and flavour != 'lnx' else ([src] if n_skips else [])
-                hip.grouped_conv1d_node(src, w, bias, skips, dst, t, 100, args.kernel, 1, ln, flavour == 'lnx', flavour == 'lnx' and bool(skips), None, variant)
+                hip.grouped_conv1d_node(src, w, bias, skips, dst, t, 100, args.kernel, args.dilation, ln, flavour == 'lnx', flavour == 'lnx' and bool(skips), None, variant)
 
-            times = {0: [], hip.GC_OSPLIT: []}
+            variants = (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT)
+            times = {v: [] for v in variants}
             for rnd in range(5):
-                for variant in (0, hip.GC_OSPLIT):
+                for variant in variants:
                     for i in range(4):
                         run(i, variant)
                     torch.cuda.synchronize()
@@ -57,6 +59,7 @@ for B in args.batches:
                     e1.record()
                     torch.cuda.synchronize()
                     times[variant].append(e0.elapsed_time(e1) * 1e3 / n)
-            print(json.dumps({'batch': B, 'block': blk, 'C': c, 'T': t, 'flavour': flavour, 'skips': n_skips,
-                              'default_us': round(statistics.median(times[0]), 1), 'osplit_us': round(statistics.median(times[hip.GC_OSPLIT]), 1)}), flush=True)
+            print(json.dumps({'k': args.kernel, 'd': args.dilation, 'batch': B, 'block': blk, 'C': c, 'T': t, 'flavour': flavour, 'skips': n_skips,
+                              'default_us': round(statistics.median(times[0]), 1), 'osplit_us': round(statistics.median(times[hip.GC_OSPLIT]), 1),
+                              'pipe_us': round(statistics.median(times[hip.GC_PIPE]), 1), 'pipe_osplit_us': round(statistics.median(times[hip.GC_PIPE | hip.GC_OSPLIT]), 1)}), flush=True)
         del bufs

@@ -12,6 +12,12 @@
 //
 // HBM-bound (7.5-21 flop/byte); algorithmic bytes per launch
 //     4 * (B*C*T * (2 + n_skips) + C*(C/groups)*k + C).
+#ifndef GC_EXP_NOLOAD
+#define GC_EXP_NOLOAD 0
+#endif
+#ifndef GC_EXP_NOFMA
+#define GC_EXP_NOFMA 0
+#endif
 #include "common.h"
 
 namespace nbasr {
@@ -86,7 +92,11 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
         for (int c = 0; c < NCH; ++c) {
             const int qq = q - QL + c;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#if GC_EXP_NOLOAD          // experiment (tools/ubench/gc_phases.py): arithmetic and stores only
+            v = make_float4(lane * 1e-3f, ci * 1e-3f, 0.5f, c * 1e-3f);
+#else
             if (active && qq >= 0 && qq < nq) v = xrow[qq];
+#endif
             xw[4 * c + 0] = v.x; xw[4 * c + 1] = v.y; xw[4 * c + 2] = v.z; xw[4 * c + 3] = v.w;
         }
         if (LNX) {
@@ -100,6 +110,16 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
                 xw[2 * p] = v.x; xw[2 * p + 1] = v.y;
             }
         }
+#if GC_EXP_NOFMA           // experiment: loads and stores only (every loaded value still reaches an output)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) t += xw[4 * c + r];
+            acc[0][r] += t;                       // (a static index: acc[ci] would move the accumulators to scratch)
+            acc[CG - 1][r] -= t;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < K; ++j) {
 #pragma unroll
@@ -110,6 +130,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
                     acc[co][r] = __builtin_fmaf(wv, xw[BASE + r + j * D], acc[co][r]);
             }
         }
+#endif
     }
 
     if (!STATS && !active) return;
