@@ -361,10 +361,12 @@ class ForwardPlan:
         from .ops import Linear
         return isinstance(nxt, SearchCell) and not isinstance(nxt.nodes[0].op, Linear)
 
-    def _norm(self, norm, act, act_frames, kind_meta, taps, tap_idx, nxt, out=None):
+    def _norm(self, norm, act, act_frames, kind_meta, taps, tap_idx, nxt, out=None, defer=None):
         """LayerNorm of ``act``: returns the pending descriptor (deferred) or None after normalising in place (or into
-        ``out``)."""
-        if self.ln_mode == 'materialize' or not self._cheap_consumer(nxt) or out is not None:
+        ``out``).  ``defer``: the caller's decision whether the consumer normalises on load (default: _cheap_consumer)."""
+        if defer is None:
+            defer = self._cheap_consumer(nxt)
+        if self.ln_mode == 'materialize' or not defer or out is not None:
             dst = act if out is None else out
             from .ops import PadConvRelu
             want_range = self.dense_mode == 'auto' and isinstance(nxt, PadConvRelu) and nxt.groups == 1 and nxt.kernel_size == 8
@@ -468,12 +470,13 @@ class ForwardPlan:
         for t in self._bufs.values():                 # allocated on the main stream, from now on also read on the side stream
             t.record_stream(self.side_stream)
 
-    def _pipeline_buffers(self, channels, frames):
-        """Double-buffered encoder output + gate pre-activations of the pipelined tail: (slot, encoder output view)."""
+    def _pipeline_buffers(self, channels, frames, need_enc=True):
+        """Double-buffered gate pre-activations of the pipelined tail (+ an fp32 hand-over copy of the encoder output where the
+        storage types differ, bf16 path): (slot, encoder output view or None)."""
         from .model import LSTM_HIDDEN
         self._ensure_pipeline()
         ld = hip.round_up4(frames)
-        enc = [self._buf(f'enc_out{i}', self.batch * channels * ld) for i in range(2)]
+        enc = [self._buf(f'enc_out{i}', self.batch * channels * ld) for i in range(2)] if need_enc else None
         self.gates_pipe = [self.gates_ws, self._buf('gates1', self.batch * self.out_frames * 4 * LSTM_HIDDEN)]
 
         def rotate():
@@ -483,7 +486,7 @@ class ForwardPlan:
                 torch.cuda.current_stream(self.device).wait_event(ev)
         self._host(rotate)
         k = self._turn
-        return k, enc[k][: self.batch * channels * ld].view(self.batch, channels, ld)
+        return k, (enc[k][: self.batch * channels * ld].view(self.batch, channels, ld) if need_enc else None)
 
     # ---- launch tapes ------------------------------------------------------------------------------------------------------
     def _host(self, step, produces=False):
@@ -651,6 +654,11 @@ class ForwardPlan:
                     raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
                 nxt = model.model[idx + 1] if idx + 1 < n_layers else None
                 feeds_tail = pipe and isinstance(nxt, (nn.Dropout, nn.LSTM))
+                # the LSTM's input projection pre-splits its operand in a streaming pass that applies a pending LayerNorm while
+                # loading (gemm_pointwise_split.hip), and it runs on the MAIN stream in both modes: the cell in front of it defers
+                # its LayerNorm like a cell in front of a grouped conv does -- no materialised copy of the encoder output
+                after = model.model[idx + 2] if isinstance(nxt, nn.Dropout) and idx + 2 < n_layers else nxt
+                defer = self.ln_mode == 'deferred' and (self._cheap_consumer(nxt) or (isinstance(after, nn.LSTM) and self.linear_mode == 'f16x2'))
                 # a deferred cell LayerNorm whose producer is a grouped conv gets its statistics from that node's
                 # epilogue (no statistics pass over the tensor)
                 last_op = layer.nodes[-1].op
@@ -669,7 +677,7 @@ class ForwardPlan:
                     src, ln0 = act, pending
                     self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0))
                     outs = [act, None, None, view]
-                epilogue_stats = (not fused and self.epilogue_stats and layer.use_norm and self.ln_mode == 'deferred' and self._cheap_consumer(nxt) and not feeds_tail
+                epilogue_stats = (not fused and self.epilogue_stats and layer.use_norm and defer
                                   and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                 if not fused:
                     outs = [act]
@@ -687,7 +695,7 @@ class ForwardPlan:
                     outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx, self._gc_variant(view, node, ln0, st, len(outs)))))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 if feeds_tail:
-                    pipe_k, enc = self._pipeline_buffers(layer.filters, act_frames)
+                    pipe_k, _ = self._pipeline_buffers(layer.filters, act_frames, need_enc=False)
                 if epilogue_stats:
                     norm = layer.norm_layer
                     self._timed('stats_finalize', (blk, layer.filters, layer.filters, 0, act_frames, 0),
@@ -700,12 +708,7 @@ class ForwardPlan:
                         taps[idx] = copy[:, :, :act_frames].clone()
                 elif layer.use_norm:
                     pending = self._norm(layer.norm_layer, act, act_frames, (blk, layer.filters, layer.filters, 0, act_frames, 0),
-                                         taps, idx, nxt, enc if feeds_tail else None)
-                    if feeds_tail:
-                        act, cur = enc, None
-                elif feeds_tail:
-                    hip.repitch(act, enc, act_frames)
-                    act, cur = enc, None
+                                         taps, idx, nxt, None, defer)
                 if taps is not None and pending is None:
                     taps[idx] = self._tap(act, act_frames)
             elif isinstance(layer, nn.Dropout):
