@@ -30,14 +30,11 @@ __device__ __forceinline__ void tile_statistics(const T* x, int channels, int ld
 #pragma unroll
     for (int r = 0; r < FR; ++r) { shift[r] = 0.f; s1[r] = 0.f; s2[r] = 0.f; lo[r] = 3.0e38f; hi[r] = -3.0e38f; }
     int n = 0;
-    if (active) {
-        for (int c = row; c < channels; c += LN_ROWS) {
-            float e[FR];
-            load_frames<FR>(x + base + static_cast<size_t>(c) * ld, e);
-            if (n == 0) {
-#pragma unroll
-                for (int r = 0; r < FR; ++r) shift[r] = e[r];
-            }
+    if (active && row < channels) {
+        // the shift is the lane's first channel (re-read in the loop: an L1 hit); four rows in flight per lane -- with one, a
+        // workgroup had 4 KiB outstanding and the kernels that call this ran at 3.6 TB/s
+        load_frames<FR>(x + base + static_cast<size_t>(row) * ld, shift);
+        auto fold = [&](const float (&e)[FR]) {
 #pragma unroll
             for (int r = 0; r < FR; ++r) {
                 const float d = e[r] - shift[r];
@@ -46,6 +43,19 @@ __device__ __forceinline__ void tile_statistics(const T* x, int channels, int ld
                 if (MINMAX) { lo[r] = fminf(lo[r], e[r]); hi[r] = fmaxf(hi[r], e[r]); }
             }
             ++n;
+        };
+        int c = row;
+        for (; c + 3 * LN_ROWS < channels; c += 4 * LN_ROWS) {       // four loads issued, then four folds (same order as one by one)
+            float e[4][FR];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load_frames<FR>(x + base + static_cast<size_t>(c + u * LN_ROWS) * ld, e[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) fold(e[u]);
+        }
+        for (; c < channels; c += LN_ROWS) {
+            float e[FR];
+            load_frames<FR>(x + base + static_cast<size_t>(c) * ld, e);
+            fold(e);
         }
     }
     const float fn = static_cast<float>(n);
@@ -303,16 +313,18 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
                                                               int bound_stride)
 {
     typedef _Float16 halfx8 __attribute__((ext_vector_type(8)));
-    // 16 frame quads x 16 channel octets per pass; a thread turns 8 channels x 4 frames into 4 + 4 image rows of 16 bytes
-    const int ql = threadIdx.x & 15, oct0 = threadIdx.x >> 4;
+    // 64 frame quads (one wave = 1 KiB of a channel row) x 4 channel octets per pass, the octets dealt over the waves of the
+    // gridDim.z workgroups of a tile; a thread turns 8 channels x 4 frames into 4 + 4 image rows of 16 bytes.  (Round 1 had 16 quads
+    // x 16 octets: 256-byte row segments, 3.7 TB/s.)
+    const int ql = threadIdx.x & 63, oct0 = (threadIdx.x >> 6) + 4 * blockIdx.z;
     const int nq = ld >> 2;
-    const int q = blockIdx.x * 16 + ql;
+    const int q = blockIdx.x * 64 + ql;
     const int b = blockIdx.y;
     const int n_groups = (channels + 15) >> 4;
     const size_t rows = static_cast<size_t>(ld) + 1;
     unsigned char* const img_b = image + static_cast<size_t>(b) * n_groups * 4 * rows * 16;
     // the zero rows (row 0 of every plane): one workgroup per utterance writes them
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.z == 0) {
         const uint4 z = make_uint4(0u, 0u, 0u, 0u);
         for (int pl = threadIdx.x; pl < n_groups * 4; pl += 256) *reinterpret_cast<uint4*>(img_b + static_cast<size_t>(pl) * rows * 16) = z;
     }
@@ -335,7 +347,7 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     }
     const float* xb = x + static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * 4;
     const int n_oct = (channels + 7) >> 3;
-    for (int oct = oct0; oct < 2 * n_groups; oct += 16) {
+    for (int oct = oct0; oct < 2 * n_groups; oct += 4 * gridDim.z) {
         float v[8][4];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -387,7 +399,7 @@ extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, c
     const int nq = ld / 4;
     hipLaunchKernelGGL(channel_stats_bound_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
                        x, gamma, beta, stats, reinterpret_cast<unsigned*>(bound), channels, frames, ld, eps);
-    hipLaunchKernelGGL(normalize_split_kernel<true>, dim3((nq + 15) / 16, batch), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(normalize_split_kernel<true>, dim3((nq + 63) / 64, batch, 4), dim3(256), 0, as_stream(stream),
                        x, stats, gamma, beta, bound, static_cast<unsigned char*>(image), channels, frames, ld, 1);
     return launch_status("nbasr_layernorm_split_image");
 }
@@ -502,7 +514,7 @@ extern "C" int nbasr_split_image_ranged(const float* x, const float* x_range, vo
     NBASR_REQUIRE(aligned16(x) && aligned16(image), NBASR_EALIGN, "nbasr_split_image_ranged: x, image must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_split_image_ranged: batch %d > 65535", batch);
     const int nq = ld / 4;
-    hipLaunchKernelGGL(normalize_split_kernel<false>, dim3((nq + 15) / 16, batch), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(normalize_split_kernel<false>, dim3((nq + 63) / 64, batch, 4), dim3(256), 0, as_stream(stream),
                        x, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
                        x_range, static_cast<unsigned char*>(image), channels, frames, ld, 4);
     return launch_status("nbasr_split_image_ranged");
@@ -587,7 +599,7 @@ __global__ __launch_bounds__(256) void bf16_image_kernel(const T* __restrict__ x
     }
     const T* xb = x + static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * FR;
     const int n_oct = (channels + 7) >> 3;
-    for (int oct = oct0; oct < 2 * n_groups; oct += 16) {
+    for (int oct = oct0; oct < 2 * n_groups; oct += 4 * gridDim.z) {
         float v[8][FR];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
