@@ -274,12 +274,13 @@ def main():
 
 
 def kernel_source_hash():
-    """Hash of the graded kernel's sources (grouped_conv.hip, grouped_cell.hip, common.h): ties a PMC summary to a build."""
+    """Hash of the graded kernel's sources (grouped_conv.hip, grouped_conv_osplit.hip, grouped_cell.hip, common.h) and of the table
+    that picks the variant per launch: ties a PMC summary to a build."""
     import hashlib
     here = os.path.dirname(os.path.abspath(__file__))
     h = hashlib.sha256()
-    for name in ('grouped_conv.hip', 'grouped_cell.hip', 'common.h'):
-        with open(os.path.join(here, 'nb_asr_amd', 'csrc', name), 'rb') as f:
+    for name in ('csrc/grouped_conv.hip', 'csrc/grouped_conv_osplit.hip', 'csrc/grouped_cell.hip', 'csrc/common.h', 'gc_variant_table.json'):
+        with open(os.path.join(here, 'nb_asr_amd', name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
@@ -346,12 +347,12 @@ def roofline_leg(model, x, args):
         e['ms'] += ms
         e['n'] += n
     if launches:
-        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_f32_kernel')
+        traffic, traffic_src = pmc_traffic_per_launch('nbasr::grouped_cell_kernel' if any(k == 'grouped_cell' for k, _ in agg) else 'nbasr::grouped_conv_f32')
         if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or args.dtype != 'f32' or any(k.startswith('NBASR_') for k in os.environ):
             traffic, traffic_src = None, None          # the committed counters are for the default workload and modes only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
         out['roofline'] = {
-            'kernel': 'grouped_conv_f32_kernel<CG,K,D,..> (bf16: grouped_conv_kernel<bf16_t,..>; opt-in whole-cell: grouped_cell_kernel<CG>) (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
+            'kernel': 'grouped_conv_f32_{pipe_,osplit_,}kernel<CG,K,D,..> (variant per launch from gc_variant_table.json; bf16: grouped_conv_kernel<bf16_t,..>; opt-in whole-cell: grouped_cell_kernel<CG>) (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
                       ' [+LayerNorm on load]; a cell launch runs its three node ops with the intermediates in LDS)',
             'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,

@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256) void bf16_image_kernel(const T* __restrict__ x
     }
     const T* xb = x + static_cast<size_t>(b) * channels * ld + static_cast<size_t>(q) * FR;
     const int n_oct = (channels + 7) >> 3;
-    for (int oct = oct0; oct < 2 * n_groups; oct += 4 * gridDim.z) {
+    for (int oct = oct0; oct < 2 * n_groups; oct += 16) {
         float v[8][FR];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
