@@ -41,6 +41,8 @@
 //  * the hi*hi products accumulate in their own register set, so the large running sum is rounded once per 32 k.
 #include "storage.h"
 
+#include <cstdlib>
+
 #include <type_traits>
 
 namespace nbasr {
@@ -149,6 +151,7 @@ struct PackedConvArgs {
     // non-finite flag, -}; a workgroup whose utterance is (not) extreme exits at once when sel_want is 0 (1); -1: no routing
     const float* x_range;
     int sel_want;
+    int staged_epilogue;         // fp32 output through LDS in whole row segments (NBASR_DENSE_EPILOGUE=direct turns it off: A/B)
 };
 
 // an utterance the scaled fp16 scheme must not take: non-finite samples, or a frame > 2^20 below the loudest sample
@@ -552,7 +555,54 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         }
         return;
     }
-    // ---- epilogue: bias + ReLU + min(20) (+ skips); a store covers 4 rows x 16 consecutive frames -----------------
+    // ---- epilogue without skips (every downsample conv of the model): bias + ReLU + min(20), then out through LDS so that a store
+    // instruction writes four 256-byte row segments (16 lanes x 16 B) instead of four 64-byte ones.  Two 16-row MFMA tiles at a time
+    // per wave: 32 rows x 64 frames fp32 (row stride 68 floats: the four row groups of a fragment land 2-way instead of 4-way on the
+    // banks) = 8.5 KiB of the staging buffers, which nobody reads any more (the last K-step ended with a barrier).
+    if (!a.s0 && !a.s1 && !a.s2 && a.staged_epilogue) {
+        constexpr int TS = 68;
+        float* const T = reinterpret_cast<float*>(smem) + wave * (32 * TS);
+        static_assert(8 * 32 * TS * 4 <= G::LDS_BYTES, "output staging must fit the operand buffers");
+        if (!wave_active) return;
+        const int nc = n0 + wn * 64 + (lane & 15) * 4;
+#pragma unroll
+        for (int i0 = 0; i0 < MI; i0 += 2) {
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = i0 + ii;
+                if (i >= MI) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = n0 + wn * 64 + j * 16 + l15 < a.frames_out;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = m0 + wm * WROWS + i * 16 + kq * 4 + r;
+                        float v = 0.f;
+                        if (live && m < a.c_out) {
+                            float acc = big[i][j][r] + small[i][j][r] * P::SMALL_SCALE;
+                            if constexpr (P::SCALED) acc = acc * x_inv * a.w_inv_scale[m];
+                            v = relu_clamp(acc + a.bias[m]);
+                        }
+                        T[(ii * 16 + kq * 4 + r) * TS + j * 16 + l15] = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: this wave's writes are done
+            const int rows_pass = (MI - i0 >= 2) ? 32 : 16;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int ml = it * 4 + (lane >> 4);
+                const int m = m0 + wm * WROWS + i0 * 16 + ml;
+                if (ml < rows_pass && m < a.c_out && nc < a.ld_out) {
+                    const floatx4 t = *reinterpret_cast<const floatx4*>(T + ml * TS + (lane & 15) * 4);
+                    *reinterpret_cast<floatx4*>(a.y + (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + nc) = t;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next pass overwrites the tile
+        }
+        return;
+    }
+    // ---- epilogue with skips: bias + ReLU + min(20) + skips; a store covers 4 rows x 16 consecutive frames -----------------
     if (!wave_active) return;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
@@ -727,6 +777,8 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
     a.ln_x = ln_ref(ln, true);
     a.x_range = x_range;
     a.sel_want = x_range ? sel_want : -1;
+    static const bool direct = [] { const char* e = getenv("NBASR_DENSE_EPILOGUE"); return e && e[0] == 'd'; }();
+    a.staged_epilogue = direct ? 0 : 1;
     if (P::SCALED) {
         NBASR_REQUIRE(x_absmax || x_range, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
         a.x_absmax = x_absmax;
