@@ -133,7 +133,9 @@ struct GeoP {
     static constexpr int XITEMS = NQUADS * (PB_CI / 2);
     static constexpr int NCHUNK = QSTEPS > 1 ? QSTEPS - 1 : 1;   // the next group's tile is staged in QSTEPS-1 chunks (register staging path)
     static constexpr int XI = (XITEMS + PB_THREADS * NCHUNK - 1) / (PB_THREADS * NCHUNK);   // items per thread per chunk
-    static constexpr int LDS_BYTES = 2 * A_STEP_BYTES + 2 * X_BYTES;   // weights and input tile both double-buffered
+    static constexpr int OPERAND_BYTES = 2 * A_STEP_BYTES + 2 * X_BYTES;   // weights and input tile both double-buffered
+    static constexpr int STAGING_BYTES = 8 * 32 * 68 * 4;            // the fp32 epilogue's output staging (8 waves x 32 rows x 68 floats)
+    static constexpr int LDS_BYTES = OPERAND_BYTES > STAGING_BYTES ? OPERAND_BYTES : STAGING_BYTES;
     __device__ static constexpr int rowmap(int row) { return (S == 1) ? row : (row & 1) * XRH + (row >> 1); }
 };
 
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 {
     static_assert(!(XIMG && LNX) && !(XIMG && !has_image_path<P>()), "the image path: scaled fp16 scheme or plain bf16, no LayerNorm on load");
     static_assert(XIMG || P::NS > 1, "plain bf16 operands exist as an image only");
-    static_assert(MI == 4 || (MI == 5 && XIMG), "160-row tiles exist for the image path only (register budget)");
+    static_assert(MI == 4 || ((MI == 5 || MI == 2) && XIMG), "160- and 64-row tiles exist for the image path only");
     using G = GeoP<P, S, MI>;
     constexpr int PB_M = G::PBM, WROWS = 16 * MI;                // rows per tile, rows per wave
     using vec8 = typename P::vec8;
@@ -692,7 +694,7 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     return launch_status(P::NAME);
 }
 
-static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : 0); }
+static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : (row_tile == 64 ? 2 : 0)); }
 
 // image-path kernel of scheme P at a given row tile (the only kernel the plain-bf16 scheme has)
 template <class P, int S, int MI>
@@ -717,7 +719,7 @@ template <class P>
 static size_t packed_bytes(int c_out, int c_in, int kernel, int row_tile = 128)
 {
     const int mi = rows_to_mi(row_tile);
-    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS || mi == 0 || (mi == 5 && !has_image_path<P>())) return 0;
+    if (c_out <= 0 || c_in <= 0 || kernel != PB_TAPS || mi == 0 || (mi != 4 && !has_image_path<P>())) return 0;
     const size_t PB_M = pb_rows(mi), n_mt = (c_out + PB_M - 1) / PB_M, n_groups = (c_in + PB_CI - 1) / PB_CI;
     return n_mt * n_groups * pb_group_bytes<P>(mi) + (P::SCALED ? 2 * n_mt * PB_M * sizeof(float) : 0);   // + row scales and inverses
 }
@@ -727,7 +729,7 @@ static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kern
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
-    NBASR_REQUIRE(mi != 0 && (mi == 4 || has_image_path<P>()), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 160 for the image-path schemes)", row_tile);
+    NBASR_REQUIRE(mi != 0 && (mi == 4 || has_image_path<P>()), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 64 / 160 for the image-path schemes)", row_tile);
     const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
@@ -755,8 +757,8 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
-    NBASR_REQUIRE(mi == 4 || (mi == 5 && x_is_image && P::SCALED), NBASR_EINVAL,
-                  "%s: row_tile=%d unsupported (128; 160 for the fp16 image path)", P::NAME, row_tile);
+    NBASR_REQUIRE(mi == 4 || ((mi == 5 || mi == 2) && x_is_image && P::SCALED), NBASR_EINVAL,
+                  "%s: row_tile=%d unsupported (128; 64 and 160 for the fp16 image path)", P::NAME, row_tile);
     const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
@@ -787,6 +789,10 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
                         + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * PB_M;
     }
     if (mi == 5) return stride == 1 ? launch_packed_rows160<P, 1>(a, as_stream(stream)) : launch_packed_rows160<P, 2>(a, as_stream(stream));
+    if (mi == 2) {
+        // 64-row tiles: twice the workgroups where a small batch leaves CUs without one (the executor's round count decides)
+        if constexpr (has_image_path<P>() && P::SCALED) return stride == 1 ? launch_image<P, 1, 2>(a, as_stream(stream)) : launch_image<P, 2, 2>(a, as_stream(stream));
+    }
     return stride == 1 ? launch_packed<P, 1>(a, as_stream(stream)) : launch_packed<P, 2>(a, as_stream(stream));
 }
 
@@ -888,7 +894,7 @@ extern "C" int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* pack
     using P = PlainBf16;
     clear_error();
     const int mi = rows_to_mi(row_tile);
-    NBASR_REQUIRE(mi != 0, NBASR_EINVAL, "%s: row_tile=%d unsupported (128 or 160)", P::NAME, row_tile);
+    NBASR_REQUIRE(mi == 4 || mi == 5, NBASR_EINVAL, "%s: row_tile=%d unsupported (128 or 160)", P::NAME, row_tile);
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
                   "%s: (kernel=%d, stride=%d) unsupported; the downsample convs have k=8, s in {1,2}", P::NAME, kernel, stride);

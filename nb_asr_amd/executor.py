@@ -182,8 +182,8 @@ class ForwardPlan:
         self.image_mode = os.environ.get('NBASR_IMAGE_MODE', '1') != '0'
         # row tile of the image-path GEMM: auto (per layer, see _row_tile) | 128 | 160
         self.row_tile_mode = os.environ.get('NBASR_ROW_TILE', 'auto')
-        if self.row_tile_mode not in ('auto', '128', '160'):
-            raise ValueError(f'NBASR_ROW_TILE must be auto, 128 or 160, got {self.row_tile_mode!r}')
+        if self.row_tile_mode not in ('auto', '64', '128', '160'):
+            raise ValueError(f'NBASR_ROW_TILE must be auto, 64, 128 or 160, got {self.row_tile_mode!r}')
         self._act_image = None
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
@@ -305,18 +305,21 @@ class ForwardPlan:
         w = layer.conv.weight
         return self._cached(w, (scheme, row_tile, layer.strides), lambda: hip.pack_dense_weights(w.detach(), layer.strides, scheme, row_tile))
 
-    def _row_tile(self, c_out, frames_out):
+    def _row_tile(self, c_out, frames_out, allow_64=True):
         """Rows per workgroup of the image-path GEMM: 128, or 160 where that means less work in whole rounds of workgroups
         (a tile's cost is proportional to its rows; 256 CUs run one workgroup each).  At the benchmark shape: 160 for
         C_out = 800 (5 full row tiles instead of 7 with the last a quarter full) and 1200 (512 workgroups instead of 640)."""
         if self.row_tile_mode != 'auto':
-            return int(self.row_tile_mode)
+            return int(self.row_tile_mode) if (allow_64 or self.row_tile_mode != '64') else 128
         n_nt = (hip.round_up4(frames_out) + 255) // 256
 
         def cost(rows):
             wgs = -(-c_out // rows) * n_nt * self.batch
             return -(-wgs // 256) * rows
-        return 160 if cost(160) < cost(128) else 128
+        rows = 160 if cost(160) < cost(128) else 128
+        # 64-row tiles where a small batch leaves CUs without a workgroup (8 utterances: 128 or 80 workgroups for convs 2 and 3)
+        # (a 64-row tile does less per operand byte staged: it has to win by a quarter, measured +4 % at 8 utterances, nothing to gain at 32)
+        return 64 if (allow_64 and 1.25 * cost(64) < cost(rows)) else rows
 
     def _packed_linear(self, linear):
         """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""
@@ -837,7 +840,7 @@ class ForwardPlan:
                 dst = 0 if cur != 0 else 1
                 t_out = self.block_frames[blk]
                 out = self._view16(dst, layer.conv.out_channels, t_out)
-                rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out)
+                rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out, allow_64=False)      # (the one-term bf16 GEMM has 128 / 160)
                 w = layer.conv.weight
                 packed = self._cached(w, ('bf16', rows, layer.strides),
                                       lambda: hip.pack_dense_weights_bf16(self._f32(w), layer.strides, rows))

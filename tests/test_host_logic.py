@@ -141,7 +141,10 @@ def test_row_tile_rule_counts_rounds_of_workgroups():
     assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 160]     # the benchmark shape: convs 1 and 3
     plan.batch = 32
     assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 160]
+    plan.batch = 8
+    assert [pick(600, 1000), pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [128, 128, 64, 64]   # under-filled launches: 64-row tiles
     plan.batch = 2
-    assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [128, 128, 128]     # a single round either way: shorter tiles
+    assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [64, 64, 64]        # a single round whatever the tile: the smallest
+    assert ForwardPlan._row_tile(plan, 1200, 250, allow_64=False) == 128               # (the bf16 GEMM has no 64-row instance)
     plan.row_tile_mode = '160'
     assert pick(1000, 500) == 160

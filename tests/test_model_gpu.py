@@ -236,8 +236,13 @@ def test_dense_scheme_selection():
         y0 = model(x)
     plan = next(iter(model._plans.values()))
     assert plan.dense_schemes == {0: 'f16x2-image', 1: 'f16x2-image', 2: 'f16x2-image', 3: 'f16x2-image'}
-    assert set(plan.dense_row_tiles) == {0, 1, 2, 3} and set(plan.dense_row_tiles.values()) <= {128, 160}
-    assert plan._row_tile(800, 1000) == 128 and plan._row_tile(1200, 250) == 128          # 2 utterances: one round either way
+    assert set(plan.dense_row_tiles) == {0, 1, 2, 3} and set(plan.dense_row_tiles.values()) <= {64, 128, 160}
+    assert plan._row_tile(800, 1000) == 64 and plan._row_tile(1200, 250) == 64            # 2 utterances: under one round, so the smallest tiles
+    plan.batch = 64
+    assert plan._row_tile(800, 1000) == 160 and plan._row_tile(1000, 500) == 128 and plan._row_tile(1200, 250) == 160 and plan._row_tile(600, 1000) == 128
+    plan.batch = 8
+    assert plan._row_tile(1000, 500) == 64 and plan._row_tile(1200, 250) == 64 and plan._row_tile(800, 1000) == 128
+    plan.batch = 2
     os.environ['NBASR_DENSE_MODE'] = 'bf16x3'
     try:
         model._plans.clear()

@@ -611,6 +611,11 @@ def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     assert torch.equal(got160, got)
     with pytest.raises(hip.HipError, match='row_tile=128'):
         hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed160, cout, 8, bias, got160, stride)
+    # 64-row tiles (small batches): the same again
+    got64 = torch.full_like(want, float('nan'))
+    packed64 = hip.pack_dense_weights(w, stride, 'f16x2', row_tile=64)
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed64, cout, 8, bias, got64, stride, row_tile=64)
+    assert torch.equal(got64, got)
 
 
 @pytest.mark.parametrize('c,cout,t,b,rows', [(80, 600, 300, 4, 128), (80, 600, 1000, 2, 160), (40, 72, 7, 3, 128), (24, 161, 64, 2, 128)])
