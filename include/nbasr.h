@@ -469,6 +469,26 @@ int nbasr_layernorm_channels_backward(const float* x, const float* stats, const 
                                       float* dgamma, float* dbeta, float* workspace, int batch, int channels, int frames, int ld,
                                       nbasr_stream_t stream);
 
+/* Building blocks of the GEMM-shaped backward passes (dense downsample convs, `linear` node op; SURVEY.md 8 row f4, bottom-up).  The
+ * products run on the exact-fp32 MFMA GEMMs of the forward (nbasr_pointwise_linear, nbasr_dense_conv1d_linear); these put the
+ * operands into the layouts those GEMMs read:
+ *   nbasr_relu_clamp_backward   dz = dy where 0 < y < 20, else 0 (n floats, n % 4 == 0)
+ *   nbasr_zero_stuff            up[r][shift + t * stride] = dz[r][t], zeros elsewhere (rows x frames_up, pitch ld_up): the input
+ *                               gradient of a strided conv is a stride-1 conv of this with the flipped, channel-transposed kernel
+ *   nbasr_dense_conv1d_linear   that conv: k = 8, stride 1, caller-chosen left padding, no activation
+ *   nbasr_conv_cols             cols[b * t_pad + t][ci * taps + j] = xpad[b][ci][t * stride + j - lpad], one column of ones behind
+ *                               them (then zeros up to ld_cols >= c_in * taps + 1), rows t >= frames_out zero
+ *   nbasr_rows_of_channels      rows[co][b * t_pad + t] = dz[b][co][t] (0 for t >= frames)
+ * so that  nbasr_pointwise_linear(x = cols as (1, batch * t_pad, ld_cols), w = rows)  yields (dw | db) in one GEMM. */
+int nbasr_relu_clamp_backward(const float* y, const float* dy, float* dz, long long n, nbasr_stream_t stream);
+int nbasr_zero_stuff(const float* dz, float* up, int rows, int frames, int ld, int frames_up, int ld_up, int stride, int shift,
+                     nbasr_stream_t stream);
+int nbasr_dense_conv1d_linear(const float* x, const float* w, const float* bias, float* y, int batch, int c_in, int frames, int ld_in,
+                              int c_out, int ld_out, int kernel, int lpad, nbasr_stream_t stream);
+int nbasr_conv_cols(const float* x, float* cols, int batch, int c_in, int frames_in, int ld_in, int frames_out, int t_pad, int taps,
+                    int stride, int lpad, int ld_cols, nbasr_stream_t stream);
+int nbasr_rows_of_channels(const float* dz, float* rows, int batch, int channels, int frames, int ld, int t_pad, nbasr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

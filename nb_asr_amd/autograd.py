@@ -4,9 +4,10 @@ backward kernels, as ``torch.autograd.Function``s.
 What exists: ``grouped_pad_conv_relu`` (reference ``ops.PadConvRelu`` with groups > 1, ops.py:24-30) and ``layer_norm_channels``
 (``nn.LayerNorm`` over the channel dimension of (B, C, T), model.py:55-58) -- forward AND backward through the C ABI, gradients
 checked against the reference modules' own autograd (tests/golden/grad_fixtures.npz).  ``ops.PadConvRelu`` (grouped) calls the
-former when a gradient is required, so the op is trainable on its own.  What does not exist yet: backward of the dense
-downsample convs, the ``linear`` op, the LSTM and the head, dropout masks, and therefore ``loss.backward()`` through
-``ASRModel`` (its forward still returns detached logits and says so).
+former when a gradient is required, so the op is trainable on its own.  Also ``dense_pad_conv_relu``: the dense k = 8 downsample convs
+(model.py:82-89) and the per-frame ``linear`` op (ops.py:42-50), correctness-first on the exact-fp32 GEMMs of the forward.  What does not
+exist yet: backward of the LSTM and the head, dropout masks, and therefore ``loss.backward()`` through ``ASRModel`` (its forward still
+returns detached logits and says so).
 """
 import torch
 
@@ -62,6 +63,38 @@ class _LayerNormChannels(torch.autograd.Function):
         dyp, _ = _pitched(dy)
         dx, dgamma, dbeta = hip.layernorm_channels_backward(xp, stats, gamma, dyp, ctx.frames)
         return dx[:, :, :ctx.frames], dgamma, dbeta, None
+
+
+class _DensePadConvRelu(torch.autograd.Function):
+    """Dense k = 8 downsample conv (stride 1 | 2) or the per-frame `linear` op (k = 1) with ReLU and clamp; forward on the exact-fp32 MFMA
+    GEMM, backward through hip.dense_conv1d_backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        xp, frames = _pitched(x)
+        kernel = weight.shape[2] if weight.dim() == 3 else 1
+        w3 = weight.detach() if weight.dim() == 3 else weight.detach().unsqueeze(-1)
+        t_out = (frames + stride - 1) // stride
+        y = torch.empty(xp.shape[0], weight.shape[0], hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
+        hip.dense_conv1d_fused(xp, frames, w3, bias.detach(), (), y, stride)
+        ctx.save_for_backward(xp, weight.detach(), y)
+        ctx.cfg = (frames, stride, t_out, kernel)
+        return y[:, :, :t_out]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, weight, y = ctx.saved_tensors
+        frames, stride, t_out, _ = ctx.cfg
+        dyp, _ = _pitched(dy)
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dw, db = hip.dense_conv1d_backward(xp, weight, y, dyp, frames, stride, need_dx, need_dw)
+        return (dx[:, :, :frames] if dx is not None else None), dw, db, None
+
+
+def dense_pad_conv_relu(x, weight, bias, stride=1):
+    """min(relu(conv1d(zero_pad(x), weight, bias, stride)), 20) for a dense (C_out, C_in, 8) kernel, or the per-frame linear map for a
+    (C_out, C_in) weight, differentiable in x, weight, bias."""
+    return _DensePadConvRelu.apply(x, weight, bias, stride)
 
 
 def grouped_pad_conv_relu(x, weight, bias, groups, kernel, dilation):

@@ -358,3 +358,125 @@ extern "C" int nbasr_layernorm_channels_backward(const float* x, const float* st
                        tiles_x * batch, channels);
     return launch_status("nbasr_layernorm_channels_backward");
 }
+
+// ---- building blocks of the GEMM-shaped backward passes (linear node op, head, dense downsample convs) -------------------------
+// The products themselves run on the exact-fp32 MFMA GEMMs that exist for the forward (nbasr_pointwise_linear,
+// nbasr_dense_conv1d_linear); these kernels put the operands into the layouts those GEMMs read.
+namespace nbasr {
+
+// dz = dy where 0 < y < 20, else 0  (y = min(relu(z), 20): the gradient passes where neither the ReLU nor the clamp is active)
+__global__ __launch_bounds__(256) void relu_clamp_backward_kernel(const float4* __restrict__ y, const float4* __restrict__ dy,
+                                                                   float4* __restrict__ dz, size_t n4)
+{
+    const size_t stride = static_cast<size_t>(gridDim.x) * blockDim.x;
+    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const float4 a = y[i], g = dy[i];
+        dz[i] = make_float4((a.x > 0.f && a.x < kClamp) ? g.x : 0.f, (a.y > 0.f && a.y < kClamp) ? g.y : 0.f,
+                            (a.z > 0.f && a.z < kClamp) ? g.z : 0.f, (a.w > 0.f && a.w < kClamp) ? g.w : 0.f);
+    }
+}
+
+// The weight gradient of a k-tap convolution is a GEMM over (utterance, output frame):
+//     dw[co][ci][j] = sum_{b,t} dz[b][co][t] * xpad[b][ci][t * stride + j - lpad]
+// cols[(b * t_pad + t)][ci * taps + j] = xpad[b][ci][t * stride + j - lpad]   (0 outside the utterance and for t >= frames_out),
+// with one extra column of ones per row (index c_in * taps, then zeros up to ld_cols) so that the same GEMM yields the bias
+// gradient.  One thread per (row, column): reads are strided, the writes of a wave are contiguous.
+__global__ __launch_bounds__(256) void conv_cols_kernel(const float* __restrict__ x, float* __restrict__ cols, int c_in, int frames_in,
+                                                        int ld_in, int frames_out, int t_pad, int taps, int stride, int lpad, int ld_cols)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;           // column
+    const int row = blockIdx.y, b = blockIdx.z;                    // output frame (padded), utterance
+    if (n >= ld_cols) return;
+    float v = 0.f;
+    const int ncols = c_in * taps;
+    if (row < frames_out) {
+        if (n < ncols) {
+            const int ci = n / taps, j = n - ci * taps;
+            const int u = row * stride + j - lpad;
+            if (u >= 0 && u < frames_in) v = x[(static_cast<size_t>(b) * c_in + ci) * ld_in + u];
+        } else if (n == ncols) {
+            v = 1.f;
+        }
+    }
+    cols[(static_cast<size_t>(b) * t_pad + row) * ld_cols + n] = v;
+}
+
+// rows[co][b * t_pad + t] = dz[b][co][t] (0 for t >= frames): the other operand of that GEMM, "weights" of (c_out, batch * t_pad)
+__global__ __launch_bounds__(256) void rows_of_channels_kernel(const float* __restrict__ dz, float* __restrict__ rows, int batch, int channels,
+                                                               int frames, int ld, int t_pad)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int co = blockIdx.y, b = blockIdx.z;
+    if (t >= t_pad) return;
+    rows[static_cast<size_t>(co) * batch * t_pad + static_cast<size_t>(b) * t_pad + t] =
+        t < frames ? dz[(static_cast<size_t>(b) * channels + co) * ld + t] : 0.f;
+}
+
+// The input gradient of a strided convolution is a stride-1 convolution of the zero-stuffed output gradient with the flipped,
+// channel-transposed kernel: up[b][co][shift + t * stride] = dz[b][co][t], zeros elsewhere (frames_up columns, pitch ld_up).
+__global__ __launch_bounds__(256) void zero_stuff_kernel(const float* __restrict__ dz, float* __restrict__ up, int rows, int frames, int ld,
+                                                         int frames_up, int ld_up, int stride, int shift)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= ld_up) return;
+    const int s = u - shift;
+    const bool hit = u < frames_up && s >= 0 && s % stride == 0 && s / stride < frames;
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        up[static_cast<size_t>(r) * ld_up + u] = hit ? dz[static_cast<size_t>(r) * ld + s / stride] : 0.f;
+}
+
+}  // namespace nbasr
+
+extern "C" int nbasr_relu_clamp_backward(const float* y, const float* dy, float* dz, long long n, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(n >= 0 && n % 4 == 0, NBASR_EINVAL, "nbasr_relu_clamp_backward: n=%lld must be a non-negative multiple of 4", n);
+    if (n == 0) return NBASR_OK;
+    NBASR_REQUIRE(y && dy && dz, NBASR_ENULL, "nbasr_relu_clamp_backward: NULL pointer");
+    NBASR_REQUIRE(aligned16(y) && aligned16(dy) && aligned16(dz), NBASR_EALIGN, "nbasr_relu_clamp_backward: pointers must be 16-byte aligned");
+    const size_t n4 = static_cast<size_t>(n / 4);
+    const unsigned grid = static_cast<unsigned>(n4 / 256 + 1 < 4096 ? n4 / 256 + 1 : 4096);
+    hipLaunchKernelGGL(relu_clamp_backward_kernel, dim3(grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const float4*>(y),
+                       reinterpret_cast<const float4*>(dy), reinterpret_cast<float4*>(dz), n4);
+    return launch_status("nbasr_relu_clamp_backward");
+}
+
+extern "C" int nbasr_conv_cols(const float* x, float* cols, int batch, int c_in, int frames_in, int ld_in, int frames_out, int t_pad,
+                               int taps, int stride, int lpad, int ld_cols, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames_in >= 0 && ld_in >= frames_in && frames_out >= 0 && t_pad >= frames_out && taps > 0 &&
+                  stride > 0 && lpad >= 0 && ld_cols >= c_in * taps + 1, NBASR_EINVAL, "nbasr_conv_cols: bad sizes");
+    if (batch == 0 || t_pad == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && cols, NBASR_ENULL, "nbasr_conv_cols: NULL pointer");
+    NBASR_REQUIRE(batch <= 65535 && t_pad <= 65535, NBASR_EINVAL, "nbasr_conv_cols: batch / frames > 65535");
+    hipLaunchKernelGGL(conv_cols_kernel, dim3((ld_cols + 255) / 256, t_pad, batch), dim3(256), 0, as_stream(stream), x, cols, c_in, frames_in,
+                       ld_in, frames_out, t_pad, taps, stride, lpad, ld_cols);
+    return launch_status("nbasr_conv_cols");
+}
+
+extern "C" int nbasr_rows_of_channels(const float* dz, float* rows, int batch, int channels, int frames, int ld, int t_pad,
+                                      nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && ld >= frames && t_pad >= frames, NBASR_EINVAL, "nbasr_rows_of_channels: bad sizes");
+    if (batch == 0 || t_pad == 0) return NBASR_OK;
+    NBASR_REQUIRE(dz && rows, NBASR_ENULL, "nbasr_rows_of_channels: NULL pointer");
+    NBASR_REQUIRE(batch <= 65535 && channels <= 65535, NBASR_EINVAL, "nbasr_rows_of_channels: batch / channels > 65535");
+    hipLaunchKernelGGL(rows_of_channels_kernel, dim3((t_pad + 255) / 256, channels, batch), dim3(256), 0, as_stream(stream), dz, rows, batch,
+                       channels, frames, ld, t_pad);
+    return launch_status("nbasr_rows_of_channels");
+}
+
+extern "C" int nbasr_zero_stuff(const float* dz, float* up, int rows, int frames, int ld, int frames_up, int ld_up, int stride, int shift,
+                                nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(rows >= 0 && frames >= 0 && ld >= frames && frames_up >= 0 && ld_up >= frames_up && stride > 0 && shift >= 0, NBASR_EINVAL,
+                  "nbasr_zero_stuff: bad sizes");
+    if (rows == 0 || ld_up == 0) return NBASR_OK;
+    NBASR_REQUIRE(dz && up, NBASR_ENULL, "nbasr_zero_stuff: NULL pointer");
+    hipLaunchKernelGGL(zero_stuff_kernel, dim3((ld_up + 255) / 256, rows < 4096 ? rows : 4096), dim3(256), 0, as_stream(stream), dz, up, rows,
+                       frames, ld, frames_up, ld_up, stride, shift);
+    return launch_status("nbasr_zero_stuff");
+}

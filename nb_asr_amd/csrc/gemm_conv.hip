@@ -346,3 +346,24 @@ extern "C" int nbasr_pointwise_linear(const float* x, const float* w, const floa
     a.lpad = 0; a.ktot = c_in; a.batch = batch;
     return launch_gemm_conv<1, 1, false, false>(a, as_stream(stream), "nbasr_pointwise_linear");
 }
+
+// y(batch, c_out, ld_out)[t] = sum_{ci,j} w[co][ci][j] * xpad(batch, c_in, .)[t + j - lpad] + bias, k = 8 taps, stride 1, NO activation and a
+// caller-chosen left padding: the input gradient of a downsample conv is this with the flipped, channel-transposed kernel over the
+// zero-stuffed output gradient (autograd.py)
+extern "C" int nbasr_dense_conv1d_linear(const float* x, const float* w, const float* bias, float* y, int batch, int c_in, int frames,
+                                         int ld_in, int c_out, int ld_out, int kernel, int lpad, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_linear: bad sizes");
+    NBASR_REQUIRE(kernel == 8 && lpad >= 0 && lpad < kernel, NBASR_EINVAL, "nbasr_dense_conv1d_linear: kernel=%d (8), lpad=%d (0..7)", kernel, lpad);
+    NBASR_REQUIRE(ld_in >= frames, NBASR_EINVAL, "nbasr_dense_conv1d_linear: ld_in=%d < frames=%d", ld_in, frames);
+    NBASR_REQUIRE(ld_out >= frames && ld_out % 4 == 0, NBASR_EALIGN, "nbasr_dense_conv1d_linear: ld_out=%d must be >= %d frames and a multiple of 4", ld_out, frames);
+    NBASR_REQUIRE((c_in * kernel) % 4 == 0 && aligned16(w), NBASR_EALIGN, "nbasr_dense_conv1d_linear: c_in*kernel must be a multiple of 4 and w 16-byte aligned");
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_linear: x, w, bias, y must be non-NULL");
+    GemmConvArgs a{};
+    a.x = x; a.w = w; a.bias = bias; a.y = y;
+    a.c_in = c_in; a.frames_in = frames; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames; a.ld_out = ld_out;
+    a.lpad = lpad; a.ktot = c_in * kernel; a.batch = batch;
+    return launch_gemm_conv<8, 1, false, false>(a, as_stream(stream), "nbasr_dense_conv1d_linear");
+}

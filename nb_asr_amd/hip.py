@@ -102,6 +102,11 @@ SIGNATURES = {
     'nbasr_grouped_conv1d_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 7 + [_c_stream]),
     'nbasr_layernorm_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_layernorm_channels_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_relu_clamp_backward': (_c_int, [_c_float_p] * 3 + [ctypes.c_longlong, _c_stream]),
+    'nbasr_zero_stuff': (_c_int, [_c_float_p] * 2 + [_c_int] * 7 + [_c_stream]),
+    'nbasr_dense_conv1d_linear': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_stream]),
+    'nbasr_conv_cols': (_c_int, [_c_float_p] * 2 + [_c_int] * 10 + [_c_stream]),
+    'nbasr_rows_of_channels': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
     # storage-type generic / bf16 path
     'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
     'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
@@ -944,3 +949,53 @@ def layernorm_channels_backward(x, stats, gamma, dy, frames):
                                                  _dev(dgamma, 'dgamma'), _dev(dbeta, 'dbeta'), _dev(ws, 'workspace'), b, c, frames, ld, _stream(x)),
            'nbasr_layernorm_channels_backward')
     return dx, dgamma, dbeta
+
+
+def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, need_dw=True):
+    """Backward of ``y = min(relu(conv1d(zero_pad(x), weight, bias, stride)), 20)`` for the dense k = 8 downsample convs (stride 1 | 2) and
+    the per-frame ``linear`` op (k = 1): x (B, C_in, ld_in), y / dy (B, C_out, ld_out) pitched -> (dx, dw, db).
+
+    Correctness-first: every product runs on the exact-fp32 MFMA GEMM of the forward -- the input gradient as a
+    stride-1 conv of the zero-stuffed, masked output gradient with the flipped, channel-transposed kernel; the weight and bias gradients
+    as ONE (C_out, B * T') x (B * T', C_in * k + 1) GEMM on a materialised column matrix."""
+    lib = load_library()
+    b, c_in, ld_in = x.shape
+    c_out, _, kernel = weight.shape if weight.dim() == 3 else (weight.shape[0], weight.shape[1], 1)
+    ld_out = y.shape[2]
+    frames_out = (frames_in + stride - 1) // stride
+    lpad = pad_amounts(kernel, 1, stride)[0]
+    stream = _stream(x)
+    dz = torch.empty_like(y)
+    _check(lib.nbasr_relu_clamp_backward(_dev(y, 'y'), _dev(dy, 'dy'), _dev(dz, 'dz'), y.numel(), stream), 'nbasr_relu_clamp_backward')
+    dx = dw = db = None
+    if need_dx:
+        dx = torch.empty(b, c_in, ld_in, device=x.device, dtype=torch.float32)
+        zero = torch.zeros(c_in, device=x.device, dtype=torch.float32)
+        if kernel == 1:
+            wt = weight.detach().reshape(c_out, c_in).t().contiguous()
+            _check(lib.nbasr_pointwise_linear(_dev(dz, 'dz'), _dev(wt, 'wt'), _dev(zero, 'zero'), _dev(dx, 'dx'), b, c_out, frames_in, ld_out,
+                                              c_in, ld_in, stream), 'nbasr_pointwise_linear')
+        else:
+            up = torch.empty(b, c_out, ld_in, device=x.device, dtype=torch.float32)
+            _check(lib.nbasr_zero_stuff(_dev(dz, 'dz'), _dev(up, 'up'), b * c_out, frames_out, ld_out, frames_in, ld_in, stride, 0, stream),
+                   'nbasr_zero_stuff')
+            wf = weight.detach().flip(2).permute(1, 0, 2).contiguous()                 # (C_in, C_out, k): flipped taps, channels swapped
+            _check(lib.nbasr_dense_conv1d_linear(_dev(up, 'up'), _dev(wf, 'wf'), _dev(zero, 'zero'), _dev(dx, 'dx'), b, c_out, frames_in, ld_in,
+                                                 c_in, ld_in, kernel, kernel - 1 - lpad, stream), 'nbasr_dense_conv1d_linear')
+    if need_dw:
+        t_pad = round_up4(max(frames_out, 1))
+        ld_cols = round_up4(c_in * kernel + 1)
+        cols = torch.empty(b * t_pad, ld_cols, device=x.device, dtype=torch.float32)
+        _check(lib.nbasr_conv_cols(_dev(x, 'x'), _dev(cols, 'cols'), b, c_in, frames_in, ld_in, frames_out, t_pad, kernel, stride, lpad, ld_cols,
+                                   stream), 'nbasr_conv_cols')
+        rows = torch.empty(c_out, b * t_pad, device=x.device, dtype=torch.float32)
+        _check(lib.nbasr_rows_of_channels(_dev(dz, 'dz'), _dev(rows, 'rows'), b, c_out, frames_out, ld_out, t_pad, stream), 'nbasr_rows_of_channels')
+        out = torch.empty(1, c_out, ld_cols, device=x.device, dtype=torch.float32)
+        zero_o = torch.zeros(c_out, device=x.device, dtype=torch.float32)
+        _check(lib.nbasr_pointwise_linear(_dev(cols, 'cols'), _dev(rows, 'rows'), _dev(zero_o, 'zero'), _dev(out, 'out'), 1, b * t_pad,
+                                          c_in * kernel + 1, ld_cols, c_out, ld_cols, stream), 'nbasr_pointwise_linear')
+        dw = out[0, :, : c_in * kernel].reshape(c_out, c_in, kernel).contiguous()
+        if weight.dim() == 2:
+            dw = dw.reshape(c_out, c_in)
+        db = out[0, :, c_in * kernel].contiguous()
+    return dx, dw, db

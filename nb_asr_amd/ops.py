@@ -71,6 +71,10 @@ class PadConvRelu(nn.Module):
         t_out = self.out_frames(frames)
         y = torch.empty(xp.shape[0], self.conv.out_channels, hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
         if self.groups == 1:
+            if torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad) and x.dtype == torch.float32 \
+                    and self.kernel_size == 8 and self.dilation == 1:
+                from .autograd import dense_pad_conv_relu           # trainable on its own
+                return dense_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.strides)
             hip.dense_conv1d_fused(xp, frames, self.conv.weight.detach(), self.conv.bias.detach(), (), y, self.strides)
         else:
             if self.strides != 1:
@@ -94,6 +98,9 @@ class Linear(nn.Module):
 
     def forward(self, x):
         _check_dropout(self)
+        if torch.is_grad_enabled() and (x.requires_grad or self.linear.weight.requires_grad) and x.dtype == torch.float32:
+            from .autograd import dense_pad_conv_relu               # trainable on its own
+            return dense_pad_conv_relu(x, self.linear.weight, self.linear.bias, 1)
         xp, frames = _pitched(x)
         y = torch.empty(xp.shape[0], self.linear.out_features, xp.shape[2], device=xp.device, dtype=xp.dtype)
         hip.dense_conv1d_fused(xp, frames, self.linear.weight.detach().unsqueeze(-1), self.linear.bias.detach(), (), y, 1)

@@ -44,6 +44,9 @@ NODE_OPS = ('conv5', 'conv7d2', 'linear', 'zero')
 GRAD_GCONV_CASES = [(6, 5, 1), (8, 5, 2), (10, 7, 1), (12, 7, 2), (12, 5, 1)]
 GRAD_GCONV100_CASES = [('conv5', 600, 5, 1), ('conv7d2', 1200, 7, 2)]
 GRAD_LN_CASES = [(600, 19), (24, 37), (1200, 7)]
+# dense k = 8 downsample convs (c_in, c_out, stride, batch, frames) and the per-frame linear op (c_in, c_out, batch, frames)
+GRAD_DENSE_CASES = [(24, 40, 1, 2, 37), (40, 24, 2, 2, 38), (16, 72, 2, 3, 33), (80, 136, 1, 1, 9)]
+GRAD_LINEAR_CASES = [(24, 24, 2, 37), (72, 72, 3, 18)]
 
 
 def keyed_params(shapes, tag, seed=7, bias_scale=0.2):

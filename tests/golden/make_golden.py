@@ -383,6 +383,8 @@ def bf16_fixtures():
 GRAD_GCONV_CASES = [(6, 5, 1), (8, 5, 2), (10, 7, 1), (12, 7, 2), (12, 5, 1)]      # (group width, kernel, dilation); C = 4 groups
 GRAD_GCONV100_CASES = [('conv5', 600), ('conv7d2', 1200)]
 GRAD_LN_CASES = [(600, 19), (24, 37), (1200, 7)]
+GRAD_DENSE_CASES = [(24, 40, 1, 2, 37), (40, 24, 2, 2, 38), (16, 72, 2, 3, 33), (80, 136, 1, 1, 9)]      # mirror of tests/cases.py
+GRAD_LINEAR_CASES = [(24, 24, 2, 37), (72, 72, 3, 18)]
 
 
 def grad_fixtures():
@@ -425,6 +427,38 @@ def grad_fixtures():
         m = fill_module_(ref_ops._ops[name](c, c), tag).eval()
         k, d = oracle.CONV_OPS[name]
         run_conv(tag, m, torch.from_numpy(keyed_normal(tag + '/x', 3, (1, c, 70))) * 2.0, k, d, 100)
+    # dense downsample convs and the linear op: gradients of ATen's autograd of the out-of-place restatement, whose forward is
+    # first checked against the reference modules (same reason as above: the reference's in-place clamp)
+    def run_generic(tag, forward, x, params):
+        torch.set_grad_enabled(True)
+        try:
+            xg = x.clone().requires_grad_(True)
+            ps = [p.detach().clone().requires_grad_(True) for p in params]
+            y = forward(xg, *ps)
+            r = torch.from_numpy(keyed_normal(tag + '/r', 5, tuple(y.shape)))
+            (y * r).sum().backward()
+        finally:
+            torch.set_grad_enabled(False)
+        fx[tag + '/dx'] = xg.grad.numpy().astype(np.float32)
+        fx[tag + '/dw'] = ps[0].grad.numpy().astype(np.float32)
+        fx[tag + '/db'] = ps[1].grad.numpy().astype(np.float32)
+        print(f'  {tag}: {float(((y > 0) & (y < 20)).float().mean()):.2f} of the outputs pass a gradient, {float((y >= 20).float().mean()):.3f} clamped')
+
+    for c_in, c_out, stride, b, t in GRAD_DENSE_CASES:
+        tag = f'grad/dense/c{c_in}_{c_out}_s{stride}_t{t}'
+        m = fill_module_(ref_ops.PadConvRelu(c_in, c_out, 8, 1, stride), tag).eval()
+        x = torch.from_numpy(keyed_normal(tag + '/x', 3, (b, c_in, t))) * 6.0
+        with torch.no_grad():
+            assert torch.equal(m(x), oracle.pad_conv_relu(x, m.conv.weight, m.conv.bias, 1, stride, 1)), tag
+        run_generic(tag, lambda xx, w, bb, stride=stride: oracle.pad_conv_relu(xx, w, bb, 1, stride, 1), x, (m.conv.weight, m.conv.bias))
+    for c_in, c_out, b, t in GRAD_LINEAR_CASES:
+        tag = f'grad/linear/c{c_in}_{c_out}_t{t}'
+        m = fill_module_(ref_ops.Linear(c_in, c_out), tag).eval()
+        x = torch.from_numpy(keyed_normal(tag + '/x', 3, (b, c_in, t))) * 6.0
+        lin = next(mod for mod in m.modules() if isinstance(mod, torch.nn.Linear))
+        with torch.no_grad():
+            assert torch.equal(m(x), oracle.linear_relu(x, lin.weight, lin.bias)), tag
+        run_generic(tag, oracle.linear_relu, x, (lin.weight, lin.bias))
     torch.set_grad_enabled(True)
     try:
         for c, t in GRAD_LN_CASES:

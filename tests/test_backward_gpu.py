@@ -126,3 +126,83 @@ def test_backward_argument_errors():
     rc = lib.nbasr_grouped_conv1d_backward(16, 16, 16, 16, 16, None, None, None, 1, 600, 10, 10, 100, 5, 1, None)
     assert rc == -2
     assert lib.nbasr_grouped_conv1d_backward_workspace_bytes(64, 1200, 100, 5) == 100 * 64 * 4 * 256 * 4
+
+
+# ---- dense downsample convs and the per-frame linear op (GEMM-shaped backward on the exact-fp32 MFMA GEMMs) --------------------
+def dense_case(tag, w_shape, x_shape, scale):
+    names = {'conv.weight': w_shape, 'conv.bias': (w_shape[0],)} if len(w_shape) == 3 else {'linear.weight': w_shape, 'linear.bias': (w_shape[0],)}
+    p = cases.keyed_params(names, tag)
+    w, bias = [p[k] for k in names]
+    x = torch.from_numpy(keyed_normal(tag + '/x', 3, x_shape)) * scale
+    return x, w, bias
+
+
+def run_dense_grad(x, w, bias, r, stride):
+    xg, wg, bg = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    y = nb_autograd.dense_pad_conv_relu(xg, wg, bg, stride)
+    (y * r.to(DEV)).sum().backward()
+    return y, xg.grad, wg.grad, bg.grad
+
+
+@pytest.mark.parametrize('c_in,c_out,stride,b,t', cases.GRAD_DENSE_CASES)
+def test_dense_conv_gradients(grad_fx, c_in, c_out, stride, b, t):
+    tag = f'grad/dense/c{c_in}_{c_out}_s{stride}_t{t}'
+    x, w, bias = dense_case(tag, (c_out, c_in, 8), (b, c_in, t), 6.0)
+    t_out = (t + stride - 1) // stride
+    r = torch.from_numpy(keyed_normal(tag + '/r', 5, (b, c_out, t_out)))
+    y, dx, dw, db = run_dense_grad(x, w, bias, r, stride)
+    assert float(y.max()) == 20.0 and tuple(dx.shape) == (b, c_in, t)
+    close(dx, grad_fx[tag + '/dx'], tag + ' dx')
+    close(dw, grad_fx[tag + '/dw'], tag + ' dw')
+    close(db, grad_fx[tag + '/db'], tag + ' db')
+    y2, dx2, dw2, db2 = run_dense_grad(x, w, bias, r, stride)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)      # no atomics: bit-reproducible
+
+
+@pytest.mark.parametrize('c_in,c_out,b,t', cases.GRAD_LINEAR_CASES)
+def test_linear_op_gradients(grad_fx, c_in, c_out, b, t):
+    tag = f'grad/linear/c{c_in}_{c_out}_t{t}'
+    x, w, bias = dense_case(tag, (c_out, c_in), (b, c_in, t), 6.0)
+    r = torch.from_numpy(keyed_normal(tag + '/r', 5, (b, c_out, t)))
+    y, dx, dw, db = run_dense_grad(x, w, bias, r, 1)
+    assert float(y.max()) == 20.0
+    close(dx, grad_fx[tag + '/dx'], tag + ' dx')
+    close(dw, grad_fx[tag + '/dw'], tag + ' dw')
+    close(db, grad_fx[tag + '/db'], tag + ' db')
+
+
+@pytest.mark.parametrize('c_in,c_out,stride,b,t', [(600, 136, 1, 2, 131), (136, 200, 2, 3, 64), (80, 600, 1, 1, 5), (1000, 24, 2, 1, 1)])
+def test_dense_conv_gradients_vs_torch_autograd(c_in, c_out, stride, b, t):
+    """Production-width channels, ragged lengths and lengths shorter than the kernel, against ATen's autograd of the oracle."""
+    from oracle import asr_oracle as oracle
+    torch.manual_seed(c_in + t)
+    x = torch.randn(b, c_in, t) * 3.0
+    w = torch.randn(c_out, c_in, 8) * (2.0 / (c_in * 8)) ** 0.5
+    bias = torch.randn(c_out) * 0.2
+    t_out = (t + stride - 1) // stride
+    r = torch.randn(b, c_out, t_out)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    (oracle.pad_conv_relu(xr, wr, br, 1, stride, 1) * r).sum().backward()
+    y, dx, dw, db = run_dense_grad(x, w, bias, r, stride)
+    close(dx, xr.grad.numpy(), 'dx', rtol=2e-4)
+    close(dw, wr.grad.numpy(), 'dw', rtol=2e-4)
+    close(db, br.grad.numpy(), 'db', rtol=2e-4)
+
+
+def test_dense_ops_train_through_the_modules():
+    """ops.PadConvRelu (dense) and ops.Linear route to the differentiable functions when a gradient is required: an SGD step
+    on each lowers a loss."""
+    torch.manual_seed(0)
+    for mod, x in ((ops.PadConvRelu(24, 40, 8, 1, 2).to(DEV), torch.randn(2, 24, 50, device=DEV)),
+                   (ops.Linear(24, 24).to(DEV), torch.randn(2, 24, 50, device=DEV))):
+        target = torch.rand(2, mod(x).shape[1], mod(x).shape[2], device=DEV)
+        losses = []
+        for _ in range(4):
+            loss = ((mod(x) - target) ** 2).mean()
+            losses.append(float(loss))
+            mod.zero_grad()
+            loss.backward()
+            with torch.no_grad():
+                for p in mod.parameters():
+                    p -= 0.05 * p.grad
+        assert losses[-1] < losses[0], losses

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='+', default=[64, 8])
 ap.add_argument('--kernel', type=int, default=5)
 ap.add_argument('--dilation', type=int, default=1)
+ap.add_argument('--lnx0', action='store_true', help='also LayerNorm on load without a skip input (the first node of a skip-free cell)')
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
 for B in args.batches:
@@ -36,7 +37,7 @@ for B in args.batches:
         stats = torch.empty(B, 2, ld, device=dev)
         hip.channel_stats_v(bufs[0], stats, t, 1e-3)
         gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
-        for flavour, n_skips in (('plain', 0), ('plain', 1), ('lnx', 1)):
+        for flavour, n_skips in (('plain', 0), ('plain', 1), ('lnx', 1)) + ((('lnx', 0),) if args.lnx0 else ()):
             ln = (stats, gamma, beta) if flavour == 'lnx' else None
 
             def run(i, variant):
