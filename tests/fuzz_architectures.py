@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Extended random sweep (diagnostic; the committed tests run 8 of these): random architectures x random (B, T) x both heads
 x both initialisations, HIP forward vs the CPU oracle with the noise-aware tolerance of tests/test_model_gpu.py, plus the
-pipelined path.  usage: python tools/fuzz_architectures.py [N=40] [first_seed=100]"""
+pipelined path.  Lives under tests/ because it uses the oracle (test infrastructure).  usage: python tests/fuzz_architectures.py [N=40] [first_seed=100]"""
 import pathlib, random, sys
 import torch
 root = pathlib.Path(__file__).resolve().parent.parent
