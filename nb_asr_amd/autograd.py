@@ -5,8 +5,8 @@ What exists: ``grouped_pad_conv_relu`` (reference ``ops.PadConvRelu`` with group
 (``nn.LayerNorm`` over the channel dimension of (B, C, T), model.py:55-58) -- forward AND backward through the C ABI, gradients
 checked against the reference modules' own autograd (tests/golden/grad_fixtures.npz).  ``ops.PadConvRelu`` (grouped) calls the
 former when a gradient is required, so the op is trainable on its own.  Also ``dense_pad_conv_relu``: the dense k = 8 downsample convs
-(model.py:82-89) and the per-frame ``linear`` op (ops.py:42-50), correctness-first on the exact-fp32 GEMMs of the forward.  What does not
-exist yet: backward of the LSTM and the head, dropout masks, and therefore ``loss.backward()`` through ``ASRModel`` (its forward still
+(model.py:82-89) and the per-frame ``linear`` op (ops.py:42-50), correctness-first on the exact-fp32 GEMMs of the forward.  ``lstm``: BPTT of the single-layer
+LSTM (model.py:100,118-121).  What does not exist yet: the head's backward, dropout masks, and therefore ``loss.backward()`` through ``ASRModel`` (its forward still
 returns detached logits and says so).
 """
 import torch
@@ -89,6 +89,37 @@ class _DensePadConvRelu(torch.autograd.Function):
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx, dw, db = hip.dense_conv1d_backward(xp, weight, y, dyp, frames, stride, need_dx, need_dw)
         return (dx[:, :, :frames] if dx is not None else None), dw, db, None
+
+
+class _LSTM(torch.autograd.Function):
+    """nn.LSTM(C, H), one layer, unidirectional, zero initial state (reference model.py:100,118-121): x (B, C, T) -> h (B, T, H)."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh):
+        xp, frames = _pitched(x)
+        b, hidden = xp.shape[0], w_hh.shape[1]
+        gates = torch.empty(max(frames, 1), b, 4 * hidden, device=xp.device, dtype=torch.float32)
+        cell = torch.empty(b, hidden, device=xp.device, dtype=torch.float32)
+        h_out = torch.empty(b, frames, hidden, device=xp.device, dtype=torch.float32)
+        if frames:
+            hip.lstm_input_projection(xp, frames, w_ih.detach(), b_ih.detach(), b_hh.detach(), gates, hidden)
+            hip.lstm_recurrence(gates, w_hh.detach(), cell, h_out)
+        ctx.save_for_backward(xp, gates, h_out, w_ih.detach(), w_hh.detach())
+        ctx.frames = frames
+        return h_out
+
+    @staticmethod
+    def backward(ctx, dh):
+        xp, gates, h_out, w_ih, w_hh = ctx.saved_tensors
+        if ctx.frames == 0:
+            return torch.zeros_like(xp[:, :, :0]), torch.zeros_like(w_ih), torch.zeros_like(w_hh), w_ih.new_zeros(w_ih.shape[0]), w_ih.new_zeros(w_ih.shape[0])
+        dx, dw_ih, dw_hh, db = hip.lstm_backward(xp, ctx.frames, gates, h_out, w_ih, w_hh, dh.contiguous())
+        return dx, dw_ih, dw_hh, db, db.clone()
+
+
+def lstm(x, w_ih, w_hh, b_ih, b_hh):
+    """Single-layer LSTM over (B, C, T) -> (B, T, H), differentiable in x and the four parameters (BPTT through the C ABI)."""
+    return _LSTM.apply(x, w_ih, w_hh, b_ih, b_hh)
 
 
 def dense_pad_conv_relu(x, weight, bias, stride=1):

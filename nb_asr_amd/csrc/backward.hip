@@ -480,3 +480,86 @@ extern "C" int nbasr_zero_stuff(const float* dz, float* up, int rows, int frames
                        frames, ld, frames_up, ld_up, stride, shift);
     return launch_status("nbasr_zero_stuff");
 }
+
+// ---- LSTM backward (BPTT), correctness first -----------------------------------------------------------------------------------------
+// Layout of everything below: (rows, frames, ldb) with the utterances innermost (ldb = batch rounded up to 4), rows = 4H for the
+// gate tensors (PyTorch order i, f, g, o) and H for the cell states -- the layout in which the per-step GEMM
+// dh_(t-1) += w_hh^T . dpre_t and the three batched GEMMs of the weight / input gradients read their operands directly.
+namespace nbasr {
+
+__device__ __forceinline__ float sigmoid_bw(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// pre (4H, T, ldb): gate pre-activations of ALL frames (input projection + w_hh . h_(t-1), recomputed from the saved h by one
+// GEMM) -> overwritten by the gate activations; cells (H, T, ldb) <- c_t.  One thread per (unit, utterance), a serial scan over t.
+__global__ __launch_bounds__(256) void lstm_gate_scan_kernel(float* __restrict__ pre, float* __restrict__ cells, int hidden, int frames,
+                                                             int batch, int ldb)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (b >= batch) return;
+    const size_t plane = static_cast<size_t>(frames) * ldb, gate_stride = static_cast<size_t>(hidden) * plane;
+    float c = 0.f;
+    for (int t = 0; t < frames; ++t) {
+        const size_t at = static_cast<size_t>(j) * plane + static_cast<size_t>(t) * ldb + b;
+        const float i = sigmoid_bw(pre[at]), f = sigmoid_bw(pre[at + gate_stride]), g = tanhf(pre[at + 2 * gate_stride]),
+                    o = sigmoid_bw(pre[at + 3 * gate_stride]);
+        c = f * c + i * g;
+        pre[at] = i; pre[at + gate_stride] = f; pre[at + 2 * gate_stride] = g; pre[at + 3 * gate_stride] = o;
+        cells[at] = c;
+    }
+}
+
+// One step of the reverse recurrence: dh_out (H, T, ldb) = dL/dh of the layer's output, rec (H, ldb) = w_hh^T . dpre[:, t + 1, :] (NULL at
+// the last frame), dc (H, ldb) the carried dL/dc_t part -> dpre[:, t, :] (4H rows) and the updated carry dL/dc_(t-1).
+__global__ __launch_bounds__(256) void lstm_backward_step_kernel(const float* __restrict__ dh_out, const float* __restrict__ rec,
+                                                                 float* __restrict__ dc, const float* __restrict__ acts,
+                                                                 const float* __restrict__ cells, float* __restrict__ dpre, int hidden,
+                                                                 int frames, int batch, int ldb, int t)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (b >= ldb) return;
+    const size_t plane = static_cast<size_t>(frames) * ldb, gate_stride = static_cast<size_t>(hidden) * plane;
+    const size_t at = static_cast<size_t>(j) * plane + static_cast<size_t>(t) * ldb + b;
+    const size_t hb = static_cast<size_t>(j) * ldb + b;
+    if (b >= batch) {                                          // pitch columns: exact zeros for the GEMMs that read them
+        dpre[at] = 0.f; dpre[at + gate_stride] = 0.f; dpre[at + 2 * gate_stride] = 0.f; dpre[at + 3 * gate_stride] = 0.f;
+        return;
+    }
+    const float i = acts[at], f = acts[at + gate_stride], g = acts[at + 2 * gate_stride], o = acts[at + 3 * gate_stride];
+    const float c = cells[at], c_prev = t > 0 ? cells[at - ldb] : 0.f;
+    const float tc = tanhf(c);
+    const float gh = dh_out[at] + (rec ? rec[hb] : 0.f);       // dL/dh_t: from the output, and from frame t + 1 through w_hh
+    const float d_o = gh * tc;
+    const float d_c = dc[hb] + gh * o * (1.f - tc * tc);
+    dpre[at] = d_c * g * i * (1.f - i);
+    dpre[at + gate_stride] = d_c * c_prev * f * (1.f - f);
+    dpre[at + 2 * gate_stride] = d_c * i * (1.f - g * g);
+    dpre[at + 3 * gate_stride] = d_o * o * (1.f - o);
+    dc[hb] = d_c * f;
+}
+
+}  // namespace nbasr
+
+extern "C" int nbasr_lstm_gate_scan(float* pre, float* cells, int hidden, int frames, int batch, int ldb, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(hidden > 0 && frames >= 0 && batch >= 0 && ldb >= batch, NBASR_EINVAL, "nbasr_lstm_gate_scan: bad sizes");
+    if (frames == 0 || batch == 0) return NBASR_OK;
+    NBASR_REQUIRE(pre && cells, NBASR_ENULL, "nbasr_lstm_gate_scan: NULL pointer");
+    NBASR_REQUIRE(hidden <= 65535, NBASR_EINVAL, "nbasr_lstm_gate_scan: hidden %d > 65535", hidden);
+    hipLaunchKernelGGL(lstm_gate_scan_kernel, dim3((batch + 63) / 64, hidden), dim3(64), 0, as_stream(stream), pre, cells, hidden, frames, batch, ldb);
+    return launch_status("nbasr_lstm_gate_scan");
+}
+
+extern "C" int nbasr_lstm_backward_step(const float* dh_out, const float* rec, float* dc, const float* acts, const float* cells, float* dpre,
+                                        int hidden, int frames, int batch, int ldb, int t, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(hidden > 0 && frames > 0 && batch > 0 && ldb >= batch && t >= 0 && t < frames, NBASR_EINVAL, "nbasr_lstm_backward_step: bad sizes");
+    NBASR_REQUIRE(dh_out && dc && acts && cells && dpre, NBASR_ENULL, "nbasr_lstm_backward_step: NULL pointer");
+    NBASR_REQUIRE(hidden <= 65535, NBASR_EINVAL, "nbasr_lstm_backward_step: hidden %d > 65535", hidden);
+    hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((ldb + 63) / 64, hidden), dim3(64), 0, as_stream(stream), dh_out, rec, dc, acts, cells, dpre,
+                       hidden, frames, batch, ldb, t);
+    return launch_status("nbasr_lstm_backward_step");
+}

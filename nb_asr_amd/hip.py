@@ -107,6 +107,8 @@ SIGNATURES = {
     'nbasr_dense_conv1d_linear': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_stream]),
     'nbasr_conv_cols': (_c_int, [_c_float_p] * 2 + [_c_int] * 10 + [_c_stream]),
     'nbasr_rows_of_channels': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_lstm_gate_scan': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_lstm_backward_step': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_stream]),
     # storage-type generic / bf16 path
     'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
     'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
@@ -999,3 +1001,69 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
             dw = dw.reshape(c_out, c_in)
         db = out[0, :, c_in * kernel].contiguous()
     return dx, dw, db
+
+
+def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
+    """BPTT of the single-layer LSTM (reference model.py:100,118-121): xp (B, C, ld) the layer input, gates (T, B, 4H) its saved input
+    projection (both biases included), h_out (B, T, H) the saved output, dh_out (B, T, H) -> (dx (B, C, T), dw_ih, dw_hh, db).
+
+    Correctness first: gate pre-activations of all frames are recomputed from the saved h by ONE GEMM, a serial
+    scan restores the cell states, the reverse recurrence is T times {H x 4H GEMM, element-wise step}, and the weight / input gradients
+    are three batched GEMMs -- every product on the exact-fp32 MFMA GEMM (nbasr_pointwise_linear); tensor re-layouts are torch copies."""
+    lib = load_library()
+    b, c, _ = xp.shape
+    t_n, hidden = frames, w_hh.shape[1]
+    g4 = 4 * hidden
+    dev, f32 = xp.device, torch.float32
+    if hidden % 4:
+        raise HipError('lstm_backward: hidden must be a multiple of 4')
+    ldb = round_up4(b)
+    n = t_n * ldb                                              # GEMM column count; (frame, utterance) pairs, utterance innermost
+    stream = _stream(xp)
+
+    def gemm(x_ptr, c_in, cols, ld_in, w, y):
+        """y (1, c_out, ld_out) = w (c_out, c_in) . x (c_in rows of `cols` floats at pitch ld_in)"""
+        zero = torch.zeros(w.shape[0], device=dev, dtype=f32)
+        _check(lib.nbasr_pointwise_linear(x_ptr, _dev(w, 'w'), _dev(zero, 'zero'), _dev(y, 'y'), 1, c_in, cols, ld_in, w.shape[0], y.shape[2],
+                                          stream), 'nbasr_pointwise_linear')
+        return y
+
+    # h_(t-1) for every (t, b): rows of the (T * ldb, H) matrix, zero for t = 0 and for the pitch utterances
+    hp = torch.zeros(t_n, ldb, hidden, device=dev, dtype=f32)
+    if t_n > 1:
+        hp[1:, :b] = h_out[:, : t_n - 1].permute(1, 0, 2)
+    hp_t = hp.reshape(n, hidden).t().contiguous()              # (H, T * ldb)
+    pre = torch.empty(1, g4, n, device=dev, dtype=f32)
+    gemm(hp_t.data_ptr(), hidden, n, n, w_hh.detach().contiguous(), pre)
+    pre = pre.view(g4, t_n, ldb)
+    pre[:, :, :b] += gates[:t_n].permute(2, 0, 1)             # + input projection and biases
+    cells = torch.zeros(hidden, t_n, ldb, device=dev, dtype=f32)
+    _check(lib.nbasr_lstm_gate_scan(_dev(pre, 'pre'), _dev(cells, 'cells'), hidden, t_n, b, ldb, stream), 'nbasr_lstm_gate_scan')
+    acts = pre                                                 # overwritten in place by the scan
+    dho = torch.zeros(hidden, t_n, ldb, device=dev, dtype=f32)
+    dho[:, :, :b] = dh_out.detach().permute(2, 1, 0)
+    dpre = torch.empty(g4, t_n, ldb, device=dev, dtype=f32)
+    dc = torch.zeros(hidden, ldb, device=dev, dtype=f32)
+    rec = torch.empty(1, hidden, ldb, device=dev, dtype=f32)
+    w_hh_t = w_hh.detach().t().contiguous()                    # (H, 4H)
+    for t in range(t_n - 1, -1, -1):
+        rec_ptr = None
+        if t + 1 < t_n:
+            gemm(dpre.data_ptr() + 4 * (t + 1) * ldb, g4, ldb, n, w_hh_t, rec)        # rows of dpre[:, t + 1, :] sit n floats apart
+            rec_ptr = rec.data_ptr()
+        _check(lib.nbasr_lstm_backward_step(_dev(dho, 'dho'), rec_ptr, _dev(dc, 'dc'), _dev(acts, 'acts'), _dev(cells, 'cells'),
+                                            _dev(dpre, 'dpre'), hidden, t_n, b, ldb, t, stream), 'nbasr_lstm_backward_step')
+    d2 = dpre.view(g4, n)
+    # dw_hh (4H, H) = dpre (4H, n) . h_prev (n, H)
+    dw_hh = gemm(hp.data_ptr(), n, hidden, hidden, d2, torch.empty(1, g4, hidden, device=dev, dtype=f32))[0]
+    # (dw_ih | db) (4H, C + 1) = dpre . (x | 1)
+    ldc = round_up4(c + 1)
+    xt = torch.zeros(t_n, ldb, ldc, device=dev, dtype=f32)
+    xt[:, :b, :c] = xp[:, :, :t_n].permute(2, 0, 1)
+    xt[:, :b, c] = 1.0
+    wb = gemm(xt.data_ptr(), n, c + 1, ldc, d2, torch.empty(1, g4, ldc, device=dev, dtype=f32))[0]
+    dw_ih, db = wb[:, :c].contiguous(), wb[:, c].contiguous()
+    # dx (C, n) = w_ih^T (C, 4H) . dpre (4H, n)
+    dxc = gemm(dpre.data_ptr(), g4, n, n, w_ih.detach().t().contiguous(), torch.empty(1, c, n, device=dev, dtype=f32))[0]
+    dx = dxc.view(c, t_n, ldb)[:, :, :b].permute(2, 0, 1).contiguous()
+    return dx, dw_ih, dw_hh, db

@@ -206,3 +206,24 @@ def test_dense_ops_train_through_the_modules():
                 for p in mod.parameters():
                     p -= 0.05 * p.grad
         assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize('c,hidden,b,t', [(24, 8, 2, 5), (40, 20, 3, 17), (1200, 500, 2, 9), (16, 4, 5, 1)])
+def test_lstm_bptt_vs_torch_autograd(c, hidden, b, t):
+    """BPTT of the single-layer LSTM against ATen's autograd of nn.LSTM (the reference's own module, model.py:100) on the CPU:
+    gradients with respect to the input and all four parameters, gate order i, f, g, o."""
+    torch.manual_seed(c + hidden + t)
+    ref = torch.nn.LSTM(c, hidden, batch_first=True)
+    x = torch.randn(b, c, t) * 1.5
+    r = torch.randn(b, t, hidden)
+    xr = x.clone().requires_grad_(True)
+    out, _ = ref(xr.permute(0, 2, 1))
+    (out * r).sum().backward()
+    params = [p.detach().clone().to(DEV).requires_grad_(True) for p in (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0)]
+    xg = x.to(DEV).requires_grad_(True)
+    h = nb_autograd.lstm(xg, *params)
+    assert torch.allclose(h.detach().cpu(), out.detach(), rtol=1e-4, atol=1e-5)
+    (h * r.to(DEV)).sum().backward()
+    close(xg.grad, xr.grad.numpy(), 'dx', rtol=2e-4)
+    for got, want, name in zip(params, (ref.weight_ih_l0, ref.weight_hh_l0, ref.bias_ih_l0, ref.bias_hh_l0), ('dw_ih', 'dw_hh', 'db_ih', 'db_hh')):
+        close(got.grad, want.grad.numpy(), name, rtol=2e-4)
