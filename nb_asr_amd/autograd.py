@@ -117,6 +117,42 @@ class _LSTM(torch.autograd.Function):
         return dx, dw_ih, dw_hh, db, db.clone()
 
 
+class _PointwiseLinear(torch.autograd.Function):
+    """Per-frame linear map WITHOUT activation over (B, C_in, T) -> (B, C_out, T): the CTC head (reference model.py:101-103,122-124).
+    The class dimension (49) is padded to a multiple of 4 rows of zeros for the GEMMs and sliced off again."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        xp, frames = _pitched(x)
+        c_out = weight.shape[0]
+        rows = (c_out + 3) & ~3
+        w = weight.detach()
+        bvec = bias.detach()
+        if rows != c_out:
+            w = torch.cat([w, w.new_zeros(rows - c_out, w.shape[1])])
+            bvec = torch.cat([bvec, bvec.new_zeros(rows - c_out)])
+        y = torch.empty(xp.shape[0], rows, xp.shape[2], device=xp.device, dtype=xp.dtype)
+        hip.pointwise_linear(xp, frames, w.contiguous(), bvec.contiguous(), y)
+        ctx.save_for_backward(xp, w.contiguous(), y)
+        ctx.cfg = (frames, c_out)
+        return y[:, :c_out, :frames]
+
+    @staticmethod
+    def backward(ctx, dy):
+        xp, w, y = ctx.saved_tensors
+        frames, c_out = ctx.cfg
+        dyp = torch.zeros_like(y)
+        dyp[:, :c_out, :frames] = dy
+        need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
+        dx, dw, db = hip.dense_conv1d_backward(xp, w, y, dyp, frames, 1, need_dx, need_dw, activation=False)
+        return (dx[:, :, :frames] if dx is not None else None), (dw[:c_out] if dw is not None else None), (db[:c_out] if db is not None else None)
+
+
+def pointwise_linear(x, weight, bias):
+    """weight (C_out, C_in) applied to every frame of (B, C_in, T), no activation, differentiable in x, weight, bias."""
+    return _PointwiseLinear.apply(x, weight, bias)
+
+
 def lstm(x, w_ih, w_hh, b_ih, b_hh):
     """Single-layer LSTM over (B, C, T) -> (B, T, H), differentiable in x and the four parameters (BPTT through the C ABI)."""
     return _LSTM.apply(x, w_ih, w_hh, b_ih, b_hh)
@@ -136,3 +172,46 @@ def grouped_pad_conv_relu(x, weight, bias, groups, kernel, dilation):
 def layer_norm_channels(x, gamma, beta, eps=1e-3):
     """LayerNorm over the channel dimension of (B, C, T), differentiable in x, gamma, beta."""
     return _LayerNormChannels.apply(x, gamma, beta, eps)
+
+
+def model_forward(model, x):
+    """The differentiable forward of an ``ASRModel`` (reference model.py:116-131 under autograd): the same layer list, every op through
+    its ``torch.autograd.Function`` above, skip sums as tensor additions.  One launch group per op, nothing fused or deferred -- the
+    inference executor stays the fast path; this is what ``loss.backward()`` runs through."""
+    import torch.nn as nn
+    from .model import SearchCell
+    from .ops import PadConvRelu, Linear, Zero, Identity
+    act = x
+    for layer in model.model:
+        if isinstance(layer, PadConvRelu):
+            act = layer(act)                                   # routes to dense_pad_conv_relu / grouped_pad_conv_relu under autograd
+        elif isinstance(layer, nn.LayerNorm):
+            if act.dim() == 3 and act.shape[1] == layer.normalized_shape[0]:
+                act = layer_norm_channels(act, layer.weight, layer.bias, layer.eps)
+            else:
+                raise RuntimeError('LayerNorm in an unexpected position of the layer list')
+        elif isinstance(layer, SearchCell):
+            outs = [act]
+            for node in layer.nodes:
+                op = node.op
+                main = None if isinstance(op, Zero) else op(outs[-1])
+                for branch, src in zip(node.branch_ops, outs):
+                    if isinstance(branch, Identity):
+                        main = src if main is None else main + src
+                if main is None:
+                    main = torch.zeros_like(outs[-1])
+                outs.append(main)
+            act = outs[-1]
+            if layer.use_norm:
+                act = layer_norm_channels(act, layer.norm_layer.weight, layer.norm_layer.bias, layer.norm_layer.eps)
+        elif isinstance(layer, nn.Dropout):
+            pass                                               # identity: p == 0 or eval (ASRModel checks)
+        elif isinstance(layer, nn.LSTM):
+            act = lstm(act, layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0)      # (B, T, H)
+        elif isinstance(layer, nn.Linear):
+            if act.dim() == 3 and act.shape[2] == layer.in_features and act.shape[1] != layer.in_features:
+                act = act.permute(0, 2, 1)                     # LSTM output (B, T, H) -> (B, H, T)
+            act = pointwise_linear(act, layer.weight, layer.bias).permute(0, 2, 1)                            # (B, T, classes)
+        else:
+            raise TypeError(f'unsupported layer {type(layer).__name__} in the model list')
+    return act

@@ -953,9 +953,10 @@ def layernorm_channels_backward(x, stats, gamma, dy, frames):
     return dx, dgamma, dbeta
 
 
-def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, need_dw=True):
+def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, need_dw=True, activation=True):
     """Backward of ``y = min(relu(conv1d(zero_pad(x), weight, bias, stride)), 20)`` for the dense k = 8 downsample convs (stride 1 | 2) and
-    the per-frame ``linear`` op (k = 1): x (B, C_in, ld_in), y / dy (B, C_out, ld_out) pitched -> (dx, dw, db).
+    the per-frame ``linear`` op (k = 1): x (B, C_in, ld_in), y / dy (B, C_out, ld_out) pitched -> (dx, dw, db).  ``activation=False``: the map
+    without ReLU / clamp (the CTC head).
 
     Correctness-first: every product runs on the exact-fp32 MFMA GEMM of the forward -- the input gradient as a
     stride-1 conv of the zero-stuffed, masked output gradient with the flipped, channel-transposed kernel; the weight and bias gradients
@@ -967,8 +968,11 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
     frames_out = (frames_in + stride - 1) // stride
     lpad = pad_amounts(kernel, 1, stride)[0]
     stream = _stream(x)
-    dz = torch.empty_like(y)
-    _check(lib.nbasr_relu_clamp_backward(_dev(y, 'y'), _dev(dy, 'dy'), _dev(dz, 'dz'), y.numel(), stream), 'nbasr_relu_clamp_backward')
+    if activation:
+        dz = torch.empty_like(y)
+        _check(lib.nbasr_relu_clamp_backward(_dev(y, 'y'), _dev(dy, 'dy'), _dev(dz, 'dz'), y.numel(), stream), 'nbasr_relu_clamp_backward')
+    else:
+        dz = dy                                             # a plain linear map (the CTC head): no mask
     dx = dw = db = None
     if need_dx:
         dx = torch.empty(b, c_in, ld_in, device=x.device, dtype=torch.float32)

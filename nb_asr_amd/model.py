@@ -152,11 +152,17 @@ class ASRModel(nn.Module):
             raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor, got {tuple(getattr(input, "shape", ()))}')
         if not input.is_cuda:
             raise hip.HipError('ASRModel.forward needs its input on a HIP device; this package has no CPU path')
-        if self.training and torch.is_grad_enabled() and not ASRModel._warned_no_autograd:
-            ASRModel._warned_no_autograd = True
-            warnings.warn('nb_asr_amd runs the forward pass only: the logits are not attached to the autograd graph, so '
-                          'loss.backward() will not reach the parameters (training support is SURVEY.md 8 row f4, not built). '
-                          'Call model.eval() / torch.no_grad() for inference.', stacklevel=2)
+        if self.training and torch.is_grad_enabled() and _taps is None and not _pipelined and input.dtype == torch.float32 \
+                and (input.requires_grad or self.model[0].conv.weight.requires_grad):
+            # training mode with gradients enabled (what the reference's trainer does, trainer.py:215-223): the differentiable forward --
+            # one op at a time through the autograd functions, unfused; eval() / torch.no_grad() take the fused inference executor
+            if not ASRModel._warned_no_autograd:
+                ASRModel._warned_no_autograd = True
+                warnings.warn('nb_asr_amd: training-mode forward with gradients enabled runs the differentiable, unfused path '
+                              '(nb_asr_amd.autograd.model_forward; correctness first, several times slower than inference). '
+                              'Call model.eval() / torch.no_grad() for inference.', stacklevel=2)
+            from .autograd import model_forward
+            return model_forward(self, input)
         # one plan per device, re-used for every batch shape (grow-only workspaces); a second plan only comes into being
         # when two threads are inside forward() on the same device at once
         plan = self._plans.acquire(input.device)

@@ -160,15 +160,21 @@ def layer_table(use_rnn=True):
     return table
 
 
-def asr_forward(params, arch_vec, x, use_rnn=True, use_norm=True, dtype=torch.float32, taps=None):
+def asr_forward(params, arch_vec, x, use_rnn=True, use_norm=True, dtype=torch.float32, taps=None, differentiable=False):
     """Full forward: x (B, 80, T) -> logits (B, ceil(ceil(T/2)/2), 49).
 
     ``params`` maps the reference's state_dict keys (``model.0.conv.weight`` ...) to tensors.
     ``taps``, if a dict, receives every layer's output keyed by its index in ``model``.
+    ``differentiable``: keep the parameters (and x) attached, so that ATen's autograd through this op sequence yields the
+    reference gradients (the tests of the backward path).
     """
-    p = {k: v.detach().to('cpu', dtype) for k, v in params.items()}
+    if differentiable:
+        p = {k: v.to('cpu', dtype) for k, v in params.items()}
+        h = x.to('cpu', dtype)
+    else:
+        p = {k: v.detach().to('cpu', dtype) for k, v in params.items()}
+        h = x.detach().to('cpu', dtype)
     names = arch_names(arch_vec)
-    h = x.detach().to('cpu', dtype)
     for idx, kind, blk in layer_table(use_rnn):
         pre = f'model.{idx}.'
         if kind == 'down':

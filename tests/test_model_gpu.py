@@ -256,25 +256,86 @@ def test_dense_scheme_selection():
     assert cases.worst_ratio(y0, y1.cpu(), 1e-4, 1e-5) <= 1.0
 
 
-def test_forward_under_autograd_warns_that_logits_are_detached():
-    """Training support is not built: a forward in training mode with autograd on must say so instead of
-    leaving the user with an opaque 'does not require grad' at backward time."""
+def test_training_mode_forward_is_attached_and_announced():
+    """Training mode with gradients enabled (what get_model returns, like the reference): the logits come from the differentiable
+    path (autograd.model_forward), equal the inference executor's to fp32 noise, and the slower path is announced once."""
     import warnings
     from nb_asr_amd.model import ASRModel
-    m = nb.get_model([[1, 0], [1, 0, 0], [1, 0, 0, 0]], use_rnn=True, dropout_rate=0.0)
+    m = nb.get_model(cases.ARCH_D, use_rnn=True, dropout_rate=0.0)
     keyed_fill_(m, 1235, 'lively')
     m = m.to(DEV)                                     # get_model returns the module in training mode, like the reference
-    x = keyed_input(1, 40, seed=0).to(DEV)
+    x = keyed_input(2, 40, seed=0).to(DEV)
     ASRModel._warned_no_autograd = False
-    with pytest.warns(UserWarning, match='not attached to the autograd graph'):
+    with pytest.warns(UserWarning, match='differentiable, unfused path'):
         out = m(x)
-    assert out.grad_fn is None and not out.requires_grad
+    assert out.grad_fn is not None and out.requires_grad
     with warnings.catch_warnings():
         warnings.simplefilter('error')
         m(x)                                          # once per process
         with torch.no_grad():
-            m(x)
-        m.eval()(x)
+            fast = m(x)
+        assert fast.grad_fn is None
+    assert cases.worst_ratio(out.detach(), fast.cpu(), 1e-4, 1e-5) <= 1.5
+    assert m.eval()(x).grad_fn is None
+
+
+@pytest.mark.parametrize('arch,use_rnn', [(cases.ARCH_D, True), (cases.ARCH_M, False), ([[0, 1], [5, 1, 0], [2, 0, 1, 1]], True)])
+def test_loss_backward_through_the_model_matches_the_reference_arithmetic(arch, use_rnn):
+    """loss.backward() through ASRModel: gradients of sum(logits * r) with respect to EVERY parameter against
+    ATen's autograd through the oracle's forward (the reference's op sequence, fp64) on the CPU.
+
+    Every op's backward is pinned on its own at the 1e-7 level (test_backward_gpu.py; a whole cell in isolation likewise); what this
+    test adds is the WIRING of ~90 functions.  Its tolerance has to live with the network not being smooth: one activation within
+    fp32 rounding of 0 (or 20) passes its gradient in one fp32 evaluation and not in the other, which moves the gradients of that layer
+    and of everything upstream by ~1e-3 relative (tests/grad_diag.py shows exactly that pattern: 2e-6 down to one node, 1e-3 above it).
+    So: every parameter within 2e-2 relative RMS (a wiring mistake is O(1)), and the layers behind the last such flip -- at least a
+    third of all parameters -- at fp32 level."""
+    m = build(arch, use_rnn, 'lively', seed=91).train()
+    x = keyed_input(2, 37, seed=7)
+    state = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    torch.set_grad_enabled(True)
+    params = {k: v.clone().double().requires_grad_(True) for k, v in state.items()}
+    ref = oracle.asr_forward(params, arch, x, use_rnn=use_rnn, dtype=torch.float64, differentiable=True)
+    r = torch.randn(ref.shape, generator=torch.Generator().manual_seed(5))
+    (ref * r.double()).sum().backward()
+    out = m(x.to(DEV))
+    assert cases.worst_ratio(out.detach(), ref.detach().float(), 1e-4, 1e-5) <= 2.0
+    m.zero_grad()
+    (out * r.to(DEV)).sum().backward()
+    named = dict(m.named_parameters())
+    rel = {}
+    for key, p in named.items():
+        truth = params[key].grad
+        if truth is None:
+            continue
+        assert p.grad is not None, key
+        rms = lambda t: float(t.double().pow(2).mean().sqrt())                   # noqa: E731
+        rel[key] = rms(p.grad.cpu().double() - truth) / (rms(truth) + 1e-30)
+        assert rel[key] <= 2e-2, f'{key}: relative rms error {rel[key]:.3e}'
+    exact = sum(v <= 1e-5 for v in rel.values())
+    print(f'{len(rel)} parameter gradients checked: worst relative rms error {max(rel.values()):.2e}, {exact} at fp32 level')
+    assert len(rel) >= len(named) - 2 and exact >= len(rel) // 3, (len(rel), len(named), exact)
+
+
+def test_an_sgd_step_on_the_ctc_loss_lowers_it():
+    """The trainer's step (trainer.py:215-225) with the HIP CTC loss: forward in training mode, loss.backward(), SGD."""
+    from nb_asr_amd import ctc
+    m = build(cases.ARCH_D, True, 'lively', seed=3).train()
+    x = keyed_input(2, 64, seed=1).to(DEV)
+    targets = torch.tensor([[3, 7, 7, 12], [5, 1, 0, 0]], dtype=torch.int32, device=DEV)
+    target_len = torch.tensor([4, 2], dtype=torch.int32, device=DEV)
+    out_len = torch.tensor([16, 16], dtype=torch.int32, device=DEV)
+    opt = torch.optim.SGD(m.parameters(), lr=0.02)
+    losses = []
+    for _ in range(3):
+        logits = m(x)
+        loss = torch.nn.functional.ctc_loss(torch.log_softmax(logits, -1).permute(1, 0, 2), targets.long(), out_len.long(), target_len.long(),
+                                            blank=0, zero_infinity=True)
+        losses.append(float(loss))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    assert losses[-1] < losses[0], losses
 
 
 # ---- boundary hardening (VERDICT r1 "What's weak" 11, 12; ADVICE r1) --------------------------------------------------------
