@@ -205,7 +205,7 @@ def model_forward(model, x):
             if layer.use_norm:
                 act = layer_norm_channels(act, layer.norm_layer.weight, layer.norm_layer.bias, layer.norm_layer.eps)
         elif isinstance(layer, nn.Dropout):
-            pass                                               # identity: p == 0 or eval (ASRModel checks)
+            act = layer(act)                                   # ATen's dropout (identity in eval mode or with p == 0)
         elif isinstance(layer, nn.LSTM):
             act = lstm(act, layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0)      # (B, T, H)
         elif isinstance(layer, nn.Linear):

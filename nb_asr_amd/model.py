@@ -147,7 +147,6 @@ class ASRModel(nn.Module):
 
     def forward(self, input, _taps=None, _pipelined=False):
         """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1)."""
-        _check_dropout(self)
         if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES:
             raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor, got {tuple(getattr(input, "shape", ()))}')
         if not input.is_cuda:
@@ -163,6 +162,7 @@ class ASRModel(nn.Module):
                               'Call model.eval() / torch.no_grad() for inference.', stacklevel=2)
             from .autograd import model_forward
             return model_forward(self, input)
+        _check_dropout(self)                         # the fused inference executor has no dropout masks: eval() or p == 0
         # one plan per device, re-used for every batch shape (grow-only workspaces); a second plan only comes into being
         # when two threads are inside forward() on the same device at once
         plan = self._plans.acquire(input.device)

@@ -38,6 +38,13 @@ def _pitched(x):
     return buf, frames
 
 
+def _train_dropout(module, y):
+    """The op's trailing nn.Dropout (reference ops.py:22,29 / 38,47) on the differentiable path: ATen's dropout on the op's output."""
+    if module.training and module.dropout_rate > 0:
+        return torch.nn.functional.dropout(y, module.dropout_rate, True)
+    return y
+
+
 def _check_dropout(module):
     if module.training and module.dropout_rate > 0:
         raise NotImplementedError('training-mode dropout (p > 0) is outside the HIP forward path; '
@@ -66,22 +73,22 @@ class PadConvRelu(nn.Module):
         return (frames + self.strides - 1) // self.strides
 
     def forward(self, x):
+        differentiable = torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad) and x.dtype == torch.float32
+        if differentiable and self.groups == 1 and self.kernel_size == 8 and self.dilation == 1:
+            from .autograd import dense_pad_conv_relu               # trainable on its own
+            return _train_dropout(self, dense_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.strides))
+        if differentiable and self.groups > 1 and self.strides == 1:
+            from .autograd import grouped_pad_conv_relu              # the node op is trainable on its own (first block)
+            return _train_dropout(self, grouped_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.groups, self.kernel_size, self.dilation))
         _check_dropout(self)
         xp, frames = _pitched(x)
         t_out = self.out_frames(frames)
         y = torch.empty(xp.shape[0], self.conv.out_channels, hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
         if self.groups == 1:
-            if torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad) and x.dtype == torch.float32 \
-                    and self.kernel_size == 8 and self.dilation == 1:
-                from .autograd import dense_pad_conv_relu           # trainable on its own
-                return dense_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.strides)
             hip.dense_conv1d_fused(xp, frames, self.conv.weight.detach(), self.conv.bias.detach(), (), y, self.strides)
         else:
             if self.strides != 1:
                 raise NotImplementedError('grouped PadConvRelu only exists with stride 1 in the search space')
-            if torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad) and x.dtype == torch.float32:
-                from .autograd import grouped_pad_conv_relu          # the node op is trainable on its own (first block)
-                return grouped_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.groups, self.kernel_size, self.dilation)
             hip.grouped_conv1d_fused(xp, self.conv.weight.detach(), self.conv.bias.detach(), (), y, frames,
                                      self.groups, self.kernel_size, self.dilation)
         return y[:, :, :t_out]
@@ -97,10 +104,10 @@ class Linear(nn.Module):
         self.linear = nn.Linear(in_features, out_features)      # parameter container
 
     def forward(self, x):
-        _check_dropout(self)
         if torch.is_grad_enabled() and (x.requires_grad or self.linear.weight.requires_grad) and x.dtype == torch.float32:
             from .autograd import dense_pad_conv_relu               # trainable on its own
-            return dense_pad_conv_relu(x, self.linear.weight, self.linear.bias, 1)
+            return _train_dropout(self, dense_pad_conv_relu(x, self.linear.weight, self.linear.bias, 1))
+        _check_dropout(self)
         xp, frames = _pitched(x)
         y = torch.empty(xp.shape[0], self.linear.out_features, xp.shape[2], device=xp.device, dtype=xp.dtype)
         hip.dense_conv1d_fused(xp, frames, self.linear.weight.detach().unsqueeze(-1), self.linear.bias.detach(), (), y, 1)

@@ -317,6 +317,28 @@ def test_loss_backward_through_the_model_matches_the_reference_arithmetic(arch, 
     assert len(rel) >= len(named) - 2 and exact >= len(rel) // 3, (len(rel), len(named), exact)
 
 
+def test_training_mode_dropout():
+    """dropout_rate > 0 (reference ops.py:22,29; model.py:106): masks on the differentiable path, identity in eval, and the fused
+    inference executor refuses to run a training-mode model with p > 0 (no silent no-op)."""
+    m = nb.get_model(cases.ARCH_D, use_rnn=True, dropout_rate=0.2)
+    keyed_fill_(m, 5, 'lively')
+    m = m.to(DEV)
+    x = keyed_input(2, 40, seed=2).to(DEV)
+    a, b = m(x), m(x)                                   # training mode, gradients enabled: two different masks
+    assert a.grad_fn is not None and not torch.equal(a, b)
+    a.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+    with torch.no_grad(), pytest.raises(NotImplementedError, match='dropout'):
+        m(x)
+    m.eval()
+    with torch.no_grad():
+        assert torch.equal(m(x), m(x))
+    op = m.model[2].nodes[0].op.train()
+    y = op(torch.randn(2, 600, 50, device=DEV).requires_grad_(True))
+    zeros = float((y == 0).float().mean())
+    assert 0.5 < zeros < 0.75                           # relu zeros (~half) plus a fifth of the rest dropped
+
+
 def test_an_sgd_step_on_the_ctc_loss_lowers_it():
     """The trainer's step (trainer.py:215-225) with the HIP CTC loss: forward in training mode, loss.backward(), SGD."""
     from nb_asr_amd import ctc

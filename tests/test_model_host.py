@@ -95,8 +95,8 @@ def test_checkpoint_round_trip_and_prunable_copy():
 
 def test_no_cpu_path_and_no_silent_dropout():
     m = nb.get_model(cases.ARCH_A, use_rnn=True, dropout_rate=0.2)
-    with pytest.raises(NotImplementedError, match='dropout'):
-        m(torch.zeros(1, 80, 16))
+    with pytest.raises(hip.HipError, match='no CPU path'):
+        m(torch.zeros(1, 80, 16))                     # (training-mode dropout itself: test_model_gpu.py::test_training_mode_dropout)
     m.eval()
     with pytest.raises(hip.HipError, match='no CPU path'):
         m(torch.zeros(1, 80, 16))
