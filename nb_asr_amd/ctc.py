@@ -91,8 +91,8 @@ def decode_per(log_probs, output_len, targets, targets_len, beam_width=12, fold_
 def ctc_loss(log_probs, output_len, targets, targets_len, blank=0):
     """The reference's loss value (``get_loss()``, trainer.py:36-42): ``F.ctc_loss(log_probs.permute(1, 0, 2), targets, output_len,
     targets_len, reduction='none', zero_infinity=True) / output_len`` averaged over the batch -- what ``Trainer.step`` reports
-    for validation and test batches.  ``log_probs`` (B, T', C) stays batch-major on the device.  Forward value only: it is not
-    attached to the autograd graph (training is SURVEY.md 8 row f4)."""
+    for validation and test batches.  ``log_probs`` (B, T', C) stays batch-major on the device.  Forward value only (validation / test); the
+    training step uses ``training_loss`` below."""
     dev = log_probs.device
     b = log_probs.shape[0]
     per = hip.ctc_loss(log_probs.contiguous(), _lengths(output_len, b, dev), targets.to(device=dev, dtype=torch.int32).contiguous(),
@@ -136,11 +136,30 @@ def evaluate(model, batches, beam_width=12):
 
 def ctc_loss_and_grad(log_probs, output_len, targets, targets_len, blank=0):
     """``ctc_loss`` together with the gradient of that scalar with respect to the LOGITS (``log_probs = log_softmax(logits)``):
-    what the reference's ``loss.backward()`` hands to the model (trainer.py:220-223, without its weight-norm term).  The first
-    step of a backward pass; the model itself has none yet.  Returns ``(loss, grad_logits)``."""
+    what the reference's ``loss.backward()`` hands to the model (trainer.py:220-223, without its weight-norm term).  Returns
+    ``(loss, grad_logits)``; ``training_loss`` wraps it as an autograd function."""
     dev = log_probs.device
     b = log_probs.shape[0]
     per, grad = hip.ctc_loss_grad(log_probs.contiguous(), _lengths(output_len, b, dev), targets.to(device=dev, dtype=torch.int32).contiguous(),
                                   _lengths(targets_len, b, dev), blank)
     return per.mean(), grad
 
+
+class _TrainingLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, output_len, targets, targets_len, blank):
+        loss, grad = ctc_loss_and_grad(log_softmax(logits.detach().contiguous()), output_len, targets, targets_len, blank)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None
+
+
+def training_loss(logits, output_len, targets, targets_len, blank=0):
+    """The trainer's loss on the LOGITS of a training-mode forward (trainer.py:215-223: ``log_softmax`` -> ``get_loss`` -> mean), attached
+    to the autograd graph: ``training_loss(model.train()(x), ...).backward()`` reaches every parameter.  Loss and gradient with respect
+    to the logits come from one HIP kernel pair (nbasr_ctc_loss_grad); add the reference's weight-norm term with torch if wanted."""
+    return _TrainingLoss.apply(logits, output_len, targets, targets_len, blank)

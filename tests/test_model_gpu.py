@@ -351,8 +351,15 @@ def test_an_sgd_step_on_the_ctc_loss_lowers_it():
     losses = []
     for _ in range(3):
         logits = m(x)
-        loss = torch.nn.functional.ctc_loss(torch.log_softmax(logits, -1).permute(1, 0, 2), targets.long(), out_len.long(), target_len.long(),
-                                            blank=0, zero_infinity=True)
+        loss = ctc.training_loss(logits, out_len, targets, target_len)
+        if not losses:                                  # the HIP loss and its gradient against ATen's CTC on the same logits
+            probe = logits.detach().clone().requires_grad_(True)
+            ref = (torch.nn.functional.ctc_loss(torch.log_softmax(probe, -1).permute(1, 0, 2), targets.long(), out_len.long(), target_len.long(),
+                                                blank=0, reduction='none', zero_infinity=True) / out_len).mean()
+            ref.backward()
+            mine = logits.detach().clone().requires_grad_(True)
+            ctc.training_loss(mine, out_len, targets, target_len).backward()
+            assert abs(float(ref) - float(loss)) <= 1e-4 * abs(float(ref)) and torch.allclose(mine.grad, probe.grad, rtol=1e-3, atol=1e-6)
         losses.append(float(loss))
         opt.zero_grad()
         loss.backward()
