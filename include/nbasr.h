@@ -493,11 +493,12 @@ int nbasr_rows_of_channels(const float* dz, float* rows, int batch, int channels
  * utterances innermost (ldb = batch rounded up to 4), rows = 4 * hidden (PyTorch gate order i, f, g, o) or hidden:
  *   nbasr_lstm_gate_scan       pre (4H, T, ldb) = input projection + w_hh . h_(t-1) for ALL frames (one GEMM on the saved h) is
  *                              overwritten by the gate activations, cells (H, T, ldb) <- c_t
- *   nbasr_lstm_backward_step   frame t of the reverse recurrence: dh_out (H, T, ldb) = dL/d(output), rec (H, ldb) = w_hh^T . dpre[:, t+1, :]
- *                              (NULL at the last frame), dc (H, ldb) the carried dL/dc_t -> dpre[:, t, :] and the new carry
+ *   nbasr_lstm_backward_step   frame t of the reverse recurrence: dh_out (H, T, ldb) = dL/d(output), w_hh_t (H, 4H) the transposed recurrent
+ *                              weight (the term w_hh^T . dpre[:, t+1, :] is formed in the kernel), dc (H, ldb) the carried dL/dc_t ->
+ *                              dpre[:, t, :] and the new carry; call for t = T-1 .. 0
  * The GEMMs in between (nbasr_pointwise_linear) and the orchestration are in nb_asr_amd/autograd.py. */
 int nbasr_lstm_gate_scan(float* pre, float* cells, int hidden, int frames, int batch, int ldb, nbasr_stream_t stream);
-int nbasr_lstm_backward_step(const float* dh_out, const float* rec, float* dc, const float* acts, const float* cells, float* dpre,
+int nbasr_lstm_backward_step(const float* dh_out, const float* w_hh_t, float* dc, const float* acts, const float* cells, float* dpre,
                              int hidden, int frames, int batch, int ldb, int t, nbasr_stream_t stream);
 
 #ifdef __cplusplus

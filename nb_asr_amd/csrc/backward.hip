@@ -509,17 +509,39 @@ __global__ __launch_bounds__(256) void lstm_gate_scan_kernel(float* __restrict__
     }
 }
 
-// One step of the reverse recurrence: dh_out (H, T, ldb) = dL/dh of the layer's output, rec (H, ldb) = w_hh^T . dpre[:, t + 1, :] (NULL at
-// the last frame), dc (H, ldb) the carried dL/dc_t part -> dpre[:, t, :] (4H rows) and the updated carry dL/dc_(t-1).
-__global__ __launch_bounds__(256) void lstm_backward_step_kernel(const float* __restrict__ dh_out, const float* __restrict__ rec,
+// One step of the reverse recurrence: dh_out (H, T, ldb) = dL/dh of the layer's output, w_hh_t (H, 4H) the transposed recurrent weight,
+// dc (H, ldb) the carried dL/dc_t part -> dpre[:, t, :] (4H rows; reads dpre[:, t + 1, :]) and the updated carry dL/dc_(t-1).
+__global__ __launch_bounds__(256) void lstm_backward_step_kernel(const float* __restrict__ dh_out, const float* __restrict__ w_hh_t,
                                                                  float* __restrict__ dc, const float* __restrict__ acts,
                                                                  const float* __restrict__ cells, float* __restrict__ dpre, int hidden,
                                                                  int frames, int batch, int ldb, int t)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // 256 threads = 64 utterances x 4 slices of the 4H gate rows: each slice sums its quarter of (w_hh^T . dpre[:, t + 1, :])[j][b],
+    // the slices meet in LDS, slice 0 does the cell arithmetic.  (As a launch of the tiled GEMM this (500 x 2000) x (2000 x 64) product
+    // ran on 4 workgroups, 240 us per frame; one 64-thread wave per unit walking all 2 000 rows took ~160 us.)
+    __shared__ float s_part[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int b = blockIdx.x * 64 + lane;
     const int j = blockIdx.y;
-    if (b >= ldb) return;
     const size_t plane = static_cast<size_t>(frames) * ldb, gate_stride = static_cast<size_t>(hidden) * plane;
+    float rec = 0.f;
+    if (t + 1 < frames && b < ldb) {
+        const int rows = 4 * hidden, per = (rows + 3) / 4;
+        const int g0 = slice * per, g1 = min(rows, g0 + per);
+        const float* __restrict__ wrow = w_hh_t + static_cast<size_t>(j) * rows;
+        const float* __restrict__ dnext = dpre + static_cast<size_t>(t + 1) * ldb + b;
+        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int g = g0;
+        for (; g + 7 < g1; g += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) r[u] = __builtin_fmaf(wrow[g + u], dnext[static_cast<size_t>(g + u) * plane], r[u]);
+        }
+        for (; g < g1; ++g) r[0] = __builtin_fmaf(wrow[g], dnext[static_cast<size_t>(g) * plane], r[0]);
+        rec = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    }
+    s_part[slice][lane] = rec;
+    __syncthreads();
+    if (slice != 0 || b >= ldb) return;
     const size_t at = static_cast<size_t>(j) * plane + static_cast<size_t>(t) * ldb + b;
     const size_t hb = static_cast<size_t>(j) * ldb + b;
     if (b >= batch) {                                          // pitch columns: exact zeros for the GEMMs that read them
@@ -529,7 +551,8 @@ __global__ __launch_bounds__(256) void lstm_backward_step_kernel(const float* __
     const float i = acts[at], f = acts[at + gate_stride], g = acts[at + 2 * gate_stride], o = acts[at + 3 * gate_stride];
     const float c = cells[at], c_prev = t > 0 ? cells[at - ldb] : 0.f;
     const float tc = tanhf(c);
-    const float gh = dh_out[at] + (rec ? rec[hb] : 0.f);       // dL/dh_t: from the output, and from frame t + 1 through w_hh
+    // dL/dh_t: from the layer's output, and from frame t + 1 through the recurrence
+    const float gh = dh_out[at] + ((s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]));
     const float d_o = gh * tc;
     const float d_c = dc[hb] + gh * o * (1.f - tc * tc);
     dpre[at] = d_c * g * i * (1.f - i);
@@ -552,14 +575,14 @@ extern "C" int nbasr_lstm_gate_scan(float* pre, float* cells, int hidden, int fr
     return launch_status("nbasr_lstm_gate_scan");
 }
 
-extern "C" int nbasr_lstm_backward_step(const float* dh_out, const float* rec, float* dc, const float* acts, const float* cells, float* dpre,
+extern "C" int nbasr_lstm_backward_step(const float* dh_out, const float* w_hh_t, float* dc, const float* acts, const float* cells, float* dpre,
                                         int hidden, int frames, int batch, int ldb, int t, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(hidden > 0 && frames > 0 && batch > 0 && ldb >= batch && t >= 0 && t < frames, NBASR_EINVAL, "nbasr_lstm_backward_step: bad sizes");
-    NBASR_REQUIRE(dh_out && dc && acts && cells && dpre, NBASR_ENULL, "nbasr_lstm_backward_step: NULL pointer");
+    NBASR_REQUIRE(dh_out && w_hh_t && dc && acts && cells && dpre, NBASR_ENULL, "nbasr_lstm_backward_step: NULL pointer");
     NBASR_REQUIRE(hidden <= 65535, NBASR_EINVAL, "nbasr_lstm_backward_step: hidden %d > 65535", hidden);
-    hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((ldb + 63) / 64, hidden), dim3(64), 0, as_stream(stream), dh_out, rec, dc, acts, cells, dpre,
+    hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((ldb + 63) / 64, hidden), dim3(256), 0, as_stream(stream), dh_out, w_hh_t, dc, acts, cells, dpre,
                        hidden, frames, batch, ldb, t);
     return launch_status("nbasr_lstm_backward_step");
 }

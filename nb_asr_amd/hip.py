@@ -8,6 +8,7 @@ There is NO fallback: if the library is missing or the tensors are not on a HIP 
 call fails loudly (build with ``python -m nb_asr_amd.build``).
 """
 import ctypes
+import os
 import threading
 import pathlib
 
@@ -996,14 +997,29 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
                                    stream), 'nbasr_conv_cols')
         rows = torch.empty(c_out, b * t_pad, device=x.device, dtype=torch.float32)
         _check(lib.nbasr_rows_of_channels(_dev(dz, 'dz'), _dev(rows, 'rows'), b, c_out, frames_out, ld_out, t_pad, stream), 'nbasr_rows_of_channels')
-        out = torch.empty(1, c_out, ld_cols, device=x.device, dtype=torch.float32)
         zero_o = torch.zeros(c_out, device=x.device, dtype=torch.float32)
-        _check(lib.nbasr_pointwise_linear(_dev(cols, 'cols'), _dev(rows, 'rows'), _dev(zero_o, 'zero'), _dev(out, 'out'), 1, b * t_pad,
-                                          c_in * kernel + 1, ld_cols, c_out, ld_cols, stream), 'nbasr_pointwise_linear')
-        dw = out[0, :, : c_in * kernel].reshape(c_out, c_in, kernel).contiguous()
+        if os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32':
+            # the (C_out, B T') x (B T', C_in k + 1) product on the fp16 matrix cores, fp32-accurate two-term split (the GEMM of the LSTM
+            # input projection: "weights" = the masked output gradient packed per call, "x" = the column matrix pre-split per column tile);
+            # it stores time-major, i.e. the transpose (C_in k + 1, C_out).  3-5 x the exact-fp32 MFMA GEMM, which was half of a training step
+            c_pad = (c_out + 15) & ~15                       # (that entry point takes 4 * hidden rows, hidden % 4 == 0)
+            if c_pad != c_out:
+                rows = torch.cat([rows, rows.new_zeros(c_pad - c_out, rows.shape[1])])
+            zero_p = torch.zeros(c_pad, device=x.device, dtype=torch.float32)
+            packed = pack_pointwise_weights(rows)
+            ws = pointwise_workspace(1, b * t_pad, ld_cols, x.device)
+            out_t = torch.empty(ld_cols, 1, c_pad, device=x.device, dtype=torch.float32)
+            lstm_input_projection_packed(cols.view(1, b * t_pad, ld_cols), c_in * kernel + 1, packed, zero_p, zero_p, out_t, c_pad // 4, ws)
+            out = out_t.view(ld_cols, c_pad).t()[:c_out]
+        else:
+            out3 = torch.empty(1, c_out, ld_cols, device=x.device, dtype=torch.float32)
+            _check(lib.nbasr_pointwise_linear(_dev(cols, 'cols'), _dev(rows, 'rows'), _dev(zero_o, 'zero'), _dev(out3, 'out'), 1, b * t_pad,
+                                              c_in * kernel + 1, ld_cols, c_out, ld_cols, stream), 'nbasr_pointwise_linear')
+            out = out3[0]
+        dw = out[:, : c_in * kernel].reshape(c_out, c_in, kernel).contiguous()
         if weight.dim() == 2:
             dw = dw.reshape(c_out, c_in)
-        db = out[0, :, c_in * kernel].contiguous()
+        db = out[:, c_in * kernel].contiguous()
     return dx, dw, db
 
 
@@ -1012,7 +1028,7 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
     projection (both biases included), h_out (B, T, H) the saved output, dh_out (B, T, H) -> (dx (B, C, T), dw_ih, dw_hh, db).
 
     Correctness first: gate pre-activations of all frames are recomputed from the saved h by ONE GEMM, a serial
-    scan restores the cell states, the reverse recurrence is T times {H x 4H GEMM, element-wise step}, and the weight / input gradients
+    scan restores the cell states, the reverse recurrence is T launches of a step kernel that forms w_hh^T . dpre of the next frame in place, and the weight / input gradients
     are three batched GEMMs -- every product on the exact-fp32 MFMA GEMM (nbasr_pointwise_linear); tensor re-layouts are torch copies."""
     lib = load_library()
     b, c, _ = xp.shape
@@ -1048,14 +1064,9 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
     dho[:, :, :b] = dh_out.detach().permute(2, 1, 0)
     dpre = torch.empty(g4, t_n, ldb, device=dev, dtype=f32)
     dc = torch.zeros(hidden, ldb, device=dev, dtype=f32)
-    rec = torch.empty(1, hidden, ldb, device=dev, dtype=f32)
     w_hh_t = w_hh.detach().t().contiguous()                    # (H, 4H)
     for t in range(t_n - 1, -1, -1):
-        rec_ptr = None
-        if t + 1 < t_n:
-            gemm(dpre.data_ptr() + 4 * (t + 1) * ldb, g4, ldb, n, w_hh_t, rec)        # rows of dpre[:, t + 1, :] sit n floats apart
-            rec_ptr = rec.data_ptr()
-        _check(lib.nbasr_lstm_backward_step(_dev(dho, 'dho'), rec_ptr, _dev(dc, 'dc'), _dev(acts, 'acts'), _dev(cells, 'cells'),
+        _check(lib.nbasr_lstm_backward_step(_dev(dho, 'dho'), _dev(w_hh_t, 'w_hh_t'), _dev(dc, 'dc'), _dev(acts, 'acts'), _dev(cells, 'cells'),
                                             _dev(dpre, 'dpre'), hidden, t_n, b, ldb, t, stream), 'nbasr_lstm_backward_step')
     d2 = dpre.view(g4, n)
     # dw_hh (4H, H) = dpre (4H, n) . h_prev (n, H)
