@@ -246,15 +246,34 @@ __global__ __launch_bounds__(256) void layernorm_backward_kernel(const float* __
     }
 }
 
+// 64 channels x 4 slices of the tile list per workgroup (a slice takes tiles s, s + 4, ...), the slices meet in LDS in a fixed order:
+// bit-reproducible.  (One thread per channel walking all 1 024 tiles of a 64 x 1000 batch ran on 5 workgroups: 250 us per LayerNorm.)
 __global__ __launch_bounds__(256) void layernorm_backward_reduce_kernel(const float* __restrict__ part, float* __restrict__ dgamma,
                                                                         float* __restrict__ dbeta, int tiles, int channels)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= channels) return;
-    float a = 0.f, bsum = 0.f;
-    for (int t = 0; t < tiles; ++t) { a += part[static_cast<size_t>(t) * 2 * channels + c]; bsum += part[static_cast<size_t>(t) * 2 * channels + channels + c]; }
-    dgamma[c] = a;
-    dbeta[c] = bsum;
+    __shared__ float s_a[4][64], s_b[4][64];
+    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}, bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < channels) {
+        int t = slice;
+        for (; t + 12 < tiles; t += 16) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t at = static_cast<size_t>(t + 4 * u) * 2 * channels + c;
+                a[u] += part[at];
+                bsum[u] += part[at + channels];
+            }
+        }
+        for (; t < tiles; t += 4) { const size_t at = static_cast<size_t>(t) * 2 * channels + c; a[0] += part[at]; bsum[0] += part[at + channels]; }
+    }
+    s_a[slice][lane] = (a[0] + a[1]) + (a[2] + a[3]);
+    s_b[slice][lane] = (bsum[0] + bsum[1]) + (bsum[2] + bsum[3]);
+    __syncthreads();
+    if (slice == 0 && c < channels) {
+        dgamma[c] = (s_a[0][lane] + s_a[1][lane]) + (s_a[2][lane] + s_a[3][lane]);
+        dbeta[c] = (s_b[0][lane] + s_b[1][lane]) + (s_b[2][lane] + s_b[3][lane]);
+    }
 }
 
 template <int CG>
@@ -354,7 +373,7 @@ extern "C" int nbasr_layernorm_channels_backward(const float* x, const float* st
     const int tiles_x = (ld / 4 + 15) / 16;
     hipLaunchKernelGGL(layernorm_backward_kernel, dim3(tiles_x, batch), dim3(256), 0, as_stream(stream), x, stats, gamma, dy, dx, workspace,
                        channels, frames, ld);
-    hipLaunchKernelGGL(layernorm_backward_reduce_kernel, dim3((channels + 255) / 256), dim3(256), 0, as_stream(stream), workspace, dgamma, dbeta,
+    hipLaunchKernelGGL(layernorm_backward_reduce_kernel, dim3((channels + 63) / 64), dim3(256), 0, as_stream(stream), workspace, dgamma, dbeta,
                        tiles_x * batch, channels);
     return launch_status("nbasr_layernorm_channels_backward");
 }
