@@ -9,6 +9,8 @@ former when a gradient is required, so the op is trainable on its own.  Also ``d
 LSTM (model.py:100,118-121).  What does not exist yet: the head's backward, dropout masks, and therefore ``loss.backward()`` through ``ASRModel`` (its forward still
 returns detached logits and says so).
 """
+import os
+
 import torch
 
 from . import hip
@@ -76,7 +78,13 @@ class _DensePadConvRelu(torch.autograd.Function):
         w3 = weight.detach() if weight.dim() == 3 else weight.detach().unsqueeze(-1)
         t_out = (frames + stride - 1) // stride
         y = torch.empty(xp.shape[0], weight.shape[0], hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
-        hip.dense_conv1d_fused(xp, frames, w3, bias.detach(), (), y, stride)
+        if kernel == 8 and os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32' and xp.data_ptr() % 16 == 0:
+            # the three-term bf16 split (fp32's range, no range information needed, fp32-level error): half the time of the exact-fp32
+            # MFMA GEMM; the weights change every step, so they are packed per call (tens of microseconds)
+            hip.dense_conv1d_fused_packed(xp, frames, hip.pack_dense_weights(w3.contiguous(), stride, 'bf16x3'), weight.shape[0], 8, bias.detach(),
+                                          (), y, stride, None, 'bf16x3')
+        else:
+            hip.dense_conv1d_fused(xp, frames, w3, bias.detach(), (), y, stride)
         ctx.save_for_backward(xp, weight.detach(), y)
         ctx.cfg = (frames, stride, t_out, kernel)
         return y[:, :, :t_out]
