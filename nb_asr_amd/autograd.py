@@ -182,9 +182,38 @@ def layer_norm_channels(x, gamma, beta, eps=1e-3):
     return _LayerNormChannels.apply(x, gamma, beta, eps)
 
 
+class _SkipSum(torch.autograd.Function):
+    """The node's sum (reference model.py:22, python ``sum`` over the main op's output and the flagged inputs) on the HIP skip-sum kernel,
+    left to right, three tensors per launch; the gradient of a sum is the incoming gradient for every term."""
+
+    @staticmethod
+    def forward(ctx, *terms):
+        pitched = [_pitched(t) for t in terms]
+        frames = pitched[0][1]
+        acc = None
+        rest = [p for p, _ in pitched]
+        while rest:
+            take = ([acc] if acc is not None else []) + rest[: 3 - (acc is not None)]
+            rest = rest[3 - (acc is not None):]
+            out = torch.empty_like(take[0])
+            hip.skip_sum(take, out, frames)
+            acc = out
+        ctx.n = len(terms)
+        return acc[:, :, :frames]
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g for _ in range(ctx.n))
+
+
+def skip_sum(terms):
+    """Sum of (B, C, T) tensors, differentiable; a single term is returned as it is."""
+    return terms[0] if len(terms) == 1 else _SkipSum.apply(*terms)
+
+
 def model_forward(model, x):
     """The differentiable forward of an ``ASRModel`` (reference model.py:116-131 under autograd): the same layer list, every op through
-    its ``torch.autograd.Function`` above, skip sums as tensor additions.  One launch group per op, nothing fused or deferred -- the
+    its ``torch.autograd.Function`` above, the node sums on the skip-sum kernel.  One launch group per op, nothing fused or deferred -- the
     inference executor stays the fast path; this is what ``loss.backward()`` runs through."""
     import torch.nn as nn
     from .model import SearchCell
@@ -202,13 +231,9 @@ def model_forward(model, x):
             outs = [act]
             for node in layer.nodes:
                 op = node.op
-                main = None if isinstance(op, Zero) else op(outs[-1])
-                for branch, src in zip(node.branch_ops, outs):
-                    if isinstance(branch, Identity):
-                        main = src if main is None else main + src
-                if main is None:
-                    main = torch.zeros_like(outs[-1])
-                outs.append(main)
+                terms = [] if isinstance(op, Zero) else [op(outs[-1])]
+                terms += [src for branch, src in zip(node.branch_ops, outs) if isinstance(branch, Identity)]
+                outs.append(skip_sum(terms) if terms else op(outs[-1]))          # (no term at all: the `zero` op's zeros)
             act = outs[-1]
             if layer.use_norm:
                 act = layer_norm_channels(act, layer.norm_layer.weight, layer.norm_layer.bias, layer.norm_layer.eps)
