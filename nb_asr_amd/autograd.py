@@ -1,13 +1,18 @@
-"""Differentiable building blocks (bottom-up): the grouped node op and the channel LayerNorm with HIP
-backward kernels, as ``torch.autograd.Function``s.
+"""The differentiable path: one ``torch.autograd.Function`` per op of the model, forward AND backward through the
+C ABI, and ``model_forward`` which strings them together -- what ``ASRModel.forward`` runs in training mode with gradients enabled,
+so that the reference's ``loss.backward()`` (trainer.py:220-223) reaches every parameter.
 
-What exists: ``grouped_pad_conv_relu`` (reference ``ops.PadConvRelu`` with groups > 1, ops.py:24-30) and ``layer_norm_channels``
-(``nn.LayerNorm`` over the channel dimension of (B, C, T), model.py:55-58) -- forward AND backward through the C ABI, gradients
-checked against the reference modules' own autograd (tests/golden/grad_fixtures.npz).  ``ops.PadConvRelu`` (grouped) calls the
-former when a gradient is required, so the op is trainable on its own.  Also ``dense_pad_conv_relu``: the dense k = 8 downsample convs
-(model.py:82-89) and the per-frame ``linear`` op (ops.py:42-50), correctness-first on the exact-fp32 GEMMs of the forward.  ``lstm``: BPTT of the single-layer
-LSTM (model.py:100,118-121).  What does not exist yet: the head's backward, dropout masks, and therefore ``loss.backward()`` through ``ASRModel`` (its forward still
-returns detached logits and says so).
+* ``grouped_pad_conv_relu``  reference ``ops.PadConvRelu`` with groups > 1 (ops.py:24-30): vector-ALU dgrad, MFMA wgrad
+* ``dense_pad_conv_relu``    the dense k = 8 downsample convs (model.py:82-89) and the per-frame ``linear`` op (ops.py:42-50)
+* ``layer_norm_channels``    ``nn.LayerNorm`` over the channel dimension of (B, C, T) (model.py:55-58)
+* ``lstm``                   the single-layer LSTM (model.py:100,118-121), BPTT
+* ``pointwise_linear``       the CTC head (model.py:101-103,122-124)
+* ``skip_sum``               a node's sum over its flagged inputs (model.py:22)
+
+Correctness first: one launch group per op, nothing fused or deferred, tensor re-layouts as torch copies; gradients are checked against
+the reference modules' own autograd (tests/golden/grad_fixtures.npz, tests/test_backward_gpu.py) and, for the whole model, against fp64
+autograd through the oracle (tests/test_model_gpu.py).  Training-mode dropout (p > 0) is ATen's dropout on each op's output, as the
+reference places it (ops.py:22,29).  The fused inference executor (executor.py) stays the fast path for eval() / torch.no_grad().
 """
 import os
 
