@@ -1,4 +1,4 @@
-"""Multi-GPU execution of the forward pass: batch-sharded replicas, one process per GPU.
+"""Multi-GPU execution: batch-sharded replicas, one process per GPU (forward: one all-gather of the logits; training: bucketed all-reduce of the gradients).
 
 Utterances are independent (no BatchNorm, LayerNorm is per frame), so the path shards along the batch with
 NO collective inside the forward; every rank holds a full weight replica (105 MB fp32).  The only exchange is
@@ -73,6 +73,43 @@ class ShardedForward:
         """Shard a replicated global batch, forward this rank's slice, gather all logits in original order."""
         begin, end = shard_bounds(global_x.shape[0], self.world_size, self.rank)
         return self.gather_ragged(model(global_x[begin:end]), global_x.shape[0])
+
+    def allreduce_gradients(self, parameters, bucket_bytes=64 << 20):
+        """Data-parallel training step (what the reference does with nn.DataParallel, trainer.py:91-92, as one process per GPU): after
+        ``loss.backward()`` on this rank's shard, average the gradients over the ranks IN PLACE.  The gradients are flattened into
+        buckets of ``bucket_bytes`` (the model's 105 MB of fp32 gradients: two 64 MiB all-reduces -- ring all-reduce over xGMI is bound
+        per link, a few large messages amortise its latency where 166 small ones would not) and copied back.  Parameters without a
+        gradient on this rank contribute zeros (every rank must pass the same parameter list)."""
+        params = [p for p in parameters if p.requires_grad]
+        if not self.collective or not params:
+            return
+        bucket, size = [], 0
+
+        def flush():
+            if not bucket:
+                return
+            flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= self.world_size
+            offset = 0
+            for p in bucket:
+                n = p.numel()
+                piece = flat[offset: offset + n].view_as(p)
+                if p.grad is None:
+                    p.grad = piece.clone()
+                else:
+                    p.grad.copy_(piece)
+                offset += n
+            bucket.clear()
+
+        for p in params:
+            nbytes = p.numel() * p.element_size()
+            if bucket and (size + nbytes > bucket_bytes or p.dtype != bucket[0].dtype):
+                flush()
+                size = 0
+            bucket.append(p)
+            size += nbytes
+        flush()
 
     def barrier(self):
         if self.collective:

@@ -75,6 +75,42 @@ def test_two_rank_gloo_sharded_forward(n_items):
         assert slowest == 10.0 + (world - 1)
 
 
+def _grad_worker(rank, world, port, out_queue):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    runner = ShardedForward(world_size=world, rank=rank, device='cpu', backend='gloo')
+    torch.manual_seed(0)                                   # the same replica on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(7, 300), torch.nn.Tanh(), torch.nn.Linear(300, 5))
+    frozen = torch.nn.Parameter(torch.ones(3), requires_grad=False)
+    unused = torch.nn.Parameter(torch.ones(11))            # no gradient on any rank: must come back as zeros, not hang
+    x = torch.randn(6, 7)
+    lo, hi = shard_bounds(6, world, rank)
+    net(x[lo:hi]).pow(2).sum().backward()                  # this rank's shard; loss = SUM over utterances
+    runner.allreduce_gradients(list(net.parameters()) + [frozen, unused], bucket_bytes=4096)     # several buckets
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 300), torch.nn.Tanh(), torch.nn.Linear(300, 5))
+    ref.load_state_dict(net.state_dict())
+    ref(x).pow(2).sum().backward()                         # the whole batch on one rank
+    ok = all(torch.allclose(p.grad * world, q.grad, rtol=1e-5, atol=1e-6) for p, q in zip(net.parameters(), ref.parameters()))
+    ok = ok and frozen.grad is None and unused.grad is not None and bool((unused.grad == 0).all())
+    runner.close()
+    out_queue.put((rank, ok))
+
+
+def test_two_rank_gradient_allreduce():
+    """Data-parallel training: per-rank backward on a shard + bucketed all-reduce == the gradient of the whole batch (averaged)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
+
+
 def test_single_process_is_a_no_op():
     runner = ShardedForward(world_size=1, rank=0, device='cpu')
     x = torch.randn(4, 80, 20)
