@@ -479,7 +479,11 @@ int nbasr_layernorm_channels_backward(const float* x, const float* stats, const 
  *   nbasr_conv_cols             cols[b * t_pad + t][ci * taps + j] = xpad[b][ci][t * stride + j - lpad], one column of ones behind
  *                               them (then zeros up to ld_cols >= c_in * taps + 1), rows t >= frames_out zero
  *   nbasr_rows_of_channels      rows[co][b * t_pad + t] = dz[b][co][t] (0 for t >= frames)
- * so that  nbasr_pointwise_linear(x = cols as (1, batch * t_pad, ld_cols), w = rows)  yields (dw | db) in one GEMM. */
+ * so that  nbasr_pointwise_linear(x = cols as (1, batch * t_pad, ld_cols), w = rows)  yields (dw | db) in one GEMM.
+ *   nbasr_conv_fold             the input gradient again, for the split 16-bit GEMM: cols (frames_out, batch, c_in * 8), time-major (what
+ *                               nbasr_lstm_input_projection_packed stores for w^T as (c_in * 8, c_out) rows (ci, tap) and x = the masked
+ *                               output gradient) -> dx[b][ci][u] = sum over taps j with u + lpad - j = t * stride of cols[t][b][ci * 8 + j];
+ *                               8 taps, stride 1 | 2; pitch columns of dx are zeroed */
 int nbasr_relu_clamp_backward(const float* y, const float* dy, float* dz, long long n, nbasr_stream_t stream);
 int nbasr_zero_stuff(const float* dz, float* up, int rows, int frames, int ld, int frames_up, int ld_up, int stride, int shift,
                      nbasr_stream_t stream);
@@ -488,6 +492,8 @@ int nbasr_dense_conv1d_linear(const float* x, const float* w, const float* bias,
 int nbasr_conv_cols(const float* x, float* cols, int batch, int c_in, int frames_in, int ld_in, int frames_out, int t_pad, int taps,
                     int stride, int lpad, int ld_cols, nbasr_stream_t stream);
 int nbasr_rows_of_channels(const float* dz, float* rows, int batch, int channels, int frames, int ld, int t_pad, nbasr_stream_t stream);
+int nbasr_conv_fold(const float* cols, float* dx, int batch, int c_in, int frames_in, int ld_in, int frames_out, int taps, int stride,
+                    int lpad, nbasr_stream_t stream);
 
 /* LSTM backward (BPTT; reference model.py:100,118-121 under autograd), correctness first.  Tensors are (rows, frames, ldb) with the
  * utterances innermost (ldb = batch rounded up to 4), rows = 4 * hidden (PyTorch gate order i, f, g, o) or hidden:

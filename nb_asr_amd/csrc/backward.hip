@@ -444,6 +444,52 @@ __global__ __launch_bounds__(256) void zero_stuff_kernel(const float* __restrict
         up[static_cast<size_t>(r) * ld_up + u] = hit ? dz[static_cast<size_t>(r) * ld + s / stride] : 0.f;
 }
 
+// The same input gradient as ONE GEMM over the un-stuffed gradient plus a fold: cols (T', B, C_in * 8), time-major -- the store of the
+// split 16-bit GEMM nbasr_lstm_input_projection_packed run on w^T (rows (ci, tap), K = C_out) and the masked output gradient -- holds
+// every tap's contribution; dx[b][ci][u] = sum over taps j with (u + lpad - j) = t * stride, 0 <= t < T', of cols[t][b][ci * 8 + j],
+// taps in ascending order (fixed summation order).  Half the products of the zero-stuffed conv at stride 2.  One workgroup: one
+// utterance x 32 channels x 32 frames; the <= 39 cols rows it needs (1 KiB each, contiguous) go through LDS so that HBM is read in
+// whole rows and written in 128-byte runs.
+constexpr int FOLD_T = 32, FOLD_C = 32, FOLD_TAPS = 8, FOLD_LD = FOLD_C * FOLD_TAPS + 4;
+template <int S>
+__global__ __launch_bounds__(256) void conv_fold_kernel(const float* __restrict__ cols, float* __restrict__ dx, int batch, int c_in,
+                                                        int frames_in, int ld_in, int frames_out, int lpad)
+{
+    constexpr int ROWS = (FOLD_T + FOLD_TAPS - 2) / S + 2;
+    __shared__ __attribute__((aligned(16))) float s_cols[ROWS][FOLD_LD];
+    const int u0 = blockIdx.x * FOLD_T, ci0 = blockIdx.y * FOLD_C, b = blockIdx.z;
+    const int n_lo = u0 + lpad - (FOLD_TAPS - 1);
+    const int t_lo = n_lo > 0 ? (n_lo + S - 1) / S : 0;
+    const int t_hi = min(frames_out - 1, (u0 + FOLD_T - 1 + lpad) / S);
+    const int row_floats = c_in * FOLD_TAPS;
+    {
+        const int q = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+        const int col = ci0 * FOLD_TAPS + q * 4;
+        for (int r = r0; t_lo + r <= t_hi; r += 4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (col < row_floats)
+                v = *reinterpret_cast<const float4*>(cols + (static_cast<size_t>(t_lo + r) * batch + b) * row_floats + col);
+            *reinterpret_cast<float4*>(&s_cols[r][q * 4]) = v;
+        }
+    }
+    __syncthreads();
+    const int u = u0 + (threadIdx.x & (FOLD_T - 1));
+    if (u >= ld_in) return;
+    for (int cl = threadIdx.x / FOLD_T; cl < FOLD_C; cl += 256 / FOLD_T) {
+        const int ci = ci0 + cl;
+        if (ci >= c_in) break;
+        float sum = 0.f;
+        if (u < frames_in) {
+#pragma unroll
+            for (int j = 0; j < FOLD_TAPS; ++j) {
+                const int n = u + lpad - j;
+                if (n >= 0 && n % S == 0 && n / S <= t_hi) sum += s_cols[n / S - t_lo][cl * FOLD_TAPS + j];
+            }
+        }
+        dx[(static_cast<size_t>(b) * c_in + ci) * ld_in + u] = sum;           // pitch columns: exact zeros
+    }
+}
+
 }  // namespace nbasr
 
 extern "C" int nbasr_relu_clamp_backward(const float* y, const float* dy, float* dz, long long n, nbasr_stream_t stream)
@@ -500,6 +546,26 @@ extern "C" int nbasr_zero_stuff(const float* dz, float* up, int rows, int frames
     return launch_status("nbasr_zero_stuff");
 }
 
+extern "C" int nbasr_conv_fold(const float* cols, float* dx, int batch, int c_in, int frames_in, int ld_in, int frames_out, int taps,
+                               int stride, int lpad, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && c_in > 0 && frames_in >= 0 && ld_in >= frames_in && frames_out >= 0 && lpad >= 0, NBASR_EINVAL,
+                  "nbasr_conv_fold: bad sizes");
+    NBASR_REQUIRE(taps == FOLD_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL, "nbasr_conv_fold: taps=%d stride=%d (8 taps, stride 1 | 2)",
+                  taps, stride);
+    NBASR_REQUIRE(batch <= 65535 && (c_in + FOLD_C - 1) / FOLD_C <= 65535, NBASR_EINVAL, "nbasr_conv_fold: batch=%d / c_in=%d beyond the grid", batch, c_in);
+    if (batch == 0 || ld_in == 0) return NBASR_OK;
+    NBASR_REQUIRE(cols && dx, NBASR_ENULL, "nbasr_conv_fold: NULL pointer");
+    NBASR_REQUIRE(aligned16(cols), NBASR_EALIGN, "nbasr_conv_fold: cols must be 16-byte aligned");
+    const dim3 grid((ld_in + FOLD_T - 1) / FOLD_T, (c_in + FOLD_C - 1) / FOLD_C, batch);
+    if (stride == 1)
+        hipLaunchKernelGGL(conv_fold_kernel<1>, grid, dim3(256), 0, as_stream(stream), cols, dx, batch, c_in, frames_in, ld_in, frames_out, lpad);
+    else
+        hipLaunchKernelGGL(conv_fold_kernel<2>, grid, dim3(256), 0, as_stream(stream), cols, dx, batch, c_in, frames_in, ld_in, frames_out, lpad);
+    return launch_status("nbasr_conv_fold");
+}
+
 // ---- LSTM backward (BPTT), correctness first -----------------------------------------------------------------------------------------
 // Layout of everything below: (rows, frames, ldb) with the utterances innermost (ldb = batch rounded up to 4), rows = 4H for the
 // gate tensors (PyTorch order i, f, g, o) and H for the cell states -- the layout in which the per-step GEMM
@@ -530,55 +596,76 @@ __global__ __launch_bounds__(256) void lstm_gate_scan_kernel(float* __restrict__
 
 // One step of the reverse recurrence: dh_out (H, T, ldb) = dL/dh of the layer's output, w_hh_t (H, 4H) the transposed recurrent weight,
 // dc (H, ldb) the carried dL/dc_t part -> dpre[:, t, :] (4H rows; reads dpre[:, t + 1, :]) and the updated carry dL/dc_(t-1).
-__global__ __launch_bounds__(256) void lstm_backward_step_kernel(const float* __restrict__ dh_out, const float* __restrict__ w_hh_t,
+constexpr int LSTM_BW_UNITS = 4;                              // hidden units per workgroup: they share every load of dpre[:, t + 1, :]
+constexpr int LSTM_BW_SLICES = 16;                            // waves per workgroup: each sums a sixteenth of the 4H gate rows
+constexpr int LSTM_BW_DEPTH = 16;                             // loads in flight per wave
+__global__ __launch_bounds__(64 * LSTM_BW_SLICES) void lstm_backward_step_kernel(const float* __restrict__ dh_out, const float* __restrict__ w_hh_t,
                                                                  float* __restrict__ dc, const float* __restrict__ acts,
                                                                  const float* __restrict__ cells, float* __restrict__ dpre, int hidden,
                                                                  int frames, int batch, int ldb, int t)
 {
-    // 256 threads = 64 utterances x 4 slices of the 4H gate rows: each slice sums its quarter of (w_hh^T . dpre[:, t + 1, :])[j][b],
-    // the slices meet in LDS, slice 0 does the cell arithmetic.  (As a launch of the tiled GEMM this (500 x 2000) x (2000 x 64) product
-    // ran on 4 workgroups, 240 us per frame; one 64-thread wave per unit walking all 2 000 rows took ~160 us.)
-    __shared__ float s_part[4][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    // 1024 threads = 64 utterances x 16 slices of the 4H gate rows: each slice (one wave) sums its part of
+    // (w_hh^T . dpre[:, t + 1, :])[j][b] for the workgroup's 4 units j -- the recurrent weights are wave-uniform scalars, 16 loads of
+    // dpre in flight -- the slices meet in LDS, slice 0 does the cell arithmetic.  The step is bound by load LATENCY, not bandwidth
+    // (512 KB of dpre[:, t + 1, :] out of L2): as a launch of the tiled GEMM this (500 x 2000) x (2000 x 64) product ran on 4
+    // workgroups, 240 us per frame; one unit per workgroup, 4 slices, 8 loads in flight -- 62 dependent round trips -- 30 us.
+    __shared__ float s_part[LSTM_BW_SLICES][LSTM_BW_UNITS][64];
+    const int lane = threadIdx.x & 63, slice = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // wave-uniform: scalar weight loads
     const int b = blockIdx.x * 64 + lane;
-    const int j = blockIdx.y;
+    const int j0 = blockIdx.y * LSTM_BW_UNITS;
     const size_t plane = static_cast<size_t>(frames) * ldb, gate_stride = static_cast<size_t>(hidden) * plane;
-    float rec = 0.f;
-    if (t + 1 < frames && b < ldb) {
-        const int rows = 4 * hidden, per = (rows + 3) / 4;
-        const int g0 = slice * per, g1 = min(rows, g0 + per);
-        const float* __restrict__ wrow = w_hh_t + static_cast<size_t>(j) * rows;
-        const float* __restrict__ dnext = dpre + static_cast<size_t>(t + 1) * ldb + b;
-        float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int g = g0;
-        for (; g + 7 < g1; g += 8) {
+    float rec[LSTM_BW_UNITS];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) r[u] = __builtin_fmaf(wrow[g + u], dnext[static_cast<size_t>(g + u) * plane], r[u]);
+    for (int q = 0; q < LSTM_BW_UNITS; ++q) rec[q] = 0.f;
+    if (t + 1 < frames && b < ldb) {
+        // 4H is a multiple of 16 (the entry point checks hidden % 4): slices of a multiple of 16 rows leave no tail
+        const int rows = 4 * hidden, per = ((rows + LSTM_BW_SLICES - 1) / LSTM_BW_SLICES + LSTM_BW_DEPTH - 1) / LSTM_BW_DEPTH * LSTM_BW_DEPTH;
+        const int g0 = min(rows, slice * per), g1 = min(rows, g0 + per);
+        const float* __restrict__ wrow = w_hh_t + static_cast<size_t>(j0) * rows;
+        const float* __restrict__ dnext = dpre + static_cast<size_t>(t + 1) * ldb + b;
+        float r[LSTM_BW_UNITS][2];
+#pragma unroll
+        for (int q = 0; q < LSTM_BW_UNITS; ++q) r[q][0] = r[q][1] = 0.f;
+        for (int g = g0; g < g1; g += LSTM_BW_DEPTH) {
+            float d[LSTM_BW_DEPTH];
+#pragma unroll
+            for (int u = 0; u < LSTM_BW_DEPTH; ++u) d[u] = dnext[static_cast<size_t>(g + u) * plane];
+#pragma unroll
+            for (int q = 0; q < LSTM_BW_UNITS; ++q)
+#pragma unroll
+                for (int u = 0; u < LSTM_BW_DEPTH; ++u) r[q][u & 1] = __builtin_fmaf(wrow[static_cast<size_t>(q) * rows + g + u], d[u], r[q][u & 1]);
         }
-        for (; g < g1; ++g) r[0] = __builtin_fmaf(wrow[g], dnext[static_cast<size_t>(g) * plane], r[0]);
-        rec = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int q = 0; q < LSTM_BW_UNITS; ++q) rec[q] = r[q][0] + r[q][1];
     }
-    s_part[slice][lane] = rec;
+#pragma unroll
+    for (int q = 0; q < LSTM_BW_UNITS; ++q) s_part[slice][q][lane] = rec[q];
     __syncthreads();
     if (slice != 0 || b >= ldb) return;
-    const size_t at = static_cast<size_t>(j) * plane + static_cast<size_t>(t) * ldb + b;
-    const size_t hb = static_cast<size_t>(j) * ldb + b;
-    if (b >= batch) {                                          // pitch columns: exact zeros for the GEMMs that read them
-        dpre[at] = 0.f; dpre[at + gate_stride] = 0.f; dpre[at + 2 * gate_stride] = 0.f; dpre[at + 3 * gate_stride] = 0.f;
-        return;
+#pragma unroll
+    for (int q = 0; q < LSTM_BW_UNITS; ++q) {
+        const int j = j0 + q;
+        const size_t at = static_cast<size_t>(j) * plane + static_cast<size_t>(t) * ldb + b;
+        const size_t hb = static_cast<size_t>(j) * ldb + b;
+        if (b >= batch) {                                      // pitch columns: exact zeros for the GEMMs that read them
+            dpre[at] = 0.f; dpre[at + gate_stride] = 0.f; dpre[at + 2 * gate_stride] = 0.f; dpre[at + 3 * gate_stride] = 0.f;
+            continue;
+        }
+        const float i = acts[at], f = acts[at + gate_stride], g = acts[at + 2 * gate_stride], o = acts[at + 3 * gate_stride];
+        const float c = cells[at], c_prev = t > 0 ? cells[at - ldb] : 0.f;
+        const float tc = tanhf(c);
+        float through = 0.f;                                   // from frame t + 1 through the recurrence, slices in ascending order
+#pragma unroll
+        for (int sl = 0; sl < LSTM_BW_SLICES; ++sl) through += s_part[sl][q][lane];
+        const float gh = dh_out[at] + through;                 // dL/dh_t: from the layer's output + the recurrence
+        const float d_o = gh * tc;
+        const float d_c = dc[hb] + gh * o * (1.f - tc * tc);
+        dpre[at] = d_c * g * i * (1.f - i);
+        dpre[at + gate_stride] = d_c * c_prev * f * (1.f - f);
+        dpre[at + 2 * gate_stride] = d_c * i * (1.f - g * g);
+        dpre[at + 3 * gate_stride] = d_o * o * (1.f - o);
+        dc[hb] = d_c * f;
     }
-    const float i = acts[at], f = acts[at + gate_stride], g = acts[at + 2 * gate_stride], o = acts[at + 3 * gate_stride];
-    const float c = cells[at], c_prev = t > 0 ? cells[at - ldb] : 0.f;
-    const float tc = tanhf(c);
-    // dL/dh_t: from the layer's output, and from frame t + 1 through the recurrence
-    const float gh = dh_out[at] + ((s_part[0][lane] + s_part[1][lane]) + (s_part[2][lane] + s_part[3][lane]));
-    const float d_o = gh * tc;
-    const float d_c = dc[hb] + gh * o * (1.f - tc * tc);
-    dpre[at] = d_c * g * i * (1.f - i);
-    dpre[at + gate_stride] = d_c * c_prev * f * (1.f - f);
-    dpre[at + 2 * gate_stride] = d_c * i * (1.f - g * g);
-    dpre[at + 3 * gate_stride] = d_o * o * (1.f - o);
-    dc[hb] = d_c * f;
 }
 
 }  // namespace nbasr
@@ -600,8 +687,8 @@ extern "C" int nbasr_lstm_backward_step(const float* dh_out, const float* w_hh_t
     clear_error();
     NBASR_REQUIRE(hidden > 0 && frames > 0 && batch > 0 && ldb >= batch && t >= 0 && t < frames, NBASR_EINVAL, "nbasr_lstm_backward_step: bad sizes");
     NBASR_REQUIRE(dh_out && w_hh_t && dc && acts && cells && dpre, NBASR_ENULL, "nbasr_lstm_backward_step: NULL pointer");
-    NBASR_REQUIRE(hidden <= 65535, NBASR_EINVAL, "nbasr_lstm_backward_step: hidden %d > 65535", hidden);
-    hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((ldb + 63) / 64, hidden), dim3(256), 0, as_stream(stream), dh_out, w_hh_t, dc, acts, cells, dpre,
+    NBASR_REQUIRE(hidden % LSTM_BW_UNITS == 0 && hidden / LSTM_BW_UNITS <= 65535, NBASR_EINVAL, "nbasr_lstm_backward_step: hidden %d (a multiple of 4, at most 262140)", hidden);
+    hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((ldb + 63) / 64, hidden / LSTM_BW_UNITS), dim3(64 * LSTM_BW_SLICES), 0, as_stream(stream), dh_out, w_hh_t, dc, acts, cells, dpre,
                        hidden, frames, batch, ldb, t);
     return launch_status("nbasr_lstm_backward_step");
 }

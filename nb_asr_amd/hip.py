@@ -105,6 +105,7 @@ SIGNATURES = {
     'nbasr_layernorm_channels_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 4 + [_c_stream]),
     'nbasr_relu_clamp_backward': (_c_int, [_c_float_p] * 3 + [ctypes.c_longlong, _c_stream]),
     'nbasr_zero_stuff': (_c_int, [_c_float_p] * 2 + [_c_int] * 7 + [_c_stream]),
+    'nbasr_conv_fold': (_c_int, [_c_float_p] * 2 + [_c_int] * 8 + [_c_stream]),
     'nbasr_dense_conv1d_linear': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_stream]),
     'nbasr_conv_cols': (_c_int, [_c_float_p] * 2 + [_c_int] * 10 + [_c_stream]),
     'nbasr_rows_of_channels': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
@@ -959,9 +960,11 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
     the per-frame ``linear`` op (k = 1): x (B, C_in, ld_in), y / dy (B, C_out, ld_out) pitched -> (dx, dw, db).  ``activation=False``: the map
     without ReLU / clamp (the CTC head).
 
-    Correctness-first: every product runs on the exact-fp32 MFMA GEMM of the forward -- the input gradient as a
-    stride-1 conv of the zero-stuffed, masked output gradient with the flipped, channel-transposed kernel; the weight and bias gradients
-    as ONE (C_out, B * T') x (B * T', C_in * k + 1) GEMM on a materialised column matrix."""
+    Correctness-first.  Weight and bias gradients: ONE (C_out, B * T') x (B * T', C_in * k + 1) GEMM on a materialised
+    column matrix.  Input gradient of the k = 8 convs: ONE (C_in * 8, C_out) x (C_out, B * T') GEMM, then a fold of the 8 tap rows onto
+    the input frames (nbasr_conv_fold).  Both GEMMs run on the fp16 matrix cores with the fp32-accurate two-term split;
+    ``NBASR_TRAIN_GEMM=f32`` keeps every product on the exact-fp32 MFMA GEMMs of the forward (there the input gradient is a stride-1 conv
+    of the zero-stuffed, masked output gradient with the flipped, channel-transposed kernel)."""
     lib = load_library()
     b, c_in, ld_in = x.shape
     c_out, _, kernel = weight.shape if weight.dim() == 3 else (weight.shape[0], weight.shape[1], 1)
@@ -982,6 +985,19 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
             wt = weight.detach().reshape(c_out, c_in).t().contiguous()
             _check(lib.nbasr_pointwise_linear(_dev(dz, 'dz'), _dev(wt, 'wt'), _dev(zero, 'zero'), _dev(dx, 'dx'), b, c_out, frames_in, ld_out,
                                               c_in, ld_in, stream), 'nbasr_pointwise_linear')
+        elif kernel == 8 and (c_in * kernel) % 16 == 0 and os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32':
+            # ONE GEMM on the fp16 matrix cores (fp32-accurate two-term split, the kernel of the LSTM input projection): rows (ci, tap) of
+            # w^T times the masked output gradient, stored time-major, every tap's contribution to dx in its own row; nbasr_conv_fold adds
+            # the 8 (stride 1) or 4 (stride 2) rows that land on one input frame.  No zero-stuffing: half the products at stride 2.
+            rows_w = c_in * kernel
+            wt = weight.detach().permute(1, 2, 0).reshape(rows_w, c_out).contiguous()
+            packed = pack_pointwise_weights(wt)
+            ws = pointwise_workspace(b, c_out, ld_out, x.device)
+            zero_r = torch.zeros(rows_w, device=x.device, dtype=torch.float32)
+            taps = torch.empty(max(frames_out, 1), b, rows_w, device=x.device, dtype=torch.float32)
+            lstm_input_projection_packed(dz, frames_out, packed, zero_r, zero_r, taps, rows_w // 4, ws)
+            _check(lib.nbasr_conv_fold(_dev(taps, 'taps'), _dev(dx, 'dx'), b, c_in, frames_in, ld_in, frames_out, kernel, stride, lpad, stream),
+                   'nbasr_conv_fold')
         else:
             up = torch.empty(b, c_out, ld_in, device=x.device, dtype=torch.float32)
             _check(lib.nbasr_zero_stuff(_dev(dz, 'dz'), _dev(up, 'up'), b * c_out, frames_out, ld_out, frames_in, ld_in, stride, 0, stream),
@@ -1029,7 +1045,8 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
 
     Correctness first: gate pre-activations of all frames are recomputed from the saved h by ONE GEMM, a serial
     scan restores the cell states, the reverse recurrence is T launches of a step kernel that forms w_hh^T . dpre of the next frame in place, and the weight / input gradients
-    are three batched GEMMs -- every product on the exact-fp32 MFMA GEMM (nbasr_pointwise_linear); tensor re-layouts are torch copies."""
+    are batched GEMMs -- on the fp16 matrix cores with the fp32-accurate two-term split (``NBASR_TRAIN_GEMM=f32``: the exact-fp32 MFMA GEMM
+    nbasr_pointwise_linear); tensor re-layouts are torch copies."""
     lib = load_library()
     b, c, _ = xp.shape
     t_n, hidden = frames, w_hh.shape[1]
@@ -1048,13 +1065,31 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
                                           stream), 'nbasr_pointwise_linear')
         return y
 
+    split = os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32'
+
+    def gemm_t(x3, cols, w):
+        """(w (rows, K) . x3 (1, K, ld))^T -> (cols, rows): the same product on the fp16 matrix cores (fp32-accurate two-term split; the
+        GEMM of the LSTM input projection, which stores time-major, i.e. transposed); w is packed per call."""
+        rows, k = w.shape
+        r_pad = (rows + 15) & ~15                               # (that entry point takes 4 * hidden rows, hidden % 4 == 0)
+        if r_pad != rows:
+            w = torch.cat([w, w.new_zeros(r_pad - rows, k)])
+        zero = torch.zeros(r_pad, device=dev, dtype=f32)
+        out_t = torch.empty(x3.shape[2], 1, r_pad, device=dev, dtype=f32)
+        lstm_input_projection_packed(x3, cols, pack_pointwise_weights(w.contiguous()), zero, zero, out_t, r_pad // 4,
+                                     pointwise_workspace(1, k, x3.shape[2], dev))
+        return out_t.view(x3.shape[2], r_pad)[:cols, :rows]
+
     # h_(t-1) for every (t, b): rows of the (T * ldb, H) matrix, zero for t = 0 and for the pitch utterances
     hp = torch.zeros(t_n, ldb, hidden, device=dev, dtype=f32)
     if t_n > 1:
         hp[1:, :b] = h_out[:, : t_n - 1].permute(1, 0, 2)
     hp_t = hp.reshape(n, hidden).t().contiguous()              # (H, T * ldb)
-    pre = torch.empty(1, g4, n, device=dev, dtype=f32)
-    gemm(hp_t.data_ptr(), hidden, n, n, w_hh.detach().contiguous(), pre)
+    if split:
+        pre = gemm_t(hp_t.view(1, hidden, n), n, w_hh.detach()).t().contiguous()
+    else:
+        pre = torch.empty(1, g4, n, device=dev, dtype=f32)
+        gemm(hp_t.data_ptr(), hidden, n, n, w_hh.detach().contiguous(), pre)
     pre = pre.view(g4, t_n, ldb)
     pre[:, :, :b] += gates[:t_n].permute(2, 0, 1)             # + input projection and biases
     cells = torch.zeros(hidden, t_n, ldb, device=dev, dtype=f32)
@@ -1069,10 +1104,21 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
         _check(lib.nbasr_lstm_backward_step(_dev(dho, 'dho'), _dev(w_hh_t, 'w_hh_t'), _dev(dc, 'dc'), _dev(acts, 'acts'), _dev(cells, 'cells'),
                                             _dev(dpre, 'dpre'), hidden, t_n, b, ldb, t, stream), 'nbasr_lstm_backward_step')
     d2 = dpre.view(g4, n)
+    ldc = round_up4(c + 1)
+    if split:
+        # (dw_ih | db | dw_hh) (4H, C + 1 + H) = dpre (4H, n) . (x | 1 | h_prev) (n, .): ONE GEMM, dpre packed once
+        xh = torch.zeros(t_n, ldb, ldc + hidden, device=dev, dtype=f32)
+        xh[:, :b, :c] = xp[:, :, :t_n].permute(2, 0, 1)
+        xh[:, :b, c] = 1.0
+        xh[:, :, ldc:] = hp
+        wb = gemm_t(xh.view(1, n, ldc + hidden), ldc + hidden, d2).t()
+        dw_ih, db, dw_hh = wb[:, :c].contiguous(), wb[:, c].contiguous(), wb[:, ldc:].contiguous()
+        # dx (C, n) = w_ih^T (C, 4H) . dpre (4H, n), delivered transposed: (n, C)
+        dx = gemm_t(dpre.view(1, g4, n), n, w_ih.detach().t()).view(t_n, ldb, c)[:, :b].permute(1, 2, 0).contiguous()
+        return dx, dw_ih, dw_hh, db
     # dw_hh (4H, H) = dpre (4H, n) . h_prev (n, H)
     dw_hh = gemm(hp.data_ptr(), n, hidden, hidden, d2, torch.empty(1, g4, hidden, device=dev, dtype=f32))[0]
     # (dw_ih | db) (4H, C + 1) = dpre . (x | 1)
-    ldc = round_up4(c + 1)
     xt = torch.zeros(t_n, ldb, ldc, device=dev, dtype=f32)
     xt[:, :b, :c] = xp[:, :, :t_n].permute(2, 0, 1)
     xt[:, :b, c] = 1.0

@@ -189,6 +189,58 @@ def test_dense_conv_gradients_vs_torch_autograd(c_in, c_out, stride, b, t):
     close(db, br.grad.numpy(), 'db', rtol=2e-4)
 
 
+@pytest.mark.parametrize('c_in,stride,b,t', [(6, 1, 2, 1), (40, 1, 3, 70), (34, 2, 2, 65), (33, 2, 1, 64), (70, 1, 1, 33)])
+def test_conv_fold_adds_the_tap_rows(c_in, stride, b, t):
+    """nbasr_conv_fold against a loop over taps: cols (T', B, C_in * 8) time-major -> dx (B, C_in, ld), pitch columns zero."""
+    import ctypes
+    t_out = (t + stride - 1) // stride
+    lpad = hip.pad_amounts(8, 1, stride)[0]
+    torch.manual_seed(c_in * 7 + t)
+    cols = torch.randn(t_out, b, c_in * 8)
+    ld = hip.round_up4(t) + 4
+    dx = torch.full((b, c_in, ld), 7.0, device=DEV)
+    lib = hip.load_library()
+    rc = lib.nbasr_conv_fold(cols.to(DEV).data_ptr(), dx.data_ptr(), b, c_in, t, ld, t_out, 8, stride, lpad, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, lib.nbasr_last_error()
+    want = torch.zeros(b, c_in, ld, dtype=torch.float64)
+    c4 = cols.double().view(t_out, b, c_in, 8)
+    for j in range(8):
+        for to in range(t_out):
+            u = to * stride + j - lpad
+            if 0 <= u < t:
+                want[:, :, u] += c4[to, :, :, j]
+    got = dx.cpu().double()
+    assert torch.equal(got[:, :, t:], torch.zeros_like(got[:, :, t:]))
+    assert float((got - want).abs().max()) <= 1e-5
+    for bad in ((7, 1), (8, 3)):
+        assert lib.nbasr_conv_fold(cols.to(DEV).data_ptr(), dx.data_ptr(), b, c_in, t, ld, t_out, bad[0], bad[1], lpad, 0) != 0
+
+
+@pytest.mark.parametrize('c_in,c_out,stride,b,t', [(600, 800, 1, 2, 97), (800, 1000, 2, 2, 131), (24, 40, 2, 3, 5)])
+def test_dense_input_gradient_on_the_split_gemm_matches_the_exact_route(monkeypatch, c_in, c_out, stride, b, t):
+    """Default route of the k = 8 input gradient (one fp16-split GEMM + nbasr_conv_fold) against NBASR_TRAIN_GEMM=f32 (zero-stuffed
+    exact-fp32 conv): same numbers to the fp32-accurate split's error, at the benchmark model's widths and ragged lengths."""
+    torch.manual_seed(c_in + stride)
+    t_out = (t + stride - 1) // stride
+    ld_in, ld_out = hip.round_up4(t), hip.round_up4(t_out)
+    x = torch.zeros(b, c_in, ld_in, device=DEV)
+    x[:, :, :t] = torch.randn(b, c_in, t, device=DEV) * 3.0
+    w = (torch.randn(c_out, c_in, 8) * (2.0 / (c_in * 8)) ** 0.5).to(DEV)
+    y = torch.zeros(b, c_out, ld_out, device=DEV)                     # one saved output for both routes: the same ReLU / clamp mask
+    y[:, :, :t_out] = (torch.randn(b, c_out, t_out, device=DEV) * 8.0).clamp(0.0, 20.0)
+    dy = torch.zeros(b, c_out, ld_out, device=DEV)
+    dy[:, :, :t_out] = torch.randn(b, c_out, t_out, device=DEV) * 1e-3
+    dx, dw, db = hip.dense_conv1d_backward(x, w, y, dy, t, stride)
+    monkeypatch.setenv('NBASR_TRAIN_GEMM', 'f32')
+    dx_e, dw_e, db_e = hip.dense_conv1d_backward(x, w, y, dy, t, stride)
+    assert not torch.equal(dx, dx_e)                                  # (two routes indeed)
+    assert torch.equal(dx[:, :, t:], torch.zeros_like(dx[:, :, t:]))
+    scale = float(dx_e.abs().max())
+    assert float((dx - dx_e).abs().max()) <= 2e-5 * scale, (float((dx - dx_e).abs().max()), scale)
+    assert float((dw - dw_e).abs().max()) <= 2e-5 * float(dw_e.abs().max())
+    assert float((db - db_e).abs().max()) <= 2e-5 * float(db_e.abs().max())
+
+
 def test_dense_ops_train_through_the_modules():
     """ops.PadConvRelu (dense) and ops.Linear route to the differentiable functions when a gradient is required: an SGD step
     on each lowers a loss."""
@@ -206,6 +258,25 @@ def test_dense_ops_train_through_the_modules():
                 for p in mod.parameters():
                     p -= 0.05 * p.grad
         assert losses[-1] < losses[0], losses
+
+
+def test_lstm_bptt_routes_agree(monkeypatch):
+    """The LSTM's backward GEMMs on the fp16-split kernel (default) and on the exact-fp32 one (NBASR_TRAIN_GEMM=f32): same gradients to
+    the split's error, from the same saved forward."""
+    torch.manual_seed(3)
+    c, hidden, b, t = 72, 36, 5, 23
+    params = [(torch.randn(4 * hidden, c) * 0.2), (torch.randn(4 * hidden, hidden) * 0.2), torch.randn(4 * hidden) * 0.1, torch.randn(4 * hidden) * 0.1]
+    x, r = torch.randn(b, c, t), torch.randn(b, t, hidden)
+    grads = []
+    for mode in ('f16x2', 'f32'):
+        monkeypatch.setenv('NBASR_TRAIN_GEMM', mode)
+        ps = [p.clone().to(DEV).requires_grad_(True) for p in params]
+        xg = x.to(DEV).requires_grad_(True)
+        (nb_autograd.lstm(xg, *ps) * r.to(DEV)).sum().backward()
+        grads.append([xg.grad] + [p.grad for p in ps])
+    for got, want in zip(*grads):
+        assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert not all(torch.equal(g, w) for g, w in zip(*grads))
 
 
 @pytest.mark.parametrize('c,hidden,b,t', [(24, 8, 2, 5), (40, 20, 3, 17), (1200, 500, 2, 9), (16, 4, 5, 1)])

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Training step after the input-gradient GEMM + fold and the 16-wave LSTM reverse step: op tests, model gradients, step time, profile.
+REPO="${GRAFT_REPO_ROOT:-/root/repo}"; OUT="$REPO/gpurun_out/r02_an"; mkdir -p "$OUT"; export TMPDIR=/tmp
+cd "$REPO"
+timeout 600 python -m pytest tests/test_backward_gpu.py -q -x > "$OUT/pytest_bw.log" 2>&1; echo "bw rc=$?"; tail -3 "$OUT/pytest_bw.log"
+timeout 900 python -m pytest tests/test_model_gpu.py -q -x -k "loss_backward or sgd_step or training_mode" > "$OUT/pytest_model.log" 2>&1; echo "model rc=$?"; tail -3 "$OUT/pytest_model.log"
+timeout 600 python tools/ubench/train_step.py --batch 64 --frames 1000 --steps 3 2>/dev/null | tail -1
+cd /tmp
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/tools/ubench/train_step.py" --batch 64 --frames 1000 --steps 3 > "$OUT/train.log" 2>&1; echo rc=$?
+S=$(find "$OUT/stats" -name '*kernel_stats.csv' | head -1)
+python3 "$REPO/tools/summarize_kernels.py" "$S" > "$OUT/r02_kernel_stats_train_step_final.csv" 2>/dev/null
+head -16 "$OUT/r02_kernel_stats_train_step_final.csv" | cut -c1-150
+grep -E "lstm_backward_step|conv_fold" "$OUT/r02_kernel_stats_train_step_final.csv" | cut -c1-40,120-260
+rm -rf "$OUT/stats"
