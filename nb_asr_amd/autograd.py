@@ -73,21 +73,35 @@ class _LayerNormChannels(torch.autograd.Function):
 
 
 class _DensePadConvRelu(torch.autograd.Function):
-    """Dense k = 8 downsample conv (stride 1 | 2) or the per-frame `linear` op (k = 1) with ReLU and clamp; forward on the exact-fp32 MFMA
-    GEMM, backward through hip.dense_conv1d_backward."""
+    """Dense k = 8 downsample conv (stride 1 | 2) or the per-frame `linear` op (k = 1) with ReLU and clamp; forward of the k = 8 convs on the
+    split 16-bit GEMMs (NBASR_TRAIN_GEMM = f16x2 (default) | bf16x3 | f32: the exact-fp32 MFMA GEMM), backward through hip.dense_conv1d_backward."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride):
+    def forward(ctx, x, weight, bias, stride, normalized_input=False):
         xp, frames = _pitched(x)
         kernel = weight.shape[2] if weight.dim() == 3 else 1
         w3 = weight.detach() if weight.dim() == 3 else weight.detach().unsqueeze(-1)
         t_out = (frames + stride - 1) // stride
         y = torch.empty(xp.shape[0], weight.shape[0], hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
-        if kernel == 8 and os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32' and xp.data_ptr() % 16 == 0:
+        mode = os.environ.get('NBASR_TRAIN_GEMM', 'f16x2')
+        if kernel == 8 and mode == 'bf16x3' and xp.data_ptr() % 16 == 0:
             # the three-term bf16 split (fp32's range, no range information needed, fp32-level error): half the time of the exact-fp32
             # MFMA GEMM; the weights change every step, so they are packed per call (tens of microseconds)
             hip.dense_conv1d_fused_packed(xp, frames, hip.pack_dense_weights(w3.contiguous(), stride, 'bf16x3'), weight.shape[0], 8, bias.detach(),
                                           (), y, stride, None, 'bf16x3')
+        elif kernel == 8 and mode != 'f32' and xp.data_ptr() % 16 == 0:
+            # what the inference executor runs for the model's first conv, for all four: a range summary of the input per utterance, its
+            # pre-split fp16 image, the LDS-DMA-only two-term fp16 GEMM (3 MFMAs per fp32 product, against 6 for bf16x3), and the bf16x3
+            # leg for utterances the summary calls extreme (non-finite samples, > 2^20 of dynamic range) -- routed on the device
+            wc = w3.contiguous()
+            rng = torch.empty(xp.shape[0], 4, device=xp.device, dtype=torch.float32)
+            hip.input_range(xp, frames, rng)
+            if normalized_input:
+                # a LayerNorm's output: only the non-finite flag routes (the inference executor scales these by max |x| alone as well);
+                # the quiet-frame rule is for caller data, and would send utterances with a near-constant frame to the slower leg
+                rng[:, 1] = rng[:, 0]
+            hip.dense_conv1d_first_ranged(xp, frames, rng, hip.pack_dense_weights(wc, stride, 'f16x2', 128), hip.pack_dense_weights(wc, stride, 'bf16x3'),
+                                          weight.shape[0], 8, bias.detach(), y, stride, hip.split_image(*xp.shape, xp.device), 128)
         else:
             hip.dense_conv1d_fused(xp, frames, w3, bias.detach(), (), y, stride)
         ctx.save_for_backward(xp, weight.detach(), y)
@@ -101,7 +115,7 @@ class _DensePadConvRelu(torch.autograd.Function):
         dyp, _ = _pitched(dy)
         need_dx, need_dw = ctx.needs_input_grad[0], ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dx, dw, db = hip.dense_conv1d_backward(xp, weight, y, dyp, frames, stride, need_dx, need_dw)
-        return (dx[:, :, :frames] if dx is not None else None), dw, db, None
+        return (dx[:, :, :frames] if dx is not None else None), dw, db, None, None
 
 
 class _LSTM(torch.autograd.Function):
@@ -171,10 +185,11 @@ def lstm(x, w_ih, w_hh, b_ih, b_hh):
     return _LSTM.apply(x, w_ih, w_hh, b_ih, b_hh)
 
 
-def dense_pad_conv_relu(x, weight, bias, stride=1):
+def dense_pad_conv_relu(x, weight, bias, stride=1, normalized_input=False):
     """min(relu(conv1d(zero_pad(x), weight, bias, stride)), 20) for a dense (C_out, C_in, 8) kernel, or the per-frame linear map for a
-    (C_out, C_in) weight, differentiable in x, weight, bias."""
-    return _DensePadConvRelu.apply(x, weight, bias, stride)
+    (C_out, C_in) weight, differentiable in x, weight, bias.  ``normalized_input``: x is a LayerNorm's output (model_forward says so for
+    convs 1-3), not caller data -- see the forward."""
+    return _DensePadConvRelu.apply(x, weight, bias, stride, normalized_input)
 
 
 def grouped_pad_conv_relu(x, weight, bias, groups, kernel, dilation):
@@ -223,13 +238,14 @@ def model_forward(model, x):
     import torch.nn as nn
     from .model import SearchCell
     from .ops import PadConvRelu, Linear, Zero, Identity
-    act = x
+    act, normalized = x, False                                 # normalized: act is a LayerNorm's output (dropout in between allowed)
     for layer in model.model:
         if isinstance(layer, PadConvRelu):
-            act = layer(act)                                   # routes to dense_pad_conv_relu / grouped_pad_conv_relu under autograd
+            layer.input_is_normalized = normalized
+            act, normalized = layer(act), False                # routes to dense_pad_conv_relu / grouped_pad_conv_relu under autograd
         elif isinstance(layer, nn.LayerNorm):
             if act.dim() == 3 and act.shape[1] == layer.normalized_shape[0]:
-                act = layer_norm_channels(act, layer.weight, layer.bias, layer.eps)
+                act, normalized = layer_norm_channels(act, layer.weight, layer.bias, layer.eps), True
             else:
                 raise RuntimeError('LayerNorm in an unexpected position of the layer list')
         elif isinstance(layer, SearchCell):
@@ -239,12 +255,13 @@ def model_forward(model, x):
                 terms = [] if isinstance(op, Zero) else [op(outs[-1])]
                 terms += [src for branch, src in zip(node.branch_ops, outs) if isinstance(branch, Identity)]
                 outs.append(skip_sum(terms) if terms else op(outs[-1]))          # (no term at all: the `zero` op's zeros)
-            act = outs[-1]
+            act, normalized = outs[-1], False
             if layer.use_norm:
-                act = layer_norm_channels(act, layer.norm_layer.weight, layer.norm_layer.bias, layer.norm_layer.eps)
+                act, normalized = layer_norm_channels(act, layer.norm_layer.weight, layer.norm_layer.bias, layer.norm_layer.eps), True
         elif isinstance(layer, nn.Dropout):
             act = layer(act)                                   # ATen's dropout (identity in eval mode or with p == 0)
         elif isinstance(layer, nn.LSTM):
+            normalized = False
             act = lstm(act, layer.weight_ih_l0, layer.weight_hh_l0, layer.bias_ih_l0, layer.bias_hh_l0)      # (B, T, H)
         elif isinstance(layer, nn.Linear):
             if act.dim() == 3 and act.shape[2] == layer.in_features and act.shape[1] != layer.in_features:

@@ -76,7 +76,8 @@ class PadConvRelu(nn.Module):
         differentiable = torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad) and x.dtype == torch.float32
         if differentiable and self.groups == 1 and self.kernel_size == 8 and self.dilation == 1:
             from .autograd import dense_pad_conv_relu               # trainable on its own
-            return _train_dropout(self, dense_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.strides))
+            return _train_dropout(self, dense_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.strides,
+                                                            getattr(self, 'input_is_normalized', False)))
         if differentiable and self.groups > 1 and self.strides == 1:
             from .autograd import grouped_pad_conv_relu              # the node op is trainable on its own (first block)
             return _train_dropout(self, grouped_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.groups, self.kernel_size, self.dilation))
