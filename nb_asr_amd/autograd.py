@@ -128,7 +128,13 @@ class _LSTM(torch.autograd.Function):
         gates = torch.empty(max(frames, 1), b, 4 * hidden, device=xp.device, dtype=torch.float32)
         cell = torch.empty(b, hidden, device=xp.device, dtype=torch.float32)
         h_out = torch.empty(b, frames, hidden, device=xp.device, dtype=torch.float32)
-        if frames:
+        if frames and hidden % 4 == 0 and os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32':
+            # as in the inference executor: the projection on the fp16-split GEMM, the recurrence on the fragment-ordered copy of w_hh
+            # (bit-identical to the unpacked step kernel); both weights change every step, so they are packed per call
+            hip.lstm_input_projection_packed(xp, frames, hip.pack_pointwise_weights(w_ih.detach().contiguous()), b_ih.detach(), b_hh.detach(), gates,
+                                             hidden, hip.pointwise_workspace(b, xp.shape[1], xp.shape[2], xp.device))
+            hip.lstm_recurrence_packed(gates, hip.lstm_pack_whh(w_hh.detach().contiguous()), cell, h_out)
+        elif frames:
             hip.lstm_input_projection(xp, frames, w_ih.detach(), b_ih.detach(), b_hh.detach(), gates, hidden)
             hip.lstm_recurrence(gates, w_hh.detach(), cell, h_out)
         ctx.save_for_backward(xp, gates, h_out, w_ih.detach(), w_hh.detach())
