@@ -247,8 +247,11 @@ def model_forward(model, x):
     act, normalized = x, False                                 # normalized: act is a LayerNorm's output (dropout in between allowed)
     for layer in model.model:
         if isinstance(layer, PadConvRelu):
-            layer.input_is_normalized = normalized
-            act, normalized = layer(act), False                # routes to dense_pad_conv_relu / grouped_pad_conv_relu under autograd
+            layer.input_is_normalized = normalized             # (for this call only: a standalone call of the module gets the strict rule)
+            try:
+                act, normalized = layer(act), False            # routes to dense_pad_conv_relu / grouped_pad_conv_relu under autograd
+            finally:
+                layer.input_is_normalized = False
         elif isinstance(layer, nn.LayerNorm):
             if act.dim() == 3 and act.shape[1] == layer.normalized_shape[0]:
                 act, normalized = layer_norm_channels(act, layer.weight, layer.bias, layer.eps), True
