@@ -243,7 +243,7 @@ def model_forward(model, x):
     inference executor stays the fast path; this is what ``loss.backward()`` runs through."""
     import torch.nn as nn
     from .model import SearchCell
-    from .ops import PadConvRelu, Linear, Zero, Identity
+    from .ops import PadConvRelu, Zero, Identity
     act, normalized = x, False                                 # normalized: act is a LayerNorm's output (dropout in between allowed)
     for layer in model.model:
         if isinstance(layer, PadConvRelu):
