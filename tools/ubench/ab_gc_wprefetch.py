@@ -2,7 +2,9 @@
 """Exploration for the next round: does issuing the scalar weight loads of channel ci + 1 before the FMAs of channel ci help the
 pipelined, output-split fp32 node kernel?  tools/ubench/x1/gc_wprefetch.hip holds that kernel's plain flavour twice (WPF on / off), built
 into its own shared object here; interleaved rounds in one process, three buffer sets in rotation (larger than the last-level cache),
-outputs compared bit for bit, the library's own PIPE | OSPLIT variant timed beside them.
+outputs compared bit for bit, the library's own PIPE | OSPLIT variant timed beside them; `gen` = the same loop inside the library kernel's
+generic prologue / epilogue (optional skips, LayerNorm on the first, ragged vote) -- what generality costs a short-lived wave; `nsk` = the
+epilogue instantiated per number of skips, branch-free.  Each with 0, 1 and 2 skip inputs.
 
     python tools/ubench/ab_gc_wprefetch.py [--batches 64 8]
 """
@@ -31,7 +33,7 @@ subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-
                 f'-I{REPO}/nb_asr_amd/csrc', '-x', 'hip', str(HERE / 'x1' / 'gc_wprefetch.hip'), '-o', str(so)], check=True)
 x1 = ctypes.CDLL(str(so))
 x1.x1_node.restype = ctypes.c_int
-x1.x1_node.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
+x1.x1_node.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_void_p]
 dev = torch.device('cuda', 0)
 stream = torch.cuda.current_stream().cuda_stream
 
@@ -48,30 +50,39 @@ for B in args.batches:
         w = torch.randn(c, c // 100, 5, device=dev) * 0.2
         bias = torch.randn(c, device=dev) * 0.1
 
-        def run(kind, i):
+        skip_sets = [torch.randn(B, c, ld, device=dev) for _ in range(2)]
+        for sk in skip_sets:
+            sk[:, :, t:] = 0
+
+        def run(kind, i, n_skips=0):
             x, y = sets[i % 3]
+            skips = skip_sets[:n_skips]
             if kind == 'lib':
-                hip.grouped_conv1d_node(x, w, bias, [], y, t, 100, 5, 1, None, False, False, None, hip.GC_PIPE | hip.GC_OSPLIT)
+                hip.grouped_conv1d_node(x, w, bias, skips, y, t, 100, 5, 1, None, False, False, None, hip.GC_PIPE | hip.GC_OSPLIT)
             else:
-                rc = x1.x1_node(int(kind == 'wpf'), x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), B, c, t, ld, stream)
+                ptr = [sk.data_ptr() for sk in skips] + [None] * (2 - n_skips)
+                rc = x1.x1_node({'base': 0, 'wpf': 1, 'gen': 2, 'nsk': 3}[kind], x.data_ptr(), w.data_ptr(), bias.data_ptr(), ptr[0], ptr[1],
+                                y.data_ptr(), B, c, t, ld, stream)
                 assert rc == 0, rc
             return y
 
-        ref = run('lib', 0).clone()
-        for kind in ('base', 'wpf'):
-            assert torch.equal(run(kind, 0), ref), (kind, 'differs from the library kernel')
-        times = {k: [] for k in ('lib', 'base', 'wpf')}
-        for r in range(args.rounds + 3):
-            for kind in times:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for i in range(6):
-                    run(kind, i)
-                e1.record()
-                e1.synchronize()
-                if r >= 3:
-                    times[kind].append(e0.elapsed_time(e1) / 6 * 1000)
-        row = {'batch': B, 'block': blk, 'channels': c, 'frames': t}
-        row.update({k + '_us': round(statistics.median(v), 2) for k, v in times.items()})
-        row['wpf_vs_base'] = round(row['wpf_us'] / row['base_us'], 4)
-        print(json.dumps(row), flush=True)
+        for n_skips in (0, 1, 2):
+            kinds = ('lib', 'base', 'wpf', 'gen', 'nsk') if n_skips == 0 else ('lib', 'gen', 'nsk')
+            ref = run('lib', 0, n_skips).clone()
+            for kind in kinds[1:]:
+                assert torch.equal(run(kind, 0, n_skips), ref), (kind, n_skips, 'differs from the library kernel')
+            times = {k: [] for k in kinds}
+            for r in range(args.rounds + 3):
+                for kind in times:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for i in range(6):
+                        run(kind, i, n_skips)
+                    e1.record()
+                    e1.synchronize()
+                    if r >= 3:
+                        times[kind].append(e0.elapsed_time(e1) / 6 * 1000)
+            row = {'batch': B, 'block': blk, 'channels': c, 'frames': t, 'skips': n_skips}
+            row.update({k + '_us': round(statistics.median(v), 2) for k, v in times.items()})
+            row['nsk_vs_gen'] = round(row['nsk_us'] / row['gen_us'], 4)
+            print(json.dumps(row), flush=True)

@@ -3,6 +3,10 @@
 // switch: WPF = the scalar weight loads of channel ci + 1 are issued BEFORE the FMAs of channel ci, into a second register set
 // (2 x CO x K SGPRs; fits only with the output split: 60 at CG = 12), the way the window loads already are.  DESIGN.md section 7.1 names
 // the weight loads -- waited for in full before a channel's first FMA -- as the next serial piece of a wave's loop.
+// GEN = the library kernel's generic prologue / epilogue around the same loop (three optional skip inputs, a deferred LayerNorm on the
+// first, the ragged-tail vote): what does generality cost a wave that lives for 12 channel iterations (block 3)?
+// NS = the alternative: the epilogue instantiated per number of skips, branch-free (hipcc puts a full vmcnt(0) at every control-flow
+// join, and stores count in vmcnt: the generic epilogue's per-channel `if (s0)` serialises its own stores).
 //   hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -shared -I nb_asr_amd/csrc -I include -x hip tools/ubench/x1/gc_wprefetch.hip -o tools/ubench/x1/libgc_wpf.so
 #include <hip/hip_runtime.h>
 #include "common.h"
@@ -10,6 +14,8 @@
 namespace x1 {
 using nbasr::pad_left;
 using nbasr::relu_clamp;
+using nbasr::LnRef;
+using nbasr::ln_apply;
 
 typedef float gc_f4 __attribute__((ext_vector_type(4)));
 
@@ -20,9 +26,10 @@ __device__ __forceinline__ float4 row_chunk(const float* row, int row_bytes, int
     return make_float4(f[0], f[1], f[2], f[3]);
 }
 
-template <int CG, int K, int D, bool WPF>
+template <int CG, int K, int D, bool WPF, bool GEN, int NS = 0>
 __global__ __launch_bounds__(256) void node_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                   float* __restrict__ y, int channels, int frames, int ld, int groups)
+                                                   const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                                   float* __restrict__ y, int channels, int frames, int ld, int groups, const LnRef ln_s0)
 {
     constexpr int OS = 2, CO = CG / OS, GPW = 4 / OS;
     constexpr int LPAD = pad_left(K, D, 1), SPAN = (K - 1) * D, QL = (LPAD + 3) / 4, QR = (SPAN - LPAD + 3) / 4, NCH = QL + 1 + QR, BASE = 4 * QL - LPAD;
@@ -81,36 +88,92 @@ __global__ __launch_bounds__(256) void node_kernel(const float* __restrict__ x, 
     }
     if (q >= nq) return;
     const int t0 = q * 4;
+    if constexpr (GEN) {
+        const bool ragged = __any(t0 + 3 >= frames) != 0;
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;
+        if (s0 && ln_s0.stats) {
+            const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_s0.stats + static_cast<size_t>(b) * 2 * ld);
+            sm = mrow[q];
+            sr = mrow[nq + q];
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            const size_t off = row0 + static_cast<size_t>(co0 + co) * ld + t0;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+            if (s0) {
+                float4 v = *reinterpret_cast<const float4*>(s0 + off);
+                if (ln_s0.stats) {
+                    const float gam = ln_s0.gamma[g * CG + co0 + co], bet = ln_s0.beta[g * CG + co0 + co];
+                    v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
+                    v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
+                }
+                o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
+            }
+            if (s1) { const float4 v = *reinterpret_cast<const float4*>(s1 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+            if (s2) { const float4 v = *reinterpret_cast<const float4*>(s2 + off); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+            if (ragged) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (t0 + r >= frames) o[r] = 0.f;
+            }
+            typedef float f4v __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + off));
+        }
+        return;
+    }
+    // branch-free in the skip dimension (NS is a template parameter): every skip load is requested before the first store, the ragged tail
+    // is a select -- no control-flow join, so no vmcnt(0) between the stores
+    float4 sk[NS > 0 ? NS : 1][CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const size_t off = row0 + static_cast<size_t>(co0 + co) * ld + t0;
+        if (NS > 0) sk[0][co] = *reinterpret_cast<const float4*>(s0 + off);
+        if (NS > 1) sk[1 % (NS > 0 ? NS : 1)][co] = *reinterpret_cast<const float4*>(s1 + off);
+    }
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
         float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = t0 + r < frames ? relu_clamp(acc[co][r]) : 0.f;
+        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+        if (NS > 0) { o[0] += sk[0][co].x; o[1] += sk[0][co].y; o[2] += sk[0][co].z; o[3] += sk[0][co].w; }
+        if (NS > 1) { const float4 v = sk[1 % (NS > 0 ? NS : 1)][co]; o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = t0 + r < frames ? o[r] : 0.f;
         typedef float f4v __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + row0 + static_cast<size_t>(co0 + co) * ld + t0));
     }
 }
 
 template <int CG>
-static int launch(int wpf, const float* x, const float* w, const float* bias, float* y, int batch, int channels, int frames, int ld, hipStream_t s)
+static int launch(int mode, const float* x, const float* w, const float* bias, const float* s0, const float* s1, float* y, int batch, int channels,
+                  int frames, int ld, hipStream_t s)
 {
     const int groups = channels / CG, nq = ld >> 2;
     const dim3 grid((nq + 63) / 64, (groups + 1) / 2, batch);
-    if (wpf) hipLaunchKernelGGL((node_kernel<CG, 5, 1, true>), grid, dim3(256), 0, s, x, w, bias, y, channels, frames, ld, groups);
-    else     hipLaunchKernelGGL((node_kernel<CG, 5, 1, false>), grid, dim3(256), 0, s, x, w, bias, y, channels, frames, ld, groups);
+    const float* none = nullptr;
+    const LnRef no_ln{nullptr, nullptr, nullptr};
+#define X1_LAUNCH(...) hipLaunchKernelGGL((node_kernel<CG, 5, 1, __VA_ARGS__>), grid, dim3(256), 0, s, x, w, bias, s0, s1, none, y, channels, frames, ld, groups, no_ln)
+    if (mode == 1)      X1_LAUNCH(true, false);
+    else if (mode == 2) X1_LAUNCH(false, true);                 // generic epilogue: s0 / s1 may be NULL
+    else if (mode == 3) { if (s1) X1_LAUNCH(false, false, 2); else if (s0) X1_LAUNCH(false, false, 1); else X1_LAUNCH(false, false, 0); }
+    else                X1_LAUNCH(false, false);
+#undef X1_LAUNCH
     return static_cast<int>(hipGetLastError());
 }
 }  // namespace x1
 
-extern "C" int x1_node(int wpf, const float* x, const float* w, const float* bias, float* y, int batch, int channels, int frames, int ld,
-                       void* stream)
+// mode: 0 = base (no skips), 1 = weight prefetch (no skips), 2 = base loop inside the generic prologue / epilogue (skips by pointer),
+//       3 = base loop with the branch-free epilogue instantiated for the number of non-NULL skips
+extern "C" int x1_node(int mode, const float* x, const float* w, const float* bias, const float* s0, const float* s1, float* y, int batch,
+                       int channels, int frames, int ld, void* stream)
 {
     hipStream_t s = static_cast<hipStream_t>(stream);
     switch (channels / 100) {
-        case 6:  return x1::launch<6>(wpf, x, w, bias, y, batch, channels, frames, ld, s);
-        case 8:  return x1::launch<8>(wpf, x, w, bias, y, batch, channels, frames, ld, s);
-        case 10: return x1::launch<10>(wpf, x, w, bias, y, batch, channels, frames, ld, s);
-        case 12: return x1::launch<12>(wpf, x, w, bias, y, batch, channels, frames, ld, s);
+        case 6:  return x1::launch<6>(mode, x, w, bias, s0, s1, y, batch, channels, frames, ld, s);
+        case 8:  return x1::launch<8>(mode, x, w, bias, s0, s1, y, batch, channels, frames, ld, s);
+        case 10: return x1::launch<10>(mode, x, w, bias, s0, s1, y, batch, channels, frames, ld, s);
+        case 12: return x1::launch<12>(mode, x, w, bias, s0, s1, y, batch, channels, frames, ld, s);
     }
     return -1;
 }
