@@ -4,7 +4,8 @@ pipelined, output-split fp32 node kernel?  tools/ubench/x1/gc_wprefetch.hip hold
 into its own shared object here; interleaved rounds in one process, three buffer sets in rotation (larger than the last-level cache),
 outputs compared bit for bit, the library's own PIPE | OSPLIT variant timed beside them; `gen` = the same loop inside the library kernel's
 generic prologue / epilogue (optional skips, LayerNorm on the first, ragged vote) -- what generality costs a short-lived wave; `nsk` = the
-epilogue instantiated per number of skips, branch-free.  Each with 0, 1 and 2 skip inputs.
+epilogue instantiated per number of skips, branch-free; `coop` = the two waves of a group share their window loads through LDS.
+Each with 0, 1 and 2 skip inputs.
 
     python tools/ubench/ab_gc_wprefetch.py [--batches 64 8]
 """
@@ -50,6 +51,9 @@ for B in args.batches:
         w = torch.randn(c, c // 100, 5, device=dev) * 0.2
         bias = torch.randn(c, device=dev) * 0.1
 
+        cg = c // 100
+        # the cooperative kernel's weight layout: [group][half][stage][co][channel of the stage][tap]
+        w_coop = w.view(100, 2, cg // 2, cg // 2, 2, 5).permute(0, 1, 3, 2, 4, 5).contiguous()
         skip_sets = [torch.randn(B, c, ld, device=dev) for _ in range(2)]
         for sk in skip_sets:
             sk[:, :, t:] = 0
@@ -61,13 +65,13 @@ for B in args.batches:
                 hip.grouped_conv1d_node(x, w, bias, skips, y, t, 100, 5, 1, None, False, False, None, hip.GC_PIPE | hip.GC_OSPLIT)
             else:
                 ptr = [sk.data_ptr() for sk in skips] + [None] * (2 - n_skips)
-                rc = x1.x1_node({'base': 0, 'wpf': 1, 'gen': 2, 'nsk': 3}[kind], x.data_ptr(), w.data_ptr(), bias.data_ptr(), ptr[0], ptr[1],
+                rc = x1.x1_node({'base': 0, 'wpf': 1, 'gen': 2, 'nsk': 3, 'coop': 4}[kind], x.data_ptr(), (w_coop if kind == 'coop' else w).data_ptr(), bias.data_ptr(), ptr[0], ptr[1],
                                 y.data_ptr(), B, c, t, ld, stream)
                 assert rc == 0, rc
             return y
 
         for n_skips in (0, 1, 2):
-            kinds = ('lib', 'base', 'wpf', 'gen', 'nsk') if n_skips == 0 else ('lib', 'gen', 'nsk')
+            kinds = ('lib', 'base', 'wpf', 'gen', 'nsk', 'coop') if n_skips == 0 else ('lib', 'gen', 'nsk')
             ref = run('lib', 0, n_skips).clone()
             for kind in kinds[1:]:
                 assert torch.equal(run(kind, 0, n_skips), ref), (kind, n_skips, 'differs from the library kernel')
@@ -85,4 +89,6 @@ for B in args.batches:
             row = {'batch': B, 'block': blk, 'channels': c, 'frames': t, 'skips': n_skips}
             row.update({k + '_us': round(statistics.median(v), 2) for k, v in times.items()})
             row['nsk_vs_gen'] = round(row['nsk_us'] / row['gen_us'], 4)
+            if 'coop_us' in row:
+                row['coop_vs_base'] = round(row['coop_us'] / row['base_us'], 4)
             print(json.dumps(row), flush=True)

@@ -145,6 +145,104 @@ __global__ __launch_bounds__(256) void node_kernel(const float* __restrict__ x, 
     }
 }
 
+// COOP: the two waves of an output-split group stop loading the same windows.  Wave h of the pair requests channel 2 s + h of stage s --
+// ONE 16-byte chunk per lane (plus the two halo chunks of the 64-chunk block, lanes 0 and 1; every other lane's halo offset is out of
+// range, i.e. a zero from the bounds check and no memory request) -- writes it to LDS, and both waves read their three chunks per channel
+// from there.  Distinct bytes in flight per wave double (2 stages x 1 KiB against 2 windows x 3 KiB of which a third is distinct and half
+// of that shared with the partner wave), L1 / TA requests drop 6 x.  One workgroup barrier per stage, LDS double-buffered.
+template <int CG, int K, int D>
+__global__ __launch_bounds__(256) void node_coop_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ y, int channels, int frames, int ld, int groups)
+{
+    static_assert(K == 5 && D == 1 && CG % 4 == 2 || CG % 4 == 0, "window = chunks q - 1, q, q + 1; stages unrolled by two where CG / 2 is even");
+    constexpr int CO = CG / 2, LPAD = pad_left(K, D, 1), BASE = 4 - LPAD, SLOTS = 67, NST = CG / 2;
+    __shared__ float4 s_win[2][2][2][SLOTS];                    // [stage buffer][group slot][channel of the stage][chunk slot]
+    const int nq = ld >> 2, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = wave >> 1, h = wave & 1;
+    const int q0 = blockIdx.x * 64, q = q0 + lane;
+    const int g_raw = __builtin_amdgcn_readfirstlane(blockIdx.y * 2 + slot);
+    const int g = g_raw < groups ? g_raw : groups - 1;
+    const int co0 = h * CO, b = blockIdx.z;
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
+    // weights re-laid-out by the caller: [group][half][stage][co][channel of the stage][tap] -- a stage's 2 x CO x K scalars contiguous
+    const float* __restrict__ wg = w + (static_cast<size_t>(g) * 2 + h) * (NST * CO * 2 * K);
+    const float* __restrict__ bg = bias + g * CG + co0;
+    const int row_bytes = ld * 4;
+    const int own_off = q * 16;
+    const int halo_off = lane == 0 ? (q0 - 1) * 16 : lane == 1 ? (q0 + 64) * 16 : 0x7ffffff0;
+    const int halo_slot = lane == 0 ? 0 : lane == 1 ? 65 : 66;
+    float acc[CO][4];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        const float bv = bg[co];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[co][r] = bv;
+    }
+    const float* __restrict__ xg = x + row0;
+    struct Stage { float4 own, halo; };
+    auto request = [&](int s) {
+        const int ci = 2 * (s < NST ? s : NST - 1) + h;          // past the end: a redundant reload instead of a branch
+        const float* row = xg + static_cast<size_t>(ci) * ld;
+        return Stage{row_chunk(row, row_bytes, own_off), row_chunk(row, row_bytes, halo_off)};
+    };
+    auto publish = [&](int s, const Stage& st) {
+        s_win[s & 1][slot][h][lane + 1] = st.own;
+        s_win[s & 1][slot][h][halo_slot] = st.halo;
+    };
+    auto consume = [&](int s) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            __builtin_amdgcn_sched_barrier(0);                  // one channel at a time: without it hipcc hoists both channels' weights
+            int sv = s;                                         // pinned here: hipcc otherwise hoists the NEXT stage's 2 x CO x K scalars
+            asm volatile("" : "+s"(sv));                         // above this stage's FMAs (120 SGPRs at CG = 12 -> spills)
+            const float* __restrict__ ws = wg + static_cast<size_t>(sv) * (CO * 2 * K);
+            float xw[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float4 v = s_win[s & 1][slot][c][lane + k];
+                xw[4 * k + 0] = v.x; xw[4 * k + 1] = v.y; xw[4 * k + 2] = v.z; xw[4 * k + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+#pragma unroll
+                for (int co = 0; co < CO; ++co) {
+                    const float wv = ws[(co * 2 + c) * K + j];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[co][r] = __builtin_fmaf(wv, xw[BASE + r + j * D], acc[co][r]);
+                }
+        }
+    };
+    Stage ra = request(0), rb = request(1);
+#pragma unroll 1
+    for (int s = 0; s < NST; s += 2) {
+        publish(s, ra);
+        __syncthreads();
+        ra = request(s + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        consume(s);
+        __builtin_amdgcn_sched_barrier(0);
+        if (NST % 2 == 0 || s + 1 < NST) {                      // (uniform; CG / 2 odd: the last pass has one stage)
+            publish(s + 1, rb);
+            __syncthreads();
+            rb = request(s + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            consume(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (q >= nq || g_raw >= groups) return;
+    const int t0 = q * 4;
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = t0 + r < frames ? relu_clamp(acc[co][r]) : 0.f;
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(y + row0 + static_cast<size_t>(co0 + co) * ld + t0));
+    }
+}
+
 template <int CG>
 static int launch(int mode, const float* x, const float* w, const float* bias, const float* s0, const float* s1, float* y, int batch, int channels,
                   int frames, int ld, hipStream_t s)
@@ -156,6 +254,7 @@ static int launch(int mode, const float* x, const float* w, const float* bias, c
 #define X1_LAUNCH(...) hipLaunchKernelGGL((node_kernel<CG, 5, 1, __VA_ARGS__>), grid, dim3(256), 0, s, x, w, bias, s0, s1, none, y, channels, frames, ld, groups, no_ln)
     if (mode == 1)      X1_LAUNCH(true, false);
     else if (mode == 2) X1_LAUNCH(false, true);                 // generic epilogue: s0 / s1 may be NULL
+    else if (mode == 4) hipLaunchKernelGGL((node_coop_kernel<CG, 5, 1>), grid, dim3(256), 0, s, x, w, bias, y, channels, frames, ld, groups);
     else if (mode == 3) { if (s1) X1_LAUNCH(false, false, 2); else if (s0) X1_LAUNCH(false, false, 1); else X1_LAUNCH(false, false, 0); }
     else                X1_LAUNCH(false, false);
 #undef X1_LAUNCH
@@ -164,7 +263,7 @@ static int launch(int mode, const float* x, const float* w, const float* bias, c
 }  // namespace x1
 
 // mode: 0 = base (no skips), 1 = weight prefetch (no skips), 2 = base loop inside the generic prologue / epilogue (skips by pointer),
-//       3 = base loop with the branch-free epilogue instantiated for the number of non-NULL skips
+//       3 = base loop with the branch-free epilogue instantiated for the number of non-NULL skips, 4 = cooperative window loads (no skips)
 extern "C" int x1_node(int mode, const float* x, const float* w, const float* bias, const float* s0, const float* s1, float* y, int batch,
                        int channels, int frames, int ld, void* stream)
 {
