@@ -27,6 +27,7 @@ from nb_asr_amd import hip
 ap = argparse.ArgumentParser()
 ap.add_argument('--batches', type=int, nargs='+', default=[64, 8])
 ap.add_argument('--rounds', type=int, default=30)
+ap.add_argument('--skips', type=int, nargs='+', default=[0, 1, 2])
 args = ap.parse_args()
 
 so = HERE / 'x1' / 'libgc_wpf.so'
@@ -70,7 +71,7 @@ for B in args.batches:
                 assert rc == 0, rc
             return y
 
-        for n_skips in (0, 1, 2):
+        for n_skips in args.skips:
             kinds = ('lib', 'base', 'wpf', 'gen', 'nsk', 'coop') if n_skips == 0 else ('lib', 'gen', 'nsk')
             ref = run('lib', 0, n_skips).clone()
             for kind in kinds[1:]:

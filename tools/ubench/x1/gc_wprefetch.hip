@@ -11,6 +11,10 @@
 #include <hip/hip_runtime.h>
 #include "common.h"
 
+#ifndef X1_SEPARATE_STAGES
+#define X1_SEPARATE_STAGES 0
+#endif
+
 namespace x1 {
 using nbasr::pad_left;
 using nbasr::relu_clamp;
@@ -214,15 +218,23 @@ __global__ __launch_bounds__(256) void node_coop_kernel(const float* __restrict_
         }
     };
     Stage ra = request(0), rb = request(1);
+    int nst = NST;
+#if X1_SEPARATE_STAGES
+    // opaque stage count: the inner branch then stays, and with it a control-flow join (vmcnt(0)) between the two stages of a pass.  60-72
+    // VGPRs instead of 62-95 and no scalar spills -- but only ONE stage of lookahead: measured 0.97 / 1.01 / 1.00 / 1.05 x the pipelined
+    // output-split kernel on blocks 0-3, against 0.97 / 0.93 / 0.92-0.94 / 1.07-1.11 x with the stages interleaved (default): the depth of
+    // the lookahead is what pays, not the occupancy.
+    asm volatile("" : "+s"(nst));
+#endif
 #pragma unroll 1
-    for (int s = 0; s < NST; s += 2) {
+    for (int s = 0; s < nst; s += 2) {
         publish(s, ra);
         __syncthreads();
         ra = request(s + 2);
         __builtin_amdgcn_sched_barrier(0);
         consume(s);
         __builtin_amdgcn_sched_barrier(0);
-        if (NST % 2 == 0 || s + 1 < NST) {                      // (uniform; CG / 2 odd: the last pass has one stage)
+        if (s + 1 < nst) {                                      // (uniform; CG / 2 odd: the last pass has one stage)
             publish(s + 1, rb);
             __syncthreads();
             rb = request(s + 3);
