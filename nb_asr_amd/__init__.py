@@ -39,6 +39,33 @@ def set_default_backend(backend):
     return get_backend_name(backend)
 
 
+def register_with(nasbench_asr=None, default=False):
+    """Make this package the ``'hip'`` model backend of an imported ``nasbench_asr`` -- the reference needs NO source change.
+
+    The reference resolves a backend name through ``nasbench_asr.model._backends`` (``utils.BackendsAccessor``,
+    reference ``utils.py:115-165``): ``get_backend(name)`` first looks the name up in its ``backends`` dict and only then
+    validates / imports a sub-package (``utils.py:150-153``).  Seeding that dict is therefore all a registration takes:
+
+        import nasbench_asr, nb_asr_amd
+        nb_asr_amd.register_with(nasbench_asr)
+        model = nasbench_asr.get_model(arch_vec, use_rnn=True, dropout_rate=0.0, gpu=0, backend='hip')   # model/__init__.py:19-20
+        nasbench_asr.model.print_model_summary(model)           # dispatches on model.backend == 'hip' (model/__init__.py:23-24)
+
+    ``default=True`` also makes it what ``get_model(...)`` without ``backend=`` returns (the accessor's ``None`` entry, which
+    the reference itself fills on first use, ``utils.py:163-164``).  Returns the backend name."""
+    import sys
+    if nasbench_asr is None:
+        import nasbench_asr
+    accessor = nasbench_asr.model._backends
+    this = sys.modules[__name__]
+    accessor.backends[_BACKEND] = this
+    if _BACKEND not in accessor.available_backends:
+        accessor.available_backends.append(_BACKEND)
+    if default:
+        accessor.backends[None] = this
+    return _BACKEND
+
+
 def get_model(arch_vec, use_rnn, dropout_rate, gpu=None, backend=None):
     """Build the model for ``arch_vec`` with the reference's initialisation.
 

@@ -294,7 +294,12 @@ class ForwardPlan:
         if hit is None or hit[0]() is not param or hit[1] != param._version:
             if len(self._packed) >= 512:
                 self._packed = {k: v for k, v in self._packed.items() if v[0]() is not None}
-            hit = (weakref.ref(param), param._version, build())
+            if hit is not None:
+                self.wait_tails()        # a pipelined tail on the side stream may still read the copy that is being replaced
+            built = build()
+            if self.side_stream is not None and isinstance(built, torch.Tensor):
+                built.record_stream(self.side_stream)
+            hit = (weakref.ref(param), param._version, built)
             self._packed[key] = hit
             self._tapes.clear()
             self._mutations += 1
@@ -472,6 +477,9 @@ class ForwardPlan:
         self.side_stream = torch.cuda.Stream(device=self.device, priority=-1)
         for t in self._bufs.values():                 # allocated on the main stream, from now on also read on the side stream
             t.record_stream(self.side_stream)
+        for _, _, built in self._packed.values():     # derived weights (packed w_ih / w_hh, fp32 copies): read by the tails too
+            if isinstance(built, torch.Tensor):
+                built.record_stream(self.side_stream)
 
     def _pipeline_buffers(self, channels, frames, need_enc=True):
         """Double-buffered gate pre-activations of the pipelined tail (+ an fp32 hand-over copy of the encoder output where the
@@ -541,7 +549,27 @@ class ForwardPlan:
         pipe = bool(pipelined) and model.use_rnn
         return (x.dtype, tuple(x.shape), x.data_ptr() % 16 == 0, bool(pipelined), (self._turn ^ 1) if pipe else -1,
                 torch.cuda.current_stream(self.device).cuda_stream, tuple(os.environ.get(k) for k in self._TAPE_ENV),
-                epoch, tuple(map(id, model.model)), params)
+                epoch, tuple(map(id, model.model)), params, self._structure_fingerprint(model))
+
+    @staticmethod
+    def _structure_fingerprint(model):
+        """The PLAIN attributes the launch sequence reads on every call and that no registration hook sees:
+        ``node.branch_ops`` is a python list, ``cell.use_norm`` / ``op.dilation`` / ``norm.eps`` / ``model.use_rnn`` are plain
+        attributes -- mutating one after a tape exists must not replay the old sequence."""
+        fp = [model.use_rnn, model.training, getattr(model, 'dropout_rate', 0.0)]
+        for layer in model.model:
+            nodes = getattr(layer, 'nodes', None)
+            if nodes is not None:
+                fp.append(layer.use_norm)
+                fp.append(layer.norm_layer.eps if layer.use_norm else None)
+                for node in nodes:
+                    op = node.op
+                    fp.append((type(op), getattr(op, 'kernel_size', 0), getattr(op, 'dilation', 0), getattr(op, 'groups', 0),
+                               tuple(map(type, node.branch_ops))))
+            else:
+                fp.append((type(layer), getattr(layer, 'eps', None), getattr(layer, 'kernel_size', 0), getattr(layer, 'strides', 0),
+                           getattr(layer, 'groups', 0), getattr(layer, 'p', None)))
+        return tuple(fp)
 
     def run(self, model, x, taps=None, pipelined=False, _capturing=False):
         """Enqueue one forward of ``model`` (its parameters are read now, so a DataParallel replica runs with its own).

@@ -84,6 +84,7 @@ class SearchCell(nn.Module):
 
 class ASRModel(nn.Module):
     _warned_no_autograd = False
+    _warned_detached = False
 
     def __init__(self, arch_desc, num_classes=48, use_rnn=False, use_norm=True, dropout_rate=0.0, **kwargs):
         super().__init__()
@@ -151,8 +152,17 @@ class ASRModel(nn.Module):
             raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor, got {tuple(getattr(input, "shape", ()))}')
         if not input.is_cuda:
             raise hip.HipError('ASRModel.forward needs its input on a HIP device; this package has no CPU path')
-        if self.training and torch.is_grad_enabled() and _taps is None and not _pipelined and input.dtype == torch.float32 \
-                and (input.requires_grad or self.model[0].conv.weight.requires_grad):
+        wants_grad = self.training and torch.is_grad_enabled() and _taps is None and not _pipelined \
+            and (input.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if wants_grad and input.dtype != torch.float32:
+            #  the differentiable path is fp32 only: falling through to the fused executor would hand back detached logits
+            if not ASRModel._warned_detached:
+                ASRModel._warned_detached = True
+                warnings.warn(f'nb_asr_amd: training-mode forward with gradients enabled on {input.dtype} tensors: the differentiable '
+                              f'path is float32 only, so this call runs the fused inference executor and its logits are NOT attached '
+                              f'to autograd.  Use float32 for training, or model.eval() / torch.no_grad() for inference.', stacklevel=2)
+            wants_grad = False
+        if wants_grad:
             # training mode with gradients enabled (what the reference's trainer does, trainer.py:215-223): the differentiable forward --
             # one op at a time through the autograd functions, unfused; eval() / torch.no_grad() take the fused inference executor
             if not ASRModel._warned_no_autograd:

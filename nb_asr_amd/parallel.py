@@ -74,23 +74,38 @@ class ShardedForward:
         begin, end = shard_bounds(global_x.shape[0], self.world_size, self.rank)
         return self.gather_ragged(model(global_x[begin:end]), global_x.shape[0])
 
-    def allreduce_gradients(self, parameters, bucket_bytes=64 << 20):
+    def allreduce_gradients(self, parameters, bucket_bytes=64 << 20, n_local=None):
         """Data-parallel training step (what the reference does with nn.DataParallel, trainer.py:91-92, as one process per GPU): after
         ``loss.backward()`` on this rank's shard, average the gradients over the ranks IN PLACE.  The gradients are flattened into
         buckets of ``bucket_bytes`` (the model's 105 MB of fp32 gradients: two 64 MiB all-reduces -- ring all-reduce over xGMI is bound
         per link, a few large messages amortise its latency where 166 small ones would not) and copied back.  Parameters without a
-        gradient on this rank contribute zeros (every rank must pass the same parameter list)."""
+        gradient on this rank contribute zeros (every rank must pass the same parameter list).
+
+        ``n_local`` = the number of utterances of THIS rank's shard.  Each rank's loss is a mean over its own shard
+        (``ctc.training_loss``), so with shards of different sizes (``shard_bounds`` when the batch is not a multiple of the world
+        size) the gradient of the GLOBAL-batch mean -- what nn.DataParallel computes from the gathered outputs -- is
+        sum_r (n_r / n) grad_r, not the plain average: every rank's gradients are scaled by n_local / n_global (one extra
+        all-reduce of the counts) before the SUM.  ``None`` = equal shards (plain average)."""
         params = [p for p in parameters if p.requires_grad]
         if not self.collective or not params:
             return
+        if n_local is None:
+            weight = 1.0 / self.world_size
+        else:
+            count = torch.tensor([float(n_local)], dtype=torch.float64, device=params[0].device)
+            dist.all_reduce(count, op=dist.ReduceOp.SUM)
+            n_global = float(count.item())
+            if n_global <= 0:
+                raise ValueError('allreduce_gradients: the ranks hold no utterances')
+            weight = float(n_local) / n_global
         bucket, size = [], 0
 
         def flush():
             if not bucket:
                 return
             flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in bucket])
+            flat *= weight                                   # n_local / n_global (1 / world for equal shards), then SUM
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-            flat /= self.world_size
             offset = 0
             for p in bucket:
                 n = p.numel()

@@ -111,6 +111,45 @@ def test_two_rank_gradient_allreduce():
     assert all(ok for _, ok in results), results
 
 
+def _grad_worker_uneven(rank, world, port, out_queue):
+    """7 utterances over 2 ranks (4 + 3), each rank's loss a MEAN over its own shard (what ctc.training_loss is)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    runner = ShardedForward(world_size=world, rank=rank, device='cpu', backend='gloo')
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 40), torch.nn.Tanh(), torch.nn.Linear(40, 5))
+    x = torch.randn(7, 7)
+    lo, hi = shard_bounds(7, world, rank)
+    net(x[lo:hi]).pow(2).sum(dim=1).mean().backward()     # mean over THIS rank's utterances
+    plain = [p.grad.clone() for p in net.parameters()]
+    runner.allreduce_gradients(list(net.parameters()), n_local=hi - lo)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 40), torch.nn.Tanh(), torch.nn.Linear(40, 5))
+    ref.load_state_dict(net.state_dict())
+    ref(x).pow(2).sum(dim=1).mean().backward()             # mean over the global batch on one rank
+    ok = all(torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6) for p, q in zip(net.parameters(), ref.parameters()))
+    # the equal-weight average is NOT that gradient on an uneven split (the bug the weighting fixes)
+    for p, g in zip(net.parameters(), plain):
+        p.grad.copy_(g)
+    runner.allreduce_gradients(list(net.parameters()))
+    differs = any(not torch.allclose(p.grad, q.grad, rtol=1e-3, atol=1e-5) for p, q in zip(net.parameters(), ref.parameters()))
+    runner.close()
+    out_queue.put((rank, ok and differs))
+
+
+def test_two_rank_gradient_allreduce_uneven_shards_mean_loss():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker_uneven, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results
+
+
 def test_single_process_is_a_no_op():
     runner = ShardedForward(world_size=1, rank=0, device='cpu')
     x = torch.randn(4, 80, 20)

@@ -64,6 +64,24 @@ def test_grouped_conv_clamp_golden(op_fx):
     close(y, op_fx[tag], rtol=2e-5, atol=2e-5)
 
 
+def test_overflowed_preactivations_are_loud():
+    """Documented divergence (common.h relu_clamp): a +-Inf PRE-activation (an overflowed conv sum) comes out as
+    NaN where the reference's relu / clamp_max_ saturate it to 20 / 0 (ops.py:27-28).  NaN propagates like in the reference, finite
+    values are exact, and the divergence is confined to the channel that overflowed -- louder than the reference, never quieter."""
+    torch.manual_seed(2)
+    c, groups = 24, 4
+    x = torch.randn(1, c, 16)
+    w = torch.randn(c, c // groups, 5) * 0.3
+    bias = torch.randn(c) * 0.2
+    bias[3], bias[7], bias[11] = float('inf'), float('-inf'), float('nan')
+    want = oracle.pad_conv_relu(x, w, bias, 1, 1, groups)
+    assert bool((want[0, 3] == 20).all()) and bool((want[0, 7] == 0).all()) and bool(want[0, 11].isnan().all())     # the reference's rule
+    got = grouped(x, w, bias, 5, 1, groups)
+    assert bool(got[0, 3].isnan().all()) and bool(got[0, 7].isnan().all()) and bool(got[0, 11].isnan().all())
+    keep = [i for i in range(c) if i not in (3, 7, 11)]
+    close(got[:, keep], want[:, keep])
+
+
 @pytest.mark.parametrize('t', [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 1000, 1027])
 @pytest.mark.parametrize('k,d', [(5, 1), (7, 2)])
 def test_grouped_conv_ragged_lengths_vs_oracle(t, k, d):

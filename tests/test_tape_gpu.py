@@ -151,3 +151,31 @@ def test_swapped_modules_are_seen(monkeypatch):
     assert not torch.equal(y1, y0) and not torch.equal(ys[0], y1)
     want = untaped(m, [x], monkeypatch)[0]
     assert all(torch.equal(y, want) for y in ys)
+
+
+def test_plain_attribute_mutations_are_seen(monkeypatch):
+    """`node.branch_ops` is a python list and `cell.use_norm` a plain attribute -- no registration hook fires when they
+    change, so the tape key carries a structural fingerprint.  After a tape exists, flipping a skip flag or dropping a cell's
+    LayerNorm must reach the next forward (the pre-tape executor re-read these on every call)."""
+    from nb_asr_amd.ops import Identity, Zero
+    m = build(cases.ARCH_D, True)
+    x = keyed_input(2, 80, seed=5).to(DEV)
+    with torch.no_grad():
+        for _ in range(3):
+            y0 = m(x)
+        (plan,) = plans(m)
+        assert plan.tape_replays == 1
+        node = m.model[3].nodes[1]
+        assert isinstance(node.branch_ops[0], Identity)
+        node.branch_ops[0] = Zero()                                       # a skip connection removed
+        ys = [m(x) for _ in range(3)]
+        m.model[4].use_norm = False                                       # a cell without its LayerNorm
+        zs = [m(x) for _ in range(3)]
+    assert not torch.equal(ys[0], y0) and not torch.equal(zs[0], ys[0])
+    assert all(torch.equal(y, ys[0]) for y in ys) and all(torch.equal(z, zs[0]) for z in zs)
+    want = untaped(m, [x], monkeypatch)[0]
+    assert torch.equal(zs[-1], want)
+    m.model[4].use_norm = True
+    node.branch_ops[0] = Identity()
+    with torch.no_grad():
+        assert torch.equal(m(x), y0)
