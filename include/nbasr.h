@@ -121,14 +121,15 @@ int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const 
                                     float* y, int batch, int c_in, int frames_in, int ld_in,
                                     int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
 
-/* The same convolution with HALF the matrix instructions: operands are split into two fp16 terms, v = hi + lo' 2^-11
- * (11 + 11 significand bits plus the rounding sign cover fp32's 24; the residual is stored pre-scaled so that it stays a
- * normal fp16 number) and three cross products are accumulated in fp32 (dropped term <= 2^-24 of a product).
+/* The same convolution with HALF the matrix instructions: operands are split into two fp16 terms, v = hi + lo
+ * (11 + 11 significand bits plus the rounding sign cover fp32's 24; the residual may be an fp16 subnormal, exact to 2^-24)
+ * and three cross products are accumulated in fp32 (dropped term <= 2^-24 of a product), as a two-level blocked sum: one
+ * block per 16 input channels x 8 taps, then the total.
  * fp16's narrow exponent range is handled by exact power-of-two scalings that the epilogue undoes: each weight row is
  * normalised at pack time, and each utterance of x by 2^k derived from x_absmax[b], a caller-supplied UPPER BOUND of
  * max|x[b, :, :]| (device pointer, `batch` floats, finite; nbasr_layernorm_channels_absmax writes it as a by-product).
  * A bound that is too small makes fp16 overflow possible (undefined results); a loose bound only costs precision of
- * elements more than 2^-29 below it.  Otherwise same arguments, layout contract and error behaviour as the bf16 entry
+ * elements more than 2^-16 below it (they keep an absolute accuracy of 2^-39 of the bound).  Otherwise same arguments, layout contract and error behaviour as the bf16 entry
  * points; the packed images are NOT interchangeable between the two schemes. */
 size_t nbasr_packed_dense_weights_bytes_f16(int c_out, int c_in, int kernel);
 int nbasr_pack_dense_weights_f16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
@@ -382,7 +383,7 @@ int nbasr_log_normalize(const float* mel, const int* lengths, const float* mean,
  * The first dense convolution takes caller data, whose range this library does not control.  nbasr_input_range writes, per
  * utterance, range[4 b] = { max finite |x|, the quietest non-silent frame's max |x| over channels, non-zero if any sample is
  * Inf / NaN, unused } (x: (batch, channels, ld) fp32, any ld >= frames).  An utterance is EXTREME when it holds a non-finite
- * sample or a frame more than 2^20 below its loudest sample: the scaled fp16 scheme would then lose precision in (or, for Inf,
+ * sample or a frame more than 2^12 below its loudest sample: the scaled fp16 scheme would then lose precision in (or, for Inf,
  * flush) the quiet part.  The two `_ranged` convolutions are launched back to back on the same output: the fp16 one computes
  * the ordinary utterances (scale from range[4 b]) and skips the extreme ones, the 3-way bf16 one (fp32's exponent range, no
  * scaling, NaN / Inf propagate like in the reference) computes exactly those.  No host synchronisation. */

@@ -92,7 +92,7 @@ class _DensePadConvRelu(torch.autograd.Function):
         elif kernel == 8 and mode != 'f32' and xp.data_ptr() % 16 == 0:
             # what the inference executor runs for the model's first conv, for all four: a range summary of the input per utterance, its
             # pre-split fp16 image, the LDS-DMA-only two-term fp16 GEMM (3 MFMAs per fp32 product, against 6 for bf16x3), and the bf16x3
-            # leg for utterances the summary calls extreme (non-finite samples, > 2^20 of dynamic range) -- routed on the device
+            # leg for utterances the summary calls extreme (non-finite samples, > 2^12 of dynamic range) -- routed on the device
             wc = w3.contiguous()
             rng = torch.empty(xp.shape[0], 4, device=xp.device, dtype=torch.float32)
             hip.input_range(xp, frames, rng)

@@ -10,10 +10,8 @@
 // (checked against an fp64 oracle in tests/).  6 MFMAs at 16x the rate = 2.67x the fp32 matrix peak.
 //
 // Second scheme, HALF the MFMAs (policy SplitF16x2): fp16 carries 11 significand bits, so TWO terms suffice,
-//     v = hi + lo' * 2^-11,   hi = rne16(v),   lo' = rne16((v - hi) * 2^11)      |v - hi - lo' 2^-11| <= 2^-24 |v|
-// (the residual is pre-scaled by 2^11 so it stays a NORMAL fp16 number; fp16 subnormal inputs are honoured by the MFMA
-// -- tools/ubench/mfma_f16_denorm.hip -- so tiny operands only lose bits below 2^-36 absolute), and
-//     a*b ~= ah*bh + 2^-11 (ah*bl' + al'*bh)            dropped: al*bl <= 2^-24 |a*b|
+//     v = hi + lo,   hi = rne16(v),   lo = rne16(v - hi)      |v - hi - lo| <= 2^-24 |v|  (23 bits + the sign of lo)
+//     a*b ~= ah*bh + ah*bl + al*bh            dropped: al*bl <= 2^-24 |a*b|
 // i.e. 3 MFMAs per fp32 product (5.3x the fp32 matrix peak).  fp16's RANGE (6e-5 .. 65504 for normal numbers) is the
 // catch, and the model's activations really do leave it (with the reference's default initialisation they shrink to 1e-9).
 // Both operands are therefore brought into range by EXACT power-of-two scalings that the epilogue undoes:
@@ -21,8 +19,19 @@
 //     absmax[b] >= max|x[b]| (nbasr_layernorm_channels_absmax produces it for free while writing x, nbasr_absmax
 //     reduces it for the model input);
 //   * row co of w is multiplied by 2^kw[co] at pack time (largest magnitude of the row -> [2^13, 2^14)).
-// Elements down to 2^-29 of their utterance's / row's maximum keep full precision; smaller ones are off by at most
-// 2^-51 of that maximum, far below fp32 resolution of any sum they enter.
+// Round 3: lo is stored UNSCALED (rounds 1-2 stored lo * 2^11 to keep it a normal fp16 number and accumulated the cross terms in
+// a second register set).  fp16 subnormals are honoured by v_cvt_f16_f32 and by the MFMA (tools/ubench/mfma_f16_denorm.hip), so
+// lo is exact down to 2^-24: elements within 2^-16 of their utterance's / row's maximum keep all 24 bits, smaller ones are off by
+// at most 2^-25 absolute = 2^-39 of that maximum -- far below fp32 resolution of any sum they enter.  What it buys: all three
+// products go to ONE accumulator, which frees the second register set for a BLOCKED sum (next paragraph).
+//
+// Accumulation (round 3).  Rounds 1-2 kept one running sum per output over the whole K = c_in * 8 (one rounding
+// per 32-k MFMA, 150-300 roundings at the magnitude of the growing sum).  Measured per layer that chain -- not the split -- was
+// the path's distance to the CPU's blocked sums: the split's representation error is 0.33 of the CPU conv's own error against
+// fp64, the chain was 1.4 x (profiles/r02_layer_noise.txt: 0.90 -> 1.25 x the CPU's error across conv 1).  Now every channel
+// group (16 channels x 8 taps = 4 k-blocks = 12 MFMAs) is summed from ZERO in `acc` and added to `tot` once: 12 + K/128
+// roundings instead of K/32 at full magnitude, the error model of a two-level blocked sum (emulated on the CPU in
+// tools/split_accumulation_model.py: 0.61 x the CPU conv's error where the single chain gave 1.0-1.4 x).
 //
 // GEMM view per utterance: M = c_out, N = output frames, K = (c_in, tap).  The 32 k of one MFMA are 16 input CHANNELS of
 // TWO consecutive taps (a lane holds 8 consecutive k = 8 channels of one tap):
@@ -38,7 +47,7 @@
 //    16 channels x 4 taps (2 for bf16 x 3 at stride 2: LDS budget), one barrier per step; the two halves of the workgroup run
 //    a step in opposite order (stage-then-multiply / multiply-then-stage) so a wave's memory phase sits beside its SIMD
 //    partner's MFMAs, and the multiply-first half runs at s_setprio 1 so that it really finishes first;
-//  * the hi*hi products accumulate in their own register set, so the large running sum is rounded once per 32 k.
+//  * accumulation is a two-level blocked sum (per channel group, then the total): see the scheme notes above.
 #include "storage.h"
 
 #include <cstdlib>
@@ -59,7 +68,6 @@ constexpr int PB_THREADS = 512;                                              // 
 struct SplitBf16x3 {
     static constexpr int NS = 3;
     typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
-    static constexpr float SMALL_SCALE = 1.f;
     static constexpr bool SCALED = false;                        // bf16 has fp32's exponent range
     __host__ __device__ static constexpr int taps_per_step(int stride) { return stride == 1 ? 4 : 2; }   // LDS budget: 160 KiB
     __device__ static __forceinline__ void split(float v, unsigned short (&s)[NS]) {
@@ -80,12 +88,11 @@ struct SplitBf16x3 {
 struct SplitF16x2 {
     static constexpr int NS = 2;
     typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
-    static constexpr float SMALL_SCALE = 1.f / 2048.f;           // the cross terms carry lo' = lo * 2^11
     static constexpr bool SCALED = true;                         // operands are range-normalised by powers of two
     __host__ __device__ static constexpr int taps_per_step(int) { return 4; }
     __device__ static __forceinline__ void split(float v, unsigned short (&s)[NS]) {
         const _Float16 hi = static_cast<_Float16>(v);
-        const _Float16 lo = static_cast<_Float16>((v - static_cast<float>(hi)) * 2048.f);
+        const _Float16 lo = static_cast<_Float16>(v - static_cast<float>(hi));      // unscaled; subnormal below 2^-14 (exact to 2^-24)
         s[0] = __builtin_bit_cast(unsigned short, hi);
         s[1] = __builtin_bit_cast(unsigned short, lo);
     }
@@ -101,7 +108,6 @@ struct SplitF16x2 {
 struct PlainBf16 {
     static constexpr int NS = 1;
     typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
-    static constexpr float SMALL_SCALE = 0.f;
     static constexpr bool SCALED = false;
     __host__ __device__ static constexpr int taps_per_step(int) { return 8; }      // all 8 taps of a channel group per K-step
     __device__ static __forceinline__ void split(float v, unsigned short (&s)[NS]) {
@@ -156,8 +162,10 @@ struct PackedConvArgs {
     int staged_epilogue;         // fp32 output through LDS in whole row segments (NBASR_DENSE_EPILOGUE=direct turns it off: A/B)
 };
 
-// an utterance the scaled fp16 scheme must not take: non-finite samples, or a frame > 2^20 below the loudest sample
-__device__ __forceinline__ bool range_is_extreme(const float* r) { return r[2] != 0.f || r[1] < r[0] * 9.5367431640625e-07f; }
+// an utterance the scaled fp16 scheme must not take: non-finite samples, or a frame > 2^12 below the loudest sample (the unscaled
+// lo term is exact to 2^-24 with the maximum at 2^14..2^15: a frame 2^12 below it still has its top three binades at full precision
+// and everything below within 2^-27 of the frame's own scale; rounds 1-2, with lo pre-scaled by 2^11, drew the line at 2^20)
+__device__ __forceinline__ bool range_is_extreme(const float* r) { return r[2] != 0.f || r[1] < r[0] * 2.44140625e-04f; }
 
 // 2^k that moves a magnitude with biased exponent field e to [2^target, 2^(target+1)), and its inverse; (1, 1) for zero
 __host__ __device__ inline void pow2_normaliser(float absmax, int target, float& scale, float& inv)
@@ -277,15 +285,25 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     // a wave whose whole tile is out of range issues no MFMAs
     const bool wave_active = (m0 + wm * WROWS) < a.c_out && (n0 + wn * 64) < a.ld_out;
 
-    // two accumulator sets: `big` only ever receives hi*hi (ONE rounding of the large running sum per 32 k, the
-    // accumulation-chain length of a blocked fp32 sum); the small cross terms go to `small`
-    floatx4 big[MI][4], small[MI][4];                 // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
+    // two accumulator sets, a two-level BLOCKED sum: `acc` takes every product of ONE channel group (smallest terms first) starting
+    // from zero, `tot` takes acc once per group (flush_group).  One-term operands (NS == 1) use `acc` alone.
+    floatx4 acc[MI][4], tot[MI][4];                   // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { big[i][j][r] = 0.f; small[i][j][r] = 0.f; }
+            for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
+    auto flush_group = [&]() {
+        if constexpr (P::NS > 1) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+        }
+    };
 
     // ---- staging helpers ---------------------------------------------------------------------------------------
     // weights of K-step `step` (index within this row tile) -> Abuf[buf] by LDS-DMA, ASTEP/1 KiB wave copies
@@ -408,22 +426,17 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             for (int k = 0; k < P::NS; ++k) f[k] = *reinterpret_cast<const vec8*>(A + ((k * TP + 2 * pp) * 2 * PB_M + i * 16) * 16);
         };
         auto block = [&](int i, int j, const vec8 (&af)[P::NS], const vec8 (&bf)[P::NS]) {
-            if constexpr (P::NS == 1) {
-                big[i][j] = P::mfma(af[0], bf[0], big[i][j]);
-                return;
-            }
-            floatx4 c = small[i][j];
-            if constexpr (P::NS == 3) {
-                c = P::mfma(af[2], bf[0], c);   // lo * hi
-                c = P::mfma(af[0], bf[2], c);   // hi * lo
-                c = P::mfma(af[1], bf[1], c);   // mid * mid
+            floatx4 c = acc[i][j];                  // ONE accumulator, smallest terms first (a dependent chain of the same MFMA
+            if constexpr (P::NS == 3) {             // issues back to back on gfx950: nothing to interleave for)
+                c = P::mfma(af[2], bf[0], c);       // lo * hi
+                c = P::mfma(af[0], bf[2], c);       // hi * lo
+                c = P::mfma(af[1], bf[1], c);       // mid * mid
             }
             if constexpr (P::NS > 1) {
-                c = P::mfma(af[1], bf[0], c);       // mid * hi   (fp16: lo' * hi)
-                c = P::mfma(af[0], bf[1], c);       // hi * mid   (fp16: hi * lo')
-                small[i][j] = c;
-                big[i][j] = P::mfma(af[0], bf[0], big[i][j]);   // hi * hi
+                c = P::mfma(af[1], bf[0], c);       // mid * hi   (fp16: lo * hi)
+                c = P::mfma(af[0], bf[1], c);       // hi * mid   (fp16: hi * lo)
             }
+            acc[i][j] = P::mfma(af[0], bf[0], c);   // hi * hi
         };
         if constexpr (PIPE) {
             vec8 bfr[4][P::NS], af[2][P::NS];
@@ -521,6 +534,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next step's weight DMA has landed (this wave's part)
             __syncthreads();               // ... every wave's part, the new input tile is written, this step's reads are done
         }
+        flush_group();                     // the group's block sum joins the total: one rounding at full magnitude per 128 k
     }
 
     if constexpr (P::NS == 1) {
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ml = i * 16 + kq * 4 + r, m = m0 + wm * WROWS + ml;
-                        const float v = (live && m < a.c_out) ? relu_clamp(big[i][j][r] + a.bias[m]) : 0.f;
+                        const float v = (live && m < a.c_out) ? relu_clamp(acc[i][j][r] + a.bias[m]) : 0.f;
                         T[ml * 64 + j * 16 + l15] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
                     }
                 }
@@ -581,9 +595,9 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                         const int m = m0 + wm * WROWS + i * 16 + kq * 4 + r;
                         float v = 0.f;
                         if (live && m < a.c_out) {
-                            float acc = big[i][j][r] + small[i][j][r] * P::SMALL_SCALE;
-                            if constexpr (P::SCALED) acc = acc * x_inv * a.w_inv_scale[m];
-                            v = relu_clamp(acc + a.bias[m]);
+                            float sum = tot[i][j][r];
+                            if constexpr (P::SCALED) sum = sum * x_inv * a.w_inv_scale[m];
+                            v = relu_clamp(sum + a.bias[m]);
                         }
                         T[(ii * 16 + kq * 4 + r) * TS + j * 16 + l15] = v;
                     }
@@ -617,10 +631,10 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             for (int r = 0; r < 4; ++r) {
                 const int m = m0 + wm * WROWS + i * 16 + kq * 4 + r;
                 if (m >= a.c_out) continue;
-                float acc = big[i][j][r] + small[i][j][r] * P::SMALL_SCALE;
-                if constexpr (P::SCALED) acc = acc * x_inv * a.w_inv_scale[m];  // exact: powers of two, applied one after the other
+                float sum = tot[i][j][r];
+                if constexpr (P::SCALED) sum = sum * x_inv * a.w_inv_scale[m];  // exact: powers of two, applied one after the other
                                                                                // (their product alone could leave fp32's range)
-                float v = relu_clamp(acc + a.bias[m]);
+                float v = relu_clamp(sum + a.bias[m]);
                 const size_t off = (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n;
                 if (a.s0) v += a.s0[off];
                 if (a.s1) v += a.s1[off];

@@ -249,7 +249,7 @@ extern "C" int nbasr_layernorm_channels_absmax(const float* x, const float* gamm
 //   1. channel_stats_bound_kernel: per-frame (mean, rstd) as channel_stats_kernel, and an upper bound of the normalised
 //      magnitudes  max_c |x_c - mean| * rstd * max|gamma| + max|beta|  (from the per-frame extrema tracked in the same
 //      pass) folded into bound[b] (atomicMax on float bits);
-//   2. normalize_split_kernel: y = (x - mean) rstd gamma + beta, scaled by 2^k(bound[b]), split v = hi + lo' 2^-11, written
+//   2. normalize_split_kernel: y = (x - mean) rstd gamma + beta, scaled by 2^k(bound[b]), split v = hi + lo (two fp16 terms, lo unscaled), written
 //      as image[b][16-channel group][split][8-channel half][1 + ld rows][8 ch] (row 0 zero, frame t at row t + 1).
 __global__ __launch_bounds__(256) void channel_stats_bound_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                                   const float* __restrict__ beta, float* __restrict__ stats,
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
             for (int c = 0; c < 8; ++c) {
                 const _Float16 h = static_cast<_Float16>(v[c][r]);
                 hi[c] = h;
-                lo[c] = static_cast<_Float16>((v[c][r] - static_cast<float>(h)) * 2048.f);
+                lo[c] = static_cast<_Float16>(v[c][r] - static_cast<float>(h));       // unscaled residual (gemm_conv_split.hip, SplitF16x2)
             }
             *reinterpret_cast<halfx8*>(plane_hi + r * 16) = hi;
             *reinterpret_cast<halfx8*>(plane_lo + r * 16) = lo;

@@ -416,7 +416,7 @@ def input_range(x, frames, out):
 
 def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride, image=None, row_tile=128):
     """The model's first dense conv with per-utterance routing on the device: ordinary utterances on the 2-way fp16 split,
-    extreme ones (non-finite samples, > 2^20 dynamic range between frames) on the 3-way bf16 split; same output tensor.
+    extreme ones (non-finite samples, > 2^12 dynamic range between frames) on the 3-way bf16 split; same output tensor.
     ``image``: uint8 workspace of ``nbasr_split_image_bytes`` -- the fp16 leg then runs on the image path (one split pass over
     x, LDS-DMA-only GEMM; ``packed_f16`` packed for ``row_tile``); None: the input is split in the GEMM's prologue."""
     lib = load_library()

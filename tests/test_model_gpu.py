@@ -53,6 +53,29 @@ def test_model_golden(model_fx, tag, arch, use_rnn, mode, b, t):
         assert abs(float(out.double().std(unbiased=False)) - stats[idx, 1]) <= 1e-4 * scale, f'{tag} layer {idx} std'
 
 
+@pytest.mark.parametrize('tag,arch,use_rnn,mode,b,t', cases.MODEL_CASES)
+def test_model_golden_on_the_default_route(model_fx, tag, arch, use_rnn, mode, b, t):
+    """`forward_with_taps` (above) skips the LayerNorm -> split-image hand-off and the launch tapes.  The stored
+    REFERENCE logits are therefore also compared with what a user gets: the plain forward (python launch sequence), its recording
+    call, a tape REPLAY (third call on the same key) and the pipelined forward -- all four under the same rule."""
+    m = build(arch, use_rnn, mode)
+    x = keyed_input(b, t, seed=0).to(DEV)
+    want = torch.from_numpy(model_fx[f'{tag}/logits'])
+    truth = torch.from_numpy(model_fx[f'{tag}/logits_f64'])
+    with torch.no_grad():
+        first = m(x).clone()
+        second = m(x).clone()                        # records the tape
+        replay = m(x).clone()                        # replays it
+        (plan,) = list(m._plans.values())
+        assert plan.tape_replays == 1 and plan.dense_schemes[1] == 'f16x2-image', (plan.tape_replays, plan.dense_schemes)
+        piped = m.forward_async(x).result().clone()
+        piped2 = m.forward_async(x).result().clone()
+    for name, got in (('plain', first), ('recorded', second), ('replayed', replay), ('pipelined', piped), ('pipelined again', piped2)):
+        assert tuple(got.shape) == tuple(want.shape) and torch.isfinite(got).all()
+        cases.assert_parity(got, want, truth, f'{tag} ({name})')
+    assert torch.equal(first, second) and torch.equal(first, replay) and torch.equal(first, piped) and torch.equal(first, piped2)
+
+
 @pytest.mark.parametrize('arch,use_rnn,b,t', [(cases.ARCH_D, True, 3, 131), (cases.ARCH_M, False, 2, 258), ([[2, 1], [3, 0, 1], [4, 1, 0, 1]], True, 2, 64),
                                               (cases.ARCH_A, True, 1, 3), (cases.ARCH_D, True, 2, 1)])
 def test_model_vs_oracle(arch, use_rnn, b, t):
@@ -288,7 +311,7 @@ def test_loss_backward_through_the_model_matches_the_reference_arithmetic(arch, 
     Every op's backward is pinned on its own at the 1e-7 level (test_backward_gpu.py; a whole cell in isolation likewise); what this
     test adds is the WIRING of ~90 functions.  Its tolerance has to live with the network not being smooth: one activation within
     fp32 rounding of 0 (or 20) passes its gradient in one fp32 evaluation and not in the other, which moves the gradients of that layer
-    and of everything upstream by ~1e-3 relative (tests/grad_diag.py shows exactly that pattern: 2e-6 down to one node, 1e-3 above it).
+    and of everything upstream by ~1e-3 relative (a per-layer gradient diff shows exactly that pattern: 2e-6 down to one node, 1e-3 above it).
     So: every parameter within 2e-2 relative RMS (a wiring mistake is O(1)), and the layers behind the last such flip -- the head and
     the last cell at the least -- at fp32 level."""
     m = build(arch, use_rnn, 'lively', seed=91).train()
@@ -625,7 +648,7 @@ def test_tiny_lengths_end_to_end(arch, t):
 
 def test_input_dynamic_range_is_routed_per_utterance():
     """The first conv runs ordinary utterances on the scaled 2-way fp16 split and, decided per utterance on the device,
-    extreme ones (a frame > 2^20 below the loudest sample) on the range-free 3-way bf16 split: fp32-level error either way."""
+    extreme ones (a frame > 2^12 below the loudest sample) on the range-free 3-way bf16 split: fp32-level error either way."""
     from nb_asr_amd import hip
     m = build(cases.ARCH_D, True, 'lively')
     x = keyed_input(4, 300, seed=2)
@@ -633,7 +656,7 @@ def test_input_dynamic_range_is_routed_per_utterance():
     x[2, 5, 100] = 2.0 ** 30                        # ONE loud sample: everything else sits 2^-30 below it
     x[3] *= 2.0 ** -40                              # uniformly tiny: not extreme (the scale follows the utterance)
     rng = hip.input_range(x.to(DEV), 300, torch.empty(16, device=DEV)).view(4, 4).cpu()
-    extreme = [bool(r[2] != 0 or r[1] < r[0] * 2.0 ** -20) for r in rng]
+    extreme = [bool(r[2] != 0 or r[1] < r[0] * 2.0 ** -12) for r in rng]
     assert extreme == [False, True, True, False]
     assert float(rng[2, 0]) == 2.0 ** 30 and abs(float(rng[0, 0]) - float(x[0].abs().max())) == 0
     params = {k: v.cpu() for k, v in m.state_dict().items()}

@@ -183,7 +183,7 @@ def test_packed_weights_extreme_values_split_exactly():
 
 
 def test_f16_split_represents_values_of_any_magnitude_to_two_ulp():
-    """hi + lo' 2^-11 carries 11 + 11 bits and a sign: a 24-bit fp32 value is represented to 2^-22 relative (2 ulp) worst
+    """hi + lo (two fp16 terms) carries 11 + 11 bits and a sign: a 24-bit fp32 value is represented to 2^-22 relative (2 ulp) worst
     case, whatever its magnitude -- weight ROWS spanning 23 decades (each row is normalised on its own) and inputs of any
     overall scale (each utterance is normalised on its own)."""
     torch.manual_seed(0)
