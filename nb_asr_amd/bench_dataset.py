@@ -96,28 +96,38 @@ class WeightBank:
     """ONE set of device parameters that every architecture of a sweep borrows from.
 
     Building 8 242 models one after the other spends its time allocating and initialising 26 M parameters and re-packing
-    the same four dense convolutions and the LSTM for the matrix cores, not measuring.  Latency does not depend on weight
-    values, so the bank holds, per state_dict key and shape, one constant-filled ``nn.Parameter``; ``build`` constructs the
-    module tree on the ``meta`` device (no allocation, no initialisation) and plugs the bank's parameters in.  All models
+    the same four dense convolutions and the LSTM for the matrix cores, not measuring.  The bank holds, per state_dict key
+    and shape, one ``nn.Parameter``; ``build`` constructs the module tree on the ``meta`` device (no allocation, no
+    initialisation) and plugs the bank's parameters in.  ``fill='lively'`` (default since round 3): the values
+    ``weights.keyed_fill_(model, 1235, 'lively')`` gives that key -- He-uniform weights, non-trivial biases / gamma / beta, so
+    activations are O(1) and distinct per channel.  Round 2 filled every weight with the constant 0.01 ("latency does not
+    depend on weight values"): all channels were then equal, every LayerNorm output the constant beta and every split's low
+    term zero -- and on this chip MFMA clocks DO depend on operand toggling.  ``fill=<float>`` keeps
+    that constant fill for an A/B (tools/latency_sweep.py --fill).  All models
     share one ``PlanPool``: workspaces are allocated once, and because the dense / LSTM / head parameters are the SAME
     tensor objects for every architecture, their packed copies are built once for the whole sweep (a `linear` node op's
     weight is shared per (position, shape), too)."""
 
-    def __init__(self, device, use_rnn=True, fill=0.01):
+    def __init__(self, device, use_rnn=True, fill='lively', seed=1235):
         import torch
         from .executor import PlanPool
-        self.device, self.use_rnn, self.fill = torch.device(device), use_rnn, fill
+        self.device, self.use_rnn, self.fill, self.seed = torch.device(device), use_rnn, fill, seed
         self._params = {}
         self.pool = PlanPool()
 
     def _param(self, key, meta_param):
         import torch
-        k = (key, tuple(meta_param.shape))
+        shape = tuple(meta_param.shape)
+        k = (key, shape)
         p = self._params.get(k)
         if p is None:
-            value = 1.0 if (key.endswith('weight') and meta_param.dim() == 1) else self.fill       # LayerNorm gamma = 1
-            p = self._params[k] = torch.nn.Parameter(torch.full(tuple(meta_param.shape), value, device=self.device,
-                                                                dtype=torch.float32), requires_grad=False)
+            if isinstance(self.fill, str):
+                from .weights import keyed_values
+                values = keyed_values('model.' + key if not key.startswith('model.') else key, shape, self.seed, self.fill).to(self.device)
+            else:
+                value = 1.0 if (key.endswith('weight') and meta_param.dim() == 1) else float(self.fill)   # LayerNorm gamma = 1
+                values = torch.full(shape, value, device=self.device, dtype=torch.float32)
+            p = self._params[k] = torch.nn.Parameter(values, requires_grad=False)
         return p
 
     def build(self, arch_vec):
@@ -137,8 +147,8 @@ class WeightBank:
 
 
 def build_for_timing(arch_vec, device, use_rnn=True, bank=None):
-    """Model on `device` with cheap constant weights (latency does not depend on weight values).  With a ``WeightBank``
-    the parameters, workspaces and packed weights are shared with every other model built from it."""
+    """Model on `device` for latency measurements.  With a ``WeightBank`` the parameters, workspaces and packed weights are
+    shared with every other model built from it."""
     return (bank or WeightBank(device, use_rnn)).build(arch_vec)
 
 
@@ -160,12 +170,12 @@ def measure_latency(model, x, warmup=2, iters=5):
     return statistics.median(times)
 
 
-def latency_sweep(work, device, batch=32, frames=1000, warmup=2, iters=5, progress=None):
+def latency_sweep(work, device, batch=32, frames=1000, warmup=2, iters=5, progress=None, fill='lively'):
     """[[hash, latency_s], ...] for the (hash, arch) pairs in `work`, one model at a time on `device` (BASELINE config 5:
     one architecture per GPU at a time; all models of the sweep borrow their parameters from one WeightBank)."""
     import torch
     x = torch.randn(batch, 80, frames, device=device)
-    bank = WeightBank(device)
+    bank = WeightBank(device, fill=fill)
     rows, t0 = [], time.time()
     for i, (h, arch) in enumerate(work):
         model = bank.build(arch)

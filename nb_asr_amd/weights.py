@@ -27,29 +27,29 @@ def _fans(shape):
     return shape[1] * receptive, shape[0] * receptive
 
 
+def keyed_values(key, shape, seed=1235, mode='xavier'):
+    """The values ``keyed_fill_`` gives the parameter ``key`` of ``shape``: a float32 CPU tensor."""
+    if mode not in ('xavier', 'lively'):
+        raise ValueError(f'unknown mode {mode!r}')
+    shape = tuple(shape)
+    if len(shape) >= 2:
+        fan_in, fan_out = _fans(shape)
+        he = mode == 'lively' and ('.conv.' in key or '.op.linear.' in key)
+        bound = math.sqrt(6.0 / fan_in) if he else math.sqrt(6.0 / (fan_in + fan_out))
+        return torch.from_numpy(keyed_uniform(key, seed, shape, -bound, bound))
+    if key.endswith('weight'):                            # LayerNorm gamma
+        return torch.from_numpy(keyed_uniform(key, seed, shape, 0.8, 1.2)) if mode == 'lively' else torch.ones(shape)
+    # biases and LayerNorm beta
+    return torch.from_numpy(keyed_uniform(key, seed, shape, -0.1, 0.1)) if mode == 'lively' else torch.zeros(shape)
+
+
 def keyed_fill_(model, seed=1235, mode='xavier'):
     """Overwrite every parameter of ``model`` in place; returns ``model``."""
     if mode not in ('xavier', 'lively'):
         raise ValueError(f'unknown mode {mode!r}')
     with torch.no_grad():
         for key, p in model.state_dict().items():
-            shape = tuple(p.shape)
-            if p.dim() >= 2:
-                fan_in, fan_out = _fans(shape)
-                he = mode == 'lively' and ('.conv.' in key or '.op.linear.' in key)
-                bound = math.sqrt(6.0 / fan_in) if he else math.sqrt(6.0 / (fan_in + fan_out))
-                vals = keyed_uniform(key, seed, shape, -bound, bound)
-            elif key.endswith('weight'):                      # LayerNorm gamma
-                vals = keyed_uniform(key, seed, shape, 0.8, 1.2) if mode == 'lively' else None
-                if vals is None:
-                    p.fill_(1.0)
-                    continue
-            else:                                             # biases and LayerNorm beta
-                vals = keyed_uniform(key, seed, shape, -0.1, 0.1) if mode == 'lively' else None
-                if vals is None:
-                    p.zero_()
-                    continue
-            p.copy_(torch.from_numpy(vals).to(p.device))
+            p.copy_(keyed_values(key, tuple(p.shape), seed, mode).to(p.device))
     return model
 
 

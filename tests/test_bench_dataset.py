@@ -68,7 +68,10 @@ def test_weight_bank_builds_models_without_allocating_per_architecture():
         assert not any(p.is_meta for p in model.parameters())
     assert a.model[0].conv.weight is b.model[0].conv.weight and a.model[27].weight_hh_l0 is b.model[27].weight_hh_l0
     assert a._plans is b._plans is bank.pool
-    assert float(a.model[1].weight[0]) == 1.0 and abs(float(a.model[0].conv.weight[0, 0, 0]) - 0.01) < 1e-8
+    from nb_asr_amd.weights import keyed_values
+    assert torch.equal(a.model[0].conv.weight.detach(), keyed_values('model.0.conv.weight', (600, 80, 8), 1235, 'lively'))     # live data, not a constant
+    const = bench_dataset.WeightBank('cpu', fill=0.01).build([[1, 0], [1, 0, 0], [1, 0, 0, 0]])                                 # the round-2 fill, kept for A/Bs
+    assert float(const.model[1].weight[0]) == 1.0 and abs(float(const.model[0].conv.weight[0, 0, 0]) - 0.01) < 1e-8
     n_unique = len({id(p) for m in (a, b) for p in m.parameters()})
     assert n_unique < sum(1 for m in (a, b) for _ in m.parameters())
 

@@ -58,16 +58,13 @@ def test_latency_sweep_emits_a_loadable_dataset(tmp_path):
 
 def test_bank_models_compute_what_ordinary_models_compute():
     """A model whose parameters come from the sweep's WeightBank is an ordinary model: same logits as a model built the
-    usual way with the same constant weights (guards the meta-device construction and the parameter plumbing)."""
+    usual way with the same keyed 'lively' weights (guards the meta-device construction and the parameter plumbing)."""
     import nb_asr_amd as nb
+    from nb_asr_amd.weights import keyed_fill_
     arch = [[0, 1], [5, 1, 0], [2, 0, 1, 1]]
     bank = bench_dataset.WeightBank(DEV)
     banked = bank.build(arch)
-    plain = nb.get_model(arch, use_rnn=True, dropout_rate=0.0)
-    with torch.no_grad():
-        for key, p in plain.state_dict().items():
-            p.fill_(1.0 if (key.endswith('weight') and p.dim() == 1) else 0.01)
-    plain = plain.to(DEV).eval()
+    plain = keyed_fill_(nb.get_model(arch, use_rnn=True, dropout_rate=0.0), seed=1235, mode='lively').to(DEV).eval()
     x = keyed_input(2, 64, seed=1).to(DEV)
     with torch.no_grad():
         assert torch.equal(banked(x), plain(x))

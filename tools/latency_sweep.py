@@ -29,6 +29,9 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--summary', default=None, help='also write the min / median / max + per-op-family summary here (JSON)')
+    ap.add_argument('--fill', default='lively', help="parameter values of the sweep's shared WeightBank: 'lively' (keyed He-uniform, default) "
+                                                     "or a constant such as 0.01 (round 2's fill, for an A/B)")
+    ap.add_argument('--stride', type=int, default=1, help='take every N-th architecture of the work list (A/B samples)')
     a = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (('WORLD_SIZE', '1'), ('RANK', '0'), ('LOCAL_RANK', '0')))
     device = torch.device('cuda', local)
@@ -38,9 +41,11 @@ def main():
         dist.init_process_group('nccl', device_id=device)
     import time
     t0 = time.time()
-    everything = bench_dataset.sweep_work_list(a.limit)
+    everything = bench_dataset.sweep_work_list(a.limit)[::a.stride]
     work = everything[rank::world]
-    rows = bench_dataset.latency_sweep(work, device, a.batch, a.frames, warmup=a.warmup, iters=a.iters, progress=500 if rank == 0 else None)
+    fill = a.fill if a.fill in ('lively', 'xavier') else float(a.fill)
+    rows = bench_dataset.latency_sweep(work, device, a.batch, a.frames, warmup=a.warmup, iters=a.iters, progress=500 if rank == 0 else None,
+                                       fill=fill)
     if world > 1:
         gathered = [None] * world
         dist.all_gather_object(gathered, rows)
@@ -53,7 +58,9 @@ def main():
         from nb_asr_amd import hip
         meta = {'batch_size': a.batch, 'frames': a.frames, 'features': 80, 'dtype': 'fp32', 'n_gpus': world, 'use_rnn': True,
                 'protocol': f'{a.warmup} warm-up + median of {a.iters} forwards, HIP events on the launch stream, one architecture '
-                            f'per GPU at a time', 'build_id': hip.build_id(), 'sweep_seconds': time.time() - t0,
+                            f'per GPU at a time; input x ~ N(0, 1); parameters shared through one WeightBank, fill = {a.fill!r} '
+                            f'(lively: weights.keyed_values(key, shape, 1235, "lively") -- He-uniform weights, live biases / gamma / beta)',
+                'weight_fill': a.fill, 'build_id': hip.build_id(), 'sweep_seconds': time.time() - t0,
                 'gpu': torch.cuda.get_device_name(device)}
         bench_dataset.write_benchmarking_dataset(path, a.device_name, sorted(rows), meta=meta)
         summary = dict(bench_dataset.summarize(rows, dict(everything)), **meta, file=path.name)
