@@ -52,6 +52,11 @@ def grouped_conv_bytes(batch, channels, frames, kernel, n_skips, groups=100, ele
     return float(elem) * batch * channels * frames * (2 + n_skips) + 4.0 * (channels * (channels // groups) * kernel + channels)
 
 
+def grouped_conv_flops(batch, channels, frames, kernel, groups=100):
+    """Algorithmic flops of one grouped-conv launch: 2 (C / groups) k C T B."""
+    return 2.0 * (channels // groups) * kernel * channels * frames * batch
+
+
 def dense_conv_flops(batch, c_in, c_out, kernel, frames_out):
     return 2.0 * batch * frames_out * c_out * c_in * kernel
 
@@ -326,7 +331,7 @@ def roofline_leg(model, x, args):
         a[1] += 1
     out = {}
     # fused grouped Conv1d (HBM-bound)
-    tot_bytes = tot_ms = 0.0
+    tot_bytes = tot_ms = tot_attain_s = alu_bound_s = tot_flops_gc = 0.0
     per_block, launches = {}, 0
     for (kind, meta), (ms, n) in agg.items():
         if kind == 'grouped_conv':
@@ -343,7 +348,17 @@ def roofline_leg(model, x, args):
         tot_bytes += b * n
         tot_ms += ms
         launches += n
-        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}_{kind}', {'bytes_per_launch': b, 'ms': 0.0, 'n': 0})
+        # attainable time of ONE launch under the kernel's own roofline: min(157.3 TF, AI x 8 TB/s), i.e. the larger of
+        # its byte time and its flop time -- fp32 storage stays below the ridge (19.7 flop/B) everywhere, bf16 storage halves the bytes
+        # and crosses it for the wide, skip-free launches (those must not be priced against HBM)
+        fl = (sum(grouped_conv_flops(args.batch, c, frames, kj) for kj in ks) if kind == 'grouped_cell'
+              else grouped_conv_flops(args.batch, c, frames, k))
+        t_hbm, t_alu = b / (HBM_PEAK_GBS * 1e9), fl / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+        tot_attain_s += max(t_hbm, t_alu) * n
+        alu_bound_s += (max(t_hbm, t_alu) * n) if t_alu > t_hbm else 0.0
+        tot_flops_gc += fl * n
+        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}_s{n_skips if kind == "grouped_conv" else "x"}_{kind}',
+                                 {'bytes_per_launch': b, 'flops_per_launch': fl, 'ms': 0.0, 'n': 0})
         e['ms'] += ms
         e['n'] += n
     if launches:
@@ -351,15 +366,29 @@ def roofline_leg(model, x, args):
         if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or args.dtype != 'f32' or any(k.startswith('NBASR_') for k in os.environ):
             traffic, traffic_src = None, None          # the committed counters are for the default workload and modes only
         achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+        ridge = FP32_MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+        def block_entry(v):
+            ai = v['flops_per_launch'] / v['bytes_per_launch']
+            t_us = 1e3 * v['ms'] / v['n']
+            roof_us = 1e6 * max(v['bytes_per_launch'] / (HBM_PEAK_GBS * 1e9), v['flops_per_launch'] / (FP32_MFMA_PEAK_TFLOPS * 1e12))
+            return {'GBps': v['bytes_per_launch'] / t_us / 1e3, 'TFLOPs': v['flops_per_launch'] / t_us / 1e6, 'us_per_launch': t_us,
+                    'bytes_per_launch': v['bytes_per_launch'], 'flop_per_byte': ai, 'bound': 'hbm' if ai < ridge else 'fp32-alu',
+                    'attainable_us': roof_us, 'frac_of_attainable': roof_us / t_us}
+        compute_bound = alu_bound_s > 0.5 * tot_attain_s
+        head = ({'bound': 'mfma', 'achieved': tot_flops_gc / (tot_ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                 'bound_note': 'most of the attainable time of these launches is flop time at the fp32 vector = fp32 matrix rate (bf16 storage halves '
+                               'the bytes); frac = sum of per-launch attainable times min(157.3 TF, AI x 8 TB/s) / measured time'}
+                if compute_bound else {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'})
         out['roofline'] = {
             'kernel': 'grouped_conv_f32_{pipe_,osplit_,}kernel<CG,K,D,..> (variant per launch from gc_variant_table.json; bf16: grouped_conv_kernel<bf16_t,..>; opt-in whole-cell: grouped_cell_kernel<CG>) (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
                       ' [+LayerNorm on load]; a cell launch runs its three node ops with the intermediates in LDS)',
-            'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            **head, 'frac': (tot_attain_s / (tot_ms * 1e-3)) if compute_bound else achieved / HBM_PEAK_GBS,
+            'frac_of_attainable': tot_attain_s / (tot_ms * 1e-3), 'hbm_GBps': achieved, 'frac_of_hbm_peak': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,
             'bytes_per_launch_avg': tot_bytes / launches, 'us_per_launch_avg': 1e3 * tot_ms / launches,
             'launches_per_forward': launches // args.steps,
-            'per_block': {k: {'GBps': v['bytes_per_launch'] * v['n'] / (v['ms'] * 1e-3) / 1e9, 'us_per_launch': 1e3 * v['ms'] / v['n'],
-                              'bytes_per_launch': v['bytes_per_launch']} for k, v in sorted(per_block.items())},
+            'per_block': {k: block_entry(v) for k, v in sorted(per_block.items())},
         }
     # dense downsample convs (MFMA-bound)
     tot_flops = tot_ms = 0.0

@@ -366,8 +366,9 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
 {
     NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "%s: dtype %d is neither NBASR_F32 nor NBASR_BF16", what, dtype);
     const bool alt2 = variant > 0 && (variant & ~(NBASR_GC_OSPLIT | NBASR_GC_PIPE)) == 0;       // output split and / or pipelined loads
-    NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || (alt2 && dtype == NBASR_F32), NBASR_EINVAL,
-                  "%s: unknown variant %d (NBASR_GC_OSPLIT / NBASR_GC_PIPE: fp32 only, not with the other bits)", what, variant);
+    const bool ring = variant == NBASR_GC_RING || variant == (NBASR_GC_RING | NBASR_GC_PERSIST);  // windows staged through LDS by LDS-DMA
+    NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || ((alt2 || ring) && dtype == NBASR_F32), NBASR_EINVAL,
+                  "%s: unknown variant %d (NBASR_GC_OSPLIT / NBASR_GC_PIPE / NBASR_GC_RING [| NBASR_GC_PERSIST]: fp32 only, not with the other bits)", what, variant);
     NBASR_REQUIRE(aligned16(stats_ws), NBASR_EALIGN, "%s: statistics buffers must be 16-byte aligned", what);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "%s: bad sizes batch=%d channels=%d frames=%d groups=%d", what, batch, channels, frames, groups);
@@ -387,6 +388,7 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
     if (dtype == NBASR_F32) {
         GroupedArgs<float> a{static_cast<const float*>(x), w, bias, static_cast<const float*>(skip0), static_cast<const float*>(skip1),
                              static_cast<const float*>(skip2), static_cast<float*>(y), batch, channels, frames, ld, groups, lx, ls, stats_ws};
+        if (ring) return grouped_conv_f32_ring(variant, a, kernel, dilation, s);
         if (alt2) return grouped_conv_f32_osplit(variant, a, kernel, dilation, s);
         return variant == 0 ? grouped_conv_f32_base(a, kernel, dilation, s) : grouped_conv_f32_alt(variant, a, kernel, dilation, s);
     }

@@ -281,6 +281,7 @@ int grouped_conv_variant(const GroupedArgs<T>& a, int kernel, int dilation, hipS
 int grouped_conv_f32_base(const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);     // FPL 4, torch weight layout
 int grouped_conv_f32_alt(int variant, const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);
 int grouped_conv_f32_osplit(int variant, const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);      // grouped_conv_osplit.hip
+int grouped_conv_f32_ring(int variant, const GroupedArgs<float>& a, int kernel, int dilation, hipStream_t stream);        // grouped_conv_ring.hip
 int grouped_conv_bf16(int variant, const GroupedArgs<bf16_t>& a, int kernel, int dilation, hipStream_t stream);
 
 }  // namespace nbasr

@@ -412,9 +412,8 @@ class ForwardPlan:
         8-frame variants; the output-split ones are never forced onto a statistics launch, which they do not have).
 
         Default: looked up in gc_variant_table.json, which tools/make_gc_variant_table.py derives from same-process A/B timings of
-        the four variants {default, output split, pipelined buffer loads, both} per (taps, dilation, channels per group, flavour,
-        size class) on an MI355X (profiles/r02_gc_variants2/): the pipelined + split kernel wins almost everywhere for k5 and for
-        >= 10 channels per group, the default kernel keeps the wide-window, narrow-group, skip-free cases."""
+        the variants {default, output split, pipelined buffer loads, both, LDS ring, persistent LDS ring} per (taps, dilation,
+        channels per group, flavour, size class) on an MI355X (tools/ubench/ab_gc_variants.py, profiles/r03_gc_variants/)."""
         forced = os.environ.get('NBASR_GC_F32_VARIANT')
         if forced is not None:
             v = int(forced)
@@ -429,9 +428,13 @@ class ForwardPlan:
         waves_per_simd = b * groups * (-(-(ld // 4) // 64)) / 1024.0
         on_x = ln0 is not None and n_inputs == 1
         has_skips = any(type(br).__name__ == 'Identity' for br in node.branch_ops)
-        key = f"{op.kernel_size},{op.dilation},{c // groups},{'lnx' if on_x else 'skip' if has_skips else 'plain'}," \
-              f"{'small' if waves_per_simd < 4.0 else 'large'}{',stats' if stats is not None else ''}"
-        return self.gc_table.get(key, 0)
+        flavour = ('lnx+skip' if has_skips else 'lnx') if on_x else ('skip' if has_skips else 'plain')
+        head = f"{op.kernel_size},{op.dilation},{c // groups},"
+        tail = f",{'small' if waves_per_simd < 4.0 else 'large'}{',stats' if stats is not None else ''}"
+        v = self.gc_table.get(head + flavour + tail)
+        if v is None and on_x:                           # (tables older than round 3 have one LayerNorm-on-load class)
+            v = self.gc_table.get(head + 'lnx' + tail)
+        return v or 0
 
     def _view(self, idx, channels, frames):
         ld = hip.round_up4(frames)

@@ -522,8 +522,13 @@ def test_dense_conv_deferred_ln_both_paths(stride):
     hip.dense_conv1d_fused(normed, t, w, bias, [], want, stride)
     hip.dense_conv1d_fused(xp, t, w, bias, [], got32, stride, ln, True, False)
     hip.dense_conv1d_fused_packed(xp, t, hip.pack_dense_weights(w, stride), cout, 8, bias, [], got16, stride, ln)
-    close(got32, want.cpu(), rtol=1e-5, atol=2e-6)
-    close(got16, want.cpu(), rtol=1e-5, atol=2e-6)
+    close(got32, want.cpu(), rtol=1e-5, atol=2e-6)                  # same kernel, LayerNorm applied on load: the same sums
+    # the split kernel sums in another order (per channel group, then the total -- round 3): both are compared with an fp64 evaluation
+    # of the same normalised input instead of with each other
+    truth = torch.zeros_like(want, dtype=torch.float64, device='cpu')
+    truth[:, :, :t_out] = oracle.pad_conv_relu(normed[:, :, :t].double().cpu(), w.double().cpu(), bias.double().cpu(), 1, stride, 1)
+    close(want, truth, rtol=1e-5, atol=2e-6)
+    close(got16, truth, rtol=1e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize('c,groups,t,k,d', [(40, 4, 133, 5, 1), (600, 100, 37, 7, 2), (36, 3, 260, 5, 2), (1200, 100, 250, 5, 1)])

@@ -59,13 +59,17 @@ for B in args.batches:
                     hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, 0)
                 elif kind == 'lib3':
                     hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, hip.GC_PIPE | hip.GC_OSPLIT)
+                elif kind == 'libring':
+                    hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, hip.GC_RING)
+                elif kind == 'libpers':
+                    hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, hip.GC_RING | hip.GC_PERSIST)
                 else:
                     mode, wgs = (0, 0) if kind == 'ring' else (1, int(kind[4:]) or lds_wgs)
                     rc = x2.x2_node(mode, x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), B, c, t, ld, k, d, wgs, stream)
                     assert rc == 0, (kind, rc)
                 return y
 
-            kinds = ['lib0', 'lib3', 'ring'] + [f'pers{n}' for n in args.wgs]
+            kinds = ['lib0', 'lib3', 'libring', 'libpers', 'ring'] + [f'pers{n}' for n in args.wgs]
             ref = run('lib0', 0).clone()
             for kind in kinds[1:]:
                 y = run(kind, 0)
