@@ -252,8 +252,7 @@ int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float
 #define NBASR_GC_WPERM 2
 #define NBASR_GC_OSPLIT 4       /* fp32, on its own, no stats_ws: a wave owns half of a group's output channels (short rows / small batches) */
 #define NBASR_GC_PIPE 8         /* fp32, alone (stats_ws allowed) or with NBASR_GC_OSPLIT (no stats_ws): software-pipelined window loads (buffer loads, zero fill by the bounds check) */
-#define NBASR_GC_RING 16       /* fp32, alone or with NBASR_GC_PERSIST (stats_ws allowed): input windows staged through LDS by LDS-DMA -- a wave requests all input rows of its tile up front, consumes them behind counted waits (grouped_conv_ring.hip) */
-#define NBASR_GC_PERSIST 32    /* with NBASR_GC_RING: as many workgroups as are resident, each walking a list of tiles; a channel's LDS slot is refilled with the next tile's row as soon as it has been read */
+#define NBASR_GC_RING 16       /* fp32, alone (stats_ws allowed): input windows staged through LDS by LDS-DMA -- a wave requests all input rows of its tile up front, consumes them behind counted waits (grouped_conv_ring.hip) */
 int nbasr_grouped_conv1d_node(const void* x, const float* w, const float* bias,
                               const void* skip0, const void* skip1, const void* skip2, void* y,
                               int batch, int channels, int frames, int ld, int groups, int kernel, int dilation,

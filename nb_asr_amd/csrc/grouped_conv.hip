@@ -366,9 +366,9 @@ static int grouped_node_impl(const char* what, const void* x, const float* w, co
 {
     NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "%s: dtype %d is neither NBASR_F32 nor NBASR_BF16", what, dtype);
     const bool alt2 = variant > 0 && (variant & ~(NBASR_GC_OSPLIT | NBASR_GC_PIPE)) == 0;       // output split and / or pipelined loads
-    const bool ring = variant == NBASR_GC_RING || variant == (NBASR_GC_RING | NBASR_GC_PERSIST);  // windows staged through LDS by LDS-DMA
+    const bool ring = variant == NBASR_GC_RING;                                                 // windows staged through LDS by LDS-DMA
     NBASR_REQUIRE((variant >= 0 && variant <= (NBASR_GC_FPL8 | NBASR_GC_WPERM)) || ((alt2 || ring) && dtype == NBASR_F32), NBASR_EINVAL,
-                  "%s: unknown variant %d (NBASR_GC_OSPLIT / NBASR_GC_PIPE / NBASR_GC_RING [| NBASR_GC_PERSIST]: fp32 only, not with the other bits)", what, variant);
+                  "%s: unknown variant %d (NBASR_GC_OSPLIT / NBASR_GC_PIPE / NBASR_GC_RING: fp32 only, not with the other bits)", what, variant);
     NBASR_REQUIRE(aligned16(stats_ws), NBASR_EALIGN, "%s: statistics buffers must be 16-byte aligned", what);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "%s: bad sizes batch=%d channels=%d frames=%d groups=%d", what, batch, channels, frames, groups);

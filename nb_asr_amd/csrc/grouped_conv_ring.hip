@@ -1,5 +1,5 @@
-// LDS-ring form of the fp32 node kernel (variant bit NBASR_GC_RING, optionally with NBASR_GC_PERSIST): the input windows of a tile
-// are staged through LDS by LDS-DMA (buffer_load ... lds) instead of through registers.
+// LDS-ring form of the fp32 node kernel (variant bit NBASR_GC_RING): the input windows of a tile are staged through LDS by LDS-DMA
+// (buffer_load ... lds) instead of through registers.
 //
 // Why (round 3).  Round 2 established that the node kernel is bound by the bytes a CU keeps in flight, not by issue, clock or its
 // surroundings: a wave of the default kernel has 1 KiB of distinct input bytes outstanding, the pipelined one 2 KiB, i.e.
@@ -7,8 +7,9 @@
 // REGISTERS (two windows in flight, cooperative loads) paid for it in occupancy.  LDS-DMA needs no registers:
 //   * a wave requests ALL CG input rows of its tile up front (CG KiB per wave, 70-150 KiB per CU at 3-6 waves per SIMD) and
 //     consumes them channel by channel behind COUNTED vmcnt waits (the first channel's FMAs start when the first row has landed);
-//   * NBASR_GC_PERSIST: a workgroup walks a list of tiles and a channel's slot is refilled with the NEXT tile's row as soon as its
-//     window has been read into registers -- a wave then has CG KiB in flight all the time, not only at its start;
+//   * (measured and dropped: a PERSISTENT form whose workgroups walk a list of tiles and refill a channel's slot with the next
+//     tile's row as soon as it has been read -- 3-13 % slower than one tile per wave in the prototype, tools/ubench/x2, and its
+//     dynamic wait counts cost 30-60 registers;)
 //   * no output split: with the window in LDS the registers are 4 CG accumulators + one window, 42-73 in all.
 // slot (per wave, per input channel): [64 main quads = 1 KiB][QL left + QR right halo quads, padded to 64 B]
 //   main DMA: lane l <- quad q0 + l of the row (beyond the row: zeros from the buffer bounds check -- the convolution's padding)
@@ -21,6 +22,8 @@
 // the DMA instructions (checked in the ISA).
 // Every output is the same sum in the same order as in the default kernel: bit-identical (tests/test_bf16_ops_gpu.py).
 #include "grouped_conv_impl.h"
+
+#include <type_traits>
 
 namespace nbasr {
 
@@ -56,11 +59,12 @@ __device__ __forceinline__ float4 ring_load4(const float* row, int row_bytes, in
     return make_float4(f[0], f[1], f[2], f[3]);
 }
 
-struct RingArgs {
-    const float* x; const float* w; const float* bias; const float* s0; const float* s1; const float* s2; float* y;
+// sizes only: every POINTER is a __restrict__ kernel argument of its own.  The explicit waits below are memory clobbers; hipcc keeps
+// wave-uniform loads (weights, bias, gamma / beta) on the scalar path across them only for noalias read-only kernel arguments.  A
+// pointer taken from a by-value struct has no such attribute: the first version loaded the weights through the VECTOR memory path --
+// which also counts in vmcnt -- and ran 35-70 % slower than the same loop with plain arguments (profiles/r03_ab_gc_ring_first.jsonl).
+struct RingDims {
     int channels, frames, ld, groups, batch;
-    LnRef ln_x, ln_s0;
-    float* part;
     int n_xt, n_items, halo;
 };
 
@@ -73,8 +77,13 @@ constexpr int ring_waves_per_simd(int cg, bool lnx)
 }
 
 // work item of a workgroup = (utterance, quad of groups, 64-quad frame tile); its four waves take the quad's four groups
-template <int CG, int K, int D, bool LNX, bool STATS, bool PERSIST>
-__global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_conv_f32_ring_kernel(const RingArgs a)
+template <int CG, int K, int D, bool LNX, bool STATS>
+__global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_conv_f32_ring_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+    const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2, float* __restrict__ y,
+    const float* __restrict__ lnx_stats, const float* __restrict__ lnx_gamma, const float* __restrict__ lnx_beta,
+    const float* __restrict__ ln0_stats, const float* __restrict__ ln0_gamma, const float* __restrict__ ln0_beta,
+    float* __restrict__ part, const RingDims a)
 {
     constexpr int LPAD = pad_left(K, D, 1);
     constexpr int SPAN = (K - 1) * D;
@@ -91,11 +100,8 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
     const int ld = a.ld, nq = ld >> 2, row_bytes = ld * 4, channels = a.channels, groups = a.groups;
     const int n_gq = (groups + 3) >> 2;
     const int dpc = a.halo ? 2 : 1;                   // DMA instructions per channel (wave-uniform)
-    const int nsk = (a.s0 ? 1 : 0) + (a.s1 ? 1 : 0) + (a.s2 ? 1 : 0);
-    const bool ln0 = a.s0 && a.ln_s0.stats;
-    // vector-memory instructions of one tile's prologue (LayerNorm statistics of the window) and epilogue (this wave)
-    const int ops_ln = LNX ? 2 * NCH : 0;
-    const int ops_epi = (ln0 ? 2 : 0) + (nsk + 1) * CG + ((STATS && wave == 0) ? 2 : 0);
+    const int nsk = (s0 ? 1 : 0) + (s1 ? 1 : 0) + (s2 ? 1 : 0);
+    const bool ln0 = s0 && ln0_stats;
 
     // per-lane read offsets of the NCH window chunks inside a slot
     int rd[NCH];
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
     f2 nmw[NP], rw[NP], kw[NP];
     // LayerNorm statistics of the window (shared by all input channels of the tile): 2 NCH bounds-checked loads
     auto load_window_stats = [&](int b, int q0) {
-        const float* __restrict__ mrow = a.ln_x.stats + static_cast<size_t>(b) * 2 * ld;
+        const float* __restrict__ mrow = lnx_stats + static_cast<size_t>(b) * 2 * ld;
         const int off0 = (q0 + lane - QL) * 16;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
@@ -145,30 +151,21 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
         }
     };
 
-    int item = blockIdx.x;
-    if (item >= a.n_items) return;
+    const int item = blockIdx.x;
     int b, g_raw, q0;
     decode(item, b, g_raw, q0);
     if (!STATS && g_raw >= groups) return;            // a surplus wave of the last quad takes no part (with STATS it must reach the barriers:
-    int g = g_raw < groups ? g_raw : groups - 1;      //  it recomputes the last group and its stores are dropped by an empty descriptor)
-    const float* xg = a.x + (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
-    if (LNX) load_window_stats(b, q0);                // first tile: OLDER than its DMAs, so waiting for them does not wait for the rows
+    const int g = g_raw < groups ? g_raw : groups - 1;      //  it recomputes the last group and its stores are dropped by an empty descriptor)
+    const float* xg = x + (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
+    if (LNX) load_window_stats(b, q0);                // OLDER than the DMAs: waiting for a row does not wait for them, and vice versa
     asm volatile("" ::: "memory");                    // (pins the order of issue the wait counts assume; no instruction)
 #pragma unroll 1
     for (int ci = 0; ci < CG; ++ci) issue_channel(xg, ci, q0);
     asm volatile("" ::: "memory");
 
-    bool first = true;
-    while (true) {
-        const int next = PERSIST ? item + static_cast<int>(gridDim.x) : a.n_items;
-        const bool have_next = next < a.n_items;
-        int nb = b, ng_raw = g_raw, nq0 = q0;
-        if (have_next) decode(next, nb, ng_raw, nq0);
-        const int ng = ng_raw < groups ? ng_raw : groups - 1;
-        const float* nxg = a.x + (static_cast<size_t>(nb) * channels + static_cast<size_t>(ng) * CG) * ld;
-        const float* __restrict__ wg = a.w + static_cast<size_t>(g) * (CG * CG * K);
-        const float* __restrict__ bg = a.bias + g * CG;
-        if (LNX && !first) load_window_stats(b, q0);  // later tiles: younger than the tile's DMAs (they were issued during the previous tile)
+    {
+        const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
+        const float* __restrict__ bg = bias + g * CG;
 
         float acc[CG][4];
 #pragma unroll
@@ -177,12 +174,9 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[co][r] = bv;
         }
-        // operations younger than the DMAs of channel ci: the rest of this tile's DMAs, (not the first tile:) the previous tile's epilogue
-        // and this tile's statistics loads, (a tile follows:) its DMAs issued so far
-        const int younger_base = first ? 0 : ops_epi + ops_ln;
 #pragma unroll 1
         for (int ci = 0; ci < CG; ++ci) {
-            ring_wait_dyn((CG - 1 - ci) * dpc + younger_base + (have_next ? ci * dpc : 0));
+            ring_wait_dyn((CG - 1 - ci) * dpc);         // operations younger than the DMAs of channel ci: the later channels' DMAs
             const unsigned char* slot = ring + ci * RING_SLOT;
             float xw[NCH * 4];
 #pragma unroll
@@ -190,10 +184,8 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
                 const rg_f4 v = *reinterpret_cast<const rg_f4*>(slot + rd[c]);
                 xw[4 * c + 0] = v[0]; xw[4 * c + 1] = v[1]; xw[4 * c + 2] = v[2]; xw[4 * c + 3] = v[3];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the window is in registers: the slot may be refilled
-            if (have_next) issue_channel(nxg, ci, nq0);
             if (LNX) {
-                const float gam = a.ln_x.gamma[g * CG + ci], bet = a.ln_x.beta[g * CG + ci];
+                const float gam = lnx_gamma[g * CG + ci], bet = lnx_beta[g * CG + ci];
                 const f2 gam2 = f2{gam, gam}, bet2 = f2{bet, bet};
 #pragma unroll
                 for (int p = 0; p < NCH * 2; ++p) {
@@ -221,37 +213,65 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
         const int boff = q * 16;
         const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
         const int store_bytes = (!STATS || g_raw < groups) ? row_bytes : 0;      // a surplus wave's stores are dropped by the bounds check
-        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;                    // statistics of this lane's own 4 frames (skip0)
-        if (ln0) {
-            const float* mrow = a.ln_s0.stats + static_cast<size_t>(b) * 2 * ld;
-            sm = ring_load4(mrow, row_bytes, boff);
-            sr = ring_load4(mrow + ld, row_bytes, boff);
-        }
+        // Instantiated per number of skip inputs, branch-free inside (round 2's finding, DESIGN 7.1: behind the wave-uniform
+        // `if (skip)` branches of a generic epilogue hipcc waits for vmcnt(0) at every join, so a wave's stores and skip loads wait for
+        // one another): the skip loads of four output channels are requested together, then their sums are formed and stored.
+        auto epilogue = [&](auto nsk_, auto ln0_) {
+            constexpr int NSK = decltype(nsk_)::value;
+            constexpr bool LN0 = decltype(ln0_)::value;
+            const float* const sk[3] = {s0, s1, s2};
+            float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;                // statistics of this lane's own 4 frames (skip0)
+            if constexpr (LN0) {
+                const float* mrow = ln0_stats + static_cast<size_t>(b) * 2 * ld;
+                sm = ring_load4(mrow, row_bytes, boff);
+                sr = ring_load4(mrow + ld, row_bytes, boff);
+            }
+            constexpr int CH = 4;
 #pragma unroll
-        for (int co = 0; co < CG; ++co) {
-            const size_t roff = row0 + static_cast<size_t>(co) * ld;
-            float o[4];
+            for (int c0 = 0; c0 < CG; c0 += CH) {
+                float4 v[CH][NSK > 0 ? NSK : 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-            if (a.s0) {
-                float4 v = ring_load4(a.s0 + roff, row_bytes, boff);
-                if (ln0) {
-                    const float gam = a.ln_s0.gamma[g * CG + co], bet = a.ln_s0.beta[g * CG + co];
-                    v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
-                    v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int k = 0; k < NSK; ++k)
+                        if (c0 + c < CG) v[c][k] = ring_load4(sk[k] + row0 + static_cast<size_t>(c0 + c) * ld, row_bytes, boff);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int co = c0 + c;
+                    if (co >= CG) break;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+#pragma unroll
+                    for (int k = 0; k < NSK; ++k) {
+                        float4 u = v[c][k];
+                        if (LN0 && k == 0) {
+                            const float gam = ln0_gamma[g * CG + co], bet = ln0_beta[g * CG + co];
+                            u.x = ln_apply(u.x, sm.x, sr.x, gam, bet); u.y = ln_apply(u.y, sm.y, sr.y, gam, bet);
+                            u.z = ln_apply(u.z, sm.z, sr.z, gam, bet); u.w = ln_apply(u.w, sm.w, sr.w, gam, bet);
+                        }
+                        o[0] += u.x; o[1] += u.y; o[2] += u.z; o[3] += u.w;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (t0 + r >= a.frames) o[r] = 0.f;   // pitch columns stay zero (a select, no branch)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u4, rg_f4{o[0], o[1], o[2], o[3]}),
+                                                           ring_rsrc(y + row0 + static_cast<size_t>(co) * ld, store_bytes), boff, 0, 2);   // aux 2 = nt
+                    if (STATS) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[co][r] = o[r];                // keep the final values for the statistics
+                    }
                 }
-                o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w;
             }
-            if (a.s1) { const float4 v = ring_load4(a.s1 + roff, row_bytes, boff); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-            if (a.s2) { const float4 v = ring_load4(a.s2 + roff, row_bytes, boff); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (t0 + r >= a.frames) o[r] = 0.f;       // pitch columns stay zero (a select, no branch)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u4, rg_f4{o[0], o[1], o[2], o[3]}), ring_rsrc(a.y + roff, store_bytes),
-                                                   boff, 0, 2);                  // aux 2 = nt (streaming store, as the default kernel)
-            if (STATS) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[co][r] = o[r];                    // keep the final values for the statistics
-            }
+        };
+        using std::integral_constant;
+        switch (nsk * 2 + (ln0 ? 1 : 0)) {
+            case 0: epilogue(integral_constant<int, 0>{}, integral_constant<bool, false>{}); break;
+            case 2: epilogue(integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+            case 3: epilogue(integral_constant<int, 1>{}, integral_constant<bool, true>{}); break;
+            case 4: epilogue(integral_constant<int, 2>{}, integral_constant<bool, false>{}); break;
+            case 5: epilogue(integral_constant<int, 2>{}, integral_constant<bool, true>{}); break;
+            case 6: epilogue(integral_constant<int, 3>{}, integral_constant<bool, false>{}); break;
+            default: epilogue(integral_constant<int, 3>{}, integral_constant<bool, true>{}); break;
         }
         if constexpr (STATS) {
             // per-lane (mean, M2) over this group's CG channels, exact two-pass in registers; wave 0 merges the workgroup's groups
@@ -285,86 +305,65 @@ __global__ __launch_bounds__(256, ring_waves_per_simd(CG, LNX)) void grouped_con
                     for (int k = 0; k < nw; ++k) { const float d = sp[k][r][lane] - mean; m2 += sp[k][4 + r][lane] + CG * d * d; }
                     om[r] = mean; o2[r] = m2;
                 }
-                float* prow = a.part + (static_cast<size_t>(g_raw >> 2) * a.batch + b) * 2 * ld;
+                float* prow = part + (static_cast<size_t>(g_raw >> 2) * a.batch + b) * 2 * ld;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u4, rg_f4{om[0], om[1], om[2], om[3]}), ring_rsrc(prow, row_bytes), boff, 0, 0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(rg_u4, rg_f4{o2[0], o2[1], o2[2], o2[3]}), ring_rsrc(prow + ld, row_bytes), boff, 0, 0);
             }
-            if (have_next) __syncthreads();           // sp is rewritten by the next tile
         }
-        if (!have_next) break;
-        asm volatile("" ::: "memory");
-        item = next; b = nb; g_raw = ng_raw; g = ng; q0 = nq0; xg = nxg;
-        first = false;
     }
 }
 
 template <int CG, int K, int D, bool LNX, bool STATS>
-static int launch_ring(int variant, RingArgs a, hipStream_t stream)
+static int launch_ring(int /* variant */, const GroupedArgs<float>& g, const RingDims& a, hipStream_t stream)
 {
     const size_t lds = 4 * CG * RING_SLOT;
-    const bool persist = (variant & NBASR_GC_PERSIST) != 0;
-    int grid = a.n_items;
-    if (persist) {
-        // as many workgroups as are resident at once (LDS: 4 CG slots each; at most 8 per CU), every one walking items grid apart
-        int per_cu = static_cast<int>((160 * 1024) / (lds + (STATS ? 8192 : 0)));
-        per_cu = per_cu > 8 ? 8 : per_cu;
-        const int resident = 256 * per_cu;
-        grid = a.n_items < resident ? a.n_items : resident;
-    }
-    if (persist) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv_f32_ring_kernel<CG, K, D, LNX, STATS, true>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (attr != hipSuccess) { set_error("nbasr_grouped_conv1d_node(ring): cannot reserve %zu bytes of LDS", lds); return static_cast<int>(attr); }
-        hipLaunchKernelGGL((grouped_conv_f32_ring_kernel<CG, K, D, LNX, STATS, true>), dim3(grid), dim3(256), lds, stream, a);
-    } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv_f32_ring_kernel<CG, K, D, LNX, STATS, false>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (attr != hipSuccess) { set_error("nbasr_grouped_conv1d_node(ring): cannot reserve %zu bytes of LDS", lds); return static_cast<int>(attr); }
-        hipLaunchKernelGGL((grouped_conv_f32_ring_kernel<CG, K, D, LNX, STATS, false>), dim3(grid), dim3(256), lds, stream, a);
-    }
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_conv_f32_ring_kernel<CG, K, D, LNX, STATS>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (attr != hipSuccess) { set_error("nbasr_grouped_conv1d_node(ring): cannot reserve %zu bytes of LDS", lds); return static_cast<int>(attr); }
+    hipLaunchKernelGGL((grouped_conv_f32_ring_kernel<CG, K, D, LNX, STATS>), dim3(a.n_items), dim3(256), lds, stream,
+                       g.x, g.w, g.bias, g.s0, g.s1, g.s2, g.y, g.ln_x.stats, g.ln_x.gamma, g.ln_x.beta,
+                       g.ln_s0.stats, g.ln_s0.gamma, g.ln_s0.beta, g.part, a);
     return launch_status("nbasr_grouped_conv1d_node(ring)");
 }
 
 template <int CG, int K, int D>
-static int launch_ring_flavour(int variant, const RingArgs& a, hipStream_t stream)
+static int launch_ring_flavour(int variant, const GroupedArgs<float>& g, const RingDims& a, hipStream_t stream)
 {
-    if (a.ln_x.stats && a.part) return launch_ring<CG, K, D, true, true>(variant, a, stream);       // (a one-node cell; not in the search space)
-    if (a.ln_x.stats) return launch_ring<CG, K, D, true, false>(variant, a, stream);
-    if (a.part) return launch_ring<CG, K, D, false, true>(variant, a, stream);
-    return launch_ring<CG, K, D, false, false>(variant, a, stream);
+    if (g.ln_x.stats && g.part) return launch_ring<CG, K, D, true, true>(variant, g, a, stream);       // (a one-node cell; not in the search space)
+    if (g.ln_x.stats) return launch_ring<CG, K, D, true, false>(variant, g, a, stream);
+    if (g.part) return launch_ring<CG, K, D, false, true>(variant, g, a, stream);
+    return launch_ring<CG, K, D, false, false>(variant, g, a, stream);
 }
 
 template <int CG>
-static int dispatch_kd_ring(int variant, int kernel, int dilation, const RingArgs& a, hipStream_t stream)
+static int dispatch_kd_ring(int variant, int kernel, int dilation, const GroupedArgs<float>& g, const RingDims& a, hipStream_t stream)
 {
-    if (kernel == 5 && dilation == 1) return launch_ring_flavour<CG, 5, 1>(variant, a, stream);
-    if (kernel == 5 && dilation == 2) return launch_ring_flavour<CG, 5, 2>(variant, a, stream);
-    if (kernel == 7 && dilation == 1) return launch_ring_flavour<CG, 7, 1>(variant, a, stream);
-    if (kernel == 7 && dilation == 2) return launch_ring_flavour<CG, 7, 2>(variant, a, stream);
+    if (kernel == 5 && dilation == 1) return launch_ring_flavour<CG, 5, 1>(variant, g, a, stream);
+    if (kernel == 5 && dilation == 2) return launch_ring_flavour<CG, 5, 2>(variant, g, a, stream);
+    if (kernel == 7 && dilation == 1) return launch_ring_flavour<CG, 7, 1>(variant, g, a, stream);
+    if (kernel == 7 && dilation == 2) return launch_ring_flavour<CG, 7, 2>(variant, g, a, stream);
     set_error("nbasr_grouped_conv1d_node: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
     return NBASR_EINVAL;
 }
 
-// variant: NBASR_GC_RING, optionally | NBASR_GC_PERSIST
+// variant: NBASR_GC_RING
 int grouped_conv_f32_ring(int variant, const GroupedArgs<float>& g, int kernel, int dilation, hipStream_t stream)
 {
     if (static_cast<long long>(g.ld) * 4 * 3 >= (1ll << 31)) {
         set_error("nbasr_grouped_conv1d_node: rows too long for 32-bit buffer offsets");
         return NBASR_EINVAL;
     }
-    RingArgs a{};
-    a.x = g.x; a.w = g.w; a.bias = g.bias; a.s0 = g.s0; a.s1 = g.s1; a.s2 = g.s2; a.y = g.y;
+    RingDims a{};
     a.channels = g.channels; a.frames = g.frames; a.ld = g.ld; a.groups = g.groups; a.batch = g.batch;
-    a.ln_x = g.ln_x; a.ln_s0 = g.ln_s0; a.part = g.part;
     const int nq = g.ld / 4;
     a.n_xt = (nq + 63) / 64;
     a.n_items = a.n_xt * ((g.groups + 3) / 4) * g.batch;
     a.halo = a.n_xt > 1 ? 1 : 0;
     switch (g.channels / g.groups) {
-        case 6:  return dispatch_kd_ring<6>(variant, kernel, dilation, a, stream);
-        case 8:  return dispatch_kd_ring<8>(variant, kernel, dilation, a, stream);
-        case 10: return dispatch_kd_ring<10>(variant, kernel, dilation, a, stream);
-        case 12: return dispatch_kd_ring<12>(variant, kernel, dilation, a, stream);
+        case 6:  return dispatch_kd_ring<6>(variant, kernel, dilation, g, a, stream);
+        case 8:  return dispatch_kd_ring<8>(variant, kernel, dilation, g, a, stream);
+        case 10: return dispatch_kd_ring<10>(variant, kernel, dilation, g, a, stream);
+        case 12: return dispatch_kd_ring<12>(variant, kernel, dilation, g, a, stream);
         default:
             set_error("nbasr_grouped_conv1d_node: channels/groups=%d unsupported; search space has 6, 8, 10, 12", g.channels / g.groups);
             return NBASR_EINVAL;

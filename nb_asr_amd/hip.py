@@ -135,7 +135,7 @@ _ENQUEUES = frozenset(name for name in SIGNATURES if name not in _HOST_ONLY and 
                       and '_bytes_' not in name)
 
 F32, BF16 = 0, 1                 # NBASR_F32 / NBASR_BF16
-GC_FPL8, GC_WPERM, GC_OSPLIT, GC_PIPE, GC_RING, GC_PERSIST = 1, 2, 4, 8, 16, 32         # NBASR_GC_* variant bits of nbasr_grouped_conv1d_node
+GC_FPL8, GC_WPERM, GC_OSPLIT, GC_PIPE, GC_RING = 1, 2, 4, 8, 16         # NBASR_GC_* variant bits of nbasr_grouped_conv1d_node
 
 
 class HipError(RuntimeError):

@@ -50,7 +50,7 @@ def test_node_variants_are_bit_identical_and_match_the_oracle(dtype, cg, k, d):
     w = (torch.randn(c, cg, k) * 0.3).to(dtype).float()
     bias = (torch.randn(c) * 0.2).to(dtype).float()
     want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + skips[0] + skips[1] + skips[2]
-    variants = (0, 1, 2, 3) + ((hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST) if dtype == torch.float32 else ())      # fp32 only
+    variants = (0, 1, 2, 3) + ((hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING) if dtype == torch.float32 else ())      # fp32 only
     outs = [node(x, w, bias, skips, k, d, groups, dtype, v) for v in variants]
     for v, out in zip(variants[1:], outs[1:]):
         assert torch.equal(out, outs[0]), f'variant {v} differs from variant 0'
@@ -69,7 +69,7 @@ def test_node_ragged_lengths_and_flattened_lanes(dtype, t):
     x = torch.randn(b, c, t).to(dtype).float()
     w, bias = (torch.randn(c, cg, k) * 0.3).to(dtype).float(), torch.randn(c).to(dtype).float() * 0.2
     want = oracle.pad_conv_relu(x, w, bias, d, 1, groups) + x
-    for v in (0, 3) + ((hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST) if dtype == torch.float32 else ()):
+    for v in (0, 3) + ((hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING) if dtype == torch.float32 else ()):
         got = node(x, w, bias, [x], k, d, groups, dtype, v).float().cpu()
         tol = (2.0 ** -8 if dtype == BF else 0.0) * want.abs() + 2e-5 + 1e-5 * want.abs()
         assert bool(((got - want).abs() <= tol).all()), (v, float(((got - want).abs() / tol).max()))
@@ -92,7 +92,7 @@ def test_node_deferred_layernorm_and_epilogue_statistics(dtype):
     hip.channel_stats_v(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     results = []
-    for v in tuple(range(4)) + ((hip.GC_PIPE, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST) if dtype == torch.float32 else ()):
+    for v in tuple(range(4)) + ((hip.GC_PIPE, hip.GC_RING) if dtype == torch.float32 else ()):
         y = torch.empty_like(xp)
         ws = hip.grouped_stats_workspace(b, ld, groups, DEV)
         wd = w.to(DEV).contiguous()
@@ -279,7 +279,7 @@ def test_output_split_variant_with_deferred_layernorm(cg, k, d):
     hip.channel_stats_v(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     outs = []
-    for v in (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST):
+    for v in (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING):
         y = torch.full_like(xp, float('nan'))
         hip.grouped_conv1d_node(xp, w.to(DEV), bias.to(DEV), [xp, s1, s2], y, t, groups, k, d, ln, True, True, None, v)
         outs.append(y)
@@ -294,8 +294,8 @@ def test_output_split_variant_with_deferred_layernorm(cg, k, d):
 @pytest.mark.parametrize('cg,k,d', [(6, 5, 1), (12, 7, 2), (10, 5, 2), (8, 7, 1), (12, 5, 1)])
 @pytest.mark.parametrize('t', [250, 1000, 1037])
 def test_ring_variant_tiles_halos_and_persistent_refills(cg, k, d, t):
-    """NBASR_GC_RING [| NBASR_GC_PERSIST] (windows staged through LDS by LDS-DMA, counted waits): rows of one tile (no halo) and of
-    several (halo DMAs on both sides), more work items than resident workgroups (a slot is refilled with the next tile's row), every
+    """NBASR_GC_RING (windows staged through LDS by LDS-DMA, counted waits): rows of one tile (no halo) and of
+    several (halo DMAs on both sides), every
     flavour -- plain, three skips with LayerNorm on skip0, LayerNorm on load, statistics epilogue with a surplus wave in the last
     group quad -- bit-identical to the default kernel, pitch columns zero."""
     torch.manual_seed(cg * k + d + t)
@@ -313,7 +313,7 @@ def test_ring_variant_tiles_halos_and_persistent_refills(cg, k, d, t):
                 'stats': ([s1], None, False, False, True), 'lnx+stats': ([], ln, True, False, True)}
     for name, (skips, lnv, on_x, on_s0, with_stats) in flavours.items():
         outs = []
-        for v in (0, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST):
+        for v in (0, hip.GC_RING):
             y = torch.full_like(xp, float('nan'))
             ws = hip.grouped_stats_workspace(b, ld, groups, DEV) if with_stats else None
             hip.grouped_conv1d_node(xp, w, bias, skips, y, t, groups, k, d, lnv, on_x, on_s0, ws, v)
@@ -322,7 +322,7 @@ def test_ring_variant_tiles_halos_and_persistent_refills(cg, k, d, t):
                 st = torch.empty(b, 2, ld, device=DEV)
                 hip.grouped_stats_finalize(ws, st, c, t, groups, 1e-3)
             outs.append((y, st))
-        for v, (y, st) in zip(('ring', 'ring+persist'), outs[1:]):
+        for v, (y, st) in zip(('ring',), outs[1:]):
             assert torch.equal(y, outs[0][0]), (name, v, float((y - outs[0][0]).abs().max()))
             assert torch.all(y[:, :, t:] == 0)
             if with_stats:

@@ -741,7 +741,7 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
     with torch.no_grad():
         y1 = m(x).clone()
     picked = {v for v, _ in chosen}
-    assert picked & {hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST}
+    assert picked & {hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING}
     assert all(not (v & hip.GC_OSPLIT) for v, with_stats in chosen if with_stats)      # statistics launches: default or pipelined only
     monkeypatch.setenv('NBASR_GC_TABLE', '0')
     m._plans.clear()
@@ -750,7 +750,7 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
         y0 = m(x).clone()
     assert {v for v, _ in chosen} == {0}
     assert torch.equal(y0, y1)
-    for forced in (hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_OSPLIT, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST):
+    for forced in (hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_OSPLIT, hip.GC_RING):
         monkeypatch.setenv('NBASR_GC_F32_VARIANT', str(forced))
         m._plans.clear()
         with torch.no_grad():

@@ -7,7 +7,7 @@ the A/B measurements of tools/ubench/ab_gc_variants.py committed under profiles/
 Key "k,d,cg,flavour,size[,stats]": kernel taps, dilation, channels per group, flavour = lnx+skip | lnx (LayerNorm on load of the main
 input, with / without a skip input) | skip (at least one skip input) | plain, size = small (under 4 default-kernel waves per SIMD:
 measured at 8 utterances) | large (measured at 64).  Value: NBASR_GC_* bits (0 default, 4 output split, 8 pipelined loads, 12 both,
-16 LDS ring, 48 persistent LDS ring); with ",stats" the choice among the variants that have a statistics epilogue (measured in that
+16 LDS ring); with ",stats" the choice among the variants that have a statistics epilogue (measured in that
 flavour).  A variant must beat the default by 2 % to be chosen.
 """
 import glob

@@ -25,6 +25,7 @@ ap.add_argument('--batches', type=int, nargs='+', default=[64, 8])
 ap.add_argument('--rounds', type=int, default=20)
 ap.add_argument('--ops', nargs='+', default=['5,1', '7,2'])
 ap.add_argument('--wgs', type=int, nargs='+', default=[0], help='persistent grid: workgroups per CU (0: as many as the LDS admits)')
+ap.add_argument('--pitch', type=int, default=4, help='row pitch rounded up to a multiple of this many frames (32 = 128-byte-aligned rows)')
 args = ap.parse_args()
 
 so = HERE / 'x2' / 'libgc_ring.so'
@@ -42,7 +43,7 @@ for B in args.batches:
         t = 1000
         for blk, (c, stride) in enumerate(zip((600, 800, 1000, 1200), (1, 1, 2, 2))):
             t = (t + stride - 1) // stride
-            ld = (t + 3) & ~3
+            ld = -(-t // args.pitch) * args.pitch
             cg = c // 100
             sets = []
             for _ in range(3):
@@ -61,15 +62,13 @@ for B in args.batches:
                     hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, hip.GC_PIPE | hip.GC_OSPLIT)
                 elif kind == 'libring':
                     hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, hip.GC_RING)
-                elif kind == 'libpers':
-                    hip.grouped_conv1d_node(x, w, bias, (), y, t, 100, k, d, None, False, False, None, hip.GC_RING | hip.GC_PERSIST)
                 else:
                     mode, wgs = (0, 0) if kind == 'ring' else (1, int(kind[4:]) or lds_wgs)
                     rc = x2.x2_node(mode, x.data_ptr(), w.data_ptr(), bias.data_ptr(), y.data_ptr(), B, c, t, ld, k, d, wgs, stream)
                     assert rc == 0, (kind, rc)
                 return y
 
-            kinds = ['lib0', 'lib3', 'libring', 'libpers', 'ring'] + [f'pers{n}' for n in args.wgs]
+            kinds = ['lib0', 'lib3', 'libring', 'ring'] + [f'pers{n}' for n in args.wgs]
             ref = run('lib0', 0).clone()
             for kind in kinds[1:]:
                 y = run(kind, 0)
@@ -87,7 +86,7 @@ for B in args.batches:
                     if r >= 3:
                         times[kind].append(e0.elapsed_time(e1) / 6 * 1000)
             nbytes = 4.0 * (2 * B * c * t + c * cg * k + c)
-            row = {'batch': B, 'op': op, 'block': blk, 'channels': c, 'frames': t}
+            row = {'batch': B, 'op': op, 'block': blk, 'channels': c, 'frames': t, 'ld': ld}
             for kk, v in times.items():
                 us = statistics.median(v)
                 row[kk + '_us'] = round(us, 2)

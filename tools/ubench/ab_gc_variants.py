@@ -26,7 +26,7 @@ ap.add_argument('--ops', nargs='+', default=['5,1', '5,2', '7,1', '7,2'])
 ap.add_argument('--rounds', type=int, default=5)
 args = ap.parse_args()
 dev = torch.device('cuda', 0)
-ALL = (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING, hip.GC_RING | hip.GC_PERSIST)
+ALL = (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING)
 for B in args.batches:
     for op in args.ops:
         k, d = (int(v) for v in op.split(','))
