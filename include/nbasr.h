@@ -262,15 +262,18 @@ int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int 
 
 /* A whole SearchCell whose three node operations are grouped convolutions, in one launch (reference model.py:49-59 over
  * model.py:13-22 and ops.py:24-30): x1 = op0(x0) + s00 x0; x2 = op1(x1) + s10 x0 + s11 x1; x3 = op2(x2) + s20 x0 + s21 x1 + s22 x2.
- * The intermediates stay in LDS; the result is bit-identical to three nbasr_grouped_conv1d_fused launches.
- * skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.  `ln` (may be NULL): pending LayerNorm of x0.
- * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup (<= 4096 frames, LDS <= 160 KiB). */
+ * The intermediates never leave the compute unit (registers + one LDS tile per group); the result is bit-identical to three
+ * nbasr_grouped_conv1d_node launches.  skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.  `ln` (may be
+ * NULL): pending LayerNorm of x0.  `stats_ws` (may be NULL; nbasr_grouped_stats_workspace_bytes): the launch also emits the partial
+ * LayerNorm statistics of x3, exactly as nbasr_grouped_conv1d_node does for a cell's last node (merge: nbasr_grouped_stats_finalize).
+ * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup: <= 1024 frames (4 groups x <= 4 waves),
+ * channels / groups in {6, 8, 10, 12}, four group tiles within 160 KiB of LDS. */
 int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups);
 int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,
                              const float* w1, const float* b1, int k1, int d1,
                              const float* w2, const float* b2, int k2, int d2, int skip_mask, float* y,
                              int batch, int channels, int frames, int ld, int groups,
-                             const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+                             const nbasr_deferred_ln* ln, float* stats_ws, nbasr_stream_t stream);
 int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y,
                       int batch, int channels, int frames, int ld,
                       const nbasr_deferred_ln* ln, int ln_on_skip0, nbasr_stream_t stream);

@@ -1,13 +1,27 @@
 // A whole SearchCell whose three node operations are grouped convolutions, in ONE launch
 // (reference model.py:49-59 SearchCell.forward over model.py:13-22 Node.forward and ops.py:24-30 PadConvRelu):
 //     x1 = op0(x0n) + s00 x0n;   x2 = op1(x1) + s10 x0n + s11 x1;   x3 = op2(x2) + s20 x0n + s21 x1 + s22 x2
-// with x0n = the cell input, optionally still carrying its LayerNorm (applied while loading, nbasr.h).
+// with x0n = the cell input, optionally still carrying its LayerNorm (applied while loading, nbasr.h), and -- round 3 -- the
+// LayerNorm statistics of x3 as a by-product (the cell's own LayerNorm is then applied by whoever loads x3).
 //
-// Channel groups never mix inside such a cell, so one workgroup owns one (utterance, group) ROW for all frames and runs the
-// three convolutions back to back; x1 and x2 never touch HBM -- they are exchanged between lanes through two LDS tiles
-// (CG x frames floats each; a lane owns 4 frames, its k-tap window comes from its neighbours' chunks).  HBM traffic per cell
-// drops from 6 tensor passes (+ skip re-reads) to 1 read + 1 write; the arithmetic is the per-node kernel's, in the same
-// order, so the result is bit-identical to three nbasr_grouped_conv1d_fused launches.
+// Channel groups never mix inside such a cell, so x1 and x2 never have to touch HBM: HBM traffic per cell drops from 6 tensor passes
+// (+ skip re-reads) to 1 read + 1 write, and the node op -- HBM-bound as three launches (0.55 of 8 TB/s) -- becomes bound by the
+// vector ALU.  The arithmetic is the per-node kernel's, in the same order: bit-identical to three nbasr_grouped_conv1d_node launches
+// (+ nbasr_grouped_stats_finalize), asserted in tests/.
+//
+// Round 3 form (round 2's: one workgroup per (utterance, group) row with TWO LDS tiles, 1-3 waves per SIMD, no statistics -- a win in
+// block 0 only, and the separate statistics pass took that back):
+//  * workgroup = (utterance, quad of groups) x the whole row: 4 groups x nt waves (nt = row length / 256 frames, <= 4), so the
+//    statistics partials are the node kernel's ([group quad][batch][2][ld], merged by stats_finalize_kernel) and neighbouring tiles of a
+//    row exchange their halo through the LDS tile itself;
+//  * ONE LDS tile per group ([CG][row + zero pads] floats) holds the INPUT of the node being computed; a node's output stays in the
+//    accumulator registers (a lane owns 4 frames x CG channels), gets its skip sum there, and is written to the tile only as the next
+//    node's input.  x0n and x2 as skip inputs are read back from the tile while it still holds them, x1 for node 2 (s21) is kept in a
+//    second register set (template KEEP1), x0n for nodes 1 / 2 is re-read from HBM;
+//  * the cell input is loaded as each lane's OWN chunk of every channel (one coalesced 1 KiB wave access per row, all CG rows in
+//    flight at once), normalised ONCE per element and dealt out through the tile -- the per-node kernel loads (and normalises) every
+//    element once per window chunk;
+//  * the window of input channel ci + 1 is read from LDS while channel ci multiplies.
 //
 // Algorithmic bytes credited per launch (bench.py): those of the three node operations it replaces.
 #include "common.h"
@@ -26,20 +40,22 @@ struct Win {
     static constexpr int BASE = 4 * QL - LPAD;          // window index of (r = 0, tap = 0)
 };
 
-struct CellArgs {
-    const float* x0; float* y;
-    const float* w0; const float* w1; const float* w2;
-    const float* b0; const float* b1; const float* b2;
-    int channels, frames, ld, groups;
+constexpr int CELL_PADL = 2, CELL_PADR = 2;             // zero chunks on either side of a tile row (QL <= 2, QR <= 1: the conv's padding)
+
+struct CellDims {
+    int channels, frames, ld, groups, batch;
     int kd0, kd1, kd2;          // 0: k5 d1, 1: k5 d2, 2: k7 d1, 3: k7 d2
     int skips;                  // bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22
-    LnRef ln;                   // pending LayerNorm of x0 (stats == nullptr: x0 is already normalised)
+    int nt;                     // 64-chunk tiles (waves) per row
 };
 
-// acc += conv over one group's CG input channels; `fetch(ci, c)` returns chunk (q - QL + c) of input channel ci (zeros outside)
-template <int CG, int K, int D, class Fetch>
-__device__ __forceinline__ void conv_accumulate(float (&acc)[CG][4], const float* __restrict__ wg, const float* __restrict__ bg,
-                                                Fetch fetch)
+typedef float cell_f4 __attribute__((ext_vector_type(4)));
+
+// acc = bias + conv over one group's CG input channels, the input read from this group's LDS tile (row pitch rl floats; a lane's own
+// chunk of channel ci at row[ci * rl + 4 * col]); the window of channel ci + 1 is requested before the FMAs of channel ci
+template <int CG, int K, int D>
+__device__ __forceinline__ void conv_from_tile(float (&acc)[CG][4], const float* __restrict__ wg, const float* __restrict__ bg,
+                                               const float* tile, int rl, int col)
 {
     using W = Win<K, D>;
 #pragma unroll
@@ -48,14 +64,18 @@ __device__ __forceinline__ void conv_accumulate(float (&acc)[CG][4], const float
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[co][r] = bv;
     }
+    const float* win = tile + 4 * (col - W::QL);
+    cell_f4 nxt[W::NCH];
+#pragma unroll
+    for (int c = 0; c < W::NCH; ++c) nxt[c] = *reinterpret_cast<const cell_f4*>(win + 4 * c);
 #pragma unroll 1
     for (int ci = 0; ci < CG; ++ci) {
         float xw[W::NCH * 4];
 #pragma unroll
-        for (int c = 0; c < W::NCH; ++c) {
-            const float4 v = fetch(ci, c);
-            xw[4 * c + 0] = v.x; xw[4 * c + 1] = v.y; xw[4 * c + 2] = v.z; xw[4 * c + 3] = v.w;
-        }
+        for (int c = 0; c < W::NCH; ++c) { xw[4 * c + 0] = nxt[c][0]; xw[4 * c + 1] = nxt[c][1]; xw[4 * c + 2] = nxt[c][2]; xw[4 * c + 3] = nxt[c][3]; }
+        const float* nwin = win + (ci + 1 < CG ? ci + 1 : ci) * rl;            // (last round: a redundant re-read instead of a branch)
+#pragma unroll
+        for (int c = 0; c < W::NCH; ++c) nxt[c] = *reinterpret_cast<const cell_f4*>(nwin + 4 * c);
 #pragma unroll
         for (int j = 0; j < K; ++j) {
 #pragma unroll
@@ -69,38 +89,66 @@ __device__ __forceinline__ void conv_accumulate(float (&acc)[CG][4], const float
     }
 }
 
-template <int CG>
-__global__ __launch_bounds__(1024) void grouped_cell_kernel(const CellArgs a)
+// NTB: the largest number of tiles per row this instantiation is launched with (1, 2 or 4): its register budget is that of a
+// 256 * NTB-thread workgroup (128 registers at 1024 threads; the 256-thread form of the narrow blocks may use more)
+template <int CG, bool KEEP1, int NTB>
+__global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
+    const float* __restrict__ x0, float* __restrict__ y,
+    const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
+    const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
+    const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
+    float* __restrict__ part, const CellDims a)
 {
-    extern __shared__ __attribute__((aligned(16))) float tiles[];
-    const int rl = blockDim.x * 4;                  // tile row length in floats (every lane owns one 16-byte chunk)
-    float* const tA = tiles;                        // x1[co][frame]
-    float* const tB = tiles + CG * rl;              // x2[co][frame]
+    extern __shared__ __attribute__((aligned(16))) float cell_tiles[];
+    const int nt = a.nt;
+    const int rl = (nt * 64 + CELL_PADL + CELL_PADR) * 4;    // tile row length in floats
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gi = wave / nt, ti = wave - gi * nt;           // group within the quad, tile within the row
+    float* const tile = cell_tiles + gi * (CG * rl);         // this group's tile: [CG][rl]
 
-    const int g = blockIdx.x, b = blockIdx.y;       // wave-uniform: weights / bias / gamma / beta come through s_load
-    const int q = threadIdx.x;
-    const int nq = a.ld >> 2, nql = blockDim.x;
-    const bool in_row = q < nq;                     // lanes beyond the pitch only keep the tiles' tail at zero
+    const int g_raw = blockIdx.x * 4 + gi, b = blockIdx.y;   // wave-uniform: weights / bias / gamma / beta come through s_load
+    const bool g_ok = g_raw < a.groups;                       // a surplus wave of the last quad recomputes the last group, stores nothing
+    const int g = g_ok ? g_raw : a.groups - 1;
+    const int q = ti * 64 + lane;                            // chunk within the row
+    const int col = CELL_PADL + q;                           // its column (in chunks) in the tile row
+    const int nq = a.ld >> 2;
+    const bool in_row = q < nq;
     const int t0 = q * 4;
     const size_t row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG) * a.ld;
-    const float* __restrict__ x0 = a.x0 + row0;
-    const bool has_ln = a.ln.stats != nullptr;
-    const float4* __restrict__ mrow = has_ln ? reinterpret_cast<const float4*>(a.ln.stats + static_cast<size_t>(b) * 2 * a.ld) : nullptr;
+    const float* __restrict__ xg = x0 + row0;
+    const bool has_ln = ln_stats != nullptr;
 
-    // own-chunk statistics (x0 as a skip input)
+    // the zero pads of every tile row (never written again)
+    for (int i = threadIdx.x; i < 4 * CG * (CELL_PADL + CELL_PADR); i += blockDim.x) {
+        const int row = i / (CELL_PADL + CELL_PADR), p = i - row * (CELL_PADL + CELL_PADR);
+        const int c = p < CELL_PADL ? p : nt * 64 + p;
+        *reinterpret_cast<cell_f4*>(cell_tiles + row * rl + 4 * c) = cell_f4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // statistics of this lane's own 4 frames (pending LayerNorm of the cell input)
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;
-    if (has_ln && in_row) { sm = mrow[q]; sr = mrow[nq + q]; }
-    auto x0n_own = [&](int co) -> float4 {          // the (normalised) cell input at this lane's frames, channel co
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in_row) {
-            v = *reinterpret_cast<const float4*>(x0 + static_cast<size_t>(co) * a.ld + t0);
-            if (has_ln) {
-                const float gam = a.ln.gamma[g * CG + co], bet = a.ln.beta[g * CG + co];
-                v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
-                v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
-            }
+    if (has_ln && in_row) {
+        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_stats + static_cast<size_t>(b) * 2 * a.ld);
+        sm = mrow[q];
+        sr = mrow[nq + q];
+    }
+    auto normalise = [&](float4 v, int co) -> float4 {
+        if (has_ln) {
+            const float gam = ln_gamma[g * CG + co], bet = ln_beta[g * CG + co];
+            v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
+            v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
         }
         return v;
+    };
+    auto x0n_own = [&](int co) -> float4 {          // the (normalised) cell input at this lane's frames, channel co, from HBM
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_row) v = normalise(*reinterpret_cast<const float4*>(xg + static_cast<size_t>(co) * a.ld + t0), co);
+        return v;
+    };
+    auto tile_own = [&](int co) -> float4 {         // this lane's chunk of the tensor the tile holds
+        const cell_f4 v = *reinterpret_cast<const cell_f4*>(tile + co * rl + 4 * col);
+        return make_float4(v[0], v[1], v[2], v[3]);
     };
     auto mask_tail = [&](float (&o)[4]) {
 #pragma unroll
@@ -108,121 +156,171 @@ __global__ __launch_bounds__(1024) void grouped_cell_kernel(const CellArgs a)
     };
 
     float acc[CG][4];
+    float keep1[KEEP1 ? CG : 1][4];
 
-    // ---- node 0: input from global memory (LayerNorm applied on load) ------------------------------------------------
-    auto node0 = [&](auto kc, auto dc) {
-        constexpr int K = decltype(kc)::value, D = decltype(dc)::value;
-        using W = Win<K, D>;
-        float mw[W::NCH * 4], rw[W::NCH * 4];
-        if (has_ln) {
+    // ---- the cell input: own chunks of all CG channels (all loads in flight together), normalised once, into the tile ------------
 #pragma unroll
-            for (int c = 0; c < W::NCH; ++c) {
-                const int qq = q - W::QL + c;
-                float4 m = make_float4(0.f, 0.f, 0.f, 0.f), r = m;
-                if (qq >= 0 && qq < nq) { m = mrow[qq]; r = mrow[nq + qq]; }
-                mw[4 * c + 0] = m.x; mw[4 * c + 1] = m.y; mw[4 * c + 2] = m.z; mw[4 * c + 3] = m.w;
-                rw[4 * c + 0] = r.x; rw[4 * c + 1] = r.y; rw[4 * c + 2] = r.z; rw[4 * c + 3] = r.w;
-            }
-        }
-        conv_accumulate<CG, K, D>(acc, a.w0 + static_cast<size_t>(g) * (CG * CG * K), a.b0 + g * CG, [&](int ci, int c) -> float4 {
-            const int qq = q - W::QL + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qq >= 0 && qq < nq) v = *reinterpret_cast<const float4*>(x0 + static_cast<size_t>(ci) * a.ld + 4 * qq);
-            if (has_ln) {
-                const float gam = a.ln.gamma[g * CG + ci], bet = a.ln.beta[g * CG + ci];
-                v.x = ln_apply(v.x, mw[4 * c + 0], rw[4 * c + 0], gam, bet); v.y = ln_apply(v.y, mw[4 * c + 1], rw[4 * c + 1], gam, bet);
-                v.z = ln_apply(v.z, mw[4 * c + 2], rw[4 * c + 2], gam, bet); v.w = ln_apply(v.w, mw[4 * c + 3], rw[4 * c + 3], gam, bet);
-            }
-            return v;
-        });
-    };
-    // ---- nodes 1, 2: input from an LDS tile ------------------------------------------------------------------------------
-    auto node_lds = [&](auto kc, auto dc, const float* tile, const float* w, const float* bias) {
-        constexpr int K = decltype(kc)::value, D = decltype(dc)::value;
-        using W = Win<K, D>;
-        conv_accumulate<CG, K, D>(acc, w + static_cast<size_t>(g) * (CG * CG * K), bias + g * CG, [&](int ci, int c) -> float4 {
-            const int qq = q - W::QL + c;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (qq >= 0 && qq < nql) v = *reinterpret_cast<const float4*>(tile + ci * rl + 4 * qq);
-            return v;
-        });
-    };
+    for (int ci = 0; ci < CG; ++ci) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_row) v = *reinterpret_cast<const float4*>(xg + static_cast<size_t>(ci) * a.ld + t0);
+        acc[ci][0] = v.x; acc[ci][1] = v.y; acc[ci][2] = v.z; acc[ci][3] = v.w;
+    }
+#pragma unroll
+    for (int ci = 0; ci < CG; ++ci) {
+        float4 v = make_float4(acc[ci][0], acc[ci][1], acc[ci][2], acc[ci][3]);
+        if (in_row) v = normalise(v, ci);
+        *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{v.x, v.y, v.z, v.w};
+    }
+    __syncthreads();
+
     using I5 = std::integral_constant<int, 5>; using I7 = std::integral_constant<int, 7>;
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-#define NBASR_KD_SWITCH(kd, CALL)                                                          \
-    switch (kd) {                                                                          \
-        case 0: CALL(I5{}, I1{}); break; case 1: CALL(I5{}, I2{}); break;                  \
-        case 2: CALL(I7{}, I1{}); break; default: CALL(I7{}, I2{}); break;                 \
+    auto conv = [&](auto kc, auto dc, const float* __restrict__ w, const float* __restrict__ bias) {
+        constexpr int K = decltype(kc)::value, D = decltype(dc)::value;
+        conv_from_tile<CG, K, D>(acc, w + static_cast<size_t>(g) * (CG * CG * K), bias + g * CG, tile, rl, col);
+    };
+#define NBASR_KD_SWITCH(kd, W_, B_)                                                                    \
+    switch (kd) {                                                                                      \
+        case 0: conv(I5{}, I1{}, W_, B_); break; case 1: conv(I5{}, I2{}, W_, B_); break;              \
+        case 2: conv(I7{}, I1{}, W_, B_); break; default: conv(I7{}, I2{}, W_, B_); break;             \
     }
+    auto tile_write = [&]() {                       // the node output in `acc` becomes the next node's input
+#pragma unroll
+        for (int co = 0; co < CG; ++co)
+            *reinterpret_cast<cell_f4*>(tile + co * rl + 4 * col) = cell_f4{acc[co][0], acc[co][1], acc[co][2], acc[co][3]};
+    };
 
-    // node 0 -> x1 -> tile A
-#define NBASR_N0(kc, dc) node0(kc, dc)
-    NBASR_KD_SWITCH(a.kd0, NBASR_N0)
-#undef NBASR_N0
+    // ---- node 0: x1 = op0(x0n) + s00 x0n (x0n read back from the tile) -------------------------------------------------------------
+    NBASR_KD_SWITCH(a.kd0, w0, b0)
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-        if (a.skips & 1) { const float4 v = x0n_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        if (a.skips & 1) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         mask_tail(o);
-        *reinterpret_cast<float4*>(tA + co * rl + t0) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { acc[co][r] = o[r]; if (KEEP1) keep1[KEEP1 ? co : 0][r] = o[r]; }
     }
+    __syncthreads();                                // every read of x0n is done
+    tile_write();
     __syncthreads();
 
-    // node 1 -> x2 -> tile B
-#define NBASR_N1(kc, dc) node_lds(kc, dc, tA, a.w1, a.b1)
-    NBASR_KD_SWITCH(a.kd1, NBASR_N1)
-#undef NBASR_N1
+    // ---- node 1: x2 = op1(x1) + s10 x0n + s11 x1 --------------------------------------------------------------------------------------
+    NBASR_KD_SWITCH(a.kd1, w1, b1)
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
         if (a.skips & 2) { const float4 v = x0n_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        if (a.skips & 4) { const float4 v = *reinterpret_cast<const float4*>(tA + co * rl + t0); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         mask_tail(o);
-        *reinterpret_cast<float4*>(tB + co * rl + t0) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[co][r] = o[r];
     }
     __syncthreads();
+    tile_write();
+    __syncthreads();
 
-    // node 2 -> x3 -> global memory
-#define NBASR_N2(kc, dc) node_lds(kc, dc, tB, a.w2, a.b2)
-    NBASR_KD_SWITCH(a.kd2, NBASR_N2)
-#undef NBASR_N2
+    // ---- node 2: x3 = op2(x2) + s20 x0n + s21 x1 + s22 x2 -> HBM ------------------------------------------------------------------------
+    NBASR_KD_SWITCH(a.kd2, w2, b2)
 #undef NBASR_KD_SWITCH
-    if (!in_row) return;
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
         float o[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
         if (a.skips & 8) { const float4 v = x0n_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        if (a.skips & 16) { const float4 v = *reinterpret_cast<const float4*>(tA + co * rl + t0); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        if (a.skips & 32) { const float4 v = *reinterpret_cast<const float4*>(tB + co * rl + t0); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        if (KEEP1) {
+            if (a.skips & 16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? co : 0][r];
+            }
+        }
+        if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         mask_tail(o);
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        __builtin_nontemporal_store(f4v{o[0], o[1], o[2], o[3]}, reinterpret_cast<f4v*>(a.y + row0 + static_cast<size_t>(co) * a.ld + t0));
+        if (in_row && g_ok)
+            __builtin_nontemporal_store(cell_f4{o[0], o[1], o[2], o[3]}, reinterpret_cast<cell_f4*>(y + row0 + static_cast<size_t>(co) * a.ld + t0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[co][r] = o[r];        // the final values, for the statistics
+    }
+    if (part == nullptr) return;                    // (workgroup-uniform)
+
+    // ---- LayerNorm statistics of x3: per lane (mean, M2) over this group's CG channels, exact two-pass in registers; the wave of the
+    // quad's first group merges the four groups (same arithmetic and order as the node kernel's statistics epilogue) -------------------
+    float pm[4], p2[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int co = 0; co < CG; ++co) sum += acc[co][r];
+        pm[r] = sum * (1.0f / CG);
+        float m2 = 0.f;
+#pragma unroll
+        for (int co = 0; co < CG; ++co) { const float d = acc[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
+        p2[r] = m2;
+    }
+    __syncthreads();                                // every read of x2 is done: the tiles become the exchange buffer [4][nt][8][64]
+    float* const sp = cell_tiles;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sp[((gi * nt + ti) * 8 + r) * 64 + lane] = pm[r];
+        sp[((gi * nt + ti) * 8 + 4 + r) * 64 + lane] = p2[r];
+    }
+    __syncthreads();
+    if (gi == 0 && in_row) {
+        const int nw = min(4, a.groups - static_cast<int>(blockIdx.x) * 4);      // groups (waves) that hold real data
+        float om[4], o2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mean = 0.f;
+            for (int k = 0; k < nw; ++k) mean += sp[((k * nt + ti) * 8 + r) * 64 + lane];
+            mean /= static_cast<float>(nw);
+            float m2 = 0.f;
+            for (int k = 0; k < nw; ++k) { const float d = sp[((k * nt + ti) * 8 + r) * 64 + lane] - mean; m2 += sp[((k * nt + ti) * 8 + 4 + r) * 64 + lane] + CG * d * d; }
+            om[r] = mean; o2[r] = m2;
+        }
+        float* prow = part + (static_cast<size_t>(blockIdx.x) * gridDim.y + b) * 2 * a.ld + t0;
+        *reinterpret_cast<float4*>(prow) = make_float4(om[0], om[1], om[2], om[3]);
+        *reinterpret_cast<float4*>(prow + a.ld) = make_float4(o2[0], o2[1], o2[2], o2[3]);
     }
 }
 
-template <int CG>
-static int launch_cell(const CellArgs& a, int batch, hipStream_t stream)
+static size_t cell_lds_bytes(int cg, int nt) { return static_cast<size_t>(4) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
+
+struct CellPtrs {
+    const float* x0; float* y; const float* w0; const float* w1; const float* w2; const float* b0; const float* b1; const float* b2;
+    const float* ln_stats; const float* ln_gamma; const float* ln_beta; float* part;
+};
+
+template <int CG, bool KEEP1, int NTB>
+static int launch_cell_kernel(const CellPtrs& p, const CellDims& a, hipStream_t stream)
 {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<CG>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<CG, KEEP1, NTB>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) {
         set_error("nbasr_grouped_cell_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
-    const int nq = a.ld / 4;
-    const int threads = ((nq + 63) / 64) * 64;
-    const size_t lds = static_cast<size_t>(2) * CG * threads * 4 * sizeof(float);
-    NBASR_REQUIRE(threads <= 1024 && lds <= 160 * 1024, NBASR_EINVAL,
-                  "nbasr_grouped_cell_fused: a row of %d frames x %d channels per group does not fit one workgroup "
-                  "(<= 4096 frames and 2*CG*frames*4 B <= 160 KiB); use the per-node launches", a.ld, CG);
-    hipLaunchKernelGGL((grouped_cell_kernel<CG>), dim3(a.groups, batch), dim3(threads), lds, stream, a);
+    const size_t lds = cell_lds_bytes(CG, a.nt);
+    hipLaunchKernelGGL((grouped_cell_kernel<CG, KEEP1, NTB>), dim3((a.groups + 3) / 4, a.batch), dim3(4 * a.nt * 64), lds, stream,
+                       p.x0, p.y, p.w0, p.w1, p.w2, p.b0, p.b1, p.b2, p.ln_stats, p.ln_gamma, p.ln_beta, p.part, a);
     return launch_status("nbasr_grouped_cell_fused");
+}
+
+template <int CG, bool KEEP1>
+static int launch_cell_nt(const CellPtrs& p, const CellDims& a, hipStream_t stream)
+{
+    if (a.nt == 1) return launch_cell_kernel<CG, KEEP1, 1>(p, a, stream);
+    if (a.nt == 2) return launch_cell_kernel<CG, KEEP1, 2>(p, a, stream);
+    return launch_cell_kernel<CG, KEEP1, 4>(p, a, stream);
+}
+
+template <int CG>
+static int launch_cell(const CellPtrs& p, const CellDims& a, hipStream_t stream)
+{
+    return (a.skips & 16) ? launch_cell_nt<CG, true>(p, a, stream) : launch_cell_nt<CG, false>(p, a, stream);
 }
 
 static int kd_code(int kernel, int dilation)
@@ -243,41 +341,43 @@ extern "C" int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups)
     if (channels <= 0 || groups <= 0 || channels % groups || frames_ld <= 0 || frames_ld % 4) return 0;
     const int cg = channels / groups;
     if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
-    const int threads = ((frames_ld / 4 + 63) / 64) * 64;
-    return threads <= 1024 && static_cast<size_t>(2) * cg * threads * 16 <= 160 * 1024;
+    const int nt = (frames_ld / 4 + 63) / 64;
+    return nt <= 4 && cell_lds_bytes(cg, nt) <= 160 * 1024;
 }
 
 extern "C" int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,
                                         const float* w1, const float* b1, int k1, int d1,
                                         const float* w2, const float* b2, int k2, int d2, int skip_mask, float* y,
                                         int batch, int channels, int frames, int ld, int groups,
-                                        const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+                                        const nbasr_deferred_ln* ln, float* stats_ws, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "nbasr_grouped_cell_fused: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(x0 && w0 && b0 && w1 && b1 && w2 && b2 && y, NBASR_ENULL, "nbasr_grouped_cell_fused: NULL pointer");
-    NBASR_REQUIRE(ld >= frames && ld % 4 == 0 && aligned16(x0) && aligned16(y), NBASR_EALIGN,
-                  "nbasr_grouped_cell_fused: ld=%d must be >= frames=%d and a multiple of 4; x0, y 16-byte aligned", ld, frames);
+    NBASR_REQUIRE(ld >= frames && ld % 4 == 0 && aligned16(x0) && aligned16(y) && aligned16(stats_ws), NBASR_EALIGN,
+                  "nbasr_grouped_cell_fused: ld=%d must be >= frames=%d and a multiple of 4; x0, y, stats_ws 16-byte aligned", ld, frames);
     NBASR_REQUIRE(batch <= 65535 && skip_mask >= 0 && skip_mask < 64, NBASR_EINVAL, "nbasr_grouped_cell_fused: bad batch / skip mask");
     NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
                   "nbasr_grouped_cell_fused: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
-    CellArgs a{};
-    a.x0 = x0; a.y = y; a.w0 = w0; a.w1 = w1; a.w2 = w2; a.b0 = b0; a.b1 = b1; a.b2 = b2;
-    a.channels = channels; a.frames = frames; a.ld = ld; a.groups = groups;
+    NBASR_REQUIRE(nbasr_grouped_cell_fits(channels, ld, groups), NBASR_EINVAL,
+                  "nbasr_grouped_cell_fused: a row of %d frames x %d channels per group does not fit one workgroup "
+                  "(<= 1024 frames, channels/groups in {6, 8, 10, 12}, 4 group tiles <= 160 KiB of LDS); use the per-node launches", ld, channels / groups);
+    CellDims a{};
+    a.channels = channels; a.frames = frames; a.ld = ld; a.groups = groups; a.batch = batch;
     a.kd0 = kd_code(k0, d0); a.kd1 = kd_code(k1, d1); a.kd2 = kd_code(k2, d2);
     NBASR_REQUIRE(a.kd0 >= 0 && a.kd1 >= 0 && a.kd2 >= 0, NBASR_EINVAL,
                   "nbasr_grouped_cell_fused: node ops must be conv5 / conv5d2 / conv7 / conv7d2 (got k=%d,%d,%d d=%d,%d,%d)", k0, k1, k2, d0, d1, d2);
-    a.skips = skip_mask; a.ln = ln_ref(ln, true);
+    a.skips = skip_mask;
+    a.nt = (ld / 4 + 63) / 64;
+    const LnRef l = ln_ref(ln, true);
+    const CellPtrs p{x0, y, w0, w1, w2, b0, b1, b2, l.stats, l.gamma, l.beta, stats_ws};
     hipStream_t s = as_stream(stream);
     switch (channels / groups) {
-        case 6:  return launch_cell<6>(a, batch, s);
-        case 8:  return launch_cell<8>(a, batch, s);
-        case 10: return launch_cell<10>(a, batch, s);
-        case 12: return launch_cell<12>(a, batch, s);
-        default:
-            set_error("nbasr_grouped_cell_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", channels / groups);
-            return NBASR_EINVAL;
+        case 6:  return launch_cell<6>(p, a, s);
+        case 8:  return launch_cell<8>(p, a, s);
+        case 10: return launch_cell<10>(p, a, s);
+        default: return launch_cell<12>(p, a, s);
     }
 }

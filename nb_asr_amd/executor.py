@@ -193,10 +193,10 @@ class ForwardPlan:
         if self.ln_mode not in ('deferred', 'materialize'):
             raise ValueError(f'NBASR_LN_MODE must be deferred or materialize, got {self.ln_mode!r}')
         self.epilogue_stats = os.environ.get('NBASR_EPILOGUE_STATS', '1') != '0'
-        # opt-in: cells whose three nodes are grouped convs run as ONE launch (x1, x2 stay in LDS).  Bit-identical, but at
-        # B=64/T=1000 it is VALU/latency-bound (45-50 TFLOP/s at 2-3 waves per SIMD): 139/263/210/164 us per cell vs
-        # 177/264/159/117 us for three HBM-bound launches -- a win only in block 0, so it is off by default
-        self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '0') == '1'
+        # cells whose three nodes are grouped convs run as ONE launch where a row fits a workgroup (<= 1024 frames): x1 and x2 never
+        # touch HBM and the cell's LayerNorm statistics come out of the same launch (grouped_cell.hip, round 3).  Bit-identical to
+        # the three node launches; NBASR_CELL_FUSION=0 turns it off (A/B)
+        self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '1') != '0'
         # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_TABLE=0: the default kernel everywhere
         self.gc_table = _GC_TABLE if os.environ.get('NBASR_GC_TABLE', '1') != '0' else {}
         self._bufs = {}              # name -> flat tensor; grow-only (see _buf)
@@ -699,6 +699,8 @@ class ForwardPlan:
                 fused = (self.cell_fusion and len(layer.nodes) == 3
                          and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)
                          and hip.grouped_cell_fits(layer.filters, hip.round_up4(act_frames), last_op.groups))
+                epilogue_stats = (self.epilogue_stats and layer.use_norm and defer
+                                  and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                 if fused:
                     mask = 0
                     for bit, (j, i) in enumerate(((0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (2, 2))):
@@ -709,10 +711,13 @@ class ForwardPlan:
                     n_skips = [sum(type(br).__name__ == 'Identity' for br in n.branch_ops) for n in layer.nodes]
                     meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_skips), act_frames, 0)
                     src, ln0 = act, pending
-                    self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0))
+                    if epilogue_stats:
+                        self._stat_turn ^= 1
+                        ld = view.shape[2]
+                        new_stats = self.stats[self._stat_turn][: self.batch * 2 * ld].view(self.batch, 2, ld)
+                    cell_ws = self.stats_ws if epilogue_stats else None
+                    self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0, cell_ws))
                     outs = [act, None, None, view]
-                epilogue_stats = (not fused and self.epilogue_stats and layer.use_norm and defer
-                                  and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                 if not fused:
                     outs = [act]
                 for j, (node, dst) in enumerate(zip(layer.nodes, free) if not fused else ()):

@@ -81,20 +81,22 @@ def test_launch_tape_reports_a_failing_call(monkeypatch):
 
 def test_variant_table_is_complete_and_well_formed():
     table = json.loads(pathlib.Path(executor.__file__).with_name('gc_variant_table.json').read_text())
-    assert table == executor._GC_TABLE and len(table) == 4 * 4 * 3 * 2 * 2
+    # (taps, dilation) x channels per group x {4 flavours + 2 statistics flavours} x {small, large}
+    assert table == executor._GC_TABLE and len(table) == 4 * 4 * (4 + 2) * 2
+    no_split = (0, hip.GC_PIPE, hip.GC_RING)
     for key, v in table.items():
         parts = key.split(',')
         k, d, cg = map(int, parts[:3])
         assert (k, d) in ((5, 1), (5, 2), (7, 1), (7, 2)) and cg in (6, 8, 10, 12)
-        assert parts[3] in ('lnx', 'skip', 'plain') and parts[4] in ('small', 'large')
+        assert parts[3] in ('lnx', 'lnx+skip', 'skip', 'plain') and parts[4] in ('small', 'large')
         if len(parts) == 6:
-            assert parts[5] == 'stats' and v in (0, hip.GC_PIPE)             # statistics launches: default or pipelined only
+            assert parts[5] == 'stats' and parts[3] in ('plain', 'skip') and v in no_split      # statistics launches: no output split
         else:
-            assert v in (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT)
+            assert v in no_split + (hip.GC_OSPLIT, hip.GC_PIPE | hip.GC_OSPLIT)
     # every key has been measured in profiles/: the table is a function of the committed logs
-    logs = list((pathlib.Path(__file__).resolve().parent.parent / 'profiles' / 'r02_gc_variants2').glob('*.jsonl'))
+    logs = list((pathlib.Path(__file__).resolve().parent.parent / 'profiles' / 'r03_gc_variants').glob('*.jsonl'))
     rows = [json.loads(line) for f in logs for line in f.read_text().splitlines() if line.startswith('{')]
-    assert len([r for r in rows if r['batch'] in (8, 64)]) * 2 == len(table)
+    assert len([r for r in rows if r['batch'] in (8, 64)]) == len(table)
 
 
 def test_variant_choice_per_launch(monkeypatch):
@@ -114,7 +116,7 @@ def test_variant_choice_per_launch(monkeypatch):
         assert plan._gc_variant(view(b, frames), node, None, None, 2) == want
         assert plan._gc_variant(view(b, frames), node, None, ('stats',), 2) == executor._GC_TABLE[f'{op.kernel_size},{op.dilation},{cg},{flavour},{size},stats']
     ln0 = ('stats', 'gamma', 'beta')
-    assert plan._gc_variant(view(64, 250), node, ln0, None, 1) == executor._GC_TABLE[f'{op.kernel_size},{op.dilation},{cg},lnx,large']
+    assert plan._gc_variant(view(64, 250), node, ln0, None, 1) == executor._GC_TABLE[f'{op.kernel_size},{op.dilation},{cg},{"lnx+skip" if has_skip else "lnx"},large']
     assert plan._gc_variant(view(64, 250), None) == 0                                   # no node: the default kernel
     monkeypatch.setenv('NBASR_GC_F32_VARIANT', str(hip.GC_PIPE | hip.GC_OSPLIT))
     assert plan._gc_variant(view(64, 250), node, None, None, 2) == hip.GC_PIPE | hip.GC_OSPLIT

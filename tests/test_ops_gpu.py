@@ -555,7 +555,7 @@ def test_grouped_conv_epilogue_statistics(c, groups, t, k, d):
     assert torch.all(got[:, :, t:] == 0)
 
 
-@pytest.mark.parametrize('c,groups,t', [(40, 4, 133), (600, 100, 37), (48, 4, 1000), (30, 5, 257), (1200, 100, 250)])
+@pytest.mark.parametrize('c,groups,t', [(40, 4, 133), (600, 100, 37), (48, 4, 1000), (30, 5, 257), (1200, 100, 250), (42, 7, 511), (72, 6, 770), (80, 10, 1)])
 @pytest.mark.parametrize('kds,mask', [(((5, 1), (5, 1), (5, 1)), 0), (((7, 1), (7, 2), (5, 2)), 63), (((5, 2), (7, 2), (7, 1)), 0b101010),
                                       (((7, 2), (5, 1), (7, 2)), 0b010101)])
 @pytest.mark.parametrize('with_ln', [False, True])
@@ -583,12 +583,24 @@ def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, m
                              *nodes[2][2:], ln if s[3] else None, False, ln is not None and s[3])
     assert torch.equal(got, x3)
     assert torch.all(got[:, :, t:] == 0)
+    # the statistics by-product (round 3): the same partials, hence the same (mean, rstd), as the last node launch's epilogue
+    ws_cell, ws_node = hip.grouped_stats_workspace(b, xp.shape[2], groups, DEV), hip.grouped_stats_workspace(b, xp.shape[2], groups, DEV)
+    got2, x3b = torch.full_like(xp, float('nan')), torch.full_like(xp, float('nan'))
+    hip.grouped_cell_fused(xp, nodes, mask, got2, t, groups, ln, ws_cell)
+    hip.grouped_conv1d_node(x2, *nodes[2][:2], ([xp] if s[3] else []) + ([x1] if s[4] else []) + ([x2] if s[5] else []), x3b, t, groups,
+                            *nodes[2][2:], ln if s[3] else None, False, ln is not None and s[3], ws_node, 0)
+    st_cell, st_node = torch.empty(b, 2, xp.shape[2], device=DEV), torch.empty(b, 2, xp.shape[2], device=DEV)
+    hip.grouped_stats_finalize(ws_cell, st_cell, c, t, groups, 1e-3)
+    hip.grouped_stats_finalize(ws_node, st_node, c, t, groups, 1e-3)
+    assert torch.equal(got2, x3) and torch.equal(x3b, x3)
+    assert torch.equal(st_cell[:, :, :t], st_node[:, :, :t])
 
 
 def test_fused_cell_limits():
-    assert not hip.grouped_cell_fits(600, 4100, 100)          # > 4096 frames per workgroup
-    assert not hip.grouped_cell_fits(1200, 2048, 100)         # 2 * 12 * 2048 * 4 B > 160 KiB
-    assert hip.grouped_cell_fits(800, 1600, 100) and hip.grouped_cell_fits(600, 1000, 100)
+    assert not hip.grouped_cell_fits(600, 1028, 100)          # > 1024 frames: more than four 64-chunk waves per row
+    assert not hip.grouped_cell_fits(1200, 1000, 100)         # 4 groups x 12 channels x 1000 frames > 160 KiB of LDS
+    assert not hip.grouped_cell_fits(700, 1000, 100)          # 7 channels per group: not a model width
+    assert hip.grouped_cell_fits(800, 1000, 100) and hip.grouped_cell_fits(600, 1000, 100) and hip.grouped_cell_fits(1200, 500, 100)
     x = torch.zeros(1, 24, 16, device=DEV)
     w, bias = torch.zeros(24, 6, 3, device=DEV), torch.zeros(24, device=DEV)
     with pytest.raises(hip.HipError, match='conv5'):
