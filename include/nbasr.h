@@ -236,6 +236,10 @@ int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* b
 size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups);
 int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
                                  int groups, float eps, nbasr_stream_t stream);
+/* the same merge for partials that cover `groups_per_part` groups each: 4 (nbasr_grouped_conv1d_node, most nbasr_grouped_cell_fused
+ * launches) or 2 (the value nbasr_grouped_cell_fits returns for the shape) */
+int nbasr_grouped_stats_finalize_parts(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                       int groups, int groups_per_part, float eps, nbasr_stream_t stream);
 int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias,
                                      const float* skip0, const float* skip1, const float* skip2,
                                      float* y, int batch, int channels, int frames, int ld,
@@ -266,8 +270,9 @@ int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int 
  * nbasr_grouped_conv1d_node launches.  skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.  `ln` (may be
  * NULL): pending LayerNorm of x0.  `stats_ws` (may be NULL; nbasr_grouped_stats_workspace_bytes): the launch also emits the partial
  * LayerNorm statistics of x3, exactly as nbasr_grouped_conv1d_node does for a cell's last node (merge: nbasr_grouped_stats_finalize).
- * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup: <= 1024 frames (4 groups x <= 4 waves),
- * channels / groups in {6, 8, 10, 12}, four group tiles within 160 KiB of LDS. */
+ * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup -- <= 1024 frames (<= 4 waves per group row),
+ * channels / groups in {6, 8, 10, 12}, the group tiles within 160 KiB of LDS: 0 = no, else the number of groups one statistics partial
+ * covers (4 or 2: the groups_per_part of nbasr_grouped_stats_finalize_parts). */
 int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups);
 int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,
                              const float* w1, const float* b1, int k1, int d1,

@@ -11,9 +11,9 @@
 //
 // Round 3 form (round 2's: one workgroup per (utterance, group) row with TWO LDS tiles, 1-3 waves per SIMD, no statistics -- a win in
 // block 0 only, and the separate statistics pass took that back):
-//  * workgroup = (utterance, quad of groups) x the whole row: 4 groups x nt waves (nt = row length / 256 frames, <= 4), so the
-//    statistics partials are the node kernel's ([group quad][batch][2][ld], merged by stats_finalize_kernel) and neighbouring tiles of a
-//    row exchange their halo through the LDS tile itself;
+//  * workgroup = (utterance, 4 or 2 groups) x the whole row: GPW groups x nt waves (nt = row length / 256 frames, <= 4): with 4
+//    groups the statistics partials are the node kernel's ([group quad][batch][2][ld], merged by stats_finalize_kernel); neighbouring
+//    tiles of a row exchange their halo through the LDS tile itself;
 //  * ONE LDS tile per group ([CG][row + zero pads] floats) holds the INPUT of the node being computed; a node's output stays in the
 //    accumulator registers (a lane owns 4 frames x CG channels), gets its skip sum there, and is written to the tile only as the next
 //    node's input.  x0n and x2 as skip inputs are read back from the tile while it still holds them, x1 for node 2 (s21) is kept in a
@@ -89,10 +89,14 @@ __device__ __forceinline__ void conv_from_tile(float (&acc)[CG][4], const float*
     }
 }
 
+// GPW: groups per workgroup -- 4 (the statistics partials are then the node kernel's group quads, bit for bit), or 2 where four group
+// tiles would leave room for only ONE workgroup per CU (its load, compute and store phases then do not overlap with anybody's:
+// measured 157 / 246 / 201 us per cell in blocks 0-2 against 183 / 254 / 185 for three node launches); the partials are then per
+// group PAIR, merged by stats_finalize_kernel with groups_per_part = 2 -- the same statistics to rounding, not bit for bit.
 // NTB: the largest number of tiles per row this instantiation is launched with (1, 2 or 4): its register budget is that of a
-// 256 * NTB-thread workgroup (128 registers at 1024 threads; the 256-thread form of the narrow blocks may use more)
-template <int CG, bool KEEP1, int NTB>
-__global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
+// 64 * GPW * NTB-thread workgroup (128 registers at 1024 threads; the narrower forms may use more)
+template <int CG, bool KEEP1, int NTB, int GPW>
+__global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     const float* __restrict__ x0, float* __restrict__ y,
     const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
     const int gi = wave / nt, ti = wave - gi * nt;           // group within the quad, tile within the row
     float* const tile = cell_tiles + gi * (CG * rl);         // this group's tile: [CG][rl]
 
-    const int g_raw = blockIdx.x * 4 + gi, b = blockIdx.y;   // wave-uniform: weights / bias / gamma / beta come through s_load
+    const int g_raw = blockIdx.x * GPW + gi, b = blockIdx.y; // wave-uniform: weights / bias / gamma / beta come through s_load
     const bool g_ok = g_raw < a.groups;                       // a surplus wave of the last quad recomputes the last group, stores nothing
     const int g = g_ok ? g_raw : a.groups - 1;
     const int q = ti * 64 + lane;                            // chunk within the row
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
     const bool has_ln = ln_stats != nullptr;
 
     // the zero pads of every tile row (never written again)
-    for (int i = threadIdx.x; i < 4 * CG * (CELL_PADL + CELL_PADR); i += blockDim.x) {
+    for (int i = threadIdx.x; i < GPW * CG * (CELL_PADL + CELL_PADR); i += blockDim.x) {
         const int row = i / (CELL_PADL + CELL_PADR), p = i - row * (CELL_PADL + CELL_PADR);
         const int c = p < CELL_PADL ? p : nt * 64 + p;
         *reinterpret_cast<cell_f4*>(cell_tiles + row * rl + 4 * c) = cell_f4{0.f, 0.f, 0.f, 0.f};
@@ -261,7 +265,7 @@ __global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
         for (int co = 0; co < CG; ++co) { const float d = acc[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
         p2[r] = m2;
     }
-    __syncthreads();                                // every read of x2 is done: the tiles become the exchange buffer [4][nt][8][64]
+    __syncthreads();                                // every read of x2 is done: the tiles become the exchange buffer [GPW][nt][8][64]
     float* const sp = cell_tiles;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
     }
     __syncthreads();
     if (gi == 0 && in_row) {
-        const int nw = min(4, a.groups - static_cast<int>(blockIdx.x) * 4);      // groups (waves) that hold real data
+        const int nw = min(GPW, a.groups - static_cast<int>(blockIdx.x) * GPW);  // groups (waves) that hold real data
         float om[4], o2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -287,24 +291,26 @@ __global__ __launch_bounds__(256 * NTB) void grouped_cell_kernel(
     }
 }
 
-static size_t cell_lds_bytes(int cg, int nt) { return static_cast<size_t>(4) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
+static size_t cell_lds_bytes(int cg, int nt, int gpw = 4) { return static_cast<size_t>(gpw) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
+// groups per workgroup: 4 while at least two such workgroups fit a CU's 160 KiB, else 2
+static int cell_gpw(int cg, int nt) { return 2 * cell_lds_bytes(cg, nt, 4) <= 160 * 1024 ? 4 : 2; }
 
 struct CellPtrs {
     const float* x0; float* y; const float* w0; const float* w1; const float* w2; const float* b0; const float* b1; const float* b2;
     const float* ln_stats; const float* ln_gamma; const float* ln_beta; float* part;
 };
 
-template <int CG, bool KEEP1, int NTB>
+template <int CG, bool KEEP1, int NTB, int GPW>
 static int launch_cell_kernel(const CellPtrs& p, const CellDims& a, hipStream_t stream)
 {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<CG, KEEP1, NTB>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<CG, KEEP1, NTB, GPW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) {
         set_error("nbasr_grouped_cell_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
-    const size_t lds = cell_lds_bytes(CG, a.nt);
-    hipLaunchKernelGGL((grouped_cell_kernel<CG, KEEP1, NTB>), dim3((a.groups + 3) / 4, a.batch), dim3(4 * a.nt * 64), lds, stream,
+    const size_t lds = cell_lds_bytes(CG, a.nt, GPW);
+    hipLaunchKernelGGL((grouped_cell_kernel<CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream,
                        p.x0, p.y, p.w0, p.w1, p.w2, p.b0, p.b1, p.b2, p.ln_stats, p.ln_gamma, p.ln_beta, p.part, a);
     return launch_status("nbasr_grouped_cell_fused");
 }
@@ -312,9 +318,14 @@ static int launch_cell_kernel(const CellPtrs& p, const CellDims& a, hipStream_t 
 template <int CG, bool KEEP1>
 static int launch_cell_nt(const CellPtrs& p, const CellDims& a, hipStream_t stream)
 {
-    if (a.nt == 1) return launch_cell_kernel<CG, KEEP1, 1>(p, a, stream);
-    if (a.nt == 2) return launch_cell_kernel<CG, KEEP1, 2>(p, a, stream);
-    return launch_cell_kernel<CG, KEEP1, 4>(p, a, stream);
+    if (cell_gpw(CG, a.nt) == 4) {
+        if (a.nt == 1) return launch_cell_kernel<CG, KEEP1, 1, 4>(p, a, stream);
+        if (a.nt == 2) return launch_cell_kernel<CG, KEEP1, 2, 4>(p, a, stream);
+        return launch_cell_kernel<CG, KEEP1, 4, 4>(p, a, stream);
+    }
+    if (a.nt == 1) return launch_cell_kernel<CG, KEEP1, 1, 2>(p, a, stream);
+    if (a.nt == 2) return launch_cell_kernel<CG, KEEP1, 2, 2>(p, a, stream);
+    return launch_cell_kernel<CG, KEEP1, 4, 2>(p, a, stream);
 }
 
 template <int CG>
@@ -342,7 +353,9 @@ extern "C" int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups)
     const int cg = channels / groups;
     if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
     const int nt = (frames_ld / 4 + 63) / 64;
-    return nt <= 4 && cell_lds_bytes(cg, nt) <= 160 * 1024;
+    if (nt > 4) return 0;
+    const int gpw = cell_gpw(cg, nt);
+    return cell_lds_bytes(cg, nt, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize)
 }
 
 extern "C" int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,

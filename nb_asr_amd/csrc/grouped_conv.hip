@@ -34,14 +34,14 @@ __global__ __launch_bounds__(256) void pack_grouped_weights_kernel(const float* 
 
 // merge the per-quad partial statistics: stats (batch, 2, ld) <- (mean, rstd) per frame, 0 in the pitch columns
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                             int batch, int frames, int ld, int groups, int cg, float eps)
+                                                             int batch, int frames, int ld, int groups, int cg, int gpp, float eps)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = blockIdx.y;
     if (t >= ld) return;
     float* srow = stats + static_cast<size_t>(b) * 2 * ld;
     if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
-    const int nquads = (groups + 3) / 4;
+    const int nquads = (groups + gpp - 1) / gpp;          // partials per frame: one per `gpp` groups (4: node kernels; 2: some fused cells)
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
     // the partials are loaded five at a time BEFORE they are merged: the merge is a serial chain, the loads need not be
     // (25 partials per frame at 100 groups: 5 round trips to memory instead of 25; same merge order, same result)
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __rest
         for (int u = 0; u < 5; ++u) {
             const int k = k0 + u;
             if (k >= nquads) break;
-            const float nb = static_cast<float>(cg * min(4, groups - 4 * k));
+            const float nb = static_cast<float>(cg * min(gpp, groups - gpp * k));
             const float tot = cnt + nb;
             const float delta = pm[u] - mean;
             mean += delta * (nb / tot);
@@ -355,7 +355,7 @@ using namespace nbasr;
 extern "C" size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups)
 {
     if (batch <= 0 || ld <= 0 || groups <= 0) return 0;
-    return static_cast<size_t>((groups + 3) / 4) * batch * 2 * ld * sizeof(float);
+    return static_cast<size_t>((groups + 1) / 2) * batch * 2 * ld * sizeof(float);      // room for per-PAIR partials (fused cells); the node kernels use half
 }
 
 // every flavour of the node op lands here: validation, then the variant's translation unit
@@ -434,17 +434,24 @@ extern "C" int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, 
     return nbasr_grouped_stats_finalize(stats_ws, stats_out, batch, channels, frames, ld, groups, eps, stream);
 }
 
-extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
-                                            int groups, float eps, nbasr_stream_t stream)
+extern "C" int nbasr_grouped_stats_finalize_parts(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                                  int groups, int groups_per_part, float eps, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && groups > 0 && channels % groups == 0 && frames >= 0 && ld >= frames, NBASR_EINVAL,
                   "nbasr_grouped_stats_finalize: bad sizes");
+    NBASR_REQUIRE(groups_per_part == 4 || groups_per_part == 2, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4 or 2)", groups_per_part);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, as_stream(stream), stats_ws, stats_out,
-                       batch, frames, ld, groups, channels / groups, eps);
+                       batch, frames, ld, groups, channels / groups, groups_per_part, eps);
     return launch_status("nbasr_grouped_stats_finalize");
+}
+
+extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                            int groups, float eps, nbasr_stream_t stream)
+{
+    return nbasr_grouped_stats_finalize_parts(stats_ws, stats_out, batch, channels, frames, ld, groups, 4, eps, stream);
 }
 
 extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,

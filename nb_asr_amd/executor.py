@@ -696,9 +696,10 @@ class ForwardPlan:
                 # a deferred cell LayerNorm whose producer is a grouped conv gets its statistics from that node's
                 # epilogue (no statistics pass over the tensor)
                 last_op = layer.nodes[-1].op
-                fused = (self.cell_fusion and len(layer.nodes) == 3
-                         and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)
-                         and hip.grouped_cell_fits(layer.filters, hip.round_up4(act_frames), last_op.groups))
+                cell_gpp = (hip.grouped_cell_fits(layer.filters, hip.round_up4(act_frames), last_op.groups)
+                            if (self.cell_fusion and len(layer.nodes) == 3
+                                and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)) else 0)
+                fused = cell_gpp > 0
                 epilogue_stats = (self.epilogue_stats and layer.use_norm and defer
                                   and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                 if fused:
@@ -739,7 +740,7 @@ class ForwardPlan:
                     norm = layer.norm_layer
                     self._timed('stats_finalize', (blk, layer.filters, layer.filters, 0, act_frames, 0),
                                 lambda: hip.grouped_stats_finalize(self.stats_ws, new_stats, layer.filters, act_frames,
-                                                                   last_op.groups, norm.eps))
+                                                                   last_op.groups, norm.eps, cell_gpp if fused else 4))
                     pending = (new_stats, norm.weight.detach(), norm.bias.detach())
                     if taps is not None:
                         copy = torch.empty_like(act)

@@ -74,6 +74,7 @@ SIGNATURES = {
     'nbasr_grouped_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_grouped_stats_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_grouped_stats_finalize': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [ctypes.c_float, _c_stream]),
+    'nbasr_grouped_stats_finalize_parts': (_c_int, [_c_float_p] * 2 + [_c_int] * 6 + [ctypes.c_float, _c_stream]),
     'nbasr_grouped_conv1d_fused_stats': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_float_p,
                                                   ctypes.c_float, _c_stream]),
     'nbasr_grouped_cell_fits': (_c_int, [_c_int] * 3),
@@ -307,7 +308,8 @@ def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dila
 
 
 def grouped_cell_fits(channels, ld, groups):
-    return bool(load_library().nbasr_grouped_cell_fits(channels, ld, groups))
+    """0 when a (channels, ld, groups) cell cannot run as one launch, else the groups per statistics partial of that launch (4 or 2)."""
+    return int(load_library().nbasr_grouped_cell_fits(channels, ld, groups))
 
 
 def grouped_cell_fused(x0, nodes, skip_mask, y, frames, groups, ln=None, stats_ws=None):
@@ -322,10 +324,12 @@ def grouped_cell_fused(x0, nodes, skip_mask, y, frames, groups, ln=None, stats_w
     return y
 
 
-def grouped_stats_finalize(stats_ws, stats_out, channels, frames, groups, eps):
+def grouped_stats_finalize(stats_ws, stats_out, channels, frames, groups, eps, groups_per_part=4):
+    """Merge the partial statistics a node / fused-cell launch left in ``stats_ws`` into (mean, rstd) rows.  ``groups_per_part``: 4 for
+    the node kernels, ``grouped_cell_fits(...)`` (4 or 2) for a fused cell."""
     b, _, ld = stats_out.shape
-    _check(load_library().nbasr_grouped_stats_finalize(_dev(stats_ws, 'stats_ws'), _dev(stats_out, 'stats_out'), b, channels,
-                                                       frames, ld, groups, float(eps), _stream(stats_out)),
+    _check(load_library().nbasr_grouped_stats_finalize_parts(_dev(stats_ws, 'stats_ws'), _dev(stats_out, 'stats_out'), b, channels,
+                                                             frames, ld, groups, int(groups_per_part), float(eps), _stream(stats_out)),
            'nbasr_grouped_stats_finalize')
     return stats_out
 

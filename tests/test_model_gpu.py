@@ -728,6 +728,7 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
     buffer loads); NBASR_GC_TABLE=0 keeps the default kernel everywhere.  Same sums in the same order: bit-identical logits."""
     from nb_asr_amd import hip
     from nb_asr_amd.executor import ForwardPlan
+    monkeypatch.setenv('NBASR_CELL_FUSION', '0')            # (with fused cells -- the default -- a conv-only cell is one launch, not three node launches)
     m = build(cases.ARCH_D, True, 'lively')
     x = keyed_input(3, 210, seed=8).to(DEV)
     chosen = []
@@ -755,3 +756,31 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
         m._plans.clear()
         with torch.no_grad():
             assert torch.equal(m(x), y0), forced
+
+
+@pytest.mark.parametrize('arch,b,t', [(cases.ARCH_A, 2, 1000), (cases.ARCH_D, 3, 515), (cases.ARCH_D, 2, 250), ([[2, 0], [4, 1, 0], [1, 0, 1, 1]], 2, 1024)])
+def test_fused_cells_against_node_launches(monkeypatch, arch, b, t):
+    """Cells of three grouped convs run as ONE launch by default (grouped_cell.hip); NBASR_CELL_FUSION=0 runs the three node launches.
+    The cell outputs are bit-identical; the cell LayerNorm's statistics are merged per group quad (bit-identical) or, for long wide
+    rows, per group pair (equal to rounding) -- so the logits agree far inside the tolerance, and exactly where every cell takes quads."""
+    from nb_asr_amd import hip
+    m = build(arch, True, 'lively', seed=5)
+    x = keyed_input(b, t, seed=3).to(DEV)
+    with torch.no_grad():
+        fused = m(x).clone()
+        (plan,) = list(m._plans.values())
+        assert plan.cell_fusion
+    monkeypatch.setenv('NBASR_CELL_FUSION', '0')
+    m._plans.clear()
+    with torch.no_grad():
+        unfused = m(x).clone()
+    assert torch.isfinite(fused).all()
+    r = cases.worst_ratio(fused, unfused, 1e-4, 1e-5)
+    assert r <= 0.15, r
+    frames = t
+    gpps = []
+    for c, stride in zip((600, 800, 1000, 1200), (1, 1, 2, 2)):
+        frames = (frames + stride - 1) // stride
+        gpps.append(hip.grouped_cell_fits(c, hip.round_up4(frames), 100))
+    if all(g == 4 for g in gpps):
+        assert torch.equal(fused, unfused)

@@ -555,7 +555,7 @@ def test_grouped_conv_epilogue_statistics(c, groups, t, k, d):
     assert torch.all(got[:, :, t:] == 0)
 
 
-@pytest.mark.parametrize('c,groups,t', [(40, 4, 133), (600, 100, 37), (48, 4, 1000), (30, 5, 257), (1200, 100, 250), (42, 7, 511), (72, 6, 770), (80, 10, 1)])
+@pytest.mark.parametrize('c,groups,t', [(40, 4, 133), (600, 100, 37), (32, 4, 1000), (30, 5, 257), (1200, 100, 250), (42, 7, 511), (72, 12, 770), (80, 10, 1), (600, 100, 1000), (800, 100, 999)])
 @pytest.mark.parametrize('kds,mask', [(((5, 1), (5, 1), (5, 1)), 0), (((7, 1), (7, 2), (5, 2)), 63), (((5, 2), (7, 2), (7, 1)), 0b101010),
                                       (((7, 2), (5, 1), (7, 2)), 0b010101)])
 @pytest.mark.parametrize('with_ln', [False, True])
@@ -590,15 +590,19 @@ def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, m
     hip.grouped_conv1d_node(x2, *nodes[2][:2], ([xp] if s[3] else []) + ([x1] if s[4] else []) + ([x2] if s[5] else []), x3b, t, groups,
                             *nodes[2][2:], ln if s[3] else None, False, ln is not None and s[3], ws_node, 0)
     st_cell, st_node = torch.empty(b, 2, xp.shape[2], device=DEV), torch.empty(b, 2, xp.shape[2], device=DEV)
-    hip.grouped_stats_finalize(ws_cell, st_cell, c, t, groups, 1e-3)
+    gpp = hip.grouped_cell_fits(c, xp.shape[2], groups)
+    hip.grouped_stats_finalize(ws_cell, st_cell, c, t, groups, 1e-3, gpp)
     hip.grouped_stats_finalize(ws_node, st_node, c, t, groups, 1e-3)
     assert torch.equal(got2, x3) and torch.equal(x3b, x3)
-    assert torch.equal(st_cell[:, :, :t], st_node[:, :, :t])
+    if gpp == 4:                                   # group quads, as the node kernel: the same partials bit for bit
+        assert torch.equal(st_cell[:, :, :t], st_node[:, :, :t])
+    else:                                          # group pairs (long, wide rows): the same statistics to rounding
+        assert torch.allclose(st_cell[:, :, :t], st_node[:, :, :t], rtol=2e-6, atol=1e-6)
 
 
 def test_fused_cell_limits():
     assert not hip.grouped_cell_fits(600, 1028, 100)          # > 1024 frames: more than four 64-chunk waves per row
-    assert not hip.grouped_cell_fits(1200, 1000, 100)         # 4 groups x 12 channels x 1000 frames > 160 KiB of LDS
+    assert hip.grouped_cell_fits(1200, 1000, 100) == 2 and hip.grouped_cell_fits(1200, 252, 100) == 4      # groups per workgroup / statistics partial
     assert not hip.grouped_cell_fits(700, 1000, 100)          # 7 channels per group: not a model width
     assert hip.grouped_cell_fits(800, 1000, 100) and hip.grouped_cell_fits(600, 1000, 100) and hip.grouped_cell_fits(1200, 500, 100)
     x = torch.zeros(1, 24, 16, device=DEV)
