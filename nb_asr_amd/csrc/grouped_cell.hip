@@ -50,6 +50,22 @@ struct CellDims {
 };
 
 typedef float cell_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned cell_u4 __attribute__((ext_vector_type(4)));
+
+// Bounds-checked 16-byte accesses to ONE row (raw buffer: out-of-range lanes read zeros / store nothing).  No predicate, no branch:
+// hipcc waits for vmcnt(0) at every control-flow join, so a lane's CG loads (or stores) each behind their own `if (in_row)` would be
+// issued one round trip after the other (the first version of this kernel: 12 exec-masked branches around 12 loads).
+__device__ __forceinline__ float4 cell_load4(const float* row, int row_bytes, int byte_offset)
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, row_bytes, 0x00020000);
+    const cell_f4 f = __builtin_bit_cast(cell_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_offset, 0, 0));
+    return make_float4(f[0], f[1], f[2], f[3]);
+}
+__device__ __forceinline__ void cell_store4_nt(float* row, int row_bytes, int byte_offset, const float (&o)[4])
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_bytes, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cell_u4, cell_f4{o[0], o[1], o[2], o[3]}), rs, byte_offset, 0, 2);   // aux 2 = nt
+}
 
 // acc = bias + conv over one group's CG input channels, the input read from this group's LDS tile (row pitch rl floats; a lane's own
 // chunk of channel ci at row[ci * rl + 4 * col]); the window of channel ci + 1 is requested before the FMAs of channel ci
@@ -130,12 +146,13 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         *reinterpret_cast<cell_f4*>(cell_tiles + row * rl + 4 * c) = cell_f4{0.f, 0.f, 0.f, 0.f};
     }
 
-    // statistics of this lane's own 4 frames (pending LayerNorm of the cell input)
+    const int row_bytes = a.ld * 4, boff = q * 16;  // a row as a bounds-checked buffer; this lane's chunk in it (beyond the row: zeros)
+    // statistics of this lane's own 4 frames (pending LayerNorm of the cell input); beyond the row rstd = 0, i.e. normalised = 0
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;
-    if (has_ln && in_row) {
-        const float4* __restrict__ mrow = reinterpret_cast<const float4*>(ln_stats + static_cast<size_t>(b) * 2 * a.ld);
-        sm = mrow[q];
-        sr = mrow[nq + q];
+    if (has_ln) {                                   // (workgroup-uniform)
+        const float* mrow = ln_stats + static_cast<size_t>(b) * 2 * a.ld;
+        sm = cell_load4(mrow, row_bytes, boff);
+        sr = cell_load4(mrow + a.ld, row_bytes, boff);
     }
     auto normalise = [&](float4 v, int co) -> float4 {
         if (has_ln) {
@@ -145,10 +162,8 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         }
         return v;
     };
-    auto x0n_own = [&](int co) -> float4 {          // the (normalised) cell input at this lane's frames, channel co, from HBM
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in_row) v = normalise(*reinterpret_cast<const float4*>(xg + static_cast<size_t>(co) * a.ld + t0), co);
-        return v;
+    auto x0_raw = [&](int co) -> float4 {           // the cell input at this lane's frames, channel co, from HBM (zeros beyond the row)
+        return cell_load4(xg + static_cast<size_t>(co) * a.ld, row_bytes, boff);
     };
     auto tile_own = [&](int co) -> float4 {         // this lane's chunk of the tensor the tile holds
         const cell_f4 v = *reinterpret_cast<const cell_f4*>(tile + co * rl + 4 * col);
@@ -159,23 +174,28 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         for (int r = 0; r < 4; ++r) if (!in_row || t0 + r >= a.frames) o[r] = 0.f;
     };
 
+    // between the phases of a node: the nt waves of a group row read each other's halo chunks, so they meet at a workgroup barrier;
+    // a one-wave row (NTB == 1) is wave-private -- LDS operations of one wave execute in order -- and its waves run free
+    auto phase_sync = [&]() {
+        if constexpr (NTB > 1) __syncthreads();
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+
     float acc[CG][4];
     float keep1[KEEP1 ? CG : 1][4];
 
     // ---- the cell input: own chunks of all CG channels (all loads in flight together), normalised once, into the tile ------------
 #pragma unroll
     for (int ci = 0; ci < CG; ++ci) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in_row) v = *reinterpret_cast<const float4*>(xg + static_cast<size_t>(ci) * a.ld + t0);
+        const float4 v = x0_raw(ci);
         acc[ci][0] = v.x; acc[ci][1] = v.y; acc[ci][2] = v.z; acc[ci][3] = v.w;
     }
 #pragma unroll
     for (int ci = 0; ci < CG; ++ci) {
-        float4 v = make_float4(acc[ci][0], acc[ci][1], acc[ci][2], acc[ci][3]);
-        if (in_row) v = normalise(v, ci);
+        const float4 v = normalise(make_float4(acc[ci][0], acc[ci][1], acc[ci][2], acc[ci][3]), ci);      // (rstd = 0 beyond the row: zeros)
         *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{v.x, v.y, v.z, v.w};
     }
-    __syncthreads();
+    __syncthreads();                                // (also orders the zero pads, which other waves wrote)
 
     using I5 = std::integral_constant<int, 5>; using I7 = std::integral_constant<int, 7>;
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
@@ -206,48 +226,69 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc[co][r] = o[r]; if (KEEP1) keep1[KEEP1 ? co : 0][r] = o[r]; }
     }
-    __syncthreads();                                // every read of x0n is done
+    phase_sync();                                   // every read of x0n is done
     tile_write();
-    __syncthreads();
+    phase_sync();
 
     // ---- node 1: x2 = op1(x1) + s10 x0n + s11 x1 --------------------------------------------------------------------------------------
     NBASR_KD_SWITCH(a.kd1, w1, b1)
+    // (the skip input x0n comes back from HBM: its four-channel groups are requested together behind ONE wave-uniform branch each)
 #pragma unroll
-    for (int co = 0; co < CG; ++co) {
-        float o[4];
+    for (int c0 = 0; c0 < CG; c0 += 4) {
+        float4 u[4];
+        if (a.skips & 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-        if (a.skips & 2) { const float4 v = x0n_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        mask_tail(o);
+            for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(c0 + c);
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[co][r] = o[r];
+        for (int c = 0; c < 4; ++c) {
+            const int co = c0 + c;
+            if (co >= CG) break;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+            if (a.skips & 2) { const float4 v = normalise(u[c], co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+            if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+            mask_tail(o);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];
+        }
     }
-    __syncthreads();
+    phase_sync();
     tile_write();
-    __syncthreads();
+    phase_sync();
 
     // ---- node 2: x3 = op2(x2) + s20 x0n + s21 x1 + s22 x2 -> HBM ------------------------------------------------------------------------
     NBASR_KD_SWITCH(a.kd2, w2, b2)
 #undef NBASR_KD_SWITCH
+    const int store_bytes = g_ok ? row_bytes : 0;   // a surplus wave's stores are dropped by the bounds check
 #pragma unroll
-    for (int co = 0; co < CG; ++co) {
-        float o[4];
+    for (int c0 = 0; c0 < CG; c0 += 4) {
+        float4 u[4];
+        if (a.skips & 8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-        if (a.skips & 8) { const float4 v = x0n_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        if (KEEP1) {
-            if (a.skips & 16) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? co : 0][r];
-            }
+            for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(c0 + c);
         }
-        if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-        mask_tail(o);
-        if (in_row && g_ok)
-            __builtin_nontemporal_store(cell_f4{o[0], o[1], o[2], o[3]}, reinterpret_cast<cell_f4*>(y + row0 + static_cast<size_t>(co) * a.ld + t0));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[co][r] = o[r];        // the final values, for the statistics
+        for (int c = 0; c < 4; ++c) {
+            const int co = c0 + c;
+            if (co >= CG) break;
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+            if (a.skips & 8) { const float4 v = normalise(u[c], co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+            if (KEEP1) {
+                if (a.skips & 16) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? co : 0][r];
+                }
+            }
+            if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+            mask_tail(o);
+            cell_store4_nt(y + row0 + static_cast<size_t>(co) * a.ld, store_bytes, boff, o);     // (no predicate: lanes beyond the row store nothing)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];    // the final values, for the statistics
+        }
     }
     if (part == nullptr) return;                    // (workgroup-uniform)
 

@@ -776,7 +776,16 @@ def test_fused_cells_against_node_launches(monkeypatch, arch, b, t):
         unfused = m(x).clone()
     assert torch.isfinite(fused).all()
     r = cases.worst_ratio(fused, unfused, 1e-4, 1e-5)
-    assert r <= 0.15, r
+    if arch is cases.ARCH_A:
+        # eighteen skip-free cells under a He initialisation amplify ANY rounding difference ~1000 x (the reference itself sits 0.96 of
+        # the tolerance from fp64 here): pair-merged statistics are another fp32 sample, judged like every other path -- against fp64
+        params = {k: v.cpu() for k, v in m.state_dict().items()}
+        want = oracle.asr_forward(params, arch, x.cpu(), use_rnn=True)
+        truth = oracle.asr_forward(params, arch, x.cpu(), use_rnn=True, dtype=torch.float64)
+        cases.assert_parity(fused, want, truth, 'fused cells')
+        cases.assert_parity(unfused, want, truth, 'node launches')
+    else:
+        assert r <= 0.15, r
     frames = t
     gpps = []
     for c, stride in zip((600, 800, 1000, 1200), (1, 1, 2, 2)):
