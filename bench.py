@@ -279,12 +279,12 @@ def main():
 
 
 def kernel_source_hash():
-    """Hash of the graded kernel's sources (grouped_conv.hip, grouped_conv_osplit.hip, grouped_cell.hip, common.h) and of the table
+    """Hash of the graded kernel's sources (grouped_conv.hip, grouped_conv_osplit.hip, grouped_conv_ring.hip, grouped_cell.hip, common.h) and of the table
     that picks the variant per launch: ties a PMC summary to a build."""
     import hashlib
     here = os.path.dirname(os.path.abspath(__file__))
     h = hashlib.sha256()
-    for name in ('csrc/grouped_conv.hip', 'csrc/grouped_conv_osplit.hip', 'csrc/grouped_cell.hip', 'csrc/common.h', 'gc_variant_table.json'):
+    for name in ('csrc/grouped_conv.hip', 'csrc/grouped_conv_osplit.hip', 'csrc/grouped_conv_ring.hip', 'csrc/grouped_cell.hip', 'csrc/common.h', 'gc_variant_table.json'):
         with open(os.path.join(here, 'nb_asr_amd', name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -341,7 +341,7 @@ def roofline_leg(model, x, args):
             # one launch = the three node operations of a cell: credited with the algorithmic bytes of those three ops
             # (SURVEY.md 8(d) per-op figure x the ops one launch processes); the intermediates never leave the CU
             blk, c, ks, skips, frames, _ = meta
-            b = sum(grouped_conv_bytes(args.batch, c, frames, kj, sj) for kj, sj in zip(ks, skips))
+            b = sum(grouped_conv_bytes(args.batch, c, frames, kj, sj, elem=2 if args.dtype == 'bf16' else 4) for kj, sj in zip(ks, skips))
             k = 'x'.join(str(v) for v in ks)
         else:
             continue
@@ -381,8 +381,11 @@ def roofline_leg(model, x, args):
                                'the bytes); frac = sum of per-launch attainable times min(157.3 TF, AI x 8 TB/s) / measured time'}
                 if compute_bound else {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s'})
         out['roofline'] = {
-            'kernel': 'grouped_conv_f32_{pipe_,osplit_,}kernel<CG,K,D,..> (variant per launch from gc_variant_table.json; bf16: grouped_conv_kernel<bf16_t,..>; opt-in whole-cell: grouped_cell_kernel<CG>) (fused pad+grouped Conv1d+bias+ReLU+clamp+skip-sum'
-                      ' [+LayerNorm on load]; a cell launch runs its three node ops with the intermediates in LDS)',
+            'kernel': 'grouped_cell_kernel<T,CG,KEEP1,NTB,GPW> where a cell is three grouped convs and a row fits a workgroup (one launch = the '
+                      'three node ops of a cell, x1 / x2 never leave the CU, LayerNorm statistics as a by-product: credited with the algorithmic '
+                      'bytes of those three ops); otherwise grouped_conv_f32_{ring_,pipe_,osplit_,}kernel<CG,K,D,..> (variant per launch from '
+                      'gc_variant_table.json; bf16: grouped_conv_kernel<bf16_t,..>): fused pad + grouped Conv1d + bias + ReLU + clamp + skip sum '
+                      '[+ LayerNorm on load]',
             **head, 'frac': (tot_attain_s / (tot_ms * 1e-3)) if compute_bound else achieved / HBM_PEAK_GBS,
             'frac_of_attainable': tot_attain_s / (tot_ms * 1e-3), 'hbm_GBps': achieved, 'frac_of_hbm_peak': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,

@@ -270,15 +270,17 @@ int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int 
  * nbasr_grouped_conv1d_node launches.  skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.  `ln` (may be
  * NULL): pending LayerNorm of x0.  `stats_ws` (may be NULL; nbasr_grouped_stats_workspace_bytes): the launch also emits the partial
  * LayerNorm statistics of x3, exactly as nbasr_grouped_conv1d_node does for a cell's last node (merge: nbasr_grouped_stats_finalize).
- * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup -- <= 1024 frames (<= 4 waves per group row),
+ * `dtype` = NBASR_F32 | NBASR_BF16: storage type of x0 and y (weights, biases, statistics, gamma / beta are fp32 either way; with
+ * bf16 storage x1 and x2 are rounded to bfloat16 exactly where the three-launch form stores them).
+ * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup -- <= 2048 frames (<= 8 waves per group row),
  * channels / groups in {6, 8, 10, 12}, the group tiles within 160 KiB of LDS: 0 = no, else the number of groups one statistics partial
  * covers (4 or 2: the groups_per_part of nbasr_grouped_stats_finalize_parts). */
 int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups);
-int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,
+int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, int k0, int d0,
                              const float* w1, const float* b1, int k1, int d1,
-                             const float* w2, const float* b2, int k2, int d2, int skip_mask, float* y,
+                             const float* w2, const float* b2, int k2, int d2, int skip_mask, void* y,
                              int batch, int channels, int frames, int ld, int groups,
-                             const nbasr_deferred_ln* ln, float* stats_ws, nbasr_stream_t stream);
+                             const nbasr_deferred_ln* ln, float* stats_ws, int dtype, nbasr_stream_t stream);
 int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y,
                       int batch, int channels, int frames, int ld,
                       const nbasr_deferred_ln* ln, int ln_on_skip0, nbasr_stream_t stream);

@@ -24,7 +24,7 @@
 //  * the window of input channel ci + 1 is read from LDS while channel ci multiplies.
 //
 // Algorithmic bytes credited per launch (bench.py): those of the three node operations it replaces.
-#include "common.h"
+#include "storage.h"
 
 #include <type_traits>
 
@@ -61,10 +61,32 @@ __device__ __forceinline__ float4 cell_load4(const float* row, int row_bytes, in
     const cell_f4 f = __builtin_bit_cast(cell_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_offset, 0, 0));
     return make_float4(f[0], f[1], f[2], f[3]);
 }
-__device__ __forceinline__ void cell_store4_nt(float* row, int row_bytes, int byte_offset, const float (&o)[4])
+// a lane's 4 frames of a row in either storage type (fp32: 16 bytes; bf16: 8 bytes, widened exactly); `chunk` = the lane's chunk index
+__device__ __forceinline__ float4 cell_load_frames(const float* row, int ld, int chunk) { return cell_load4(row, ld * 4, chunk * 16); }
+__device__ __forceinline__ float4 cell_load_frames(const bf16_t* row, int ld, int chunk)
 {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_bytes, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cell_u4, cell_f4{o[0], o[1], o[2], o[3]}), rs, byte_offset, 0, 2);   // aux 2 = nt
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(row), 0, ld * 2, 0x00020000);
+    const u2v t = __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rs, chunk * 8, 0, 0));
+    return make_float4(bf16_lo(t.x), bf16_hi(t.x), bf16_lo(t.y), bf16_hi(t.y));
+}
+// streaming store of a lane's 4 frames (bf16: ONE rounding, here); row_len = the row's pitch, or 0 to drop the store
+__device__ __forceinline__ void cell_store_frames(float* row, int row_len, int chunk, const float (&o)[4])
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_len * 4, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(cell_u4, cell_f4{o[0], o[1], o[2], o[3]}), rs, chunk * 16, 0, 2);   // aux 2 = nt
+}
+__device__ __forceinline__ void cell_store_frames(bf16_t* row, int row_len, int chunk, const float (&o)[4])
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(row, 0, row_len * 2, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])}, rs, chunk * 8, 0, 2);
+}
+// what a stored-and-reloaded value is: itself (fp32) or its bfloat16 rounding (the bf16 path rounds every tensor once, when stored)
+template <typename T> __device__ __forceinline__ void cell_round(float (&o)[4])
+{
+    if constexpr (sizeof(T) == 2) {
+        const unsigned a = pack_bf16x2(o[0], o[1]), b = pack_bf16x2(o[2], o[3]);
+        o[0] = bf16_lo(a); o[1] = bf16_hi(a); o[2] = bf16_lo(b); o[3] = bf16_hi(b);
+    }
 }
 
 // acc = bias + conv over one group's CG input channels, the input read from this group's LDS tile (row pitch rl floats; a lane's own
@@ -111,9 +133,11 @@ __device__ __forceinline__ void conv_from_tile(float (&acc)[CG][4], const float*
 // group PAIR, merged by stats_finalize_kernel with groups_per_part = 2 -- the same statistics to rounding, not bit for bit.
 // NTB: the largest number of tiles per row this instantiation is launched with (1, 2 or 4): its register budget is that of a
 // 64 * GPW * NTB-thread workgroup (128 registers at 1024 threads; the narrower forms may use more)
-template <int CG, bool KEEP1, int NTB, int GPW>
+// T: storage type of the cell input and output (float, or bf16_t: the bf16 path -- x1 and x2 are then rounded to bfloat16 exactly
+// where the three-launch form stores them, the statistics describe x3 before its rounding)
+template <typename T, int CG, bool KEEP1, int NTB, int GPW>
 __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
-    const float* __restrict__ x0, float* __restrict__ y,
+    const T* __restrict__ x0, T* __restrict__ y,
     const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
     const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
     const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
@@ -136,7 +160,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     const bool in_row = q < nq;
     const int t0 = q * 4;
     const size_t row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG) * a.ld;
-    const float* __restrict__ xg = x0 + row0;
+    const T* __restrict__ xg = x0 + row0;
     const bool has_ln = ln_stats != nullptr;
 
     // the zero pads of every tile row (never written again)
@@ -146,7 +170,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         *reinterpret_cast<cell_f4*>(cell_tiles + row * rl + 4 * c) = cell_f4{0.f, 0.f, 0.f, 0.f};
     }
 
-    const int row_bytes = a.ld * 4, boff = q * 16;  // a row as a bounds-checked buffer; this lane's chunk in it (beyond the row: zeros)
+    const int row_bytes = a.ld * 4, boff = q * 16;  // a statistics row as a bounds-checked buffer; this lane's chunk in it (beyond the row: zeros)
     // statistics of this lane's own 4 frames (pending LayerNorm of the cell input); beyond the row rstd = 0, i.e. normalised = 0
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;
     if (has_ln) {                                   // (workgroup-uniform)
@@ -163,7 +187,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         return v;
     };
     auto x0_raw = [&](int co) -> float4 {           // the cell input at this lane's frames, channel co, from HBM (zeros beyond the row)
-        return cell_load4(xg + static_cast<size_t>(co) * a.ld, row_bytes, boff);
+        return cell_load_frames(xg + static_cast<size_t>(co) * a.ld, a.ld, q);
     };
     auto tile_own = [&](int co) -> float4 {         // this lane's chunk of the tensor the tile holds
         const cell_f4 v = *reinterpret_cast<const cell_f4*>(tile + co * rl + 4 * col);
@@ -223,6 +247,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
         if (a.skips & 1) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         mask_tail(o);
+        cell_round<T>(o);
 #pragma unroll
         for (int r = 0; r < 4; ++r) { acc[co][r] = o[r]; if (KEEP1) keep1[KEEP1 ? co : 0][r] = o[r]; }
     }
@@ -250,6 +275,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
             if (a.skips & 2) { const float4 v = normalise(u[c], co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
             if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
             mask_tail(o);
+            cell_round<T>(o);
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[co][r] = o[r];
         }
@@ -261,7 +287,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     // ---- node 2: x3 = op2(x2) + s20 x0n + s21 x1 + s22 x2 -> HBM ------------------------------------------------------------------------
     NBASR_KD_SWITCH(a.kd2, w2, b2)
 #undef NBASR_KD_SWITCH
-    const int store_bytes = g_ok ? row_bytes : 0;   // a surplus wave's stores are dropped by the bounds check
+    const int store_len = g_ok ? a.ld : 0;          // a surplus wave's stores are dropped by the bounds check
 #pragma unroll
     for (int c0 = 0; c0 < CG; c0 += 4) {
         float4 u[4];
@@ -285,7 +311,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
             }
             if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
             mask_tail(o);
-            cell_store4_nt(y + row0 + static_cast<size_t>(co) * a.ld, store_bytes, boff, o);     // (no predicate: lanes beyond the row store nothing)
+            cell_store_frames(y + row0 + static_cast<size_t>(co) * a.ld, store_len, q, o);        // (no predicate: lanes beyond the row store nothing)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[co][r] = o[r];    // the final values, for the statistics
         }
@@ -332,47 +358,49 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     }
 }
 
-static size_t cell_lds_bytes(int cg, int nt, int gpw = 4) { return static_cast<size_t>(gpw) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
-// groups per workgroup: 4 while at least two such workgroups fit a CU's 160 KiB, else 2
-static int cell_gpw(int cg, int nt) { return 2 * cell_lds_bytes(cg, nt, 4) <= 160 * 1024 ? 4 : 2; }
+static size_t cell_lds_bytes(int cg, int nt, int gpw) { return static_cast<size_t>(gpw) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
+// groups per workgroup: 4 while at least two such workgroups fit a CU's 160 KiB and the workgroup its 16 waves, else 2
+static int cell_gpw(int cg, int nt) { return (nt <= 4 && 2 * cell_lds_bytes(cg, nt, 4) <= 160 * 1024) ? 4 : 2; }
 
+template <typename T>
 struct CellPtrs {
-    const float* x0; float* y; const float* w0; const float* w1; const float* w2; const float* b0; const float* b1; const float* b2;
+    const T* x0; T* y; const float* w0; const float* w1; const float* w2; const float* b0; const float* b1; const float* b2;
     const float* ln_stats; const float* ln_gamma; const float* ln_beta; float* part;
 };
 
-template <int CG, bool KEEP1, int NTB, int GPW>
-static int launch_cell_kernel(const CellPtrs& p, const CellDims& a, hipStream_t stream)
+template <typename T, int CG, bool KEEP1, int NTB, int GPW>
+static int launch_cell_kernel(const CellPtrs<T>& p, const CellDims& a, hipStream_t stream)
 {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<CG, KEEP1, NTB, GPW>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) {
         set_error("nbasr_grouped_cell_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
     const size_t lds = cell_lds_bytes(CG, a.nt, GPW);
-    hipLaunchKernelGGL((grouped_cell_kernel<CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream,
+    hipLaunchKernelGGL((grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream,
                        p.x0, p.y, p.w0, p.w1, p.w2, p.b0, p.b1, p.b2, p.ln_stats, p.ln_gamma, p.ln_beta, p.part, a);
     return launch_status("nbasr_grouped_cell_fused");
 }
 
-template <int CG, bool KEEP1>
-static int launch_cell_nt(const CellPtrs& p, const CellDims& a, hipStream_t stream)
+template <typename T, int CG, bool KEEP1>
+static int launch_cell_nt(const CellPtrs<T>& p, const CellDims& a, hipStream_t stream)
 {
     if (cell_gpw(CG, a.nt) == 4) {
-        if (a.nt == 1) return launch_cell_kernel<CG, KEEP1, 1, 4>(p, a, stream);
-        if (a.nt == 2) return launch_cell_kernel<CG, KEEP1, 2, 4>(p, a, stream);
-        return launch_cell_kernel<CG, KEEP1, 4, 4>(p, a, stream);
+        if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 4>(p, a, stream);
+        if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 4>(p, a, stream);
+        return launch_cell_kernel<T, CG, KEEP1, 4, 4>(p, a, stream);
     }
-    if (a.nt == 1) return launch_cell_kernel<CG, KEEP1, 1, 2>(p, a, stream);
-    if (a.nt == 2) return launch_cell_kernel<CG, KEEP1, 2, 2>(p, a, stream);
-    return launch_cell_kernel<CG, KEEP1, 4, 2>(p, a, stream);
+    if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 2>(p, a, stream);
+    if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 2>(p, a, stream);
+    if (a.nt <= 4) return launch_cell_kernel<T, CG, KEEP1, 4, 2>(p, a, stream);
+    return launch_cell_kernel<T, CG, KEEP1, 8, 2>(p, a, stream);
 }
 
-template <int CG>
-static int launch_cell(const CellPtrs& p, const CellDims& a, hipStream_t stream)
+template <typename T, int CG>
+static int launch_cell(const CellPtrs<T>& p, const CellDims& a, hipStream_t stream)
 {
-    return (a.skips & 16) ? launch_cell_nt<CG, true>(p, a, stream) : launch_cell_nt<CG, false>(p, a, stream);
+    return (a.skips & 16) ? launch_cell_nt<T, CG, true>(p, a, stream) : launch_cell_nt<T, CG, false>(p, a, stream);
 }
 
 static int kd_code(int kernel, int dilation)
@@ -382,6 +410,20 @@ static int kd_code(int kernel, int dilation)
     if (kernel == 7 && dilation == 1) return 2;
     if (kernel == 7 && dilation == 2) return 3;
     return -1;
+}
+
+template <typename T>
+static int cell_fused_impl(const T* x0, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2, const float* b2,
+                           T* y, const CellDims& a, const nbasr_deferred_ln* ln, float* stats_ws, hipStream_t s)
+{
+    const LnRef l = ln_ref(ln, true);
+    const CellPtrs<T> p{x0, y, w0, w1, w2, b0, b1, b2, l.stats, l.gamma, l.beta, stats_ws};
+    switch (a.channels / a.groups) {
+        case 6:  return launch_cell<T, 6>(p, a, s);
+        case 8:  return launch_cell<T, 8>(p, a, s);
+        case 10: return launch_cell<T, 10>(p, a, s);
+        default: return launch_cell<T, 12>(p, a, s);
+    }
 }
 
 }  // namespace nbasr
@@ -394,30 +436,32 @@ extern "C" int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups)
     const int cg = channels / groups;
     if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
     const int nt = (frames_ld / 4 + 63) / 64;
-    if (nt > 4) return 0;
+    if (nt > 8) return 0;                                              // 2 groups x 8 waves = the 1024 threads of a workgroup
     const int gpw = cell_gpw(cg, nt);
-    return cell_lds_bytes(cg, nt, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize)
+    return cell_lds_bytes(cg, nt, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize_parts)
 }
 
-extern "C" int nbasr_grouped_cell_fused(const float* x0, const float* w0, const float* b0, int k0, int d0,
+extern "C" int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, int k0, int d0,
                                         const float* w1, const float* b1, int k1, int d1,
-                                        const float* w2, const float* b2, int k2, int d2, int skip_mask, float* y,
+                                        const float* w2, const float* b2, int k2, int d2, int skip_mask, void* y,
                                         int batch, int channels, int frames, int ld, int groups,
-                                        const nbasr_deferred_ln* ln, float* stats_ws, nbasr_stream_t stream)
+                                        const nbasr_deferred_ln* ln, float* stats_ws, int dtype, nbasr_stream_t stream)
 {
     clear_error();
+    NBASR_REQUIRE(dtype == NBASR_F32 || dtype == NBASR_BF16, NBASR_EINVAL, "nbasr_grouped_cell_fused: dtype %d is neither NBASR_F32 nor NBASR_BF16", dtype);
     NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
                   "nbasr_grouped_cell_fused: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(x0 && w0 && b0 && w1 && b1 && w2 && b2 && y, NBASR_ENULL, "nbasr_grouped_cell_fused: NULL pointer");
-    NBASR_REQUIRE(ld >= frames && ld % 4 == 0 && aligned16(x0) && aligned16(y) && aligned16(stats_ws), NBASR_EALIGN,
-                  "nbasr_grouped_cell_fused: ld=%d must be >= frames=%d and a multiple of 4; x0, y, stats_ws 16-byte aligned", ld, frames);
+    const int pitch = dtype == NBASR_BF16 ? 8 : 4;
+    NBASR_REQUIRE(ld >= frames && ld % pitch == 0 && aligned16(x0) && aligned16(y) && aligned16(stats_ws), NBASR_EALIGN,
+                  "nbasr_grouped_cell_fused: ld=%d must be >= frames=%d and a multiple of %d; x0, y, stats_ws 16-byte aligned", ld, frames, pitch);
     NBASR_REQUIRE(batch <= 65535 && skip_mask >= 0 && skip_mask < 64, NBASR_EINVAL, "nbasr_grouped_cell_fused: bad batch / skip mask");
     NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
                   "nbasr_grouped_cell_fused: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
     NBASR_REQUIRE(nbasr_grouped_cell_fits(channels, ld, groups), NBASR_EINVAL,
                   "nbasr_grouped_cell_fused: a row of %d frames x %d channels per group does not fit one workgroup "
-                  "(<= 1024 frames, channels/groups in {6, 8, 10, 12}, 4 group tiles <= 160 KiB of LDS); use the per-node launches", ld, channels / groups);
+                  "(<= 2048 frames, channels/groups in {6, 8, 10, 12}, the group tiles <= 160 KiB of LDS); use the per-node launches", ld, channels / groups);
     CellDims a{};
     a.channels = channels; a.frames = frames; a.ld = ld; a.groups = groups; a.batch = batch;
     a.kd0 = kd_code(k0, d0); a.kd1 = kd_code(k1, d1); a.kd2 = kd_code(k2, d2);
@@ -425,13 +469,8 @@ extern "C" int nbasr_grouped_cell_fused(const float* x0, const float* w0, const 
                   "nbasr_grouped_cell_fused: node ops must be conv5 / conv5d2 / conv7 / conv7d2 (got k=%d,%d,%d d=%d,%d,%d)", k0, k1, k2, d0, d1, d2);
     a.skips = skip_mask;
     a.nt = (ld / 4 + 63) / 64;
-    const LnRef l = ln_ref(ln, true);
-    const CellPtrs p{x0, y, w0, w1, w2, b0, b1, b2, l.stats, l.gamma, l.beta, stats_ws};
     hipStream_t s = as_stream(stream);
-    switch (channels / groups) {
-        case 6:  return launch_cell<6>(p, a, s);
-        case 8:  return launch_cell<8>(p, a, s);
-        case 10: return launch_cell<10>(p, a, s);
-        default: return launch_cell<12>(p, a, s);
-    }
+    if (dtype == NBASR_F32)
+        return cell_fused_impl<float>(static_cast<const float*>(x0), w0, b0, w1, b1, w2, b2, static_cast<float*>(y), a, ln, stats_ws, s);
+    return cell_fused_impl<bf16_t>(static_cast<const bf16_t*>(x0), w0, b0, w1, b1, w2, b2, static_cast<bf16_t*>(y), a, ln, stats_ws, s);
 }

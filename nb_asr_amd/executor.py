@@ -899,7 +899,24 @@ class ForwardPlan:
                     epilogue_stats = (self.epilogue_stats and norm is not None and self._cheap_consumer(nxt) and not use_mfma
                                       and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                     outs = [act]
-                    for j, (node, dst) in enumerate(zip(layer.nodes, free)):
+                    # three grouped convs: ONE launch where a row fits a workgroup (grouped_cell.hip; x1 and x2 rounded to bf16 exactly
+                    # where the node launches store them, so the result is the same bit for bit)
+                    cell_gpp = (hip.grouped_cell_fits(layer.filters, act.shape[2], last_op.groups)
+                                if (self.cell_fusion and not use_mfma and len(layer.nodes) == 3
+                                    and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)) else 0)
+                    if cell_gpp:
+                        mask = 0
+                        for bit, (j, i) in enumerate(((0, 0), (1, 0), (1, 1), (2, 0), (2, 1), (2, 2))):
+                            if isinstance(layer.nodes[j].branch_ops[i], Identity):
+                                mask |= 1 << bit
+                        view = self._view16(free[2], layer.filters, act_frames)
+                        specs = [(self._f32(n.op.conv.weight), self._f32(n.op.conv.bias), n.op.kernel_size, n.op.dilation) for n in layer.nodes]
+                        n_sk = [sum(isinstance(br, Identity) for br in n.branch_ops) for n in layer.nodes]
+                        meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_sk), act_frames, 0)
+                        src, ln0, cell_ws = act, pending, (self.stats_ws if epilogue_stats else None)
+                        self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0, cell_ws))
+                        outs = [act, None, None, view]
+                    for j, (node, dst) in enumerate(zip(layer.nodes, free) if not cell_gpp else ()):
                         if len(outs) != len(node.branch_ops):
                             raise AssertionError('Branch op and input list have different lenghts')
                         skips = [src for br, src in zip(node.branch_ops, outs) if isinstance(br, Identity)]
@@ -956,7 +973,7 @@ class ForwardPlan:
                         outs.append(view)
                     act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 else:
-                    norm, epilogue_stats = layer, False
+                    norm, epilogue_stats, cell_gpp = layer, False, 0
                     if act.dim() != 3 or pending is not None:
                         raise RuntimeError('LayerNorm in an unexpected position of the layer list')
                 feeds_tail = isinstance(nxt, (nn.Dropout, nn.LSTM, nn.Linear))
@@ -997,7 +1014,7 @@ class ForwardPlan:
                     elif self._cheap_consumer(nxt) and self.ln_mode == 'deferred':
                         if epilogue_stats:
                             self._timed('stats_finalize', meta, lambda: hip.grouped_stats_finalize(self.stats_ws, stats, c, act_frames,
-                                                                                                 last_op.groups, norm.eps))
+                                                                                                 last_op.groups, norm.eps, cell_gpp or 4))
                         else:
                             self._timed('channel_stats', meta, lambda: hip.channel_stats_v(src, stats, act_frames, norm.eps))
                         pending = (stats, g32, b32)

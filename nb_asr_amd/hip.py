@@ -79,7 +79,7 @@ SIGNATURES = {
                                                   ctypes.c_float, _c_stream]),
     'nbasr_grouped_cell_fits': (_c_int, [_c_int] * 3),
     'nbasr_grouped_cell_fused': (_c_int, [_c_float_p, _c_float_p, _c_float_p, _c_int, _c_int, _c_float_p, _c_float_p, _c_int, _c_int,
-                                          _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_float_p, _c_stream]),
+                                          _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_float_p, _c_int, _c_stream]),
     'nbasr_skip_sum_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_stream]),
     'nbasr_dense_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_dense_conv1d_fused_packed_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_ln_p, _c_stream]),
@@ -319,8 +319,9 @@ def grouped_cell_fused(x0, nodes, skip_mask, y, frames, groups, ln=None, stats_w
     args = []
     for w, bias, k, d in nodes:
         args += [_dev(w, 'weight'), _dev(bias, 'bias'), k, d]
-    _check(load_library().nbasr_grouped_cell_fused(_dev(x0, 'x0'), *args, skip_mask, _dev(y, 'y'), b, c, frames, ld, groups,
-                                                   _ln(ln), _opt(stats_ws, 'stats_ws'), _stream(x0)), 'nbasr_grouped_cell_fused')
+    dtype = x0.dtype
+    _check(load_library().nbasr_grouped_cell_fused(_act(x0, 'x0', dtype), *args, skip_mask, _act(y, 'y', dtype), b, c, frames, ld, groups,
+                                                   _ln(ln), _opt(stats_ws, 'stats_ws'), dtype_code(dtype), _stream(x0)), 'nbasr_grouped_cell_fused')
     return y
 
 

@@ -327,3 +327,46 @@ def test_ring_variant_tiles_halos_and_persistent_refills(cg, k, d, t):
             assert torch.all(y[:, :, t:] == 0)
             if with_stats:
                 assert torch.equal(st[:, :, :t], outs[0][1][:, :, :t]), (name, v, 'statistics')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, BF])
+@pytest.mark.parametrize('c,groups,t', [(600, 100, 1600), (1200, 100, 400), (40, 5, 801), (48, 4, 2048), (36, 6, 77)])
+@pytest.mark.parametrize('kds,mask,with_ln', [(((7, 1), (7, 2), (5, 2)), 63, True), (((5, 1), (5, 1), (5, 1)), 0, True), (((5, 2), (7, 2), (7, 1)), 0b010110, False)])
+def test_fused_cell_either_storage_type_equals_three_node_launches(dtype, c, groups, t, kds, mask, with_ln):
+    """nbasr_grouped_cell_fused for fp32 and bf16 storage, rows up to 2048 frames (8 waves per group row, 2 groups per workgroup): the
+    output equals three nbasr_grouped_conv1d_node launches BIT FOR BIT -- with bf16 storage x1 and x2 are rounded exactly where the
+    node launches store them -- and the statistics by-product equals the last node launch's (per group quad: bit for bit; per pair:
+    to rounding)."""
+    torch.manual_seed(c + t + mask)
+    b = 2
+    x = (torch.randn(b, c, t) * 1.5 + 0.3).to(dtype).float()
+    xp = pitched(x, dtype)
+    ld = xp.shape[2]
+    ln = None
+    if with_ln:
+        stats = torch.empty(b, 2, ld, device=DEV)
+        hip.channel_stats_v(xp, stats, t, 1e-3)
+        ln = (stats, torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.2)
+    nodes = [((torch.randn(c, c // groups, k) * 0.3).to(dtype).float().to(DEV), (torch.randn(c) * 0.2).to(dtype).float().to(DEV), k, d) for k, d in kds]
+    gpp = hip.grouped_cell_fits(c, ld, groups)
+    assert gpp in (2, 4)
+    s = [bool(mask >> i & 1) for i in range(6)]
+    x1, x2, x3 = (torch.full_like(xp, 7.0) for _ in range(3))
+    ws_node = hip.grouped_stats_workspace(b, ld, groups, DEV)
+    hip.grouped_conv1d_node(xp, *nodes[0][:2], [xp] if s[0] else [], x1, t, groups, *nodes[0][2:], ln, ln is not None, ln is not None and s[0], None, 0)
+    hip.grouped_conv1d_node(x1, *nodes[1][:2], ([xp] if s[1] else []) + ([x1] if s[2] else []), x2, t, groups, *nodes[1][2:],
+                            ln if s[1] else None, False, ln is not None and s[1], None, 0)
+    hip.grouped_conv1d_node(x2, *nodes[2][:2], ([xp] if s[3] else []) + ([x1] if s[4] else []) + ([x2] if s[5] else []), x3, t, groups,
+                            *nodes[2][2:], ln if s[3] else None, False, ln is not None and s[3], ws_node, 0)
+    got = torch.full_like(xp, 7.0)
+    ws_cell = hip.grouped_stats_workspace(b, ld, groups, DEV)
+    hip.grouped_cell_fused(xp, nodes, mask, got, t, groups, ln, ws_cell)
+    assert torch.equal(got, x3), float((got.float() - x3.float()).abs().max())
+    assert torch.all(got[:, :, t:] == 0)
+    st_cell, st_node = torch.empty(b, 2, ld, device=DEV), torch.empty(b, 2, ld, device=DEV)
+    hip.grouped_stats_finalize(ws_cell, st_cell, c, t, groups, 1e-3, gpp)
+    hip.grouped_stats_finalize(ws_node, st_node, c, t, groups, 1e-3)
+    if gpp == 4:
+        assert torch.equal(st_cell[:, :, :t], st_node[:, :, :t])
+    else:
+        assert torch.allclose(st_cell[:, :, :t], st_node[:, :, :t], rtol=2e-6, atol=1e-6)
