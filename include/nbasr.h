@@ -452,18 +452,6 @@ int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* packed_w, const
                                 int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
                                 nbasr_stream_t stream);
 
-/* The bf16 node op on the matrix cores (v_mfma_f32_16x16x32_bf16): same arguments and results (to bf16 rounding of a different
- * fp32 summation order) as nbasr_grouped_conv1d_node with dtype NBASR_BF16, without the statistics by-product; packed_w = the
- * per-group weight fragments built once per weight version by nbasr_pack_grouped_weights_mfma from the fp32 weights
- * (nbasr_grouped_mfma_weights_bytes bytes; 0 = unsupported shape). */
-size_t nbasr_grouped_mfma_weights_bytes(int channels, int groups, int kernel, int dilation);
-int nbasr_pack_grouped_weights_mfma(const float* w, void* packed, int channels, int groups, int kernel, int dilation,
-                                    nbasr_stream_t stream);
-int nbasr_grouped_conv1d_node_mfma(const void* x, const void* packed_w, const float* bias, const void* skip0, const void* skip1,
-                                   const void* skip2, void* y, int batch, int channels, int frames, int ld, int groups,
-                                   int kernel, int dilation, const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
-                                   nbasr_stream_t stream);
-
 /* ---- backward building blocks (bottom-up; fp32) -------------------------------------------------------------------
  * The node op z = min(relu(conv1d(zero_pad(x), w, b, dilation, groups)), 20) (reference ops.py:24-30) given dz = dL/dz:
  *   the relu / clamp_max_ masks are taken from the op's OUTPUT z (0 < z < 20), so no pre-activation has to be kept;

@@ -178,27 +178,19 @@ class ForwardPlan:
         self.linear_mode = os.environ.get('NBASR_LINEAR_MODE', 'f16x2')
         if self.linear_mode not in ('f16x2', 'f32'):
             raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
-        # LayerNorm -> dense conv hand-off as a pre-split fp16 image (NBASR_IMAGE_MODE=0: fp32 tensor + in-GEMM staging)
-        self.image_mode = os.environ.get('NBASR_IMAGE_MODE', '1') != '0'
-        # row tile of the image-path GEMM: auto (per layer, see _row_tile) | 128 | 160
-        self.row_tile_mode = os.environ.get('NBASR_ROW_TILE', 'auto')
-        if self.row_tile_mode not in ('auto', '64', '128', '160'):
-            raise ValueError(f'NBASR_ROW_TILE must be auto, 64, 128 or 160, got {self.row_tile_mode!r}')
+        # (round 3: the A/B switches of rounds 1-2 whose alternatives lost everywhere are gone -- NBASR_IMAGE_MODE, NBASR_ROW_TILE,
+        # NBASR_LN_MODE, NBASR_EPILOGUE_STATS, NBASR_LSTM_UNPACKED, NBASR_GC_TABLE, NBASR_GC_BF16_VARIANT, NBASR_GC_BF16_MFMA; what is
+        # left: NBASR_DENSE_MODE, NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_TAPE here, NBASR_TRAIN_GEMM in autograd.py)
         self._act_image = None
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
-        # LayerNorm: 'deferred' = one statistics pass, consumers normalise while loading (default);
-        # 'materialize' = the stand-alone LayerNorm kernel writes the normalised tensor
-        self.ln_mode = os.environ.get('NBASR_LN_MODE', 'deferred')
-        if self.ln_mode not in ('deferred', 'materialize'):
-            raise ValueError(f'NBASR_LN_MODE must be deferred or materialize, got {self.ln_mode!r}')
-        self.epilogue_stats = os.environ.get('NBASR_EPILOGUE_STATS', '1') != '0'
         # cells whose three nodes are grouped convs run as ONE launch where a row fits a workgroup (<= 1024 frames): x1 and x2 never
         # touch HBM and the cell's LayerNorm statistics come out of the same launch (grouped_cell.hip, round 3).  Bit-identical to
         # the three node launches; NBASR_CELL_FUSION=0 turns it off (A/B)
         self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '1') != '0'
-        # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_TABLE=0: the default kernel everywhere
-        self.gc_table = _GC_TABLE if os.environ.get('NBASR_GC_TABLE', '1') != '0' else {}
+        # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_F32_VARIANT=<bits> forces one (0: the
+        # default kernel everywhere)
+        self.gc_table = _GC_TABLE
         self._bufs = {}              # name -> flat tensor; grow-only (see _buf)
         self.grow_count = 0          # number of (re)allocations so far (tests: a smaller batch must not allocate)
         # pipelined mode (forward_async): the latency-bound LSTM + head of batch i run on a side stream while the main
@@ -314,8 +306,6 @@ class ForwardPlan:
         """Rows per workgroup of the image-path GEMM: 128, or 160 where that means less work in whole rounds of workgroups
         (a tile's cost is proportional to its rows; 256 CUs run one workgroup each).  At the benchmark shape: 160 for
         C_out = 800 (5 full row tiles instead of 7 with the last a quarter full) and 1200 (512 workgroups instead of 640)."""
-        if self.row_tile_mode != 'auto':
-            return int(self.row_tile_mode) if (allow_64 or self.row_tile_mode != '64') else 128
         n_nt = (hip.round_up4(frames_out) + 255) // 256
 
         def cost(rows):
@@ -374,11 +364,11 @@ class ForwardPlan:
         ``out``).  ``defer``: the caller's decision whether the consumer normalises on load (default: _cheap_consumer)."""
         if defer is None:
             defer = self._cheap_consumer(nxt)
-        if self.ln_mode == 'materialize' or not defer or out is not None:
+        if not defer or out is not None:
             dst = act if out is None else out
             from .ops import PadConvRelu
             want_range = self.dense_mode == 'auto' and isinstance(nxt, PadConvRelu) and nxt.groups == 1 and nxt.kernel_size == 8
-            if want_range and self.image_mode and taps is None and out is None:
+            if want_range and taps is None and out is None:
                 # the consumer is the fp16-split convolution: write its pre-split operand image instead of the fp32 tensor
                 # (same traffic; the convolution then gathers its tiles by LDS-DMA and does no vector staging)
                 b, c, ld = act.shape
@@ -538,7 +528,7 @@ class ForwardPlan:
             return t
         return self._host(alloc, produces=True)
 
-    _TAPE_ENV = ('NBASR_LSTM_UNPACKED', 'NBASR_GC_F32_VARIANT', 'NBASR_GC_BF16_VARIANT', 'NBASR_GC_BF16_MFMA')
+    _TAPE_ENV = ('NBASR_GC_F32_VARIANT',)
 
     def _tape_key(self, model, x, pipelined):
         """Everything the recorded launch sequence depends on; None: this call cannot use a tape."""
@@ -659,11 +649,9 @@ class ForwardPlan:
                     rng, input_range = input_range, None
                     # fp16 split with per-utterance fall-back to bf16x3 (extreme / non-finite input); image path: one split
                     # pass over the input, then the same DMA-only GEMM as convs 1-3
-                    image, rows = None, 128
-                    if self.image_mode:
-                        bi, ci, ldi = src.shape
-                        image = self._buf('input_image', max(hip.load_library().nbasr_split_image_bytes(bi, ci, ldi), 16), torch.uint8)
-                        rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out)
+                    bi, ci, ldi = src.shape
+                    image = self._buf('input_image', max(hip.load_library().nbasr_split_image_bytes(bi, ci, ldi), 16), torch.uint8)
+                    rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out)
                     self.dense_schemes[blk] = 'f16x2' if image is None else 'f16x2-image'
                     w16 = self._packed_weights(layer, 'f16x2', rows) if image is not None else self._packed_weights(layer, 'f16x2')
                     self._timed('dense_conv', meta, lambda: hip.dense_conv1d_first_ranged(
@@ -692,7 +680,7 @@ class ForwardPlan:
                 # loading (gemm_pointwise_split.hip), and it runs on the MAIN stream in both modes: the cell in front of it defers
                 # its LayerNorm like a cell in front of a grouped conv does -- no materialised copy of the encoder output
                 after = model.model[idx + 2] if isinstance(nxt, nn.Dropout) and idx + 2 < n_layers else nxt
-                defer = self.ln_mode == 'deferred' and (self._cheap_consumer(nxt) or (isinstance(after, nn.LSTM) and self.linear_mode == 'f16x2'))
+                defer = self._cheap_consumer(nxt) or (isinstance(after, nn.LSTM) and self.linear_mode == 'f16x2')
                 # a deferred cell LayerNorm whose producer is a grouped conv gets its statistics from that node's
                 # epilogue (no statistics pass over the tensor)
                 last_op = layer.nodes[-1].op
@@ -700,7 +688,7 @@ class ForwardPlan:
                             if (self.cell_fusion and len(layer.nodes) == 3
                                 and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)) else 0)
                 fused = cell_gpp > 0
-                epilogue_stats = (self.epilogue_stats and layer.use_norm and defer
+                epilogue_stats = (layer.use_norm and defer
                                   and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                 if fused:
                     mask = 0
@@ -772,13 +760,9 @@ class ForwardPlan:
                     self._to_side_stream()
                     tail_ctx = torch.cuda.stream(self.side_stream)
                     tail_ctx.__enter__()
-                if os.environ.get('NBASR_LSTM_UNPACKED') == '1':       # diagnostics: the (4H, H)-layout step kernel
-                    self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                                lambda: hip.lstm_recurrence(gates, w_hh, self.cell_ws, self.h_out))
-                else:
-                    packed_hh = self._packed_whh(layer.weight_hh_l0)
-                    self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                                lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
+                packed_hh = self._packed_whh(layer.weight_hh_l0)
+                self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                            lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
                 act, pending = self.h_out, None            # (batch, frames, hidden)
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)
@@ -832,17 +816,11 @@ class ForwardPlan:
         lds = [hip.row_pitch(t, bf16) for t in self.block_frames]
         elems = max(B * c * ld for c, ld in zip(FILTERS, lds))
         self.pool16 = [self._buf(f'pool16_{i}', elems, bf16) for i in range(4)]
-        forced = os.environ.get('NBASR_GC_BF16_VARIANT')
-        # node ops on the matrix cores (grouped_conv_mfma.hip): opt-in (NBASR_GC_BF16_MFMA=1).  Measured at 32 x 1600: node ops 3.82 ms
-        # against 3.93 ms on the vector ALU, but the LayerNorm statistics then need their own pass (+0.43 ms): 6.85 vs 6.47 ms per step
-        use_mfma = os.environ.get('NBASR_GC_BF16_MFMA', '0') == '1'
         lib = hip.load_library()
 
         def variant_for(frames):
             # 8 frames per lane (16-byte accesses) where rows are long; the narrow blocks run better as more, lighter waves
             # (tools/bench_gc_variants.py on an MI355X: 40 vs 49 us at 1 600 frames, 39 vs 37 us at 400)
-            if forced is not None:
-                return int(forced)
             return (hip.GC_FPL8 | hip.GC_WPERM) if frames >= 512 else hip.GC_WPERM
 
         def image_of(act, frames, norm=None, stats=None, eps=0.0):
@@ -896,13 +874,13 @@ class ForwardPlan:
                         raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
                     last_op = layer.nodes[-1].op
                     norm = layer.norm_layer if layer.use_norm else None
-                    epilogue_stats = (self.epilogue_stats and norm is not None and self._cheap_consumer(nxt) and not use_mfma
+                    epilogue_stats = (norm is not None and self._cheap_consumer(nxt)
                                       and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                     outs = [act]
                     # three grouped convs: ONE launch where a row fits a workgroup (grouped_cell.hip; x1 and x2 rounded to bf16 exactly
                     # where the node launches store them, so the result is the same bit for bit)
                     cell_gpp = (hip.grouped_cell_fits(layer.filters, act.shape[2], last_op.groups)
-                                if (self.cell_fusion and not use_mfma and len(layer.nodes) == 3
+                                if (self.cell_fusion and len(layer.nodes) == 3
                                     and all(isinstance(n.op, PadConvRelu) and n.op.groups > 1 for n in layer.nodes)) else 0)
                     if cell_gpp:
                         mask = 0
@@ -926,14 +904,7 @@ class ForwardPlan:
                         ln = pending if (on_x or on_s0) else None
                         view, op, last = self._view16(dst, layer.filters, act_frames), node.op, outs[-1]
                         meta = (blk, layer.filters, layer.filters, getattr(op, 'kernel_size', 1), act_frames, n_skips)
-                        if isinstance(op, PadConvRelu) and use_mfma:
-                            wk = op.conv.weight
-                            frag = self._cached(wk, ('gc_mfma', op.dilation),
-                                                lambda: hip.pack_grouped_weights_mfma(self._f32(wk), op.groups, op.dilation))
-                            bs = self._f32(op.conv.bias)
-                            self._timed('grouped_conv', meta, lambda: hip.grouped_conv1d_node_mfma(
-                                last, frag, bs, skips, view, act_frames, op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0))
-                        elif isinstance(op, PadConvRelu):
+                        if isinstance(op, PadConvRelu):
                             ws = self.stats_ws if (epilogue_stats and j == len(layer.nodes) - 1) else None
                             variant = variant_for(act_frames)
                             wt, bs = grouped_weight(op, variant), self._f32(op.conv.bias)
@@ -1011,7 +982,7 @@ class ForwardPlan:
                             copy = torch.empty_like(act)
                             hip.layernorm_channels_v(act, g32, b32, copy, act_frames, norm.eps)
                             taps[idx] = copy[:, :, :act_frames].clone()
-                    elif self._cheap_consumer(nxt) and self.ln_mode == 'deferred':
+                    elif self._cheap_consumer(nxt):
                         if epilogue_stats:
                             self._timed('stats_finalize', meta, lambda: hip.grouped_stats_finalize(self.stats_ws, stats, c, act_frames,
                                                                                                  last_op.groups, norm.eps, cell_gpp or 4))

@@ -97,9 +97,6 @@ SIGNATURES = {
     'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_f16_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
     'nbasr_dense_conv1d_fused_packed_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
-    'nbasr_grouped_mfma_weights_bytes': (ctypes.c_size_t, [_c_int] * 4),
-    'nbasr_pack_grouped_weights_mfma': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_grouped_conv1d_node_mfma': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_grouped_conv1d_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 4),
     'nbasr_grouped_conv1d_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 7 + [_c_stream]),
     'nbasr_layernorm_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
@@ -811,33 +808,6 @@ def grouped_conv1d_node(x, weight, bias, skips, y, frames, groups, kernel, dilat
         _act(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _act_opt(s[0], 'skip0', dt), _act_opt(s[1], 'skip1', dt),
         _act_opt(s[2], 'skip2', dt), _act(y, 'y', dt), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
         int(ln_on_skip0), _opt(stats_ws, 'stats_ws'), dtype_code(dt), variant, _stream(x)), 'nbasr_grouped_conv1d_node')
-    return y
-
-
-def pack_grouped_weights_mfma(weight, groups, dilation):
-    """(C, C/groups, k) fp32 weight (the values of a bf16 parameter) -> per-group MFMA weight fragments (uint8 tensor)."""
-    c, cg, k = weight.shape
-    lib = load_library()
-    nbytes = lib.nbasr_grouped_mfma_weights_bytes(c, groups, k, dilation)
-    if nbytes == 0:
-        raise HipError(f'no matrix-core node kernel for (channels/groups={cg}, kernel={k}, dilation={dilation})')
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _check(lib.nbasr_pack_grouped_weights_mfma(_dev(weight, 'weight'), packed.data_ptr(), c, groups, k, dilation, _stream(weight)),
-           'nbasr_pack_grouped_weights_mfma')
-    return packed
-
-
-def grouped_conv1d_node_mfma(x, packed, bias, skips, y, frames, groups, kernel, dilation, ln=None, ln_on_x=False, ln_on_skip0=False):
-    """The bf16 node op on the matrix cores; ``packed`` from pack_grouped_weights_mfma.  No statistics by-product."""
-    b, c, ld = x.shape
-    if packed.dtype != torch.uint8 or packed.numel() != load_library().nbasr_grouped_mfma_weights_bytes(c, groups, kernel, dilation):
-        raise HipError('packed weights are not the MFMA fragments of this (channels, groups, kernel, dilation)')
-    dt = torch.bfloat16
-    s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_grouped_conv1d_node_mfma(
-        _act(x, 'x', dt), packed.data_ptr(), _dev(bias, 'bias'), _act_opt(s[0], 'skip0', dt), _act_opt(s[1], 'skip1', dt),
-        _act_opt(s[2], 'skip2', dt), _act(y, 'y', dt), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
-        int(ln_on_skip0), _stream(x)), 'nbasr_grouped_conv1d_node_mfma')
     return y
 
 

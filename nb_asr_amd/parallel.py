@@ -25,13 +25,13 @@ def shard_bounds(n_items, world_size, rank):
 class ShardedForward:
     """Owns the process group (if any) and runs ``model`` on this rank's shard."""
 
-    def __init__(self, world_size=None, rank=None, device=None, backend=None):
+    def __init__(self, world_size=None, rank=None, device=None, backend=None, force_collective=False):
         self.world_size = int(os.environ.get('WORLD_SIZE', '1')) if world_size is None else world_size
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else rank
         self.device = device
         self._own_group = False
-        force = os.environ.get('NBASR_FORCE_DIST') == '1'       # exercise the collective path with a single rank (tests)
-        self.collective = self.world_size > 1 or force
+        # ``force_collective``: take the collective path with a single rank too (tests; bench.py --force-collective)
+        self.collective = self.world_size > 1 or bool(force_collective)
         if self.collective and not dist.is_initialized():
             if backend is None:
                 backend = 'nccl' if (device is not None and torch.device(device).type == 'cuda') else 'gloo'

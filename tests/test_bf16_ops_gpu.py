@@ -184,86 +184,6 @@ def test_convert_and_skip_sum_and_repitch_bf16():
     assert torch.equal(dst[:, :, :13], src) and torch.all(dst[:, :, 13:] == 0)
 
 
-# ---- the bf16 node op on the matrix cores (grouped_conv_mfma.hip) -----------------------------------------------------------
-def node_mfma(x, w, bias, skips, k, d, groups, ln=None, on_x=False, on_s0=False):
-    frames = x.shape[2]
-    xp = pitched(x, BF)
-    sp = [pitched(s, BF) for s in skips]
-    y = torch.full_like(xp, 7.0)
-    packed = hip.pack_grouped_weights_mfma(w.to(DEV).contiguous(), groups, d)
-    hip.grouped_conv1d_node_mfma(xp, packed, bias.to(DEV), sp, y, frames, groups, k, d, ln, on_x, on_s0)
-    torch.cuda.synchronize()
-    assert torch.all(y[:, :, frames:] == 0)
-    return y[:, :, :frames]
-
-
-@pytest.mark.parametrize('cg', [6, 8, 10, 12])
-@pytest.mark.parametrize('k,d', [(5, 1), (5, 2), (7, 1), (7, 2)])
-@pytest.mark.parametrize('n_skips', [0, 3])
-def test_mfma_node_op_matches_the_oracle_and_the_vector_kernel(cg, k, d, n_skips):
-    torch.manual_seed(cg * 100 + k * 10 + d + n_skips)
-    groups, b, t = 4, 3, 203
-    c = cg * groups
-    x = torch.randn(b, c, t).to(BF).float()
-    skips = [torch.randn(b, c, t).to(BF).float() for _ in range(n_skips)]
-    w = (torch.randn(c, cg, k) * 0.3).to(BF).float()
-    bias = (torch.randn(c) * 0.2).to(BF).float()
-    z = oracle.pad_conv_relu(x, w, bias, d, 1, groups)
-    want = z
-    for s in skips:
-        want = want + s
-    got = node_mfma(x, w, bias, skips, k, d, groups).float().cpu()
-    # one rounding of the result, plus (with skips) one of the op's output z before the sum, which can be larger than the sum
-    tol = 2.0 ** -8 * want.abs() + (2.0 ** -8 * z.abs() if skips else 0.0) + 2e-5 + 1e-5 * want.abs()
-    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
-    # against the vector-ALU bf16 kernel: without skips the same value up to one bf16 ulp where a different fp32 summation order
-    # crosses a rounding boundary; with skips this kernel rounds the op's output before the skip sum (as the reference does)
-    ref = node(x, w, bias, skips, k, d, groups, BF, 0).float().cpu()
-    if n_skips == 0:
-        assert float(((got - ref).abs() > 2.0 ** -7 * ref.abs() + 1e-6).float().mean()) == 0.0
-        assert float((got != ref).float().mean()) < 0.02
-    else:
-        assert float((got - ref).abs().max()) <= 2.0 ** -7 * float(torch.maximum(ref.abs(), z.abs()).max())
-
-
-@pytest.mark.parametrize('t', [1, 7, 8, 9, 120, 127, 128, 129, 255, 256, 257, 400, 1027])
-def test_mfma_node_op_ragged_lengths(t):
-    """Tile edges (128 frames), chunk edges (8) and rows shorter than one tile, five utterances, production group count."""
-    torch.manual_seed(t)
-    groups, b, cg, k, d = 100, 2, 6, 7, 2
-    c = cg * groups
-    x = torch.randn(b, c, t).to(BF).float()
-    w, bias = (torch.randn(c, cg, k) * 0.3).to(BF).float(), (torch.randn(c) * 0.2).to(BF).float()
-    z = oracle.pad_conv_relu(x, w, bias, d, 1, groups)
-    want = z + x
-    got = node_mfma(x, w, bias, [x], k, d, groups).float().cpu()
-    tol = 2.0 ** -8 * (want.abs() + z.abs()) + 2e-5 + 1e-5 * want.abs()
-    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
-
-
-@pytest.mark.parametrize('cg,k,d', [(6, 5, 1), (12, 7, 2), (10, 5, 2), (8, 7, 1)])
-def test_mfma_node_op_deferred_layernorm(cg, k, d):
-    """LayerNorm on load for the main input (applied once per staged element) and for skip0 (in the epilogue)."""
-    torch.manual_seed(cg + k + d)
-    groups, b, t = 100, 2, 150
-    c = cg * groups
-    x = (torch.randn(b, c, t) * 1.5 + 0.3).to(BF).float()
-    gamma, beta = torch.rand(c) * 0.4 + 0.8, torch.randn(c) * 0.1
-    w, bias = (torch.randn(c, cg, k) * 0.3).to(BF).float(), (torch.randn(c) * 0.2).to(BF).float()
-    xn = oracle.layer_norm_channels(x, gamma, beta)
-    z = oracle.pad_conv_relu(xn.to(BF).float(), w, bias, d, 1, groups)                # the operand is rounded to bf16 when it is staged
-    want = z + xn
-    xp = pitched(x, BF)
-    stats = torch.empty(b, 2, xp.shape[2], device=DEV)
-    hip.channel_stats_v(xp, stats, t, 1e-3)
-    ln = (stats, gamma.to(DEV), beta.to(DEV))
-    got = node_mfma(x, w, bias, [x], k, d, groups, ln, True, True).float().cpu()
-    # z is rounded to bf16 before the skip sum and the sum once more; 2e-2: a staged operand one bf16 step off the oracle's
-    tol = 2.0 ** -8 * (want.abs() + z.abs()) + 2e-2
-    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
-    assert float((got - want).abs().mean()) <= 2.0 ** -9 * float(want.abs().mean()) + 2e-3
-
-
 @pytest.mark.parametrize('cg,k,d', [(6, 5, 1), (12, 7, 2), (10, 5, 2), (8, 7, 1)])
 def test_output_split_variant_with_deferred_layernorm(cg, k, d):
     """NBASR_GC_OSPLIT (a wave owns half of a group's output channels): bit-identical to the default kernel with LayerNorm on load

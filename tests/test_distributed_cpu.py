@@ -200,3 +200,22 @@ def test_two_rank_sharded_forward_with_the_hip_model():
     for rank, ok_global, ok_local in results:
         assert ok_global, f'rank {rank}: sharded logits differ from the unsharded forward'
         assert ok_local, f'rank {rank}: all-gathered logits are not the per-rank results in rank order'
+
+
+def test_single_rank_takes_the_collective_path_when_asked():
+    """`force_collective=True`: a single rank initialises a process group and runs the same all-gather / all-reduce / barrier calls as
+    N ranks do (what the driver's `torch.distributed.run --nproc-per-node 1` launch exercises with RCCL on the GPU box)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1')
+    runner = ShardedForward(world_size=1, rank=0, device='cpu', backend='gloo', force_collective=True)
+    try:
+        assert runner.collective
+        x = torch.randn(3, 80, 20)
+        assert torch.equal(runner.forward(_fake_model, x), _fake_model(x))
+        assert runner.max_over_ranks(2.5) == 2.5
+        p = torch.nn.Parameter(torch.ones(5))
+        p.grad = torch.full((5,), 3.0)
+        runner.allreduce_gradients([p], n_local=3)
+        assert torch.equal(p.grad, torch.full((5,), 3.0))
+        runner.barrier()
+    finally:
+        runner.close()

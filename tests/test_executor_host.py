@@ -122,7 +122,7 @@ def test_variant_choice_per_launch(monkeypatch):
     assert plan._gc_variant(view(64, 250), node, None, None, 2) == hip.GC_PIPE | hip.GC_OSPLIT
     assert plan._gc_variant(view(64, 250), node, None, ('stats',), 2) == hip.GC_PIPE       # the split is never forced onto a statistics launch
     monkeypatch.delenv('NBASR_GC_F32_VARIANT')
-    monkeypatch.setenv('NBASR_GC_TABLE', '0')
+    monkeypatch.setenv('NBASR_GC_F32_VARIANT', '0')                                     # the default kernel everywhere
     assert executor.ForwardPlan('cpu')._gc_variant(view(64, 250), node, None, None, 2) == 0
 
 

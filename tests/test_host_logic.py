@@ -136,7 +136,7 @@ def test_row_tile_rule_counts_rounds_of_workgroups():
     """Image-path GEMM: 160-row tiles exactly where they mean fewer (rows x rounds of 256 workgroups) than 128-row tiles."""
     import types
     from nb_asr_amd.executor import ForwardPlan
-    plan = types.SimpleNamespace(row_tile_mode='auto', batch=64)
+    plan = types.SimpleNamespace(batch=64)
     pick = lambda c, t: ForwardPlan._row_tile(plan, c, t)                      # noqa: E731
     assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 160]     # the benchmark shape: convs 1 and 3
     plan.batch = 32
@@ -146,5 +146,3 @@ def test_row_tile_rule_counts_rounds_of_workgroups():
     plan.batch = 2
     assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [64, 64, 64]        # a single round whatever the tile: the smallest
     assert ForwardPlan._row_tile(plan, 1200, 250, allow_64=False) == 128               # (the bf16 GEMM has no 64-row instance)
-    plan.row_tile_mode = '160'
-    assert pick(1000, 500) == 160

@@ -725,7 +725,7 @@ def test_exact_fp32_mode_on_the_noisy_cases(model_fx, case):
 
 def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
     """The executor picks the fp32 node kernel's variant per launch from the measured table (output split and / or pipelined
-    buffer loads); NBASR_GC_TABLE=0 keeps the default kernel everywhere.  Same sums in the same order: bit-identical logits."""
+    buffer loads, LDS ring); NBASR_GC_F32_VARIANT=0 keeps the default kernel everywhere.  Same sums in the same order: bit-identical logits."""
     from nb_asr_amd import hip
     from nb_asr_amd.executor import ForwardPlan
     monkeypatch.setenv('NBASR_CELL_FUSION', '0')            # (with fused cells -- the default -- a conv-only cell is one launch, not three node launches)
@@ -744,7 +744,7 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
     picked = {v for v, _ in chosen}
     assert picked & {hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING}
     assert all(not (v & hip.GC_OSPLIT) for v, with_stats in chosen if with_stats)      # statistics launches: default or pipelined only
-    monkeypatch.setenv('NBASR_GC_TABLE', '0')
+    monkeypatch.setenv('NBASR_GC_F32_VARIANT', '0')
     m._plans.clear()
     chosen.clear()
     with torch.no_grad():
