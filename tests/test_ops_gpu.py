@@ -601,7 +601,8 @@ def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, m
 
 
 def test_fused_cell_limits():
-    assert not hip.grouped_cell_fits(600, 1028, 100)          # > 1024 frames: more than four 64-chunk waves per row
+    assert not hip.grouped_cell_fits(600, 2052, 100)          # > 2048 frames: more than eight 64-chunk waves per group row
+    assert hip.grouped_cell_fits(600, 1600, 100) == 2 and not hip.grouped_cell_fits(1200, 1600, 100)    # (2 x 12 x 1600 x 4 B of tiles > 160 KiB)
     assert hip.grouped_cell_fits(1200, 1000, 100) == 2 and hip.grouped_cell_fits(1200, 252, 100) == 4      # groups per workgroup / statistics partial
     assert not hip.grouped_cell_fits(700, 1000, 100)          # 7 channels per group: not a model width
     assert hip.grouped_cell_fits(800, 1000, 100) and hip.grouped_cell_fits(600, 1000, 100) and hip.grouped_cell_fits(1200, 500, 100)
