@@ -106,7 +106,10 @@ __device__ __forceinline__ void conv_from_tile(float (&acc)[CG][4], const float*
     cell_f4 nxt[W::NCH];
 #pragma unroll
     for (int c = 0; c < W::NCH; ++c) nxt[c] = *reinterpret_cast<const cell_f4*>(win + 4 * c);
-#pragma unroll 1
+    // two channels per trip where their 2 CG K scalar weights fit the scalar registers: one `lgkmcnt(0)` stall (scalar loads return out
+    // of order, so hipcc never counts them) per TWO channels' FMAs
+    constexpr int UNROLL = (2 * CG * K <= 84) ? 2 : 1;
+#pragma unroll UNROLL
     for (int ci = 0; ci < CG; ++ci) {
         float xw[W::NCH * 4];
 #pragma unroll

@@ -1,8 +1,8 @@
-"""The random-architecture sweep as a collected test (missing 4 / next 1): 48 fixed seeds of tests/fuzz_architectures.py
+"""The random-architecture sweep as a collected test (missing 4 / next 1): 40 fixed seeds of tests/fuzz_architectures.py
 on the DEFAULT path (fp16-split GEMMs), each under the two-leg parity rule of tests/cases.py, pipelined == plain, finite.
 
 The list holds the five cases the round-2 default arithmetic missed and the exact-fp32 mode passed (5026, 5028, 5063, 5075,
-5085: all no-LSTM models -- profiles/r02_fuzz_misses_default_vs_exact_fp32.txt), sixteen no-LSTM cases at T >= 257, and a spread of
+5085: all no-LSTM models -- profiles/r02_fuzz_misses_default_vs_exact_fp32.txt), eleven no-LSTM cases at T >= 257, and a spread of
 the rest.  Round 3's blocked accumulation (gemm_conv_split.hip) is what this pins: the default path may not fail a case at all."""
 import pytest
 
@@ -11,9 +11,9 @@ import fuzz_architectures as fuzz
 pytestmark = pytest.mark.gpu
 
 R2_MISSES = [5026, 5028, 5063, 5075, 5085]
-NO_LSTM_LONG = [5002, 5009, 5034, 5041, 5048, 5064, 5067, 5074, 5081, 5108, 5130, 5148, 5149]      # + 5026, 5063, 5075 above
+NO_LSTM_LONG = [5002, 5009, 5041, 5064, 5067, 5081, 5130, 5149]      # + 5026, 5063, 5075 above: eleven no-LSTM cases at T >= 257
 SPREAD = [5000, 5001, 5003, 5004, 5005, 5007, 5010, 5013, 5017, 5020, 5023, 5029, 5031, 5037, 5040, 5044, 5050, 5055, 5060, 5070,
-          5079, 5090, 5095, 5100, 5110, 5120, 5125, 5135, 5140, 5145]
+          5079, 5090, 5095, 5100, 5120, 5125, 5135]
 SEEDS = R2_MISSES + NO_LSTM_LONG + SPREAD
 
 
