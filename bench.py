@@ -257,7 +257,7 @@ def main():
                    'dense_scheme_legend': 'f16x2 = 2 fp16 terms per operand, 3 v_mfma_f32_16x16x32_f16 per fp32 product; '
                                           'f16x2-image = the same with the LayerNorm writing the pre-split operand; '
                                           'bf16x3 = 3 bf16 terms, 6 MFMAs; f32 = v_mfma_f32_32x32x2_f32',
-                   'linear_scheme': plan.linear_mode, 'ln_mode': plan.ln_mode,
+                   'linear_scheme': plan.linear_mode, 'cell_fusion': bool(plan.cell_fusion),
                    'nbasr_env': {k: v for k, v in sorted(os.environ.items()) if k.startswith('NBASR_')}},
     }
 

@@ -134,3 +134,13 @@ def test_structure_epoch_counts_registrations():
     seq = nn.Sequential(m)
     seq[0] = nn.Linear(3, 3)
     assert executor._structure_epoch[0] > mid
+
+
+def test_bench_reads_only_attributes_a_plan_has():
+    """bench.py reports bookkeeping of the last plan in its JSON line; a removed plan attribute must not survive there (round 3 pruned
+    several switches -- the bench line is produced on the GPU box only, so this is checked here, without a GPU)."""
+    import re
+    root = pathlib.Path(__file__).resolve().parent.parent
+    plan = executor.ForwardPlan('cpu')
+    for name in sorted(set(re.findall(r'\bplan\.([A-Za-z_]+)', (root / 'bench.py').read_text()))):
+        assert hasattr(plan, name), f'bench.py reads plan.{name}, which ForwardPlan does not have'
