@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NBASR_ABI_VERSION 2
+#define NBASR_ABI_VERSION 3
 
 #define NBASR_OK 0
 #define NBASR_EINVAL (-1)   /* bad size / unsupported shape */
@@ -63,36 +63,23 @@ int nbasr_pad_amounts(int kernel, int dilation, int stride, int* left, int* righ
  * convs, reference model.py:76): ceil(ceil(T/2)/2).  Host arithmetic. */
 int nbasr_output_frames(int frames);
 
-/* Node operation, grouped-convolution flavour, fused with the node's skip-sum
- * (reference ops.py:24-30 with groups=100 from the table ops.py:73-76, Node.forward model.py:13-22):
- *     y = min(relu(conv1d(zero_pad(x), w, bias, dilation, groups)), 20) + skip0 + skip1 + skip2
- * x, y, skip*: (batch, channels, ld); w: (channels, channels/groups, kernel); bias: (channels).
- * NULL skips are absent (a Zero branch).  Supported: kernel in {5,7}, dilation in {1,2},
- * channels/groups in {6,8,10,12}.  Skips are added left to right (python `sum` order). */
-int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias,
-                               const float* skip0, const float* skip1, const float* skip2,
-                               float* y, int batch, int channels, int frames, int ld,
-                               int groups, int kernel, int dilation, nbasr_stream_t stream);
-
-/* Node whose main op is `zero` (reference ops.py:67-68): y = 0 + skip0 + skip1 + skip2. */
-int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, float* y,
-                   int batch, int channels, int frames, int ld, nbasr_stream_t stream);
+/* One entry point per operation.  Tensors x / y / skips are `dtype` tensors (NBASR_F32 | NBASR_BF16) where an entry point takes a
+ * `dtype`; weights, biases, gamma / beta and statistics are fp32 everywhere.  A pending LayerNorm travels as a nbasr_deferred_ln
+ * ("normalise on load"; NULL = none). */
+typedef struct nbasr_deferred_ln {
+    const float* stats;   /* (batch, 2, ld): row 0 = mean, row 1 = rstd = 1/sqrt(var + eps); both 0 in columns >= frames */
+    const float* gamma;   /* (channels) */
+    const float* beta;    /* (channels) */
+} nbasr_deferred_ln;
 
 /* LayerNorm over the channel dimension of (batch, channels, ld), biased variance
- * (reference model.py:92 + 125-128 and model.py:46-47 + 55-58; eps = 1e-3 there).
- * In-place (y == x) is allowed. */
-int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y,
-                             int batch, int channels, int frames, int ld, float eps,
+ * (reference model.py:92 + 125-128 and model.py:46-47 + 55-58; eps = 1e-3 there).  x of in_dtype -> y of out_dtype:
+ * f32 -> f32, bf16 -> bf16, or bf16 -> f32 (the encoder output handed to the fp32 LSTM); in place (y == x) only when the two types
+ * are equal.  absmax (may be NULL; f32 -> f32 only): absmax[b] = max |y[b, :, :]| (device pointer, `batch` floats, overwritten),
+ * the range information the 2-way fp16 dense convolution below needs, produced while the normalised tensor is being written. */
+int nbasr_layernorm_channels(const void* x, const float* gamma, const float* beta, void* y, float* absmax,
+                             int batch, int channels, int frames, int ld, float eps, int in_dtype, int out_dtype,
                              nbasr_stream_t stream);
-/* The same, and absmax[b] = max |y[b, :, :]| (device pointer, `batch` floats, overwritten): the range information the
- * 2-way fp16 dense convolution below needs, produced while the normalised tensor is being written. */
-int nbasr_layernorm_channels_absmax(const float* x, const float* gamma, const float* beta, float* y, float* absmax,
-                                    int batch, int channels, int frames, int ld, float eps,
-                                    nbasr_stream_t stream);
-
-/* absmax[b] = max |x[b, 0..n-1]| for `batch` utterances of n contiguous floats each (n % 4 == 0, x 16-byte aligned): the
- * x_absmax argument of nbasr_dense_conv1d_fused_packed_f16 for an input that does not come out of the LayerNorm kernel. */
-int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_stream_t stream);
 
 /* Dense PadConvRelu (groups = 1) on the fp32 matrix cores, fused bias + relu + clamp (+ skips):
  *   kernel == 8: the four downsample convs (reference model.py:82-89, ops.py:24-30), stride 1|2;
@@ -103,95 +90,102 @@ int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_st
 int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
                              const float* skip0, const float* skip1, const float* skip2,
                              float* y, int batch, int c_in, int frames_in, int ld_in,
-                             int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
+                             int c_out, int ld_out, int kernel, int stride,
+                             const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
 
-/* fp32-accurate variant of the k=8 dense PadConvRelu on the bf16 matrix cores (16x the fp32 MFMA rate): operands are
- * split exactly into three bf16 terms and six cross products are accumulated in fp32 (dropped terms <= 2^-24 of a
- * product).  Weights are split and re-laid-out once per weight version:
- *   bytes = nbasr_packed_dense_weights_bytes(c_out, c_in, 8);  nbasr_pack_dense_weights(w, packed, ..., stride, ...);
- * then nbasr_dense_conv1d_fused_packed(...) takes `packed` in place of w (same arguments otherwise, kernel == 8),
- * except that x must follow the activation layout strictly: 16-byte aligned, ld_in a multiple of 4 and columns
- * frames_in..ld_in-1 zero (the kernel fetches aligned 4-frame quads; nbasr_repitch brings a caller tensor into it).
- * The packed image depends on the stride of the convolution that will consume it (taps per K-step differ). */
-size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel);
-int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
+/* ---- the k = 8 dense PadConvRelu on the 16-bit matrix cores: ONE convolution entry point, three operand schemes ----------------
+ * (reference model.py:82-89, ops.py:24-30).  Weights are split / re-laid-out once per weight version:
+ *   bytes = nbasr_packed_dense_weights_bytes(scheme, c_out, c_in, 8, row_tile);
+ *   nbasr_pack_dense_weights(scheme, w, packed, c_out, c_in, 8, stride, row_tile, stream);
+ * (the packed image depends on the stride of the convolution that will consume it and on the row tile; images of different
+ * schemes are NOT interchangeable), then nbasr_dense_conv1d_packed(scheme, ...) takes `packed` in place of w.
+ *
+ * NBASR_DENSE_BF16X3  fp32-accurate on the bf16 matrix cores (16x the fp32 MFMA rate): operands are split exactly into three bf16
+ *     terms and six cross products are accumulated in fp32 (dropped terms <= 2^-24 of a product); fp32's exponent range, NaN / Inf
+ *     propagate like in the reference.  x: a plain fp32 tensor in the activation layout (16-byte aligned, ld_in % 4 == 0, columns
+ *     frames_in..ld_in-1 zero: the kernel fetches aligned 4-frame quads; nbasr_repitch brings a caller tensor into it); `ln`: its
+ *     pending LayerNorm; skips allowed; row_tile 128.
+ * NBASR_DENSE_F16X2   the same convolution with HALF the matrix instructions: operands are split into two fp16 terms, v = hi + lo
+ *     (11 + 11 significand bits plus the rounding sign cover fp32's 24; the residual may be an fp16 subnormal, exact to 2^-24), and
+ *     three cross products are accumulated in fp32 (dropped term <= 2^-24 of a product) as a two-level blocked sum: one block per
+ *     16 input channels x 8 taps, then the total.  fp16's narrow exponent range is handled by exact power-of-two scalings that the
+ *     epilogue undoes: each weight row is normalised at pack time, and each utterance of x by 2^k derived from x_absmax[b], a
+ *     caller-supplied UPPER BOUND of max|x[b, :, :]| (device pointer, `batch` floats, finite; nbasr_layernorm_channels writes it as
+ *     a by-product).  A bound that is too small makes fp16 overflow possible (undefined results); a loose bound only costs precision
+ *     of elements more than 2^-16 below it (they keep an absolute accuracy of 2^-39 of the bound).
+ *     x: a plain fp32 tensor as above (x_is_image = 0; skips allowed; row_tile 128), or (x_is_image = 1; no skips; row_tile 64, 128
+ *     or 160) the pre-split fp16 OPERAND IMAGE that nbasr_layernorm_split_image / nbasr_split_image_ranged write,
+ *       image[b][16-channel group][split][8-channel half][1 + ld rows][8 ch]   (row 0 zero, frame t at row t + 1;
+ *       nbasr_split_image_bytes(batch, channels, ld) bytes),
+ *     which the GEMM gathers by LDS-DMA (no vector work in the GEMM).  row_tile = output channels per workgroup: 160 pays where 128
+ *     leaves a mostly empty last row tile (c_out = 800: 7 tiles, the last a quarter full, vs 5 full ones) or a partial last round of
+ *     workgroups; 64 doubles the workgroups of a small batch.  Results are bit-identical between row tiles.
+ * NBASR_DENSE_BF16    the bf16 storage path (BASELINE config 4): ONE v_mfma_f32_16x16x32_bf16 per 32 products, fp32 accumulation,
+ *     bias + relu + min(20) in fp32, one rounding to the bf16 output y (ld_out % 8 == 0).  x: nbasr_bf16_image's operand image
+ *     (x_is_image = 1); weights: the fp32 values of the bf16 parameter; row_tile 128 or 160; no bound, range, LayerNorm or skips.
+ *
+ * Per-utterance routing of caller data (x_range != NULL in place of x_absmax; the model input, whose range this library does not
+ * control): nbasr_input_range writes, per utterance, range[4 b] = { max finite |x|, the quietest non-silent frame's max |x| over
+ * channels, non-zero if any sample is Inf / NaN, unused } (x: (batch, channels, ld) fp32, any ld >= frames).  An utterance is
+ * EXTREME when it holds a non-finite sample or a frame more than 2^12 below its loudest sample: the scaled fp16 scheme would then
+ * lose precision in (or, for Inf, flush) the quiet part.  The two schemes are launched back to back on the same output with the same
+ * x_range: NBASR_DENSE_F16X2 computes the ordinary utterances (scale from range[4 b]) and skips the extreme ones,
+ * NBASR_DENSE_BF16X3 computes exactly those.  No host synchronisation. */
+#define NBASR_DENSE_BF16X3 0
+#define NBASR_DENSE_F16X2 1
+#define NBASR_DENSE_BF16 2
+size_t nbasr_packed_dense_weights_bytes(int scheme, int c_out, int c_in, int kernel, int row_tile);
+int nbasr_pack_dense_weights(int scheme, const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
                              nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias,
-                                    const float* skip0, const float* skip1, const float* skip2,
-                                    float* y, int batch, int c_in, int frames_in, int ld_in,
-                                    int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
+int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_image, const float* x_absmax, const float* x_range,
+                              const void* packed_w, const float* bias,
+                              const float* skip0, const float* skip1, const float* skip2, void* y,
+                              int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                              int row_tile, const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+int nbasr_input_range(const float* x, float* range, int batch, int channels, int frames, int ld, nbasr_stream_t stream);
 
-/* The same convolution with HALF the matrix instructions: operands are split into two fp16 terms, v = hi + lo
- * (11 + 11 significand bits plus the rounding sign cover fp32's 24; the residual may be an fp16 subnormal, exact to 2^-24)
- * and three cross products are accumulated in fp32 (dropped term <= 2^-24 of a product), as a two-level blocked sum: one
- * block per 16 input channels x 8 taps, then the total.
- * fp16's narrow exponent range is handled by exact power-of-two scalings that the epilogue undoes: each weight row is
- * normalised at pack time, and each utterance of x by 2^k derived from x_absmax[b], a caller-supplied UPPER BOUND of
- * max|x[b, :, :]| (device pointer, `batch` floats, finite; nbasr_layernorm_channels_absmax writes it as a by-product).
- * A bound that is too small makes fp16 overflow possible (undefined results); a loose bound only costs precision of
- * elements more than 2^-16 below it (they keep an absolute accuracy of 2^-39 of the bound).  Otherwise same arguments, layout contract and error behaviour as the bf16 entry
- * points; the packed images are NOT interchangeable between the two schemes. */
-size_t nbasr_packed_dense_weights_bytes_f16(int c_out, int c_in, int kernel);
-int nbasr_pack_dense_weights_f16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
-                                 nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_f16(const float* x, const float* x_absmax, const void* packed_w, const float* bias,
-                                        const float* skip0, const float* skip1, const float* skip2,
-                                        float* y, int batch, int c_in, int frames_in, int ld_in,
-                                        int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
-
-/* The LayerNorm-fed form of the fp16 convolution: the LayerNorm writes the convolution's operand directly.
- * nbasr_layernorm_split_image normalises x (batch, channels, ld) and writes it as the pre-split fp16 image
- *   image[b][16-channel group][split][8-channel half][1 + ld rows][8 ch]   (row 0 zero, frame t at row t + 1;
- *   nbasr_split_image_bytes(batch, channels, ld) bytes), scaled per utterance by the power of two that brings bound[b] into
- * [2^14, 2^15), where bound[b] (batch floats, written here) is an upper bound of max|LayerNorm(x)[b]| computed together with
- * the statistics (stats: (batch, 2, ld) as nbasr_channel_stats).  Two kernels, 2 reads (the second L2-warm) + 1 write: the same
- * traffic as nbasr_layernorm_channels.  nbasr_dense_conv1d_fused_packed_f16_img then gathers its input tiles from the image
- * by LDS-DMA (no vector work in the GEMM); x_absmax must be that bound array.  No skips (the downsample convs have none). */
+/* The operand images of the fp16 scheme.  nbasr_layernorm_split_image normalises x (batch, channels, ld) and writes it as the
+ * image, scaled per utterance by the power of two that brings bound[b] into [2^14, 2^15), where bound[b] (batch floats, written
+ * here; the convolution's x_absmax) is an upper bound of max|LayerNorm(x)[b]| computed together with the statistics (stats:
+ * (batch, 2, ld) as nbasr_channel_stats).  Two kernels, 2 reads (the second L2-warm) + 1 write: the same traffic as
+ * nbasr_layernorm_channels.  nbasr_split_image_ranged writes x -- the model input -- as the image, every utterance scaled by the
+ * power of two that its x_range[4 b] implies (conv 0 then runs like convs 1-3). */
 size_t nbasr_split_image_bytes(int batch, int channels, int ld);
 int nbasr_layernorm_split_image(const float* x, const float* gamma, const float* beta, float* stats, float* bound,
                                 void* image, int batch, int channels, int frames, int ld, float eps,
                                 nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_f16_img(const void* x_image, const float* x_absmax, const void* packed_w,
-                                            const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
-                                            int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream);
-/* The same with a choice of the GEMM's row tile: row_tile = 128 (as above) or 160 output channels per workgroup.  160 pays
- * where 128 leaves a mostly empty last row tile (c_out = 800: 7 tiles, the last a quarter full, vs 5 full ones) or a partial
- * last round of workgroups (c_out = 1200 at 64 utterances x 250 frames: 640 workgroups on 256 CUs vs 512).  Weights must be
- * packed with the same row_tile (the packed sizes can coincide, the layouts do not); results are bit-identical between the two. */
-size_t nbasr_packed_dense_weights_bytes_f16_rows(int c_out, int c_in, int kernel, int row_tile);
-int nbasr_pack_dense_weights_f16_rows(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
-                                      nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_f16_img_rows(const void* x_image, const float* x_absmax, const void* packed_w,
-                                                 const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
-                                                 int c_out, int ld_out, int kernel, int stride, int row_tile,
-                                                 nbasr_stream_t stream);
+int nbasr_split_image_ranged(const float* x, const float* x_range, void* image, int batch, int channels, int frames, int ld,
+                             nbasr_stream_t stream);
 
 /* nn.LSTM(input_size=c_in, hidden_size=hidden, batch_first) forward with zero initial state
- * (reference model.py:100 and 118-121): gates i,f,g,o; biases b_ih + b_hh.
- * x: (batch, c_in, ld) encoder layout (the reference's permute is folded into the loader);
+ * (reference model.py:100 and 118-121): gates i,f,g,o; biases b_ih + b_hh, as two calls so that a caller can run the input
+ * projection (one large GEMM) on one stream and the latency-bound recurrence (frames dependent steps) on another:
+ *   gates_ws(frames, batch, 4*hidden) = x . w_ih^T + b_ih + b_hh ;   then h_out from gates_ws and the recurrent weight.
+ * x: (batch, c_in, ld) encoder layout (the reference's permute is folded into the loader), `ln` its pending LayerNorm;
  * w_ih: (4*hidden, c_in); w_hh: (4*hidden, hidden); h_out: (batch, frames, hidden).
- * Workspaces (caller-owned): gates_ws (batch*frames*4*hidden floats), cell_ws (batch*hidden). */
-int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh,
-                       const float* b_ih, const float* b_hh, float* gates_ws, float* cell_ws,
-                       float* h_out, int batch, int c_in, int frames, int ld, int hidden,
-                       nbasr_stream_t stream);
-
-/* The two halves of nbasr_lstm_forward as separate calls, so that a caller can run the input projection (one large GEMM)
- * on one stream and the latency-bound recurrence (frames dependent steps) on another:
- *   gates_ws(frames, batch, 4*hidden) = x . w_ih^T + b_ih + b_hh ;   then h_out from gates_ws, w_hh (cell_ws: scratch).
- * `ln` (may be NULL) is the pending LayerNorm of x, as in nbasr_lstm_forward_ln below. */
-struct nbasr_deferred_ln;
+ * Workspaces (caller-owned): gates_ws (batch*frames*4*hidden floats), cell_ws (batch*hidden; holds c_T afterwards). */
 int nbasr_lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, const float* b_hh,
                                 float* gates_ws, int batch, int c_in, int frames, int ld, int hidden,
-                                const struct nbasr_deferred_ln* ln, nbasr_stream_t stream);
-int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, float* cell_ws, float* h_out,
-                          int batch, int frames, int hidden, nbasr_stream_t stream);
-/* The recurrence on a fragment-ordered copy of w_hh (nbasr_lstm_packed_whh_bytes / nbasr_lstm_pack_whh, once per weight
- * version): identical arithmetic and results, but every operand load of a wave is 1 KiB contiguous instead of 16 rows x 64 B. */
+                                const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+/* The recurrence, one launch per frame, on a fragment-ordered copy of w_hh (nbasr_lstm_packed_whh_bytes / nbasr_lstm_pack_whh, once
+ * per weight version): every operand load of a wave is 1 KiB contiguous instead of 16 rows x 64 B of the (4H, H) matrix. */
 size_t nbasr_lstm_packed_whh_bytes(int hidden);
 int nbasr_lstm_pack_whh(const float* w_hh, void* packed, int hidden, nbasr_stream_t stream);
 int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out,
                                  int batch, int frames, int hidden, nbasr_stream_t stream);
+/* The same recurrence, all frames in ONE launch (reference model.py:100,118-121: the LSTM's time loop): the grid of the per-frame
+ * kernel stays resident, every workgroup keeps its slice of w_hh in registers and its cell state in registers, h_t is exchanged
+ * through a double-buffered image in `seq_ws` with one flag per (hidden slice, utterance tile) and step (write-through stores,
+ * agent-scope flag, L1-bypassing loads); utterance tiles never synchronise with each other.  Bit-identical h_out to
+ * nbasr_lstm_recurrence_packed.  For the single forward (latency) and for small batches; a pipelined caller whose next encoder
+ * needs the CUs keeps the per-frame launches.  nbasr_lstm_seq_workspace_bytes returns 0 where the form does not apply
+ * (hidden > 512, or more than 256 workgroups = ceil(hidden / 8) * ceil(batch / 16): every workgroup must be resident).
+ * Every wait is bounded (1 s): on a timeout the kernel raises the status word in seq_ws and fills the rest of h_out with NaN;
+ * nbasr_lstm_seq_status (synchronises `stream`) returns NBASR_EINVAL then. */
+size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden);
+int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
+                              int batch, int frames, int hidden, nbasr_stream_t stream);
+int nbasr_lstm_seq_status(const void* seq_ws, nbasr_stream_t stream);
 
 /* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
  * logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias. */
@@ -199,56 +193,38 @@ int nbasr_linear_head(const float* h, const float* w, const float* bias, float* 
                       int rows, int features, int classes, nbasr_stream_t stream);
 
 /* Head for the use_rnn=False model (reference model.py:103): input is the encoder output
- * x (batch, features, ld); logits (batch, frames, classes). */
+ * x (batch, features, ld), `ln` its pending LayerNorm; logits (batch, frames, classes). */
 int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits,
                           int batch, int features, int frames, int ld, int classes,
-                          nbasr_stream_t stream);
+                          const nbasr_deferred_ln* ln, nbasr_stream_t stream);
 
 /* ---- deferred LayerNorm ("normalise on load") ---------------------------------------------------------------
  * Instead of materialising LayerNorm(x) (2 reads + 1 write of the tensor), nbasr_channel_stats makes ONE read pass
- * and stores per-frame statistics; every consumer of the normalised tensor then applies
+ * and stores per-frame statistics (stats: (batch, 2, ld) floats, see nbasr_deferred_ln); every consumer of the normalised
+ * tensor then applies
  *     xn[b][c][t] = (x[b][c][t] - mean[b][t]) * rstd[b][t] * gamma[c] + beta[c]
  * while loading (zero padding and pitch columns stay exactly zero).  Same arithmetic as nbasr_layernorm_channels
- * (reference model.py:92 + 125-128, model.py:46-47 + 55-58).
- * stats: (batch, 2, ld) floats -- row 0 = mean, row 1 = rstd = 1/sqrt(var + eps); both 0 in columns >= frames. */
-typedef struct nbasr_deferred_ln {
-    const float* stats;
-    const float* gamma;   /* (channels) */
-    const float* beta;    /* (channels) */
-} nbasr_deferred_ln;
-
-int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
+ * (reference model.py:92 + 125-128, model.py:46-47 + 55-58).  Entry points that take `ln` also take flags saying which operand
+ * carries it: the main input x and/or skip0 (inside a cell only the cell input is a LayerNorm output, and it is always skip0
+ * when it is a skip). */
+int nbasr_channel_stats(const void* x, float* stats, int batch, int channels, int frames, int ld, float eps, int dtype,
                         nbasr_stream_t stream);
 
-/* The `_ln` variants take the same arguments as their plain counterparts plus `ln` (may be NULL = plain behaviour) and
- * flags saying which operand carries the pending LayerNorm: the main input x and/or skip0 (inside a cell only the
- * cell input is a LayerNorm output, and it is always skip0 when it is a skip). */
-int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias,
-                                  const float* skip0, const float* skip1, const float* skip2,
-                                  float* y, int batch, int channels, int frames, int ld,
-                                  int groups, int kernel, int dilation,
-                                  const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
-/* As nbasr_grouped_conv1d_fused_ln, and ALSO emits the LayerNorm statistics of the output y (what nbasr_channel_stats(y)
- * would give) from the convolution's epilogue: workgroups write per-(group quad) partial (mean, M2) to stats_ws
- * (nbasr_grouped_stats_workspace_bytes), a small second kernel merges them into stats_out (batch, 2, ld).  With
- * stats_out == NULL only the partials are written and nbasr_grouped_stats_finalize merges them later; stats_ws == NULL
- * gives the plain _ln behaviour. */
+/* LayerNorm statistics of a node's output from the convolution's own epilogue (what nbasr_channel_stats(y) would give):
+ * workgroups write per-part partial (mean, M2) to stats_ws (nbasr_grouped_stats_workspace_bytes), nbasr_grouped_stats_finalize
+ * merges them into stats_out (batch, 2, ld).  A part covers `groups_per_part` groups: 4 (nbasr_grouped_conv1d_node, most
+ * nbasr_grouped_cell_fused launches) or 2 (the value nbasr_grouped_cell_fits returns for the shape). */
 size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups);
 int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
-                                 int groups, float eps, nbasr_stream_t stream);
-/* the same merge for partials that cover `groups_per_part` groups each: 4 (nbasr_grouped_conv1d_node, most nbasr_grouped_cell_fused
- * launches) or 2 (the value nbasr_grouped_cell_fits returns for the shape) */
-int nbasr_grouped_stats_finalize_parts(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
-                                       int groups, int groups_per_part, float eps, nbasr_stream_t stream);
-int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias,
-                                     const float* skip0, const float* skip1, const float* skip2,
-                                     float* y, int batch, int channels, int frames, int ld,
-                                     int groups, int kernel, int dilation,
-                                     const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
-                                     float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream);
-/* The node operation for either storage type and in the kernel variants kept for measurement (one C symbol instead of
- * one per combination).  Arguments as nbasr_grouped_conv1d_fused_stats without stats_out / eps (merge the partials with
- * nbasr_grouped_stats_finalize); x, skips, y are `dtype` tensors, everything else fp32.
+                                 int groups, int groups_per_part, float eps, nbasr_stream_t stream);
+
+/* Node operation, grouped-convolution flavour, fused with the node's skip-sum
+ * (reference ops.py:24-30 with groups=100 from the table ops.py:73-76, Node.forward model.py:13-22):
+ *     y = min(relu(conv1d(zero_pad(x), w, bias, dilation, groups)), 20) + skip0 + skip1 + skip2
+ * x, y, skip*: (batch, channels, ld) `dtype` tensors; w: (channels, channels/groups, kernel); bias: (channels).
+ * NULL skips are absent (a Zero branch).  Supported: kernel in {5,7}, dilation in {1,2},
+ * channels/groups in {6,8,10,12}.  Skips are added left to right (python `sum` order).  `ln` / ln_on_x / ln_on_skip0: pending
+ * LayerNorm of x and / or skip0.  stats_ws (may be NULL): also emit the partial LayerNorm statistics of y (see above).
  * variant: 0 = 4 frames per lane, weights as torch stores them; NBASR_GC_FPL8 = 8 frames per lane (fp32: ld % 8 == 0);
  * NBASR_GC_WPERM = `w` is the [group][ci][tap][co] copy made by nbasr_pack_grouped_weights (channels * channels/groups *
  * kernel floats), whose per-input-channel weights are contiguous for the scalar loads.  Results do not depend on the variant. */
@@ -274,32 +250,17 @@ int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int 
  * bf16 storage x1 and x2 are rounded to bfloat16 exactly where the three-launch form stores them).
  * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup -- <= 2048 frames (<= 8 waves per group row),
  * channels / groups in {6, 8, 10, 12}, the group tiles within 160 KiB of LDS: 0 = no, else the number of groups one statistics partial
- * covers (4 or 2: the groups_per_part of nbasr_grouped_stats_finalize_parts). */
+ * covers (4 or 2: the groups_per_part of nbasr_grouped_stats_finalize). */
 int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups);
 int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, int k0, int d0,
                              const float* w1, const float* b1, int k1, int d1,
                              const float* w2, const float* b2, int k2, int d2, int skip_mask, void* y,
                              int batch, int channels, int frames, int ld, int groups,
                              const nbasr_deferred_ln* ln, float* stats_ws, int dtype, nbasr_stream_t stream);
-int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y,
-                      int batch, int channels, int frames, int ld,
-                      const nbasr_deferred_ln* ln, int ln_on_skip0, nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_ln(const float* x, const float* w, const float* bias,
-                                const float* skip0, const float* skip1, const float* skip2,
-                                float* y, int batch, int c_in, int frames_in, int ld_in,
-                                int c_out, int ld_out, int kernel, int stride,
-                                const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_ln(const float* x, const void* packed_w, const float* bias,
-                                       float* y, int batch, int c_in, int frames_in, int ld_in,
-                                       int c_out, int ld_out, int kernel, int stride,
-                                       const nbasr_deferred_ln* ln, nbasr_stream_t stream);
-int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh,
-                          const float* b_ih, const float* b_hh, float* gates_ws, float* cell_ws,
-                          float* h_out, int batch, int c_in, int frames, int ld, int hidden,
-                          const nbasr_deferred_ln* ln, nbasr_stream_t stream);
-int nbasr_linear_head_bct_ln(const float* x, const float* w, const float* bias, float* logits,
-                             int batch, int features, int frames, int ld, int classes,
-                             const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+/* Node whose main op is `zero` (reference ops.py:67-68): y = 0 + skip0 + skip1 + skip2 (`dtype` tensors; `ln`: pending LayerNorm of
+ * skip0 when ln_on_skip0). */
+int nbasr_skip_sum(const void* skip0, const void* skip1, const void* skip2, void* y, int batch, int channels, int frames,
+                   int ld, const nbasr_deferred_ln* ln, int ln_on_skip0, int dtype, nbasr_stream_t stream);
 
 /* Post-logits step of the reference's trainer (training/torch/trainer.py:217-219, 229-247), SURVEY.md 8 row f2:
  *   log_probs(batch, frames, classes) = log_softmax(logits, classes)                      (NULL: not wanted)
@@ -348,17 +309,16 @@ int nbasr_ctc_beam_search(const float* log_probs, const int* lengths, void* ws, 
 int nbasr_token_error_counts(const int* hyp, const int* hyp_len, int ld_hyp, const int* ref, const int* ref_len, int ld_ref,
                              const int* table, int n_table, int blank, int* counts, int batch, nbasr_stream_t stream);
 
-/* Copy (batch, channels, frames) with pitch ld_src into pitch ld_dst, zero-filling columns
+/* Copy (batch, channels, frames) `dtype` rows with pitch ld_src into pitch ld_dst, zero-filling columns
  * frames..ld_dst-1 (used to bring caller tensors into the pitched internal layout). */
-int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,
-                  nbasr_stream_t stream);
+int nbasr_repitch(const void* src, void* dst, int rows, int frames, int ld_src, int ld_dst, int dtype, nbasr_stream_t stream);
 
-/* ---- per-frame linear maps on the fp16 matrix cores (fp32-accurate two-way operand split, see the _f16 convolution) ------
+/* ---- per-frame linear maps on the fp16 matrix cores (fp32-accurate two-way operand split, see NBASR_DENSE_F16X2) ------
  * The `linear` node op (reference ops.py:42-50 + the node's skip sum, model.py:13-22) and the LSTM input projection.  The
  * activation is split once by a streaming pre-pass into `ws` (nbasr_pointwise_workspace_bytes; scratch, no state between
  * calls) with one exact power-of-two scale per (utterance, 256-frame tile); the weights are packed once per weight version
  * (nbasr_pointwise_packed_weights_bytes / nbasr_pack_pointwise_weights, row-wise power-of-two scales).  No range contract:
- * both scalings are computed from the data.  Arguments otherwise as nbasr_dense_conv1d_fused_ln with kernel = 1 and as
+ * both scalings are computed from the data.  Arguments otherwise as nbasr_dense_conv1d_fused with kernel = 1 and as
  * nbasr_lstm_input_projection. */
 size_t nbasr_pointwise_packed_weights_bytes(int c_out, int c_in);
 size_t nbasr_pointwise_workspace_bytes(int batch, int c_in, int ld);
@@ -390,48 +350,11 @@ int nbasr_power_spectrum(const float* spec, float* power, int batch, int bins, i
 int nbasr_log_normalize(const float* mel, const int* lengths, const float* mean, const float* inv_scale, float* feats,
                         int batch, int samples, int hop, int n_mels, int ld, nbasr_stream_t stream);
 
-/* ---- the model input: range summary and per-utterance routing ---------------------------------------------------------------
- * The first dense convolution takes caller data, whose range this library does not control.  nbasr_input_range writes, per
- * utterance, range[4 b] = { max finite |x|, the quietest non-silent frame's max |x| over channels, non-zero if any sample is
- * Inf / NaN, unused } (x: (batch, channels, ld) fp32, any ld >= frames).  An utterance is EXTREME when it holds a non-finite
- * sample or a frame more than 2^12 below its loudest sample: the scaled fp16 scheme would then lose precision in (or, for Inf,
- * flush) the quiet part.  The two `_ranged` convolutions are launched back to back on the same output: the fp16 one computes
- * the ordinary utterances (scale from range[4 b]) and skips the extreme ones, the 3-way bf16 one (fp32's exponent range, no
- * scaling, NaN / Inf propagate like in the reference) computes exactly those.  No host synchronisation. */
-int nbasr_input_range(const float* x, float* range, int batch, int channels, int frames, int ld, nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_f16_ranged(const float* x, const float* x_range, const void* packed_w_f16, const float* bias,
-                                               float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
-                                               int kernel, int stride, nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_ranged(const float* x, const float* x_range, const void* packed_w_bf16x3, const float* bias,
-                                           float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
-                                           int kernel, int stride, nbasr_stream_t stream);
-
-/* Image-path form of the fp16 leg (conv 0 then runs like convs 1-3: the GEMM copies pre-split operands by LDS-DMA instead of
- * splitting the input in its own prologue).  nbasr_split_image_ranged writes x (batch, channels, ld) -- the model input -- as
- * the fp16 image of nbasr_split_image_bytes, every utterance scaled by the power of two that its x_range[4 b] (the maximum
- * written by nbasr_input_range) implies; the _img_ranged convolution computes the utterances that are NOT extreme, the bf16
- * `_ranged` convolution above the others, on the same output. */
-int nbasr_split_image_ranged(const float* x, const float* x_range, void* image, int batch, int channels, int frames, int ld,
-                             nbasr_stream_t stream);
-int nbasr_dense_conv1d_fused_packed_f16_img_ranged(const void* x_image, const float* x_range, const void* packed_w_f16,
-                                                   const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
-                                                   int c_out, int ld_out, int kernel, int stride, int row_tile,
-                                                   nbasr_stream_t stream);
-
 /* ---- bf16 path (BASELINE config 4: activations and GEMM operands stored as bfloat16) ------------------------------------------
  * Mirrors `model.to(torch.bfloat16)(x.bfloat16())` of the reference (ops.py:24-30, model.py:116-131 run on bf16 tensors).
- * Storage is bf16, arithmetic is fp32, a tensor is rounded once when it is written; the `_v` entry points below are the
- * fp32 ones with a storage-type argument (x / y / skips are `dtype` tensors, everything else -- weights of the node op,
- * bias, gamma, beta, statistics -- stays fp32).  bf16 rows: ld % 8 == 0, 16-byte aligned, pitch columns zero. */
-int nbasr_skip_sum_v(const void* skip0, const void* skip1, const void* skip2, void* y, int batch, int channels, int frames,
-                     int ld, const nbasr_deferred_ln* ln, int ln_on_skip0, int dtype, nbasr_stream_t stream);
-int nbasr_repitch_v(const void* src, void* dst, int rows, int frames, int ld_src, int ld_dst, int dtype, nbasr_stream_t stream);
-int nbasr_channel_stats_v(const void* x, float* stats, int batch, int channels, int frames, int ld, float eps, int dtype,
-                          nbasr_stream_t stream);
-/* LayerNorm over channels, x of in_dtype -> y of out_dtype: f32 -> f32, bf16 -> bf16, or bf16 -> f32 (the encoder output
- * handed to the fp32 LSTM).  In place only when the two types are equal. */
-int nbasr_layernorm_channels_v(const void* x, const float* gamma, const float* beta, void* y, int batch, int channels, int frames,
-                               int ld, float eps, int in_dtype, int out_dtype, nbasr_stream_t stream);
+ * Storage is bf16, arithmetic is fp32, a tensor is rounded once when it is written: the entry points above that take a `dtype`
+ * serve both storage types (x / y / skips are `dtype` tensors, everything else -- weights of the node op, bias, gamma, beta,
+ * statistics -- stays fp32).  bf16 rows: ld % 8 == 0, 16-byte aligned, pitch columns zero. */
 /* Element-wise conversion between the two storage types (n % 8 == 0, both pointers 16-byte aligned): the bridge to the
  * operators that exist in fp32 only. */
 int nbasr_convert(const void* x, void* y, long long n, int in_dtype, int out_dtype, nbasr_stream_t stream);
@@ -442,15 +365,7 @@ int nbasr_convert(const void* x, void* y, long long n, int in_dtype, int out_dty
 size_t nbasr_bf16_image_bytes(int batch, int channels, int ld);
 int nbasr_bf16_image(const void* x, const float* gamma, const float* beta, float* stats, void* image, int batch, int channels,
                      int frames, int ld, float eps, int dtype, nbasr_stream_t stream);
-/* Dense PadConvRelu k = 8 (reference model.py:82-89) on bf16 operands: ONE v_mfma_f32_16x16x32_bf16 per 32 products, fp32
- * accumulation, bias + relu + min(20) in fp32, one rounding to the bf16 output (batch, c_out, ld_out), ld_out % 8 == 0.
- * Weights: the fp32 values of the bf16 parameter, packed once per version (row_tile 128 or 160). */
-size_t nbasr_packed_dense_weights_bytes_bf16(int c_out, int c_in, int kernel, int row_tile);
-int nbasr_pack_dense_weights_bf16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
-                                  nbasr_stream_t stream);
-int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
-                                int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
-                                nbasr_stream_t stream);
+/* (the bf16 convolution itself: nbasr_dense_conv1d_packed with NBASR_DENSE_BF16) */
 
 /* ---- backward building blocks (bottom-up; fp32) -------------------------------------------------------------------
  * The node op z = min(relu(conv1d(zero_pad(x), w, b, dilation, groups)), 20) (reference ops.py:24-30) given dz = dL/dz:

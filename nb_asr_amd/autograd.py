@@ -83,7 +83,7 @@ class _DensePadConvRelu(torch.autograd.Function):
         w3 = weight.detach() if weight.dim() == 3 else weight.detach().unsqueeze(-1)
         t_out = (frames + stride - 1) // stride
         y = torch.empty(xp.shape[0], weight.shape[0], hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
-        mode = os.environ.get('NBASR_TRAIN_GEMM', 'f16x2')
+        mode = os.environ.get('NBASR_DENSE_MODE', 'auto')
         if kernel == 8 and mode == 'bf16x3' and xp.data_ptr() % 16 == 0:
             # the three-term bf16 split (fp32's range, no range information needed, fp32-level error): half the time of the exact-fp32
             # MFMA GEMM; the weights change every step, so they are packed per call (tens of microseconds)
@@ -128,7 +128,7 @@ class _LSTM(torch.autograd.Function):
         gates = torch.empty(max(frames, 1), b, 4 * hidden, device=xp.device, dtype=torch.float32)
         cell = torch.empty(b, hidden, device=xp.device, dtype=torch.float32)
         h_out = torch.empty(b, frames, hidden, device=xp.device, dtype=torch.float32)
-        if frames and hidden % 4 == 0 and os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32':
+        if frames and hidden % 4 == 0 and os.environ.get('NBASR_DENSE_MODE', 'auto') != 'f32':
             # as in the inference executor: the projection on the fp16-split GEMM, the recurrence on the fragment-ordered copy of w_hh
             # (bit-identical to the unpacked step kernel); both weights change every step, so they are packed per call
             hip.lstm_input_projection_packed(xp, frames, hip.pack_pointwise_weights(w_ih.detach().contiguous()), b_ih.detach(), b_hh.detach(), gates,

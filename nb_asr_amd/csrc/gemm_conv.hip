@@ -278,17 +278,17 @@ int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, 
     a.lpad = 0; a.ktot = c_in; a.batch = batch;
     a.row_stride_t = batch; a.row_stride_b = 1;
     a.ln_x = ln;
-    return launch_gemm_conv<1, 1, true, false>(a, stream, "nbasr_lstm_forward(input projection)");
+    return launch_gemm_conv<1, 1, true, false>(a, stream, "nbasr_lstm_input_projection");
 }
 
 }  // namespace nbasr
 
 using namespace nbasr;
 
-extern "C" int nbasr_dense_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
-                                           const float* skip1, const float* skip2, float* y, int batch, int c_in,
-                                           int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                                           const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
+extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
+                                        const float* skip1, const float* skip2, float* y, int batch, int c_in,
+                                        int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
+                                        const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "nbasr_dense_conv1d_fused: bad sizes");
@@ -304,9 +304,9 @@ extern "C" int nbasr_dense_conv1d_fused_ln(const float* x, const float* w, const
     NBASR_REQUIRE(x && w && bias && y, NBASR_ENULL, "nbasr_dense_conv1d_fused: x, w, bias, y must be non-NULL");
     const bool any_ln = ln && (ln_on_x || (ln_on_skip0 && skip0));
     NBASR_REQUIRE(!any_ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL,
-                  "nbasr_dense_conv1d_fused_ln: deferred LayerNorm needs stats, gamma and beta");
+                  "nbasr_dense_conv1d_fused: deferred LayerNorm needs stats, gamma and beta");
     NBASR_REQUIRE(!(ln && ln_on_x && ln_on_skip0 && skip0) || (c_in == c_out && ld_in == ld_out), NBASR_EINVAL,
-                  "nbasr_dense_conv1d_fused_ln: one descriptor for x and skip0 needs equal shapes");
+                  "nbasr_dense_conv1d_fused: one descriptor for x and skip0 needs equal shapes");
     GemmConvArgs a{};
     a.x = x; a.w = w; a.bias = bias; a.bias2 = nullptr; a.s0 = skip0; a.s1 = skip1; a.s2 = skip2; a.y = y;
     a.c_in = c_in; a.frames_in = frames_in; a.ld_in = ld_in; a.c_out = c_out; a.frames_out = frames_out; a.ld_out = ld_out;
@@ -316,15 +316,6 @@ extern "C" int nbasr_dense_conv1d_fused_ln(const float* x, const float* w, const
     if (kernel == 8 && stride == 1) return launch_gemm_conv<8, 1, false, true>(a, s, "nbasr_dense_conv1d_fused");
     if (kernel == 8 && stride == 2) return launch_gemm_conv<8, 2, false, true>(a, s, "nbasr_dense_conv1d_fused");
     return launch_gemm_conv<1, 1, false, true>(a, s, "nbasr_dense_conv1d_fused");
-}
-
-extern "C" int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
-                                        const float* skip1, const float* skip2, float* y, int batch, int c_in,
-                                        int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                                        nbasr_stream_t stream)
-{
-    return nbasr_dense_conv1d_fused_ln(x, w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                       kernel, stride, nullptr, 0, 0, stream);
 }
 
 // y(batch, c_out, ld_out) = w(c_out, c_in) . x(batch, c_in, ld_in) + bias, no activation: the plain per-frame linear map

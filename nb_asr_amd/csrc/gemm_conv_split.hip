@@ -16,8 +16,8 @@
 // catch, and the model's activations really do leave it (with the reference's default initialisation they shrink to 1e-9).
 // Both operands are therefore brought into range by EXACT power-of-two scalings that the epilogue undoes:
 //   * x of utterance b is multiplied by 2^kx[b] so that its largest magnitude lands in [2^14, 2^15); the caller passes
-//     absmax[b] >= max|x[b]| (nbasr_layernorm_channels_absmax produces it for free while writing x, nbasr_absmax
-//     reduces it for the model input);
+//     absmax[b] >= max|x[b]| (nbasr_layernorm_channels produces it for free while writing x; the model input is
+//     ranged by nbasr_input_range);
 //   * row co of w is multiplied by 2^kw[co] at pack time (largest magnitude of the row -> [2^13, 2^14)).
 // Round 3: lo is stored UNSCALED (rounds 1-2 stored lo * 2^11 to keep it a normal fp16 number and accumulated the cross terms in
 // a second register set).  fp16 subnormals are honoured by v_cvt_f16_f32 and by the MFMA (tools/ubench/mfma_f16_denorm.hip), so
@@ -82,7 +82,7 @@ struct SplitBf16x3 {
     __device__ static __forceinline__ floatx4 mfma(vec8 a, vec8 b, floatx4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
-    static constexpr const char* NAME = "nbasr_dense_conv1d_fused_packed";
+    static constexpr const char* NAME = "nbasr_dense_conv1d_packed(bf16x3)";
 };
 
 struct SplitF16x2 {
@@ -99,7 +99,7 @@ struct SplitF16x2 {
     __device__ static __forceinline__ floatx4 mfma(vec8 a, vec8 b, floatx4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
     }
-    static constexpr const char* NAME = "nbasr_dense_conv1d_fused_packed_f16";
+    static constexpr const char* NAME = "nbasr_dense_conv1d_packed(f16x2)";
 };
 
 // bf16 path (BASELINE config 4): operands ARE bfloat16 -- one term, one MFMA per product, no scaling (bf16 has fp32's exponent
@@ -116,7 +116,7 @@ struct PlainBf16 {
     __device__ static __forceinline__ floatx4 mfma(vec8 a, vec8 b, floatx4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
     }
-    static constexpr const char* NAME = "nbasr_dense_conv1d_bf16_img";
+    static constexpr const char* NAME = "nbasr_dense_conv1d_packed(bf16)";
 };
 
 template <class P> constexpr bool has_image_path() { return P::SCALED || P::NS == 1; }
@@ -813,96 +813,39 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
 
 using namespace nbasr;
 
-extern "C" size_t nbasr_packed_dense_weights_bytes(int c_out, int c_in, int kernel) { return packed_bytes<SplitBf16x3>(c_out, c_in, kernel); }
-extern "C" size_t nbasr_packed_dense_weights_bytes_f16(int c_out, int c_in, int kernel) { return packed_bytes<SplitF16x2>(c_out, c_in, kernel); }
-
-extern "C" int nbasr_pack_dense_weights(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
-                                        nbasr_stream_t stream)
-{
-    return pack_impl<SplitBf16x3>(w, packed, c_out, c_in, kernel, stride, stream);
-}
-
-extern "C" int nbasr_pack_dense_weights_f16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride,
-                                            nbasr_stream_t stream)
-{
-    return pack_impl<SplitF16x2>(w, packed, c_out, c_in, kernel, stride, stream);
-}
-
-extern "C" int nbasr_dense_conv1d_fused_packed(const float* x, const void* packed_w, const float* bias, const float* skip0,
-                                               const float* skip1, const float* skip2, float* y, int batch, int c_in,
-                                               int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                                               nbasr_stream_t stream)
-{
-    return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                          kernel, stride, nullptr, nullptr, stream);
-}
-
-extern "C" int nbasr_dense_conv1d_fused_packed_ln(const float* x, const void* packed_w, const float* bias, float* y, int batch,
-                                                  int c_in, int frames_in, int ld_in, int c_out, int ld_out, int kernel,
-                                                  int stride, const nbasr_deferred_ln* ln, nbasr_stream_t stream)
-{
-    return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out,
-                                          ld_out, kernel, stride, ln, nullptr, stream);
-}
-
-extern "C" int nbasr_dense_conv1d_fused_packed_f16(const float* x, const float* x_absmax, const void* packed_w, const float* bias,
-                                                   const float* skip0, const float* skip1, const float* skip2, float* y,
-                                                   int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
-                                                   int kernel, int stride, nbasr_stream_t stream)
-{
-    return dense_packed_impl<SplitF16x2>(x, packed_w, bias, skip0, skip1, skip2, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                         kernel, stride, nullptr, x_absmax, stream);
-}
-
 extern "C" size_t nbasr_split_image_bytes(int batch, int channels, int ld)
 {
     if (batch <= 0 || channels <= 0 || ld < 0) return 0;
     return static_cast<size_t>(batch) * ((channels + PB_CI - 1) / PB_CI) * 4 * (static_cast<size_t>(ld) + 1) * 16;
 }
 
-extern "C" int nbasr_dense_conv1d_fused_packed_f16_img(const void* x_image, const float* x_absmax, const void* packed_w,
-                                                       const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
-                                                       int c_out, int ld_out, int kernel, int stride, nbasr_stream_t stream)
+extern "C" size_t nbasr_packed_dense_weights_bytes(int scheme, int c_out, int c_in, int kernel, int row_tile)
 {
-    return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
-                                         frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, x_absmax, stream, true);
+    switch (scheme) {
+        case NBASR_DENSE_BF16X3: return packed_bytes<SplitBf16x3>(c_out, c_in, kernel, row_tile);
+        case NBASR_DENSE_F16X2:  return packed_bytes<SplitF16x2>(c_out, c_in, kernel, row_tile);
+        case NBASR_DENSE_BF16:   return packed_bytes<PlainBf16>(c_out, c_in, kernel, row_tile);
+        default: return 0;
+    }
 }
 
-extern "C" size_t nbasr_packed_dense_weights_bytes_f16_rows(int c_out, int c_in, int kernel, int row_tile)
+extern "C" int nbasr_pack_dense_weights(int scheme, const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
+                                        nbasr_stream_t stream)
 {
-    return packed_bytes<SplitF16x2>(c_out, c_in, kernel, row_tile);
+    switch (scheme) {
+        case NBASR_DENSE_BF16X3: return pack_impl<SplitBf16x3>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
+        case NBASR_DENSE_F16X2:  return pack_impl<SplitF16x2>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
+        case NBASR_DENSE_BF16:   return pack_impl<PlainBf16>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
+        default: break;
+    }
+    clear_error();
+    NBASR_REQUIRE(false, NBASR_EINVAL, "nbasr_pack_dense_weights: unknown scheme %d", scheme);
+    return NBASR_EINVAL;
 }
 
-extern "C" int nbasr_pack_dense_weights_f16_rows(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
-                                                 nbasr_stream_t stream)
-{
-    return pack_impl<SplitF16x2>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
-}
-
-extern "C" int nbasr_dense_conv1d_fused_packed_f16_img_rows(const void* x_image, const float* x_absmax, const void* packed_w,
-                                                            const float* bias, float* y, int batch, int c_in, int frames_in, int ld_in,
-                                                            int c_out, int ld_out, int kernel, int stride, int row_tile,
-                                                            nbasr_stream_t stream)
-{
-    return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
-                                         frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, x_absmax, stream, true, row_tile);
-}
-
-// ---- bf16 path ------------------------------------------------------------------------------------------------------------
-extern "C" size_t nbasr_packed_dense_weights_bytes_bf16(int c_out, int c_in, int kernel, int row_tile)
-{
-    return packed_bytes<PlainBf16>(c_out, c_in, kernel, row_tile);
-}
-
-extern "C" int nbasr_pack_dense_weights_bf16(const float* w, void* packed, int c_out, int c_in, int kernel, int stride, int row_tile,
-                                             nbasr_stream_t stream)
-{
-    return pack_impl<PlainBf16>(w, packed, c_out, c_in, kernel, stride, stream, row_tile);
-}
-
-extern "C" int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
-                                           int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
-                                           nbasr_stream_t stream)
+static int dense_bf16_image_impl(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
+                                 int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                 nbasr_stream_t stream)
 {
     using P = PlainBf16;
     clear_error();
@@ -930,33 +873,35 @@ extern "C" int nbasr_dense_conv1d_bf16_img(const void* x_image, const void* pack
     return stride == 1 ? launch_image<P, 1, 4>(a, s) : launch_image<P, 2, 4>(a, s);
 }
 
-// ---- the model input: per-utterance routing between the two fp32-accurate schemes (nbasr_input_range) -------------------------
-extern "C" int nbasr_dense_conv1d_fused_packed_f16_ranged(const float* x, const float* x_range, const void* packed_w, const float* bias,
-                                                          float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
-                                                          int kernel, int stride, nbasr_stream_t stream)
+// ONE entry point for the packed k = 8 convolution (nbasr.h: the schemes, the two operand forms and the per-utterance routing)
+extern "C" int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_image, const float* x_absmax, const float* x_range,
+                                         const void* packed_w, const float* bias, const float* skip0, const float* skip1,
+                                         const float* skip2, void* y, int batch, int c_in, int frames_in, int ld_in, int c_out,
+                                         int ld_out, int kernel, int stride, int row_tile, const nbasr_deferred_ln* ln,
+                                         nbasr_stream_t stream)
 {
-    NBASR_REQUIRE(x_range, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_f16_ranged: x_range is NULL");
-    return dense_packed_impl<SplitF16x2>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                         kernel, stride, nullptr, nullptr, stream, false, 128, x_range, 0);
-}
-
-extern "C" int nbasr_dense_conv1d_fused_packed_ranged(const float* x, const float* x_range, const void* packed_w, const float* bias,
-                                                      float* y, int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out,
-                                                      int kernel, int stride, nbasr_stream_t stream)
-{
-    NBASR_REQUIRE(x_range, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_ranged: x_range is NULL");
-    return dense_packed_impl<SplitBf16x3>(x, packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                          kernel, stride, nullptr, nullptr, stream, false, 128, x_range, 1);
-}
-
-// image-path form of the fp16 leg: x_image = nbasr_split_image_ranged(x, x_range) (the GEMM only copies operands by LDS-DMA)
-extern "C" int nbasr_dense_conv1d_fused_packed_f16_img_ranged(const void* x_image, const float* x_range, const void* packed_w,
-                                                              const float* bias, float* y, int batch, int c_in, int frames_in,
-                                                              int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
-                                                              nbasr_stream_t stream)
-{
-    NBASR_REQUIRE(x_range, NBASR_ENULL, "nbasr_dense_conv1d_fused_packed_f16_img_ranged: x_range is NULL");
-    return dense_packed_impl<SplitF16x2>(static_cast<const float*>(x_image), packed_w, bias, nullptr, nullptr, nullptr, y, batch, c_in,
-                                         frames_in, ld_in, c_out, ld_out, kernel, stride, nullptr, nullptr, stream, true, row_tile,
-                                         x_range, 0);
+    clear_error();
+    const float* xf = static_cast<const float*>(x);
+    float* yf = static_cast<float*>(y);
+    const bool image = x_is_image != 0;
+    switch (scheme) {
+        case NBASR_DENSE_BF16X3:
+            NBASR_REQUIRE(!image && !x_absmax, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the bf16x3 scheme reads a plain fp32 tensor and takes no bound");
+            // with x_range: only the EXTREME utterances (the fp16 leg computes the others on the same output)
+            return dense_packed_impl<SplitBf16x3>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                                  kernel, stride, ln, nullptr, stream, false, row_tile, x_range, 1);
+        case NBASR_DENSE_F16X2:
+            NBASR_REQUIRE(!ln, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the fp16x2 scheme takes no pending LayerNorm (nbasr_layernorm_split_image writes its operand)");
+            NBASR_REQUIRE(!(image && (skip0 || skip1 || skip2)), NBASR_EINVAL, "nbasr_dense_conv1d_packed: the image path takes no skips");
+            NBASR_REQUIRE(!(x_absmax && x_range), NBASR_EINVAL, "nbasr_dense_conv1d_packed: give x_absmax or x_range, not both");
+            return dense_packed_impl<SplitF16x2>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
+                                                 kernel, stride, nullptr, x_absmax, stream, image, row_tile, x_range, 0);
+        case NBASR_DENSE_BF16:
+            NBASR_REQUIRE(image && !x_absmax && !x_range && !ln && !skip0 && !skip1 && !skip2, NBASR_EINVAL,
+                          "nbasr_dense_conv1d_packed: the bf16 scheme reads nbasr_bf16_image's operand image only (no bound, range, LayerNorm or skips)");
+            return dense_bf16_image_impl(x, packed_w, bias, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, stream);
+        default: break;
+    }
+    NBASR_REQUIRE(false, NBASR_EINVAL, "nbasr_dense_conv1d_packed: unknown scheme %d", scheme);
+    return NBASR_EINVAL;
 }

@@ -18,7 +18,6 @@
 //              time-major store of the LSTM gates.
 #include "common.h"
 
-#include <cstdlib>
 
 namespace nbasr {
 
@@ -370,9 +369,8 @@ static int pw_launch(PointwiseArgs a, hipStream_t stream, const char* what)
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", what, nwg);
     // tile order: stream the SMALLER operand (per K-step a row tile costs PW_A_STEP bytes of weights, a frame tile PW_X_STEP of image)
-    static const int forced = [] { const char* e = getenv("NBASR_PW_ORDER"); return e ? (e[0] == 'n' ? 1 : 0) : -1; }();   // A/B: n | m
-    a.n_major = forced >= 0 ? forced
-                            : (static_cast<long long>(a.n_mt) * PW_A_STEP <= static_cast<long long>(a.n_nt) * a.batch * PW_X_STEP ? 1 : 0);
+    // (A/B on the LSTM projection, 64 x 250 frames: 1.45 GB -> 0.56 GB of HBM traffic per launch, 254 -> 248 us; throughput equal within noise)
+    a.n_major = static_cast<long long>(a.n_mt) * PW_A_STEP <= static_cast<long long>(a.n_nt) * a.batch * PW_X_STEP ? 1 : 0;
     hipLaunchKernelGGL((pw_gemm_kernel<SWAP, RELU>), dim3(static_cast<unsigned>(nwg)), dim3(PW_THREADS), PW_LDS, stream, a);
     return launch_status(what);
 }

@@ -441,7 +441,7 @@ extern "C" int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups)
     const int nt = (frames_ld / 4 + 63) / 64;
     if (nt > 8) return 0;                                              // 2 groups x 8 waves = the 1024 threads of a workgroup
     const int gpw = cell_gpw(cg, nt);
-    return cell_lds_bytes(cg, nt, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize_parts)
+    return cell_lds_bytes(cg, nt, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize)
 }
 
 extern "C" int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, int k0, int d0,

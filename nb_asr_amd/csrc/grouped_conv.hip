@@ -321,7 +321,7 @@ static int launch_grouped_f32(const GroupedArgs<float>& a, hipStream_t stream)
     if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
     else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
 #undef NBASR_LAUNCH_GROUPED
-    return launch_status("nbasr_grouped_conv1d_fused");
+    return launch_status("nbasr_grouped_conv1d_node");
 }
 
 template <int CG>
@@ -331,7 +331,7 @@ static int dispatch_kd_f32(int kernel, int dilation, const GroupedArgs<float>& a
     if (kernel == 5 && dilation == 2) return launch_grouped_f32<CG, 5, 2>(a, stream);
     if (kernel == 7 && dilation == 1) return launch_grouped_f32<CG, 7, 1>(a, stream);
     if (kernel == 7 && dilation == 2) return launch_grouped_f32<CG, 7, 2>(a, stream);
-    set_error("nbasr_grouped_conv1d_fused: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
+    set_error("nbasr_grouped_conv1d_node: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
     return NBASR_EINVAL;
 }
 
@@ -343,7 +343,7 @@ int grouped_conv_f32_base(const GroupedArgs<float>& a, int kernel, int dilation,
         case 10: return dispatch_kd_f32<10>(kernel, dilation, a, stream);
         case 12: return dispatch_kd_f32<12>(kernel, dilation, a, stream);
         default:
-            set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", a.channels / a.groups);
+            set_error("nbasr_grouped_conv1d_node: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", a.channels / a.groups);
             return NBASR_EINVAL;
     }
 }
@@ -418,24 +418,8 @@ extern "C" int nbasr_pack_grouped_weights(const float* w, float* packed, int cha
     return launch_status("nbasr_pack_grouped_weights");
 }
 
-extern "C" int nbasr_grouped_conv1d_fused_stats(const float* x, const float* w, const float* bias, const float* skip0,
-                                                const float* skip1, const float* skip2, float* y, int batch, int channels,
-                                                int frames, int ld, int groups, int kernel, int dilation,
-                                                const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0,
-                                                float* stats_out, float* stats_ws, float eps, nbasr_stream_t stream)
-{
-    clear_error();
-    NBASR_REQUIRE(!stats_out || stats_ws, NBASR_ENULL,
-                  "nbasr_grouped_conv1d_fused_stats: stats_out needs the partial-statistics workspace stats_ws");
-    NBASR_REQUIRE(aligned16(stats_out), NBASR_EALIGN, "nbasr_grouped_conv1d_fused_stats: statistics buffers must be 16-byte aligned");
-    const int rc = grouped_node_impl("nbasr_grouped_conv1d_fused", x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups,
-                                     kernel, dilation, ln, ln_on_x, ln_on_skip0, stats_ws, NBASR_F32, 0, stream);
-    if (rc != NBASR_OK || !stats_out || batch == 0 || ld == 0) return rc;   // stats_ws alone: partials only, merge later with nbasr_grouped_stats_finalize
-    return nbasr_grouped_stats_finalize(stats_ws, stats_out, batch, channels, frames, ld, groups, eps, stream);
-}
-
-extern "C" int nbasr_grouped_stats_finalize_parts(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
-                                                  int groups, int groups_per_part, float eps, nbasr_stream_t stream)
+extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
+                                            int groups, int groups_per_part, float eps, nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && groups > 0 && channels % groups == 0 && frames >= 0 && ld >= frames, NBASR_EINVAL,
@@ -448,31 +432,7 @@ extern "C" int nbasr_grouped_stats_finalize_parts(const float* stats_ws, float* 
     return launch_status("nbasr_grouped_stats_finalize");
 }
 
-extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
-                                            int groups, float eps, nbasr_stream_t stream)
-{
-    return nbasr_grouped_stats_finalize_parts(stats_ws, stats_out, batch, channels, frames, ld, groups, 4, eps, stream);
-}
-
-extern "C" int nbasr_grouped_conv1d_fused_ln(const float* x, const float* w, const float* bias, const float* skip0,
-                                             const float* skip1, const float* skip2, float* y, int batch, int channels,
-                                             int frames, int ld, int groups, int kernel, int dilation,
-                                             const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream)
-{
-    return nbasr_grouped_conv1d_fused_stats(x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, kernel,
-                                            dilation, ln, ln_on_x, ln_on_skip0, nullptr, nullptr, 0.f, stream);
-}
-
-extern "C" int nbasr_grouped_conv1d_fused(const float* x, const float* w, const float* bias, const float* skip0,
-                                          const float* skip1, const float* skip2, float* y, int batch, int channels,
-                                          int frames, int ld, int groups, int kernel, int dilation,
-                                          nbasr_stream_t stream)
-{
-    return nbasr_grouped_conv1d_fused_ln(x, w, bias, skip0, skip1, skip2, y, batch, channels, frames, ld, groups, kernel,
-                                         dilation, nullptr, 0, 0, stream);
-}
-
-extern "C" int nbasr_skip_sum_v(const void* skip0, const void* skip1, const void* skip2, void* y, int batch,
+extern "C" int nbasr_skip_sum(const void* skip0, const void* skip1, const void* skip2, void* y, int batch,
                                 int channels, int frames, int ld, const nbasr_deferred_ln* ln, int ln_on_skip0, int dtype,
                                 nbasr_stream_t stream)
 {
@@ -487,7 +447,7 @@ extern "C" int nbasr_skip_sum_v(const void* skip0, const void* skip1, const void
                   "nbasr_skip_sum: pointers must be 16-byte aligned");
     const bool use_ln = ln && ln_on_skip0 && skip0;
     NBASR_REQUIRE(!use_ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
-                  "nbasr_skip_sum_ln: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
+                  "nbasr_skip_sum: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
     const size_t nchunks = static_cast<size_t>(batch) * channels * ld / fr;
     const unsigned blocks = static_cast<unsigned>(nchunks / 256 + 1 < 4096 ? nchunks / 256 + 1 : 4096);
     if (dtype == NBASR_BF16)
@@ -501,20 +461,7 @@ extern "C" int nbasr_skip_sum_v(const void* skip0, const void* skip1, const void
     return launch_status("nbasr_skip_sum");
 }
 
-extern "C" int nbasr_skip_sum_ln(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
-                                 int channels, int frames, int ld, const nbasr_deferred_ln* ln, int ln_on_skip0,
-                                 nbasr_stream_t stream)
-{
-    return nbasr_skip_sum_v(skip0, skip1, skip2, y, batch, channels, frames, ld, ln, ln_on_skip0, NBASR_F32, stream);
-}
-
-extern "C" int nbasr_skip_sum(const float* skip0, const float* skip1, const float* skip2, float* y, int batch,
-                              int channels, int frames, int ld, nbasr_stream_t stream)
-{
-    return nbasr_skip_sum_ln(skip0, skip1, skip2, y, batch, channels, frames, ld, nullptr, 0, stream);
-}
-
-extern "C" int nbasr_repitch_v(const void* src, void* dst, int rows, int frames, int ld_src, int ld_dst, int dtype,
+extern "C" int nbasr_repitch(const void* src, void* dst, int rows, int frames, int ld_src, int ld_dst, int dtype,
                                nbasr_stream_t stream)
 {
     clear_error();
@@ -532,8 +479,3 @@ extern "C" int nbasr_repitch_v(const void* src, void* dst, int rows, int frames,
     return launch_status("nbasr_repitch");
 }
 
-extern "C" int nbasr_repitch(const float* src, float* dst, int rows, int frames, int ld_src, int ld_dst,
-                             nbasr_stream_t stream)
-{
-    return nbasr_repitch_v(src, dst, rows, frames, ld_src, ld_dst, NBASR_F32, stream);
-}

@@ -248,7 +248,7 @@ static int launch_grouped(const GroupedArgs<T>& a, hipStream_t stream)
     if (a.ln_x.stats) { if (a.part) NBASR_LAUNCH_GROUPED(true, true); else NBASR_LAUNCH_GROUPED(true, false); }
     else              { if (a.part) NBASR_LAUNCH_GROUPED(false, true); else NBASR_LAUNCH_GROUPED(false, false); }
 #undef NBASR_LAUNCH_GROUPED
-    return launch_status("nbasr_grouped_conv1d_fused");
+    return launch_status("nbasr_grouped_conv1d_node");
 }
 
 template <typename T, int FPL, bool WPERM, int CG>
@@ -258,7 +258,7 @@ static int dispatch_kd(int kernel, int dilation, const GroupedArgs<T>& a, hipStr
     if (kernel == 5 && dilation == 2) return launch_grouped<T, FPL, WPERM, CG, 5, 2>(a, stream);
     if (kernel == 7 && dilation == 1) return launch_grouped<T, FPL, WPERM, CG, 7, 1>(a, stream);
     if (kernel == 7 && dilation == 2) return launch_grouped<T, FPL, WPERM, CG, 7, 2>(a, stream);
-    set_error("nbasr_grouped_conv1d_fused: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
+    set_error("nbasr_grouped_conv1d_node: unsupported (kernel=%d, dilation=%d); search space has k in {5,7}, d in {1,2}", kernel, dilation);
     return NBASR_EINVAL;
 }
 
@@ -272,7 +272,7 @@ int grouped_conv_variant(const GroupedArgs<T>& a, int kernel, int dilation, hipS
         case 10: return dispatch_kd<T, FPL, WPERM, 10>(kernel, dilation, a, stream);
         case 12: return dispatch_kd<T, FPL, WPERM, 12>(kernel, dilation, a, stream);
         default:
-            set_error("nbasr_grouped_conv1d_fused: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", a.channels / a.groups);
+            set_error("nbasr_grouped_conv1d_node: channels/groups=%d unsupported (model widths give 6, 8, 10, 12)", a.channels / a.groups);
             return NBASR_EINVAL;
     }
 }

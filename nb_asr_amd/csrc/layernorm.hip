@@ -222,24 +222,13 @@ static int layernorm_impl(const char* what, const void* x, const float* gamma, c
     return launch_status(what);
 }
 
-extern "C" int nbasr_layernorm_channels_v(const void* x, const float* gamma, const float* beta, void* y, int batch, int channels,
-                                          int frames, int ld, float eps, int in_dtype, int out_dtype, nbasr_stream_t stream)
-{
-    return layernorm_impl("nbasr_layernorm_channels_v", x, gamma, beta, y, nullptr, batch, channels, frames, ld, eps, stream, in_dtype, out_dtype);
-}
-
-extern "C" int nbasr_layernorm_channels(const float* x, const float* gamma, const float* beta, float* y, int batch,
-                                        int channels, int frames, int ld, float eps, nbasr_stream_t stream)
-{
-    return layernorm_impl("nbasr_layernorm_channels", x, gamma, beta, y, nullptr, batch, channels, frames, ld, eps, stream);
-}
-
-extern "C" int nbasr_layernorm_channels_absmax(const float* x, const float* gamma, const float* beta, float* y, float* absmax,
-                                               int batch, int channels, int frames, int ld, float eps, nbasr_stream_t stream)
+extern "C" int nbasr_layernorm_channels(const void* x, const float* gamma, const float* beta, void* y, float* absmax, int batch,
+                                        int channels, int frames, int ld, float eps, int in_dtype, int out_dtype, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(absmax != nullptr || batch == 0, NBASR_ENULL, "nbasr_layernorm_channels_absmax: absmax is NULL");
-    return layernorm_impl("nbasr_layernorm_channels_absmax", x, gamma, beta, y, absmax, batch, channels, frames, ld, eps, stream);
+    NBASR_REQUIRE(!absmax || (in_dtype == NBASR_F32 && out_dtype == NBASR_F32), NBASR_EINVAL,
+                  "nbasr_layernorm_channels: the max|y| by-product exists for fp32 -> fp32 only");
+    return layernorm_impl("nbasr_layernorm_channels", x, gamma, beta, y, absmax, batch, channels, frames, ld, eps, stream, in_dtype, out_dtype);
 }
 
 // ---- LayerNorm whose consumer is the fp16-split dense convolution: statistics + range bound, then normalise + split ------
@@ -404,28 +393,12 @@ extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, c
     return launch_status("nbasr_layernorm_split_image");
 }
 
-// absmax[b] = max |x[b, :]| over n contiguous floats per utterance (n % 4 == 0): the range information of the 2-way fp16
-// dense convolution when its input does not come out of the LayerNorm kernel (the model input)
-__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, unsigned* __restrict__ absmax, size_t n4)
-{
-    const int b = blockIdx.y;
-    const float4* __restrict__ xb = reinterpret_cast<const float4*>(x) + static_cast<size_t>(b) * n4;
-    float m = 0.f;
-    for (size_t i = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < n4; i += static_cast<size_t>(gridDim.x) * blockDim.x) {
-        const float4 v = xb[i];
-        m = fmaxf(fmaxf(m, fmaxf(finite_abs(v.x), finite_abs(v.y))), fmaxf(finite_abs(v.z), finite_abs(v.w)));
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
-}
-
 // Range summary of a caller-supplied tensor (the MODEL INPUT, the one activation whose range this library does not control):
 // range[b] = { max finite |x[b]|,  min over frames of (max over channels of |x[b, :, t]|) among frames where that is > 0,
 //              non-zero if x[b] holds an Inf or NaN,  unused }.
 // The scaled fp16 convolution keeps full fp32 precision for elements down to 2^-29 of the utterance's maximum; an utterance
 // whose quietest frame lies more than 2^20 below its loudest sample (or that holds non-finite values) is EXTREME and is
-// routed to the range-free 3-way bf16 split instead (nbasr_dense_conv1d_fused_packed_ranged), per utterance, on the device.
+// routed to the range-free 3-way bf16 split instead (nbasr_dense_conv1d_packed with x_range), per utterance, on the device.
 // 64 lanes x 4 frames wide, 4 channel slices deep: 16-byte loads, all of a thread's loads independent
 __global__ __launch_bounds__(256) void input_range_kernel(const float* __restrict__ x, unsigned* __restrict__ range,
                                                           int channels, int frames, int ld)
@@ -520,25 +493,7 @@ extern "C" int nbasr_split_image_ranged(const float* x, const float* x_range, vo
     return launch_status("nbasr_split_image_ranged");
 }
 
-extern "C" int nbasr_absmax(const float* x, float* absmax, int batch, long long n, nbasr_stream_t stream)
-{
-    clear_error();
-    NBASR_REQUIRE(batch >= 0 && n >= 0 && n % 4 == 0, NBASR_EINVAL, "nbasr_absmax: batch >= 0 and n %% 4 == 0 required (n=%lld)", n);
-    if (batch == 0) return NBASR_OK;
-    NBASR_REQUIRE(absmax, NBASR_ENULL, "nbasr_absmax: absmax is NULL");
-    const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * batch, as_stream(stream));
-    if (e != hipSuccess) { set_error("nbasr_absmax: hipMemsetAsync failed: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-    if (n == 0) return NBASR_OK;
-    NBASR_REQUIRE(x, NBASR_ENULL, "nbasr_absmax: x is NULL");
-    NBASR_REQUIRE(aligned16(x), NBASR_EALIGN, "nbasr_absmax: x must be 16-byte aligned");
-    NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_absmax: batch %d > 65535", batch);
-    const size_t n4 = static_cast<size_t>(n / 4);
-    const unsigned gx = static_cast<unsigned>(n4 / 1024 + 1 < 64 ? n4 / 1024 + 1 : 64);
-    hipLaunchKernelGGL(absmax_kernel, dim3(gx, batch), dim3(256), 0, as_stream(stream), x, reinterpret_cast<unsigned*>(absmax), n4);
-    return launch_status("nbasr_absmax");
-}
-
-extern "C" int nbasr_channel_stats_v(const void* x, float* stats, int batch, int channels, int frames, int ld, float eps, int dtype,
+extern "C" int nbasr_channel_stats(const void* x, float* stats, int batch, int channels, int frames, int ld, float eps, int dtype,
                                      nbasr_stream_t stream)
 {
     clear_error();
@@ -557,12 +512,6 @@ extern "C" int nbasr_channel_stats_v(const void* x, float* stats, int batch, int
     else
         hipLaunchKernelGGL(channel_stats_kernel<float>, grid, dim3(256), 0, as_stream(stream), static_cast<const float*>(x), stats, channels, frames, ld, eps);
     return launch_status("nbasr_channel_stats");
-}
-
-extern "C" int nbasr_channel_stats(const float* x, float* stats, int batch, int channels, int frames, int ld, float eps,
-                                   nbasr_stream_t stream)
-{
-    return nbasr_channel_stats_v(x, stats, batch, channels, frames, ld, eps, NBASR_F32, stream);
 }
 
 // ---- bf16 path: the dense convolution's operand image in ONE bf16 term --------------------------------------------------
@@ -651,7 +600,7 @@ extern "C" int nbasr_bf16_image(const void* x, const float* gamma, const float* 
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_bf16_image: batch %d > 65535", batch);
     const int nq = ld / fr;
     if (norm) {
-        const int rc = nbasr_channel_stats_v(x, stats, batch, channels, frames, ld, eps, dtype, stream);
+        const int rc = nbasr_channel_stats(x, stats, batch, channels, frames, ld, eps, dtype, stream);
         if (rc != NBASR_OK) return rc;
     }
     const dim3 grid((nq + 15) / 16, batch);

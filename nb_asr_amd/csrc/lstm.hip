@@ -4,18 +4,22 @@
 //  1. input projection for ALL frames at once: one fp32-MFMA GEMM (gemm_conv.hip, transposed store)
 //     gates[t][b][4H] = x[b][:, t] . W_ih^T + b_ih + b_hh      -- the reference's permute(0,2,1) is
 //     folded into the operand loader, nothing is transposed in memory;
-//  2. the recurrence: one launch per frame.  A workgroup owns 16 hidden units x 16 utterances and
-//     all four gates; its 8 waves split K = hidden eight ways (v_mfma_f32_16x16x4_f32, 16-byte
-//     operand loads: the 4 components of a lane's float4 feed 4 consecutive MFMAs, which is a
-//     k-permutation applied identically to W_hh and h and therefore leaves the sums unchanged),
-//     partial tiles are reduced through LDS and the gate nonlinearities, cell update and h store are
-//     fused behind the reduction.  h_{t-1} is read straight from the (batch, frames, hidden) output.
+//  2. the recurrence, on a fragment-ordered copy of W_hh: one launch per frame (lstm_step_packed_kernel), or all frames in one
+//     launch with W_hh resident in registers (lstm_seq_kernel).  A workgroup owns 8 hidden units x 16 utterances and all four
+//     gates; its 8 waves split K = hidden eight ways (v_mfma_f32_16x16x4_f32, 16-byte operand loads: the 4 components of a
+//     lane's float4 feed 4 consecutive MFMAs, a k-permutation applied identically to W_hh and h, which leaves the sums
+//     unchanged), partial tiles are reduced through LDS and the gate nonlinearities, cell update and h store are fused behind
+//     the reduction.
 //  3. head: logits = h . W^T + b on 16x16x4 MFMA tiles (classes padded to 64 in registers only).
 //
-// The recurrence is latency-bound (frames dependent steps); steps are plain stream-ordered launches.
+// The recurrence is latency-bound (frames dependent steps).
 #include "common.h"
 
+#include <mutex>
+
 namespace nbasr {
+
+constexpr int NBASR_MAX_DEVICES = 64;
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
@@ -24,109 +28,18 @@ int lstm_input_projection(const float* x, const float* w_ih, const float* b_ih, 
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + expf(-v)); }
 
-// grid: (ceil(hidden/16), ceil(batch/16)); block 512 = 8 waves, each owning one eighth of K per round
+// block 512 = 8 waves, each owning one eighth of K per round
 constexpr int LSTM_WAVES = 8;
 constexpr int LSTM_CHUNKS = 4;      // 16-deep k chunks per wave per round (8 waves x 4 x 16 = 512 >= hidden 500)
 
-__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_kernel(
-    const float* __restrict__ gates_in,   // (frames, batch, 4*hidden): input projection incl. biases, time-major
-    const float* __restrict__ w_hh,       // (4*hidden, hidden)
-    float* __restrict__ cell,             // (batch, hidden) running cell state
-    float* h_out,                         // (batch, frames, hidden); row t-1 is read, row t written
-    int batch, int frames, int hidden, int t)
-{
-    __shared__ float red[LSTM_WAVES][4][4][64];    // [wave][gate][reg][lane]
-
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i16 = lane & 15, kq = lane >> 4;
-    const int j0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-
-    // epilogue role of threads 0..255: one (hidden unit, utterance) each, lanes along the HIDDEN index so the gate
-    // reads, the cell state and the h store are 64-byte contiguous per 16 lanes.  Their gate pre-activations come
-    // from HBM (written once by the input GEMM): issue those loads FIRST so their latency hides under the matmul.
-    const int jj = threadIdx.x & 15, bb = (threadIdx.x >> 4) & 15;
-    const int ej = j0 + jj, eb = b0 + bb;
-    const bool e_ok = threadIdx.x < 256 && ej < hidden && eb < batch;
-    float pre[4] = {0.f, 0.f, 0.f, 0.f};
-    float c_prev = 0.f;
-    if (e_ok) {
-        const float* gin = gates_in + (static_cast<size_t>(t) * batch + eb) * (4 * hidden);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = gin[g * hidden + ej];
-        if (t > 0) c_prev = cell[static_cast<size_t>(eb) * hidden + ej];
-    }
-
-    floatx4 acc[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) acc[g] = floatx4{0.f, 0.f, 0.f, 0.f};
-
-    if (t > 0) {
-        const int kchunks = (hidden + 15) / 16;              // 16 k per chunk
-        const bool row_ok = (j0 + i16) < hidden;
-        const bool col_ok = (b0 + i16) < batch;
-        const float* hrow = h_out + (static_cast<size_t>(b0 + i16) * frames + (t - 1)) * hidden;
-        // wave w owns chunks [4w + 32r, 4w + 32r + 4) of round r; all 20 16-byte loads of a round are issued before
-        // the first MFMA so their L2 latencies overlap (one round covers hidden <= 512)
-        for (int base = wave * LSTM_CHUNKS; base < kchunks; base += LSTM_WAVES * LSTM_CHUNKS) {
-            float4 hv[LSTM_CHUNKS], wv[LSTM_CHUNKS][4];
-#pragma unroll
-            for (int c = 0; c < LSTM_CHUNKS; ++c) {
-                const int k = (base + c) * 16 + kq * 4;
-                const bool kok = k < hidden;                  // hidden % 4 == 0: whole float4 in or out
-                hv[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (col_ok && kok) hv[c] = *reinterpret_cast<const float4*>(hrow + k);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    wv[c][g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (row_ok && kok)
-                        wv[c][g] = *reinterpret_cast<const float4*>(w_hh + (static_cast<size_t>(g) * hidden + j0 + i16) * hidden + k);
-                }
-            }
-            // consecutive MFMAs go to different accumulators (40-cycle dependent latency vs 32-cycle issue)
-#pragma unroll
-            for (int c = 0; c < LSTM_CHUNKS; ++c) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].x, hv[c].x, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].y, hv[c].y, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].z, hv[c].z, acc[g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][g].w, hv[c].w, acc[g], 0, 0, 0);
-            }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][g][r][lane] = acc[g][r];
-    __syncthreads();
-
-    // C/D layout of the tiles: col = lane & 15 (utterance), row = (lane >> 4) * 4 + reg (hidden unit)
-    //   =>  element (jj, bb) sits at reg = jj & 3, lane = (jj >> 2) * 16 + bb
-    if (!e_ok) return;
-    const int pr = jj & 3, pl = (jj >> 2) * 16 + bb;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        float s = red[0][g][pr][pl];
-#pragma unroll
-        for (int w = 1; w < LSTM_WAVES; ++w) s += red[w][g][pr][pl];
-        pre[g] += s;
-    }
-    const float c_new = sigmoidf_(pre[1]) * c_prev + sigmoidf_(pre[0]) * tanhf(pre[2]);
-    const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
-    cell[static_cast<size_t>(eb) * hidden + ej] = c_new;
-    h_out[(static_cast<size_t>(eb) * frames + t) * hidden + ej] = h_new;
-}
-
 // ---- the recurrence on a fragment-ordered copy of w_hh -------------------------------------------------------------------
-// Stamps on the kernel above: the 160 operand wave-loads of a workgroup (each touching 16 rows x 64 B of the (4H, H) matrix)
-// need 4 100 - 8 000 cycles to land -- the L2 -> CU fill rate (~20 B/clk per CU), not latency -- while half of the CUs have
-// no workgroup at all.  So (1) the weight is re-laid-out ONCE so that every wave-load is 1 KiB contiguous, and (2) a
-// workgroup owns 8 hidden units instead of 16 (252 workgroups at H = 500, B = 64: 96 KiB of operands each instead of 160).
-// MFMA tile rows are (hidden unit, gate) = (row >> 2, row & 3), so the four gates of a (unit, utterance) pair sit in the four
-// accumulator registers of ONE lane (C/D row = (lane >> 4) * 4 + reg): after the cross-wave K reduction the cell update
-// needs no further exchange.  Same fmaf chains per output as the kernel above up to the order of the 8 wave partials.
+// Stamps on the first version of the step kernel (16 hidden units per workgroup, operands read from the (4H, H) matrix as it lies):
+// its 160 operand wave-loads per workgroup (each touching 16 rows x 64 B) needed 4 100 - 8 000 cycles to land -- the L2 -> CU fill
+// rate (~20 B/clk per CU), not latency -- while half of the CUs had no workgroup at all.  So (1) the weight is re-laid-out ONCE so
+// that every wave-load is 1 KiB contiguous, and (2) a workgroup owns 8 hidden units (252 workgroups at H = 500, B = 64: 96 KiB of
+// operands each instead of 160).  MFMA tile rows are (hidden unit, gate) = (row >> 2, row & 3), so the four gates of a (unit,
+// utterance) pair sit in the four accumulator registers of ONE lane (C/D row = (lane >> 4) * 4 + reg): after the cross-wave K
+// reduction the cell update needs no further exchange.
 constexpr int LSTMP_HU = 8;                                   // hidden units per workgroup (2 MFMA row tiles of 4 units x 4 gates)
 
 // packed[((slice * kchunks_p + kc) * 2 + mt) * 64 + lane] (float4) = w_hh[gate*H + unit][kc*16 + (lane >> 4)*4 .. +3] with
@@ -296,6 +209,154 @@ __global__ __launch_bounds__(256) void head_kernel(
     }
 }
 
+// ---- the whole recurrence in ONE launch ------------------------------------------------------------------------------------------
+// One launch per frame pays, per frame, a kernel boundary (1.5-1.9 us) and the L2 -> CU fill of the workgroup's 64 KiB slice of w_hh
+// (~2 us at ~20 B/clk per CU) for 0.85 us of matrix work.  Here the grid of lstm_step_packed_kernel stays resident for all frames:
+//   * a workgroup = (slice of 8 hidden units, tile of 16 utterances), its w_hh fragments loaded ONCE into registers (32 per lane),
+//     its cell state kept in registers;
+//   * h_t is exchanged through a double-buffered image in fragment order, hx[t & 1][k quad][utterance] (float4 = 4 consecutive k),
+//     so that a wave's operand load is 1 KiB contiguous.  Utterance tiles are independent: only the (<= 64) slices of ONE tile
+//     synchronise, each step, through one flag word per slice;
+//   * hand-off (the write-through form of the programming guide's inter-workgroup recipe; placement-independent): the two epilogue
+//     waves store their 16 x 16-byte pieces of the image `sc1`, drain them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier,
+//     ONE lane stores the flag (= frames done) `sc1`; a consumer's wave 0 polls the tile's flags with ONE relaxed agent-scope load
+//     per lane, the workgroup meets at a barrier, then every load of the image is a 16-byte `sc1` buffer load (never L1-served).
+//     Two buffers suffice: a workgroup can only start step t + 1 (and overwrite image (t + 1) & 1) after every slice has published
+//     step t, i.e. has finished reading image (t - 1) & 1;
+//   * every spin is bounded (1 s of the constant 100 MHz clock): on a timeout the workgroup raises the status word, fills the rest of
+//     its h rows with NaN and leaves; nbasr_lstm_seq_status reports it.
+// Same MFMA sequence per wave, same order of the eight wave partials and the same gate arithmetic as lstm_step_packed_kernel:
+// bit-identical h.  Needs hidden <= 512 (all of K in ONE round of the 8 waves' 4 chunks) and <= 256 workgroups (co-residency).
+constexpr int LSTMS_FLAGS = 64;                              // flag words per utterance tile (one per slice)
+constexpr int LSTMS_QUADS = LSTM_WAVES * LSTM_CHUNKS * 4;    // k quads of an exchange image (128: hidden <= 512)
+constexpr int LSTMS_IMAGE_FLOATS = LSTMS_QUADS * 16 * 4;     // one image of one tile (32 KiB)
+constexpr int LSTMS_HEADER_WORDS = 64;                       // [0] status
+constexpr unsigned long long LSTMS_TIMEOUT_TICKS = 100000000ull;
+
+typedef unsigned lstm_u4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
+    const float* __restrict__ gates_in,   // (frames, batch, 4*hidden)
+    const float4* __restrict__ wp,        // packed w_hh
+    float* __restrict__ cell, float* __restrict__ h_out, unsigned* status, unsigned* flags, float* hx,
+    int batch, int frames, int hidden, int kchunks_p)
+{
+    __shared__ float4 red[LSTM_WAVES][2][64];    // [wave][row tile][lane] -> the lane's 4 accumulator registers (= gates)
+    __shared__ int stop;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int slice = blockIdx.x, tile = blockIdx.y, nslices = gridDim.x;
+    const int b0 = tile * 16;
+    if (threadIdx.x == 0) stop = 0;
+
+    float4 wv[LSTM_CHUNKS][2];
+    {   // (a narrow layer has fewer chunks than the 8 waves cover: the surplus waves hold zeros and multiply the image's zero quads)
+        const bool mine = wave * LSTM_CHUNKS < kchunks_p;
+        const float4* wslice = wp + (static_cast<size_t>(slice) * kchunks_p + (mine ? wave * LSTM_CHUNKS : 0)) * 2 * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < LSTM_CHUNKS; ++c) {
+            wv[c][0] = mine ? wslice[c * 128] : make_float4(0.f, 0.f, 0.f, 0.f);
+            wv[c][1] = mine ? wslice[c * 128 + 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+
+    // epilogue role of waves 0 and 1: wave m owns row tile m -- lane = (unit kq of the tile, utterance i16), its 4 gates are the 4
+    // accumulator registers.  Every wave issues the (clamped, branch-free) gate loads; only the epilogue waves use them.
+    const int eu = slice * LSTMP_HU + (wave & 1) * 4 + kq, eb = b0 + i16;
+    const bool e_ok = eu < hidden && eb < batch;
+    const size_t gate_off = static_cast<size_t>(min(eb, batch - 1)) * (4 * hidden) + min(eu, hidden - 1);
+    const int quad = slice * 2 + (wave & 1);
+    const bool q_ok = kq == 0 && quad * 4 < hidden && eb < batch;      // lanes 0..15 store the tile's 4 units of one utterance
+    float c_state = 0.f;
+
+    float* const image = hx + static_cast<size_t>(tile) * 2 * LSTMS_IMAGE_FLOATS;
+    const __amdgpu_buffer_rsrc_t hxr = __builtin_amdgcn_make_buffer_rsrc(image, 0, 2 * LSTMS_IMAGE_FLOATS * 4, 0x00020000);
+    unsigned* const tflags = flags + tile * LSTMS_FLAGS;
+    __syncthreads();
+
+    int t = 0;
+    for (; t < frames; ++t) {
+        float pre[4];
+        {
+            const float* gin = gates_in + static_cast<size_t>(t) * batch * (4 * hidden) + gate_off;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) pre[g] = gin[g * hidden];
+        }
+        floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
+        if (t > 0) {
+            if (wave == 0) {                      // every slice of this tile has published h_(t-1): its flag reads >= t
+                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+                bool ok = false;
+                for (;;) {
+                    const unsigned v = lane < nslices ? __hip_atomic_load(tflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+                    ok = __all(v >= static_cast<unsigned>(t));
+                    if (ok || __builtin_amdgcn_s_memrealtime() - t_start > LSTMS_TIMEOUT_TICKS) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok && lane == 0) { stop = 1; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+            }
+            __syncthreads();
+            if (stop) break;                      // (LDS, read behind the barrier; workgroup-uniform)
+            const int img = ((t - 1) & 1) * LSTMS_QUADS;
+            floatx4 hr[LSTM_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+                const int k4 = (wave * LSTM_CHUNKS + c) * 4 + kq;
+                // (bit_cast of the builtin's own result type: assigned to an `unsigned` ext-vector it degrades to ONE dword, splatted)
+                hr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(hxr, ((img + k4) * 16 + i16) * 16, 0, 16));   // aux 16 = sc1
+            }
+            // all four loads in flight together (left alone, hipcc issues load / wait / 8 MFMAs four times over: 4 round trips per step)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]));
+            float4 hv[LSTM_CHUNKS];
+#pragma unroll
+            for (int c = 0; c < LSTM_CHUNKS; ++c) hv[c] = make_float4(hr[c][0], hr[c][1], hr[c][2], hr[c][3]);
+#pragma unroll
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].x, hv[c].x, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].y, hv[c].y, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].z, hv[c].z, acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].w, hv[c].w, acc[m], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m) red[wave][m][lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        __syncthreads();
+        if (wave < 2) {
+            float4 s = red[0][wave][lane];
+#pragma unroll
+            for (int w = 1; w < LSTM_WAVES; ++w) { const float4 r = red[w][wave][lane]; s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w; }
+            pre[0] += s.x; pre[1] += s.y; pre[2] += s.z; pre[3] += s.w;
+            const float c_new = sigmoidf_(pre[1]) * c_state + sigmoidf_(pre[0]) * tanhf(pre[2]);
+            const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
+            c_state = c_new;
+            const float4 hq = make_float4(__shfl(h_new, i16), __shfl(h_new, i16 + 16), __shfl(h_new, i16 + 32), __shfl(h_new, i16 + 48));
+            if (q_ok) {
+                *reinterpret_cast<float4*>(h_out + (static_cast<size_t>(eb) * frames + t) * hidden + quad * 4) = hq;
+                const lstm_u4 bits = {__builtin_bit_cast(unsigned, hq.x), __builtin_bit_cast(unsigned, hq.y), __builtin_bit_cast(unsigned, hq.z),
+                                      __builtin_bit_cast(unsigned, hq.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(bits, hxr, (((t & 1) * LSTMS_QUADS + quad) * 16 + i16) * 16, 0, 16);   // write-through
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                          // both storing waves have drained their stores
+        if (threadIdx.x == 0) __hip_atomic_store(tflags + slice, static_cast<unsigned>(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < frames) {                             // timed out: make the failure visible in the output too
+        if (wave < 2 && q_ok) {
+            const float nan = __builtin_nanf("");
+            for (int u = t; u < frames; ++u)
+                *reinterpret_cast<float4*>(h_out + (static_cast<size_t>(eb) * frames + u) * hidden + quad * 4) = make_float4(nan, nan, nan, nan);
+        }
+        return;
+    }
+    if (wave < 2 && e_ok) cell[static_cast<size_t>(eb) * hidden + eu] = c_state;
+}
+
 }  // namespace nbasr
 
 using namespace nbasr;
@@ -319,21 +380,6 @@ extern "C" int nbasr_lstm_input_projection(const float* x, const float* w_ih, co
     NBASR_REQUIRE(aligned16(w_ih), NBASR_EALIGN, "nbasr_lstm_input_projection: w_ih must be 16-byte aligned");
     NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_lstm_input_projection: deferred LayerNorm needs stats, gamma and beta");
     return lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, 4 * hidden, ln_ref(ln, true), as_stream(stream));
-}
-
-extern "C" int nbasr_lstm_recurrence(const float* gates_ws, const float* w_hh, float* cell_ws, float* h_out, int batch,
-                                     int frames, int hidden, nbasr_stream_t stream)
-{
-    clear_error();
-    const int rc = lstm_check("nbasr_lstm_recurrence", batch, 4, frames, frames, hidden);
-    if (rc != NBASR_OK) return rc;
-    if (batch == 0 || frames == 0) return NBASR_OK;
-    NBASR_REQUIRE(gates_ws && w_hh && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_recurrence: NULL pointer");
-    NBASR_REQUIRE(aligned16(w_hh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence: w_hh, h_out must be 16-byte aligned");
-    const dim3 grid((hidden + 15) / 16, (batch + 15) / 16);
-    for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, t);
-    return launch_status("nbasr_lstm_recurrence");
 }
 
 static inline int lstm_slices(int hidden) { return (hidden + LSTMP_HU - 1) / LSTMP_HU; }
@@ -372,21 +418,73 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     return launch_status("nbasr_lstm_recurrence_packed");
 }
 
-extern "C" int nbasr_lstm_forward_ln(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
-                                     const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
-                                     int c_in, int frames, int ld, int hidden, const nbasr_deferred_ln* ln,
-                                     nbasr_stream_t stream)
+static bool lstm_seq_fits(int batch, int hidden)
 {
-    const int rc = nbasr_lstm_input_projection(x, w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, hidden, ln, stream);
-    if (rc != NBASR_OK) return rc;
-    return nbasr_lstm_recurrence(gates_ws, w_hh, cell_ws, h_out, batch, frames, hidden, stream);
+    if (batch <= 0 || hidden <= 0 || hidden % 4) return false;
+    if (lstm_kchunks_p(hidden) > LSTM_WAVES * LSTM_CHUNKS || lstm_slices(hidden) > LSTMS_FLAGS) return false;
+    return static_cast<long>(lstm_slices(hidden)) * ((batch + 15) / 16) <= 256;      // every workgroup resident: one per CU
 }
 
-extern "C" int nbasr_lstm_forward(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
-                                  const float* b_hh, float* gates_ws, float* cell_ws, float* h_out, int batch,
-                                  int c_in, int frames, int ld, int hidden, nbasr_stream_t stream)
+extern "C" size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden)
 {
-    return nbasr_lstm_forward_ln(x, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out, batch, c_in, frames, ld, hidden, nullptr, stream);
+    if (!lstm_seq_fits(batch, hidden)) return 0;
+    const size_t tiles = (batch + 15) / 16;
+    return (LSTMS_HEADER_WORDS + tiles * LSTMS_FLAGS) * sizeof(unsigned) + tiles * 2 * LSTMS_IMAGE_FLOATS * sizeof(float);
+}
+
+extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
+                                         int batch, int frames, int hidden, nbasr_stream_t stream)
+{
+    clear_error();
+    const int rc = lstm_check("nbasr_lstm_recurrence_seq", batch, 4, frames, frames, hidden);
+    if (rc != NBASR_OK) return rc;
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(gates_ws && packed_whh && cell_ws && h_out && seq_ws, NBASR_ENULL, "nbasr_lstm_recurrence_seq: NULL pointer");
+    NBASR_REQUIRE(aligned16(packed_whh) && aligned16(h_out) && aligned16(seq_ws), NBASR_EALIGN,
+                  "nbasr_lstm_recurrence_seq: packed_whh, h_out, seq_ws must be 16-byte aligned");
+    NBASR_REQUIRE(lstm_seq_fits(batch, hidden), NBASR_EINVAL,
+                  "nbasr_lstm_recurrence_seq: batch=%d hidden=%d does not fit one resident grid (hidden <= 512, ceil(hidden/8) * ceil(batch/16) "
+                  "<= 256 workgroups); use nbasr_lstm_recurrence_packed", batch, hidden);
+    const size_t tiles = (batch + 15) / 16;
+    unsigned* const words = static_cast<unsigned*>(seq_ws);
+    float* const hx = reinterpret_cast<float*>(words + LSTMS_HEADER_WORDS + tiles * LSTMS_FLAGS);
+    // Two of these grids fit the chip together, three do not, and a grid whose workgroups are only partly resident waits for peers that
+    // cannot start: launches of this kernel from different streams of the process are therefore chained, stream-ordered (each waits for
+    // the event behind the previous one; no host synchronisation).  A stream under capture cannot take part in that chain.
+    static std::mutex chain_mutex;
+    static hipEvent_t chain_done[NBASR_MAX_DEVICES] = {};
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    hipError_t e = hipStreamIsCapturing(as_stream(stream), &capturing);
+    NBASR_REQUIRE(e == hipSuccess && capturing == hipStreamCaptureStatusNone, NBASR_EINVAL,
+                  "nbasr_lstm_recurrence_seq: the stream is being captured; a captured graph uses nbasr_lstm_recurrence_packed");
+    int device = 0;
+    e = hipGetDevice(&device);
+    NBASR_REQUIRE(e == hipSuccess && device >= 0 && device < NBASR_MAX_DEVICES, NBASR_EINVAL, "nbasr_lstm_recurrence_seq: device %d out of range", device);
+    std::lock_guard<std::mutex> lock(chain_mutex);
+    hipEvent_t& done = chain_done[device];
+    if (done == nullptr) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
+    else e = hipStreamWaitEvent(as_stream(stream), done, 0);
+    if (e == hipSuccess) e = hipMemsetAsync(seq_ws, 0, nbasr_lstm_seq_workspace_bytes(batch, hidden), as_stream(stream));
+    if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    hipLaunchKernelGGL(lstm_seq_kernel, dim3(lstm_slices(hidden), static_cast<unsigned>(tiles)), dim3(64 * LSTM_WAVES), 0, as_stream(stream),
+                       gates_ws, static_cast<const float4*>(packed_whh), cell_ws, h_out, words, words + LSTMS_HEADER_WORDS, hx, batch, frames, hidden,
+                       lstm_kchunks_p(hidden));
+    e = hipEventRecord(done, as_stream(stream));
+    if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: hipEventRecord: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    return launch_status("nbasr_lstm_recurrence_seq");
+}
+
+extern "C" int nbasr_lstm_seq_status(const void* seq_ws, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(seq_ws, NBASR_ENULL, "nbasr_lstm_seq_status: NULL pointer");
+    unsigned word = 0;
+    hipError_t e = hipMemcpyAsync(&word, seq_ws, sizeof(word), hipMemcpyDeviceToHost, as_stream(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(as_stream(stream));
+    if (e != hipSuccess) { set_error("nbasr_lstm_seq_status: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    NBASR_REQUIRE(word == 0, NBASR_EINVAL, "nbasr_lstm_seq_status: a step of the one-launch recurrence timed out waiting for its peers "
+                  "(status %u): the grid was not co-resident", word);
+    return NBASR_OK;
 }
 
 extern "C" int nbasr_linear_head(const float* h, const float* w, const float* bias, float* logits, int rows,
@@ -405,9 +503,9 @@ extern "C" int nbasr_linear_head(const float* h, const float* w, const float* bi
     return launch_status("nbasr_linear_head");
 }
 
-extern "C" int nbasr_linear_head_bct_ln(const float* x, const float* w, const float* bias, float* logits, int batch,
-                                        int features, int frames, int ld, int classes, const nbasr_deferred_ln* ln,
-                                        nbasr_stream_t stream)
+extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits, int batch,
+                                     int features, int frames, int ld, int classes, const nbasr_deferred_ln* ln,
+                                     nbasr_stream_t stream)
 {
     clear_error();
     NBASR_REQUIRE(batch >= 0 && features > 0 && frames >= 0 && ld >= frames && classes > 0 && classes <= 64, NBASR_EINVAL,
@@ -415,7 +513,7 @@ extern "C" int nbasr_linear_head_bct_ln(const float* x, const float* w, const fl
     if (batch == 0 || frames == 0) return NBASR_OK;
     NBASR_REQUIRE(x && w && bias && logits, NBASR_ENULL, "nbasr_linear_head_bct: NULL pointer");
     NBASR_REQUIRE(features % 4 == 0 && aligned16(w), NBASR_EALIGN, "nbasr_linear_head_bct: features must be a multiple of 4, w 16-byte aligned");
-    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_linear_head_bct_ln: deferred LayerNorm needs stats, gamma and beta");
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta), NBASR_ENULL, "nbasr_linear_head_bct: deferred LayerNorm needs stats, gamma and beta");
     const long long rows = static_cast<long long>(batch) * frames;
     if (rows == 0) return NBASR_OK;
     hipLaunchKernelGGL(head_kernel<true>, dim3(static_cast<unsigned>((rows + 63) / 64)), dim3(256), 0, as_stream(stream),
@@ -423,8 +521,3 @@ extern "C" int nbasr_linear_head_bct_ln(const float* x, const float* w, const fl
     return launch_status("nbasr_linear_head_bct");
 }
 
-extern "C" int nbasr_linear_head_bct(const float* x, const float* w, const float* bias, float* logits, int batch,
-                                     int features, int frames, int ld, int classes, nbasr_stream_t stream)
-{
-    return nbasr_linear_head_bct_ln(x, w, bias, logits, batch, features, frames, ld, classes, nullptr, stream);
-}

@@ -188,6 +188,13 @@ class ForwardPlan:
         # touch HBM and the cell's LayerNorm statistics come out of the same launch (grouped_cell.hip, round 3).  Bit-identical to
         # the three node launches; NBASR_CELL_FUSION=0 turns it off (A/B)
         self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '1') != '0'
+        # the LSTM recurrence in ONE launch (w_hh resident in registers; nbasr.h: nbasr_lstm_recurrence_seq): 'auto' = in the plain forward
+        # (latency: 4.2 instead of 5.6 us per frame), not in a pipelined tail, whose resident grid would hold CUs the next batch's
+        # encoder needs (measured: -3...-8 % utterances/s at 8-64 utterances); '0' = one launch per frame everywhere; '1' = wherever
+        # the form applies
+        self.lstm_seq_mode = os.environ.get('NBASR_LSTM_SEQ', 'auto')
+        if self.lstm_seq_mode not in ('auto', '0', '1'):
+            raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', '0' or '1'")
         # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_F32_VARIANT=<bits> forces one (0: the
         # default kernel everywhere)
         self.gc_table = _GC_TABLE
@@ -223,6 +230,16 @@ class ForwardPlan:
                 t.record_stream(self.side_stream)
             self.grow_count += 1
         return t
+
+    def _recurrence(self, gates, packed_hh, hidden, pipe, capturing=False):
+        """The LSTM recurrence into ``self.h_out``: all frames in one launch where that form applies and pays, else one launch per frame."""
+        # (launches of the resident grid are chained across the process's streams by an event, which a graph capture cannot hold)
+        use = self.lstm_seq_mode != '0' and not capturing and (self.lstm_seq_mode == '1' or not pipe)
+        nbytes = hip.load_library().nbasr_lstm_seq_workspace_bytes(self.batch, hidden) if use else 0
+        if nbytes:
+            ws = self._buf('lstm_seq', nbytes, torch.uint8)
+            return hip.lstm_recurrence_seq(gates, packed_hh, self.cell_ws, self.h_out, ws)
+        return hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out)
 
     def wait_tails(self):
         """Make the current stream wait for every pipelined LSTM tail enqueued through this plan (a plain
@@ -528,7 +545,7 @@ class ForwardPlan:
             return t
         return self._host(alloc, produces=True)
 
-    _TAPE_ENV = ('NBASR_GC_F32_VARIANT',)
+    _TAPE_ENV = ('NBASR_GC_F32_VARIANT',)       # (NBASR_LSTM_SEQ and the other plan switches are read once, when the plan is built)
 
     def _tape_key(self, model, x, pipelined):
         """Everything the recorded launch sequence depends on; None: this call cannot use a tape."""
@@ -762,7 +779,7 @@ class ForwardPlan:
                     tail_ctx.__enter__()
                 packed_hh = self._packed_whh(layer.weight_hh_l0)
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
+                            lambda: self._recurrence(gates, packed_hh, layer.hidden_size, pipe, _capturing))
                 act, pending = self.h_out, None            # (batch, frames, hidden)
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)
@@ -838,7 +855,7 @@ class ForwardPlan:
         act, act_frames, cur = x, self.frames, None
         if x.shape[-1] % 8 or x.data_ptr() % 16:
             cur = 2
-            act = hip.repitch_v(x, self._view16(cur, x.shape[1], self.frames), self.frames)
+            act = hip.repitch(x, self._view16(cur, x.shape[1], self.frames), self.frames)
         pending, image = None, None            # deferred LayerNorm of `act` / operand image holding (the LayerNorm of) `act`
         self._stat_turn = 0
         pipe_k, tail_ctx, logits = None, None, None
@@ -911,7 +928,7 @@ class ForwardPlan:
                             self._timed('grouped_conv', meta, lambda: hip.grouped_conv1d_node(
                                 last, wt, bs, skips, view, act_frames, op.groups, op.kernel_size, op.dilation, ln, on_x, on_s0, ws, variant))
                         elif isinstance(op, Zero):
-                            self._timed('skip_sum', meta, lambda: hip.skip_sum_v(skips, view, act_frames, ln if on_s0 else None, on_s0))
+                            self._timed('skip_sum', meta, lambda: hip.skip_sum(skips, view, act_frames, ln if on_s0 else None, on_s0))
                         elif isinstance(op, Linear):
                             # no bf16 GEMM for the per-frame linear map yet (BASELINE config 4 does not use the op): bridge through
                             # the fp32 one.  x -> fp32 (its pending LayerNorm applied on the way), the fp16-split GEMM, the op's
@@ -921,7 +938,7 @@ class ForwardPlan:
                             x32 = self._buf('bridge_x32', n)[:n].view(b_, c_, ld_)
                             y32 = self._buf('bridge_y32', n)[:n].view(b_, c_, ld_)
                             if on_x:
-                                hip.layernorm_channels_v(last, ln[1], ln[2], x32, act_frames, LN_EPS)
+                                hip.layernorm_channels(last, ln[1], ln[2], x32, act_frames, LN_EPS)
                             else:
                                 hip.convert(last, x32)
                             wl = op.linear.weight
@@ -934,11 +951,11 @@ class ForwardPlan:
                                 op16 = self._buf('bridge_op16', n, bf16)[:n].view(b_, c_, ld_)
                                 hip.convert(y32, op16)
                                 if len(skips) <= 2:
-                                    hip.skip_sum_v(skips + [op16], view, act_frames, ln if on_s0 else None, on_s0)
+                                    hip.skip_sum(skips + [op16], view, act_frames, ln if on_s0 else None, on_s0)
                                 else:
                                     part = self._buf('bridge_sum16', n, bf16)[:n].view(b_, c_, ld_)
-                                    hip.skip_sum_v(skips, part, act_frames, ln if on_s0 else None, on_s0)
-                                    hip.skip_sum_v([op16, part], view, act_frames)
+                                    hip.skip_sum(skips, part, act_frames, ln if on_s0 else None, on_s0)
+                                    hip.skip_sum([op16, part], view, act_frames)
                         else:
                             raise TypeError(f'unsupported node operation {type(op).__name__}')
                         outs.append(view)
@@ -959,7 +976,7 @@ class ForwardPlan:
                     src = act
                     if norm is not None:
                         g32, b32 = self._f32(norm.weight), self._f32(norm.bias)
-                        self._timed('layernorm', meta, lambda: hip.layernorm_channels_v(src, g32, b32, enc, act_frames, norm.eps))
+                        self._timed('layernorm', meta, lambda: hip.layernorm_channels(src, g32, b32, enc, act_frames, norm.eps))
                     else:
                         hip.convert(src, enc)
                     act, cur, act_is_f32 = enc, None, True
@@ -980,21 +997,21 @@ class ForwardPlan:
                         image = self._bufs['image16']
                         if taps is not None:
                             copy = torch.empty_like(act)
-                            hip.layernorm_channels_v(act, g32, b32, copy, act_frames, norm.eps)
+                            hip.layernorm_channels(act, g32, b32, copy, act_frames, norm.eps)
                             taps[idx] = copy[:, :, :act_frames].clone()
                     elif self._cheap_consumer(nxt):
                         if epilogue_stats:
                             self._timed('stats_finalize', meta, lambda: hip.grouped_stats_finalize(self.stats_ws, stats, c, act_frames,
                                                                                                  last_op.groups, norm.eps, cell_gpp or 4))
                         else:
-                            self._timed('channel_stats', meta, lambda: hip.channel_stats_v(src, stats, act_frames, norm.eps))
+                            self._timed('channel_stats', meta, lambda: hip.channel_stats(src, stats, act_frames, norm.eps))
                         pending = (stats, g32, b32)
                         if taps is not None:
                             copy = torch.empty_like(act)
-                            hip.layernorm_channels_v(act, g32, b32, copy, act_frames, norm.eps)
+                            hip.layernorm_channels(act, g32, b32, copy, act_frames, norm.eps)
                             taps[idx] = copy[:, :, :act_frames].clone()
                     else:
-                        self._timed('layernorm', meta, lambda: hip.layernorm_channels_v(src, g32, b32, src, act_frames, norm.eps))
+                        self._timed('layernorm', meta, lambda: hip.layernorm_channels(src, g32, b32, src, act_frames, norm.eps))
                         if taps is not None:
                             taps[idx] = act[:, :, :act_frames].clone()
             elif isinstance(layer, nn.Dropout):
@@ -1017,7 +1034,7 @@ class ForwardPlan:
                     tail_ctx.__enter__()
                 packed_hh = self._cached(layer.weight_hh_l0, 'whh', lambda: hip.lstm_pack_whh(w_hh32))
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out))
+                            lambda: self._recurrence(gates, packed_hh, layer.hidden_size, pipe, capturing))
                 act = self.h_out
                 if taps is not None:
                     taps[idx] = act.permute(0, 2, 1).clone()

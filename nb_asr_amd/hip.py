@@ -15,7 +15,7 @@ import pathlib
 import torch
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libnbasr_hip.so'
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
 _c_int = ctypes.c_int
@@ -35,56 +35,48 @@ SIGNATURES = {
     'nbasr_last_error': (ctypes.c_char_p, []),
     'nbasr_pad_amounts': (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'nbasr_output_frames': (_c_int, [_c_int]),
-    'nbasr_grouped_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_stream]),
-    'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
+    # LayerNorm, statistics, node ops (storage-type generic: a trailing dtype code)
+    'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_int, _c_stream]),
+    'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
+    'nbasr_grouped_stats_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_grouped_stats_finalize': (_c_int, [_c_float_p] * 2 + [_c_int] * 6 + [ctypes.c_float, _c_stream]),
+    'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
+    'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_grouped_cell_fits': (_c_int, [_c_int] * 3),
+    'nbasr_grouped_cell_fused': (_c_int, [_c_float_p, _c_float_p, _c_float_p, _c_int, _c_int, _c_float_p, _c_float_p, _c_int, _c_int,
+                                          _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_float_p, _c_int, _c_stream]),
+    'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_convert': (_c_int, [_c_float_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_stream]),
+    # dense convolutions
+    'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 5),
+    'nbasr_pack_dense_weights': (_c_int, [_c_int] + [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_dense_conv1d_packed': (_c_int, [_c_int, _c_float_p, _c_int] + [_c_float_p] * 8 + [_c_int] * 9 + [_c_ln_p, _c_stream]),
+    'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_split_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_layernorm_split_image': (_c_int, [_c_float_p] * 6 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
-    'nbasr_dense_conv1d_fused_packed_f16_img': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
-    'nbasr_packed_dense_weights_bytes_f16_rows': (ctypes.c_size_t, [_c_int] * 4),
-    'nbasr_pack_dense_weights_f16_rows': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
-    'nbasr_dense_conv1d_fused_packed_f16_img_rows': (_c_int, [_c_float_p] * 5 + [_c_int] * 9 + [_c_stream]),
-    'nbasr_absmax': (_c_int, [_c_float_p] * 2 + [_c_int, ctypes.c_longlong, _c_stream]),
-    'nbasr_layernorm_channels_absmax': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
-    'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
-    'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 3),
-    'nbasr_pack_dense_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_dense_conv1d_fused_packed': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_stream]),
-    'nbasr_packed_dense_weights_bytes_f16': (ctypes.c_size_t, [_c_int] * 3),
-    'nbasr_pack_dense_weights_f16': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_dense_conv1d_fused_packed_f16': (_c_int, [_c_float_p] * 8 + [_c_int] * 8 + [_c_stream]),
-    'nbasr_lstm_forward': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_stream]),
+    'nbasr_split_image_ranged': (_c_int, [_c_float_p] * 3 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_bf16_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_bf16_image': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
+    # per-frame linear maps
     'nbasr_pointwise_packed_weights_bytes': (ctypes.c_size_t, [_c_int] * 2),
     'nbasr_pointwise_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_pack_pointwise_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 2 + [_c_stream]),
     'nbasr_linear_fused_packed': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_int, _c_int, _c_stream]),
-    'nbasr_lstm_input_projection_packed': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
-    'nbasr_frame_signal': (_c_int, [_c_float_p, ctypes.c_void_p, _c_float_p] + [_c_int] * 6 + [_c_stream]),
     'nbasr_pointwise_linear': (_c_int, [_c_float_p] * 4 + [_c_int] * 6 + [_c_stream]),
-    'nbasr_power_spectrum': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_log_normalize': (_c_int, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 3 + [_c_int] * 5 + [_c_stream]),
+    # LSTM + head
     'nbasr_lstm_input_projection': (_c_int, [_c_float_p] * 5 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
-    'nbasr_lstm_recurrence': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_lstm_input_projection_packed': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_packed_whh_bytes': (ctypes.c_size_t, [_c_int]),
     'nbasr_lstm_pack_whh': (_c_int, [_c_float_p] * 2 + [_c_int, _c_stream]),
     'nbasr_lstm_recurrence_packed': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_lstm_seq_workspace_bytes': (ctypes.c_size_t, [_c_int] * 2),
+    'nbasr_lstm_recurrence_seq': (_c_int, [_c_float_p] * 5 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_lstm_seq_status': (_c_int, [_c_float_p, _c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
-    'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_stream]),
-    'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
-    'nbasr_grouped_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_stream]),
-    'nbasr_grouped_stats_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
-    'nbasr_grouped_stats_finalize': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [ctypes.c_float, _c_stream]),
-    'nbasr_grouped_stats_finalize_parts': (_c_int, [_c_float_p] * 2 + [_c_int] * 6 + [ctypes.c_float, _c_stream]),
-    'nbasr_grouped_conv1d_fused_stats': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_float_p,
-                                                  ctypes.c_float, _c_stream]),
-    'nbasr_grouped_cell_fits': (_c_int, [_c_int] * 3),
-    'nbasr_grouped_cell_fused': (_c_int, [_c_float_p, _c_float_p, _c_float_p, _c_int, _c_int, _c_float_p, _c_float_p, _c_int, _c_int,
-                                          _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_float_p, _c_int, _c_stream]),
-    'nbasr_skip_sum_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_stream]),
-    'nbasr_dense_conv1d_fused_ln': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
-    'nbasr_dense_conv1d_fused_packed_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 8 + [_c_ln_p, _c_stream]),
-    'nbasr_lstm_forward_ln': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
-    'nbasr_linear_head_bct_ln': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    # post-logits step
     'nbasr_ctc_postprocess': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
     'nbasr_ctc_loss': (_c_int, [_c_float_p] * 5 + [_c_int] * 6 + [_c_stream]),
     'nbasr_ctc_grad_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
@@ -93,10 +85,11 @@ SIGNATURES = {
     'nbasr_ctc_beam_search': (_c_int, [_c_float_p] * 6 + [_c_int] * 6 + [_c_stream]),
     'nbasr_token_error_counts': (_c_int, [_c_float_p, _c_float_p, _c_int, _c_float_p, _c_float_p, _c_int, _c_float_p, _c_int, _c_int,
                                           _c_float_p, _c_int, _c_stream]),
-    'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_dense_conv1d_fused_packed_f16_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
-    'nbasr_dense_conv1d_fused_packed_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 8 + [_c_stream]),
+    # front-end
+    'nbasr_frame_signal': (_c_int, [_c_float_p, ctypes.c_void_p, _c_float_p] + [_c_int] * 6 + [_c_stream]),
+    'nbasr_power_spectrum': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_log_normalize': (_c_int, [_c_float_p, ctypes.c_void_p] + [_c_float_p] * 3 + [_c_int] * 5 + [_c_stream]),
+    # backward building blocks
     'nbasr_grouped_conv1d_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 4),
     'nbasr_grouped_conv1d_backward': (_c_int, [_c_float_p] * 8 + [_c_int] * 7 + [_c_stream]),
     'nbasr_layernorm_backward_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
@@ -109,21 +102,6 @@ SIGNATURES = {
     'nbasr_rows_of_channels': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
     'nbasr_lstm_gate_scan': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_lstm_backward_step': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_stream]),
-    # storage-type generic / bf16 path
-    'nbasr_grouped_conv1d_node': (_c_int, [_c_float_p] * 7 + [_c_int] * 7 + [_c_ln_p, _c_int, _c_int, _c_float_p, _c_int, _c_int, _c_stream]),
-    'nbasr_pack_grouped_weights': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
-    'nbasr_skip_sum_v': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_int, _c_stream]),
-    'nbasr_repitch_v': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
-    'nbasr_channel_stats_v': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
-    'nbasr_layernorm_channels_v': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_int, _c_stream]),
-    'nbasr_convert': (_c_int, [_c_float_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_stream]),
-    'nbasr_bf16_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
-    'nbasr_bf16_image': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
-    'nbasr_packed_dense_weights_bytes_bf16': (ctypes.c_size_t, [_c_int] * 4),
-    'nbasr_pack_dense_weights_bf16': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
-    'nbasr_dense_conv1d_bf16_img': (_c_int, [_c_float_p] * 4 + [_c_int] * 9 + [_c_stream]),
-    'nbasr_split_image_ranged': (_c_int, [_c_float_p] * 3 + [_c_int] * 4 + [_c_stream]),
-    'nbasr_dense_conv1d_fused_packed_f16_img_ranged': (_c_int, [_c_float_p] * 5 + [_c_int] * 9 + [_c_stream]),
 }
 
 # entry points that only answer on the host (never recorded on a launch tape); every other one enqueues work on a stream
@@ -292,15 +270,14 @@ def round_up4(n):
 # ---------------------------------------------------------------------------------------------
 def grouped_conv1d_fused(x, weight, bias, skips, y, frames, groups, kernel, dilation, ln=None, ln_on_x=False,
                          ln_on_skip0=False, stats_out=None, stats_ws=None, eps=0.0):
-    """`ln` = (stats, gamma, beta) of a pending LayerNorm carried by x (ln_on_x) and/or skips[0] (ln_on_skip0).
-    `stats_out` (B, 2, ld) + `stats_ws` (grouped_stats_workspace): also emit the LayerNorm statistics of y."""
-    b, c, ld = x.shape
-    s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_grouped_conv1d_fused_stats(
-        _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
-        _opt(s[2], 'skip2'), _dev(y, 'y'), b, c, frames, ld, groups, kernel, dilation, _ln(ln), int(ln_on_x),
-        int(ln_on_skip0), _opt(stats_out, 'stats_out'), _opt(stats_ws, 'stats_ws'), float(eps), _stream(x)),
-        'nbasr_grouped_conv1d_fused')
+    """The fp32 node op (the default kernel of grouped_conv1d_node).  `ln` = (stats, gamma, beta) of a pending LayerNorm carried by x
+    (ln_on_x) and/or skips[0] (ln_on_skip0).  `stats_ws` (grouped_stats_workspace): also emit the partial LayerNorm statistics of y;
+    with `stats_out` (B, 2, ld) they are merged at once (grouped_stats_finalize)."""
+    if stats_out is not None and stats_ws is None:
+        raise HipError('grouped_conv1d_fused: stats_out needs the partial-statistics workspace stats_ws')
+    grouped_conv1d_node(x, weight, bias, skips, y, frames, groups, kernel, dilation, ln, ln_on_x, ln_on_skip0, stats_ws, 0)
+    if stats_out is not None and x.shape[0] and x.shape[2]:
+        grouped_stats_finalize(stats_ws, stats_out, x.shape[1], frames, groups, eps)
     return y
 
 
@@ -326,8 +303,8 @@ def grouped_stats_finalize(stats_ws, stats_out, channels, frames, groups, eps, g
     """Merge the partial statistics a node / fused-cell launch left in ``stats_ws`` into (mean, rstd) rows.  ``groups_per_part``: 4 for
     the node kernels, ``grouped_cell_fits(...)`` (4 or 2) for a fused cell."""
     b, _, ld = stats_out.shape
-    _check(load_library().nbasr_grouped_stats_finalize_parts(_dev(stats_ws, 'stats_ws'), _dev(stats_out, 'stats_out'), b, channels,
-                                                             frames, ld, groups, int(groups_per_part), float(eps), _stream(stats_out)),
+    _check(load_library().nbasr_grouped_stats_finalize(_dev(stats_ws, 'stats_ws'), _dev(stats_out, 'stats_out'), b, channels,
+                                                       frames, ld, groups, int(groups_per_part), float(eps), _stream(stats_out)),
            'nbasr_grouped_stats_finalize')
     return stats_out
 
@@ -338,35 +315,33 @@ def grouped_stats_workspace(batch, ld, groups, device):
 
 
 def skip_sum(skips, y, frames, ln=None, ln_on_skip0=False):
+    """Node whose main op is `zero`: y = sum of the skips (float32 or bfloat16 tensors, all of y's type)."""
     b, c, ld = y.shape
+    dt = y.dtype
     s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_skip_sum_ln(_opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
-                                            _dev(y, 'y'), b, c, frames, ld, _ln(ln), int(ln_on_skip0), _stream(y)),
+    _check(load_library().nbasr_skip_sum(_act_opt(s[0], 'skip0', dt), _act_opt(s[1], 'skip1', dt), _act_opt(s[2], 'skip2', dt),
+                                         _act(y, 'y'), b, c, frames, ld, _ln(ln), int(ln_on_skip0), dtype_code(dt), _stream(y)),
            'nbasr_skip_sum')
     return y
 
 
 def channel_stats(x, stats, frames, eps):
-    """One read pass over x (B, C, ld): stats (B, 2, ld) <- per-frame (mean, 1/sqrt(var + eps)) over channels."""
+    """One read pass over x (B, C, ld), float32 or bfloat16: stats (B, 2, ld) <- per-frame (mean, 1/sqrt(var + eps)) over channels."""
     b, c, ld = x.shape
-    _check(load_library().nbasr_channel_stats(_dev(x, 'x'), _dev(stats, 'stats'), b, c, frames, ld, float(eps), _stream(x)),
-           'nbasr_channel_stats')
+    _check(load_library().nbasr_channel_stats(_act(x, 'x'), _dev(stats, 'stats'), b, c, frames, ld, float(eps), dtype_code(x.dtype),
+                                              _stream(x)), 'nbasr_channel_stats')
     return stats
 
 
 def layernorm_channels(x, gamma, beta, y, frames, eps, absmax=None):
-    """LayerNorm over channels; with ``absmax`` (a (B,) float32 device tensor) also max|y[b]| per utterance."""
+    """LayerNorm over channels, x -> y (float32 -> float32, bfloat16 -> bfloat16 or bfloat16 -> float32); with ``absmax`` (a (B,)
+    float32 device tensor; float32 tensors only) also max|y[b]| per utterance."""
     b, c, ld = x.shape
-    if absmax is not None:
-        if absmax.numel() != b:
-            raise HipError('absmax must hold one float per utterance')
-        _check(load_library().nbasr_layernorm_channels_absmax(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
-                                                              _dev(y, 'y'), _dev(absmax, 'absmax'), b, c, frames, ld,
-                                                              float(eps), _stream(x)), 'nbasr_layernorm_channels_absmax')
-        return y
-    _check(load_library().nbasr_layernorm_channels(_dev(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'),
-                                                   _dev(y, 'y'), b, c, frames, ld, float(eps), _stream(x)),
-           'nbasr_layernorm_channels')
+    if absmax is not None and absmax.numel() != b:
+        raise HipError('absmax must hold one float per utterance')
+    _check(load_library().nbasr_layernorm_channels(_act(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'), _act(y, 'y'),
+                                                   _opt(absmax, 'absmax'), b, c, frames, ld, float(eps), dtype_code(x.dtype),
+                                                   dtype_code(y.dtype), _stream(x)), 'nbasr_layernorm_channels')
     return y
 
 
@@ -388,24 +363,12 @@ def layernorm_split_image(x, gamma, beta, stats, bound, image, frames, eps):
 
 def dense_conv1d_fused_packed_f16_img(image, bound, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride,
                                       row_tile=128):
-    lib = load_library()
-    if packed.numel() != lib.nbasr_packed_dense_weights_bytes_f16_rows(c_out, c_in, kernel, row_tile) or \
-            getattr(packed, 'nbasr_row_tile', 128) != row_tile:
-        raise HipError(f'packed weights are not an f16x2 image of a ({c_out}, {c_in}, {kernel}) weight for row_tile={row_tile}')
-    if image.numel() < lib.nbasr_split_image_bytes(batch, c_in, ld_in):
+    """The fp16x2 convolution on the pre-split operand image (layernorm_split_image): LDS-DMA-only GEMM."""
+    _check_packed(packed, 'f16x2', c_out, c_in, kernel, row_tile)
+    if image.numel() < load_library().nbasr_split_image_bytes(batch, c_in, ld_in):
         raise HipError('image buffer too small for (batch, c_in, ld_in)')
-    _check(lib.nbasr_dense_conv1d_fused_packed_f16_img_rows(image.data_ptr(), _dev(bound, 'bound'), packed.data_ptr(),
-                                                            _dev(bias, 'bias'), _dev(y, 'y'), batch, c_in, frames_in, ld_in, c_out,
-                                                            y.shape[2], kernel, stride, row_tile, _stream(y)),
-           'nbasr_dense_conv1d_fused_packed_f16_img_rows')
-    return y
-
-
-def absmax(x, out):
-    """out[b] = max |x[b]| over everything but the leading dimension (x contiguous, numel per utterance % 4 == 0)."""
-    b = x.shape[0]
-    _check(load_library().nbasr_absmax(_dev(x, 'x'), _dev(out, 'absmax'), b, x.numel() // max(b, 1), _stream(x)), 'nbasr_absmax')
-    return out
+    return _dense_packed('f16x2', image.data_ptr(), True, bound, None, packed, bias, (None, None, None), y, _dev(y, 'y'), batch, c_in,
+                         frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y))
 
 
 def input_range(x, frames, out):
@@ -424,25 +387,21 @@ def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, 
     x, LDS-DMA-only GEMM; ``packed_f16`` packed for ``row_tile``); None: the input is split in the GEMM's prologue."""
     lib = load_library()
     b, c_in, ld_in = x.shape
-    want_f16 = lib.nbasr_packed_dense_weights_bytes_f16(c_out, c_in, kernel) if image is None else \
-        lib.nbasr_packed_dense_weights_bytes_f16_rows(c_out, c_in, kernel, row_tile)
-    if packed_f16.numel() != want_f16 or packed_bf16x3.numel() != lib.nbasr_packed_dense_weights_bytes(c_out, c_in, kernel):
-        raise HipError('packed weights do not match the (c_out, c_in, kernel) of this convolution')
-    args = (_dev(bias, 'bias'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride, _stream(x))
+    _check_packed(packed_f16, 'f16x2', c_out, c_in, kernel, 128 if image is None else row_tile)
+    _check_packed(packed_bf16x3, 'bf16x3', c_out, c_in, kernel)
+    none3, stream = (None, None, None), _stream(x)
     if image is not None:
         if image.dtype != torch.uint8 or image.numel() < lib.nbasr_split_image_bytes(b, c_in, ld_in):
             raise HipError('dense_conv1d_first_ranged: image workspace too small (nbasr_split_image_bytes)')
-        _check(lib.nbasr_split_image_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), image.data_ptr(), b, c_in, frames_in, ld_in, _stream(x)),
+        _check(lib.nbasr_split_image_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), image.data_ptr(), b, c_in, frames_in, ld_in, stream),
                'nbasr_split_image_ranged')
-        _check(lib.nbasr_dense_conv1d_fused_packed_f16_img_ranged(image.data_ptr(), _dev(x_range, 'x_range'), packed_f16.data_ptr(),
-                                                                  *args[:-1], row_tile, args[-1]),
-               'nbasr_dense_conv1d_fused_packed_f16_img_ranged')
+        _dense_packed('f16x2', image.data_ptr(), True, None, x_range, packed_f16, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in, ld_in,
+                      c_out, kernel, stride, row_tile, None, stream)
     else:
-        _check(lib.nbasr_dense_conv1d_fused_packed_f16_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_f16.data_ptr(), *args),
-               'nbasr_dense_conv1d_fused_packed_f16_ranged')
-    _check(lib.nbasr_dense_conv1d_fused_packed_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), packed_bf16x3.data_ptr(), *args),
-           'nbasr_dense_conv1d_fused_packed_ranged')
-    return y
+        _dense_packed('f16x2', _dev(x, 'x'), False, None, x_range, packed_f16, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in, ld_in,
+                      c_out, kernel, stride, 128, None, stream)
+    return _dense_packed('bf16x3', _dev(x, 'x'), False, None, x_range, packed_bf16x3, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in,
+                         ld_in, c_out, kernel, stride, 128, None, stream)
 
 
 def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln_on_x=False, ln_on_skip0=False):
@@ -450,91 +409,85 @@ def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln
     c_out, _, kernel = weight.shape if weight.dim() == 3 else (weight.shape[0], weight.shape[1], 1)
     ld_out = y.shape[2]
     s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_dense_conv1d_fused_ln(
+    _check(load_library().nbasr_dense_conv1d_fused(
         _dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
         _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _ln(ln), int(ln_on_x),
         int(ln_on_skip0), _stream(x)), 'nbasr_dense_conv1d_fused')
     return y
 
 
+DENSE_SCHEMES = {'bf16x3': 0, 'f16x2': 1, 'bf16': 2}        # NBASR_DENSE_* of nbasr_dense_conv1d_packed
+
+
+def _scheme_code(scheme):
+    if scheme not in DENSE_SCHEMES:
+        raise HipError(f"unknown operand scheme {scheme!r} (expected 'bf16x3', 'f16x2' or 'bf16')")
+    return DENSE_SCHEMES[scheme]
+
+
+def packed_dense_weights_bytes(scheme, c_out, c_in, kernel, row_tile=128):
+    return load_library().nbasr_packed_dense_weights_bytes(_scheme_code(scheme), c_out, c_in, kernel, row_tile)
+
+
 def pack_dense_weights(weight, stride, scheme='bf16x3', row_tile=128):
-    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its split (3 x bf16, or 2 x fp16 for
-    ``scheme='f16x2'``) in the LDS layout of the stride-`stride` kernel that will consume it.  ``row_tile`` = 160 packs for
-    the 160-row tiles of the fp16 image-path kernel (``dense_conv1d_fused_packed_f16_img(..., row_tile=160)``)."""
-    sfx = _scheme_suffix(scheme)
+    """(c_out, c_in, 8) fp32 weight -> opaque uint8 tensor holding its operand form (3 x bf16 split, 2 x fp16 split for
+    ``scheme='f16x2'``, one bf16 term for 'bf16') in the LDS layout of the stride-`stride` kernel that will consume it.  ``row_tile``
+    other than 128: the 64- / 160-row tiles of the image-path kernels (f16x2: 64, 160; bf16: 160)."""
+    code = _scheme_code(scheme)
     lib = load_library()
     c_out, c_in, kernel = weight.shape
-    if row_tile != 128 and scheme != 'f16x2':
-        raise HipError('row_tile other than 128 exists for the f16x2 scheme only')
-    if row_tile == 128:
-        nbytes = getattr(lib, 'nbasr_packed_dense_weights_bytes' + sfx)(c_out, c_in, kernel)
-    else:
-        nbytes = lib.nbasr_packed_dense_weights_bytes_f16_rows(c_out, c_in, kernel, row_tile)
+    nbytes = lib.nbasr_packed_dense_weights_bytes(code, c_out, c_in, kernel, row_tile)
     if nbytes == 0:
-        raise HipError(f'packed dense path does not cover weight shape {tuple(weight.shape)} with row_tile={row_tile}')
+        raise HipError(f'packed dense path ({scheme}) does not cover weight shape {tuple(weight.shape)} with row_tile={row_tile}')
     if not weight.is_cuda:
         raise HipError('weight must be on a HIP device')
     packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    if row_tile == 128:
-        _check(getattr(lib, 'nbasr_pack_dense_weights' + sfx)(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel,
-                                                              stride, _stream(weight)), 'nbasr_pack_dense_weights' + sfx)
-    else:
-        _check(lib.nbasr_pack_dense_weights_f16_rows(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride, row_tile,
-                                                     _stream(weight)), 'nbasr_pack_dense_weights_f16_rows')
+    _check(lib.nbasr_pack_dense_weights(code, _dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride, row_tile,
+                                        _stream(weight)), 'nbasr_pack_dense_weights')
     packed.nbasr_row_tile = row_tile           # the packed sizes of the two tilings can coincide (c_out = 1200): remember which
     return packed
 
 
-def _scheme_suffix(scheme):
-    if scheme not in ('bf16x3', 'f16x2'):
-        raise HipError(f"unknown operand-split scheme {scheme!r} (expected 'bf16x3' or 'f16x2')")
-    return '' if scheme == 'bf16x3' else '_f16'
+def _dense_packed(scheme, x_ptr, image, x_absmax, x_range, packed, bias, s, y, y_ptr, b, c_in, frames_in, ld_in, c_out, kernel, stride,
+                  row_tile, ln, stream):
+    """The one C entry point of the packed k = 8 convolution (nbasr.h: nbasr_dense_conv1d_packed)."""
+    _check(load_library().nbasr_dense_conv1d_packed(
+        _scheme_code(scheme), x_ptr, int(image), _opt(x_absmax, 'x_absmax'), _opt(x_range, 'x_range'), packed.data_ptr(),
+        _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'), y_ptr, b, c_in, frames_in, ld_in, c_out,
+        y.shape[2], kernel, stride, row_tile, _ln(ln), stream), 'nbasr_dense_conv1d_packed')
+    return y
+
+
+def _check_packed(packed, scheme, c_out, c_in, kernel, row_tile=128):
+    if not packed.is_cuda or packed.dtype != torch.uint8:
+        raise HipError('packed weights must be the uint8 device tensor returned by pack_dense_weights')
+    if packed.numel() != packed_dense_weights_bytes(scheme, c_out, c_in, kernel, row_tile) or getattr(packed, 'nbasr_row_tile', 128) != row_tile:
+        raise HipError(f'packed weights have {packed.numel()} bytes: not a {scheme} image of a ({c_out}, {c_in}, {kernel}) weight for '
+                       f'row_tile={row_tile}')
 
 
 def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride, ln=None, scheme='bf16x3',
                               x_absmax=None):
     """Dense k=8 conv on packed weights; ``scheme`` must be the one the weights were packed with.  'f16x2' needs
     ``x_absmax``: a (B,) float32 device tensor of upper bounds of max|x[b]| (see nbasr.h) and takes no deferred LayerNorm."""
-    sfx = _scheme_suffix(scheme)
-    lib = load_library()
     b, c_in, ld_in = x.shape
-    ld_out = y.shape[2]
     s = list(skips) + [None] * (3 - len(skips))
-    if not packed.is_cuda or packed.dtype != torch.uint8:
-        raise HipError('packed weights must be the uint8 device tensor returned by pack_dense_weights')
-    if packed.numel() != getattr(lib, 'nbasr_packed_dense_weights_bytes' + sfx)(c_out, c_in, kernel):
-        raise HipError(f'packed weights have {packed.numel()} bytes: not a {scheme} image of a ({c_out}, {c_in}, {kernel}) weight')
-    name = 'nbasr_dense_conv1d_fused_packed' + sfx
+    _check_packed(packed, scheme, c_out, c_in, kernel)
     if scheme == 'f16x2':
         if ln is not None:
             raise HipError('the f16x2 scheme takes no deferred LayerNorm (it needs the range of the normalised tensor)')
         if x_absmax is None or x_absmax.numel() != b:
             raise HipError('the f16x2 scheme needs x_absmax: one float32 bound of max|x[b]| per utterance')
-        _check(lib.nbasr_dense_conv1d_fused_packed_f16(
-            _dev(x, 'x'), _dev(x_absmax, 'x_absmax'), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'),
-            _opt(s[2], 'skip2'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)), name)
-        return y
-    if ln is not None:
-        if any(t is not None for t in s):
-            raise HipError('the packed path takes a deferred LayerNorm only without skip inputs')
-        _check(getattr(lib, name + '_ln')(
-            _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out,
-            kernel, stride, _ln(ln), _stream(x)), name + '_ln')
-        return y
-    _check(getattr(lib, name)(
-        _dev(x, 'x'), packed.data_ptr(), _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'),
-        _dev(y, 'y'), b, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, _stream(x)), name)
-    return y
+    elif ln is not None and any(t is not None for t in s):
+        raise HipError('the packed path takes a deferred LayerNorm only without skip inputs')
+    return _dense_packed(scheme, _dev(x, 'x'), False, x_absmax if scheme == 'f16x2' else None, None, packed, bias, s, y, _dev(y, 'y'),
+                         b, c_in, frames_in, ld_in, c_out, kernel, stride, 128, ln, _stream(x))
 
 
 def lstm_forward(x, frames, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out, ln=None):
-    b, c_in, ld = x.shape
-    hidden = w_hh.shape[1]
-    _check(load_library().nbasr_lstm_forward_ln(
-        _dev(x, 'x'), _dev(w_ih, 'w_ih'), _dev(w_hh, 'w_hh'), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'),
-        _dev(gates_ws, 'gates_ws'), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
-        b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_forward')
-    return h_out
+    """nn.LSTM forward as its two library calls on one stream: the exact-fp32 input projection, then the per-frame recurrence."""
+    lstm_input_projection(x, frames, w_ih, b_ih, b_hh, gates_ws, w_hh.shape[1], ln)
+    return lstm_recurrence(gates_ws, w_hh, cell_ws, h_out)
 
 
 def lstm_input_projection(x, frames, w_ih, b_ih, b_hh, gates_ws, hidden, ln=None):
@@ -564,13 +517,36 @@ def lstm_recurrence_packed(gates_ws, packed_whh, cell_ws, h_out):
     return h_out
 
 
-def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):
-    """h_out (batch, frames, hidden) from the projected gates (second half of lstm_forward), on the current stream."""
+def lstm_seq_workspace(batch, hidden, device):
+    """Workspace of the one-launch recurrence (flags + the exchange images of h), or None where that form does not apply."""
+    nbytes = load_library().nbasr_lstm_seq_workspace_bytes(int(batch), int(hidden))
+    return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
+
+
+def lstm_recurrence_seq(gates_ws, packed_whh, cell_ws, h_out, seq_ws):
+    """lstm_recurrence_packed with all frames in ONE launch (w_hh resident in registers, flag-synchronised steps); same h_out, bit for bit."""
     b, frames, hidden = h_out.shape
-    _check(load_library().nbasr_lstm_recurrence(_dev(gates_ws, 'gates_ws'), _dev(w_hh, 'w_hh'), _dev(cell_ws, 'cell_ws'),
-                                                _dev(h_out, 'h_out'), b, frames, hidden, _stream(h_out)),
-           'nbasr_lstm_recurrence')
+    lib = load_library()
+    if not packed_whh.is_cuda or packed_whh.dtype != torch.uint8 or packed_whh.numel() != lib.nbasr_lstm_packed_whh_bytes(hidden):
+        raise HipError('packed_whh must be the uint8 device tensor returned by lstm_pack_whh for this hidden size')
+    need = lib.nbasr_lstm_seq_workspace_bytes(b, hidden)
+    if need == 0 or seq_ws is None or not seq_ws.is_cuda or seq_ws.dtype != torch.uint8 or seq_ws.numel() < need:
+        raise HipError(f'lstm_recurrence_seq: batch={b} hidden={hidden} needs a uint8 device workspace of {need} bytes from lstm_seq_workspace '
+                       '(0 = this form does not apply)')
+    _check(lib.nbasr_lstm_recurrence_seq(_dev(gates_ws, 'gates_ws'), packed_whh.data_ptr(), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
+                                         seq_ws.data_ptr(), b, frames, hidden, _stream(h_out)), 'nbasr_lstm_recurrence_seq')
     return h_out
+
+
+def lstm_seq_status(seq_ws):
+    """Synchronises the current stream and raises HipError if a step of the last one-launch recurrence timed out."""
+    _check(load_library().nbasr_lstm_seq_status(seq_ws.data_ptr(), _stream(seq_ws)), 'nbasr_lstm_seq_status')
+
+
+def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):
+    """h_out (batch, frames, hidden) from the projected gates (second half of lstm_forward), on the current stream; packs w_hh per call
+    (a caller that keeps the weight packs it once: lstm_pack_whh + lstm_recurrence_packed)."""
+    return lstm_recurrence_packed(gates_ws, lstm_pack_whh(w_hh), cell_ws, h_out)
 
 
 def pack_pointwise_weights(weight):
@@ -668,17 +644,17 @@ def linear_head(h, weight, bias, logits):
 def linear_head_bct(x, frames, weight, bias, logits, ln=None):
     b, features, ld = x.shape
     classes = weight.shape[0]
-    _check(load_library().nbasr_linear_head_bct_ln(_dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'),
-                                                   _dev(logits, 'logits'), b, features, frames, ld, classes, _ln(ln),
-                                                   _stream(x)), 'nbasr_linear_head_bct')
+    _check(load_library().nbasr_linear_head_bct(_dev(x, 'x'), _dev(weight, 'weight'), _dev(bias, 'bias'),
+                                                _dev(logits, 'logits'), b, features, frames, ld, classes, _ln(ln),
+                                                _stream(x)), 'nbasr_linear_head_bct')
     return logits
 
 
 def repitch(src, dst, frames):
-    """src (..., ld_src) -> dst (..., ld_dst): copy `frames` columns, zero the rest of dst's pitch."""
+    """src (..., ld_src) -> dst (..., ld_dst), float32 or bfloat16: copy `frames` columns, zero the rest of dst's pitch."""
     rows = src.numel() // src.shape[-1]
-    _check(load_library().nbasr_repitch(_dev(src, 'src'), _dev(dst, 'dst'), rows, frames, src.shape[-1],
-                                        dst.shape[-1], _stream(src)), 'nbasr_repitch')
+    _check(load_library().nbasr_repitch(_act(src, 'src'), _act(dst, 'dst', src.dtype), rows, frames, src.shape[-1], dst.shape[-1],
+                                        dtype_code(src.dtype), _stream(src)), 'nbasr_repitch')
     return dst
 
 
@@ -811,39 +787,6 @@ def grouped_conv1d_node(x, weight, bias, skips, y, frames, groups, kernel, dilat
     return y
 
 
-def skip_sum_v(skips, y, frames, ln=None, ln_on_skip0=False):
-    b, c, ld = y.shape
-    dt = y.dtype
-    s = list(skips) + [None] * (3 - len(skips))
-    _check(load_library().nbasr_skip_sum_v(_act_opt(s[0], 'skip0', dt), _act_opt(s[1], 'skip1', dt), _act_opt(s[2], 'skip2', dt),
-                                           _act(y, 'y'), b, c, frames, ld, _ln(ln), int(ln_on_skip0), dtype_code(dt), _stream(y)),
-           'nbasr_skip_sum_v')
-    return y
-
-
-def repitch_v(src, dst, frames):
-    rows = src.numel() // src.shape[-1]
-    _check(load_library().nbasr_repitch_v(_act(src, 'src'), _act(dst, 'dst', src.dtype), rows, frames, src.shape[-1], dst.shape[-1],
-                                          dtype_code(src.dtype), _stream(src)), 'nbasr_repitch_v')
-    return dst
-
-
-def channel_stats_v(x, stats, frames, eps):
-    b, c, ld = x.shape
-    _check(load_library().nbasr_channel_stats_v(_act(x, 'x'), _dev(stats, 'stats'), b, c, frames, ld, float(eps), dtype_code(x.dtype),
-                                                _stream(x)), 'nbasr_channel_stats_v')
-    return stats
-
-
-def layernorm_channels_v(x, gamma, beta, y, frames, eps):
-    """LayerNorm over channels; y may be float32 for a bfloat16 x (the hand-off to the fp32 LSTM)."""
-    b, c, ld = x.shape
-    _check(load_library().nbasr_layernorm_channels_v(_act(x, 'x'), _dev(gamma, 'gamma'), _dev(beta, 'beta'), _act(y, 'y'), b, c, frames,
-                                                     ld, float(eps), dtype_code(x.dtype), dtype_code(y.dtype), _stream(x)),
-           'nbasr_layernorm_channels_v')
-    return y
-
-
 def convert(x, y):
     """Storage conversion float32 <-> bfloat16 of equally shaped contiguous tensors (numel % 8 == 0)."""
     if x.shape != y.shape:
@@ -871,29 +814,15 @@ def bf16_image(x, image, frames, norm=None, stats=None, eps=0.0):
 
 def pack_dense_weights_bf16(weight, stride, row_tile=128):
     """(c_out, c_in, 8) fp32 weight (the values of a bf16 parameter) -> packed one-term bf16 image of the stride-`stride` kernel."""
-    lib = load_library()
-    c_out, c_in, kernel = weight.shape
-    nbytes = lib.nbasr_packed_dense_weights_bytes_bf16(c_out, c_in, kernel, row_tile)
-    if nbytes == 0:
-        raise HipError(f'bf16 dense path does not cover weight shape {tuple(weight.shape)} with row_tile={row_tile}')
-    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
-    _check(lib.nbasr_pack_dense_weights_bf16(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, kernel, stride, row_tile,
-                                             _stream(weight)), 'nbasr_pack_dense_weights_bf16')
-    packed.nbasr_row_tile = row_tile
-    return packed
+    return pack_dense_weights(weight, stride, 'bf16', row_tile)
 
 
 def dense_conv1d_bf16_img(image, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride, row_tile=128):
-    lib = load_library()
-    if packed.numel() != lib.nbasr_packed_dense_weights_bytes_bf16(c_out, c_in, kernel, row_tile) or \
-            getattr(packed, 'nbasr_row_tile', 128) != row_tile:
-        raise HipError(f'packed weights are not a bf16 image of a ({c_out}, {c_in}, {kernel}) weight for row_tile={row_tile}')
-    if image.numel() < lib.nbasr_bf16_image_bytes(batch, c_in, ld_in):
+    _check_packed(packed, 'bf16', c_out, c_in, kernel, row_tile)
+    if image.numel() < load_library().nbasr_bf16_image_bytes(batch, c_in, ld_in):
         raise HipError('image buffer too small for (batch, c_in, ld_in)')
-    _check(lib.nbasr_dense_conv1d_bf16_img(image.data_ptr(), packed.data_ptr(), _dev(bias, 'bias'), _act(y, 'y', torch.bfloat16), batch,
-                                           c_in, frames_in, ld_in, c_out, y.shape[2], kernel, stride, row_tile, _stream(y)),
-           'nbasr_dense_conv1d_bf16_img')
-    return y
+    return _dense_packed('bf16', image.data_ptr(), True, None, None, packed, bias, (None, None, None), y, _act(y, 'y', torch.bfloat16), batch,
+                         c_in, frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -961,7 +890,7 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
             wt = weight.detach().reshape(c_out, c_in).t().contiguous()
             _check(lib.nbasr_pointwise_linear(_dev(dz, 'dz'), _dev(wt, 'wt'), _dev(zero, 'zero'), _dev(dx, 'dx'), b, c_out, frames_in, ld_out,
                                               c_in, ld_in, stream), 'nbasr_pointwise_linear')
-        elif kernel == 8 and (c_in * kernel) % 16 == 0 and os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32':
+        elif kernel == 8 and (c_in * kernel) % 16 == 0 and os.environ.get('NBASR_DENSE_MODE', 'auto') != 'f32':
             # ONE GEMM on the fp16 matrix cores (fp32-accurate two-term split, the kernel of the LSTM input projection): rows (ci, tap) of
             # w^T times the masked output gradient, stored time-major, every tap's contribution to dx in its own row; nbasr_conv_fold adds
             # the 8 (stride 1) or 4 (stride 2) rows that land on one input frame.  No zero-stuffing: half the products at stride 2.
@@ -990,7 +919,7 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
         rows = torch.empty(c_out, b * t_pad, device=x.device, dtype=torch.float32)
         _check(lib.nbasr_rows_of_channels(_dev(dz, 'dz'), _dev(rows, 'rows'), b, c_out, frames_out, ld_out, t_pad, stream), 'nbasr_rows_of_channels')
         zero_o = torch.zeros(c_out, device=x.device, dtype=torch.float32)
-        if os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32':
+        if os.environ.get('NBASR_DENSE_MODE', 'auto') != 'f32':
             # the (C_out, B T') x (B T', C_in k + 1) product on the fp16 matrix cores, fp32-accurate two-term split (the GEMM of the LSTM
             # input projection: "weights" = the masked output gradient packed per call, "x" = the column matrix pre-split per column tile);
             # it stores time-major, i.e. the transpose (C_in k + 1, C_out).  3-5 x the exact-fp32 MFMA GEMM, which was half of a training step
@@ -1041,7 +970,7 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
                                           stream), 'nbasr_pointwise_linear')
         return y
 
-    split = os.environ.get('NBASR_TRAIN_GEMM', 'f16x2') != 'f32'
+    split = os.environ.get('NBASR_DENSE_MODE', 'auto') != 'f32'
 
     def gemm_t(x3, cols, w):
         """(w (rows, K) . x3 (1, K, ld))^T -> (cols, rows): the same product on the fp16 matrix cores (fp32-accurate two-term split; the

@@ -218,7 +218,7 @@ def test_conv_fold_adds_the_tap_rows(c_in, stride, b, t):
 
 @pytest.mark.parametrize('c_in,c_out,stride,b,t', [(600, 800, 1, 2, 97), (800, 1000, 2, 2, 131), (24, 40, 2, 3, 5)])
 def test_dense_input_gradient_on_the_split_gemm_matches_the_exact_route(monkeypatch, c_in, c_out, stride, b, t):
-    """Default route of the k = 8 input gradient (one fp16-split GEMM + nbasr_conv_fold) against NBASR_TRAIN_GEMM=f32 (zero-stuffed
+    """Default route of the k = 8 input gradient (one fp16-split GEMM + nbasr_conv_fold) against NBASR_DENSE_MODE=f32 (zero-stuffed
     exact-fp32 conv): same numbers to the fp32-accurate split's error, at the benchmark model's widths and ragged lengths."""
     torch.manual_seed(c_in + stride)
     t_out = (t + stride - 1) // stride
@@ -231,7 +231,7 @@ def test_dense_input_gradient_on_the_split_gemm_matches_the_exact_route(monkeypa
     dy = torch.zeros(b, c_out, ld_out, device=DEV)
     dy[:, :, :t_out] = torch.randn(b, c_out, t_out, device=DEV) * 1e-3
     dx, dw, db = hip.dense_conv1d_backward(x, w, y, dy, t, stride)
-    monkeypatch.setenv('NBASR_TRAIN_GEMM', 'f32')
+    monkeypatch.setenv('NBASR_DENSE_MODE', 'f32')
     dx_e, dw_e, db_e = hip.dense_conv1d_backward(x, w, y, dy, t, stride)
     assert not torch.equal(dx, dx_e)                                  # (two routes indeed)
     assert torch.equal(dx[:, :, t:], torch.zeros_like(dx[:, :, t:]))
@@ -261,15 +261,15 @@ def test_dense_ops_train_through_the_modules():
 
 
 def test_lstm_bptt_routes_agree(monkeypatch):
-    """The LSTM's backward GEMMs on the fp16-split kernel (default) and on the exact-fp32 one (NBASR_TRAIN_GEMM=f32): same gradients to
+    """The LSTM's backward GEMMs on the fp16-split kernel (default) and on the exact-fp32 one (NBASR_DENSE_MODE=f32): same gradients to
     the split's error, from the same saved forward."""
     torch.manual_seed(3)
     c, hidden, b, t = 72, 36, 5, 23
     params = [(torch.randn(4 * hidden, c) * 0.2), (torch.randn(4 * hidden, hidden) * 0.2), torch.randn(4 * hidden) * 0.1, torch.randn(4 * hidden) * 0.1]
     x, r = torch.randn(b, c, t), torch.randn(b, t, hidden)
     grads = []
-    for mode in ('f16x2', 'f32'):
-        monkeypatch.setenv('NBASR_TRAIN_GEMM', mode)
+    for mode in ('auto', 'f32'):
+        monkeypatch.setenv('NBASR_DENSE_MODE', mode)
         ps = [p.clone().to(DEV).requires_grad_(True) for p in params]
         xg = x.to(DEV).requires_grad_(True)
         (nb_autograd.lstm(xg, *ps) * r.to(DEV)).sum().backward()

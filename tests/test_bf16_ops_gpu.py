@@ -89,7 +89,7 @@ def test_node_deferred_layernorm_and_epilogue_statistics(dtype):
     xp = pitched(x, dtype)
     ld = xp.shape[2]
     stats = torch.empty(b, 2, ld, device=DEV)
-    hip.channel_stats_v(xp, stats, t, 1e-3)
+    hip.channel_stats(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     results = []
     for v in tuple(range(4)) + ((hip.GC_PIPE, hip.GC_RING) if dtype == torch.float32 else ()):
@@ -122,13 +122,13 @@ def test_layernorm_bf16_storage(c, t):
     want = oracle.layer_norm_channels(x, gamma, beta)
     xp = pitched(x, BF)
     y16, y32 = torch.full_like(xp, 3.0), torch.full(xp.shape, 3.0, device=DEV)
-    hip.layernorm_channels_v(xp, gamma.to(DEV), beta.to(DEV), y16, t, 1e-3)
-    hip.layernorm_channels_v(xp, gamma.to(DEV), beta.to(DEV), y32, t, 1e-3)
+    hip.layernorm_channels(xp, gamma.to(DEV), beta.to(DEV), y16, t, 1e-3)
+    hip.layernorm_channels(xp, gamma.to(DEV), beta.to(DEV), y32, t, 1e-3)
     assert torch.all(y16[:, :, t:] == 0) and torch.all(y32[:, :, t:] == 0)
     assert torch.allclose(y32[:, :, :t].cpu(), want, rtol=1e-5, atol=2e-5)                   # fp32 out: exact LayerNorm of the bf16 input
     assert torch.equal(y16[:, :, :t].cpu(), y32[:, :, :t].cpu().to(BF))                      # bf16 out: the same, rounded once
     stats = torch.empty(2, 2, xp.shape[2], device=DEV)
-    hip.channel_stats_v(xp, stats, t, 1e-3)
+    hip.channel_stats(xp, stats, t, 1e-3)
     assert torch.allclose(stats[:, 0, :t].cpu(), x.mean(dim=1), atol=1e-5)
     assert torch.all(stats[:, :, t:] == 0)
 
@@ -176,11 +176,11 @@ def test_convert_and_skip_sum_and_repitch_bf16():
     assert torch.equal(back, y.float())
     s = [torch.randn(2, 16, 24, device=DEV).to(BF) for _ in range(3)]
     out = torch.empty_like(s[0])
-    hip.skip_sum_v(s, out, 24)
+    hip.skip_sum(s, out, 24)
     assert torch.equal(out, (s[0].float() + s[1].float() + s[2].float()).to(BF))
     src = torch.randn(2, 5, 13, device=DEV).to(BF)
     dst = torch.full((2, 5, 16), 9.0, dtype=BF, device=DEV)
-    hip.repitch_v(src, dst, 13)
+    hip.repitch(src, dst, 13)
     assert torch.equal(dst[:, :, :13], src) and torch.all(dst[:, :, 13:] == 0)
 
 
@@ -196,7 +196,7 @@ def test_output_split_variant_with_deferred_layernorm(cg, k, d):
     w, bias = torch.randn(c, cg, k) * 0.3, torch.randn(c) * 0.2
     xp, s1, s2 = pitched(x, torch.float32), pitched(torch.randn(b, c, t), torch.float32), pitched(torch.randn(b, c, t), torch.float32)
     stats = torch.empty(b, 2, xp.shape[2], device=DEV)
-    hip.channel_stats_v(xp, stats, t, 1e-3)
+    hip.channel_stats(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     outs = []
     for v in (0, hip.GC_OSPLIT, hip.GC_PIPE, hip.GC_PIPE | hip.GC_OSPLIT, hip.GC_RING):
@@ -227,7 +227,7 @@ def test_ring_variant_tiles_halos_and_persistent_refills(cg, k, d, t):
     xp, s1, s2 = pitched(x, torch.float32), pitched(torch.randn(b, c, t), torch.float32), pitched(torch.randn(b, c, t), torch.float32)
     ld = xp.shape[2]
     stats = torch.empty(b, 2, ld, device=DEV)
-    hip.channel_stats_v(xp, stats, t, 1e-3)
+    hip.channel_stats(xp, stats, t, 1e-3)
     ln = (stats, gamma.to(DEV), beta.to(DEV))
     flavours = {'plain': ([], None, False, False, False), 'skips': ([xp, s1, s2], ln, False, True, False), 'lnx': ([xp], ln, True, True, False),
                 'stats': ([s1], None, False, False, True), 'lnx+stats': ([], ln, True, False, True)}
@@ -265,7 +265,7 @@ def test_fused_cell_either_storage_type_equals_three_node_launches(dtype, c, gro
     ln = None
     if with_ln:
         stats = torch.empty(b, 2, ld, device=DEV)
-        hip.channel_stats_v(xp, stats, t, 1e-3)
+        hip.channel_stats(xp, stats, t, 1e-3)
         ln = (stats, torch.rand(c, device=DEV) + 0.5, torch.randn(c, device=DEV) * 0.2)
     nodes = [((torch.randn(c, c // groups, k) * 0.3).to(dtype).float().to(DEV), (torch.randn(c) * 0.2).to(dtype).float().to(DEV), k, d) for k, d in kds]
     gpp = hip.grouped_cell_fits(c, ld, groups)

@@ -758,6 +758,44 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
             assert torch.equal(m(x), y0), forced
 
 
+def test_recurrence_in_one_launch_or_per_frame_same_logits(monkeypatch):
+    """NBASR_LSTM_SEQ: 'auto' (default) runs the LSTM recurrence of a PLAIN forward as one resident launch and keeps one launch per frame
+    in a pipelined tail; '0' = per frame everywhere, '1' = one launch everywhere.  Same arithmetic in the same order: bit-identical logits
+    on every route (plain, tape replay, pipelined), and the choice is really made (spied on the library wrappers)."""
+    from nb_asr_amd import hip
+    m = build(cases.ARCH_D, True, 'lively')
+    x = keyed_input(5, 333, seed=12).to(DEV)
+    calls = []
+    for name in ('lstm_recurrence_seq', 'lstm_recurrence_packed'):
+        original = getattr(hip, name)
+        monkeypatch.setattr(hip, name, (lambda orig, tag: lambda *a, **k: (calls.append(tag), orig(*a, **k))[1])(original, name))
+    outs = {}
+    for mode in ('0', 'auto', '1'):
+        monkeypatch.setenv('NBASR_LSTM_SEQ', mode)
+        monkeypatch.setenv('NBASR_TAPE', '0')                  # (a tape replays recorded C calls: the python wrappers would not be seen)
+        m._plans.clear()
+        with torch.no_grad():
+            calls.clear()
+            plain = m(x).clone()
+            plain_route = set(calls)
+            calls.clear()
+            piped = m.forward_async(x).result().clone()
+            piped_route = set(calls)
+        assert plain_route == ({'lstm_recurrence_packed'} if mode == '0' else {'lstm_recurrence_seq'}), (mode, plain_route)
+        assert piped_route == ({'lstm_recurrence_seq'} if mode == '1' else {'lstm_recurrence_packed'}), (mode, piped_route)
+        monkeypatch.setenv('NBASR_TAPE', '1')
+        m._plans.clear()
+        with torch.no_grad():
+            replays = [m(x).clone() for _ in range(3)]          # the third call replays the tape
+        assert all(torch.equal(r, plain) for r in replays) and torch.equal(piped, plain), mode
+        outs[mode] = plain
+    assert torch.equal(outs['0'], outs['auto']) and torch.equal(outs['0'], outs['1'])
+    monkeypatch.setenv('NBASR_LSTM_SEQ', 'sometimes')
+    m._plans.clear()
+    with pytest.raises(ValueError, match='NBASR_LSTM_SEQ'):
+        m(x)
+
+
 @pytest.mark.parametrize('arch,b,t', [(cases.ARCH_A, 2, 1000), (cases.ARCH_D, 3, 515), (cases.ARCH_D, 2, 250), ([[2, 0], [4, 1, 0], [1, 0, 1, 1]], 2, 1024)])
 def test_fused_cells_against_node_launches(monkeypatch, arch, b, t):
     """Cells of three grouped convs run as ONE launch by default (grouped_cell.hip); NBASR_CELL_FUSION=0 runs the three node launches.

@@ -220,6 +220,7 @@ def test_f16_split_accuracy_is_scale_invariant(x_scale):
 
 @pytest.mark.parametrize('b,t,h', [(3, 7, 500), (17, 5, 36), (64, 3, 500), (2, 4, 12)])
 def test_lstm_recurrence_packed_is_bit_identical(b, t, h):
+    """(hip.lstm_recurrence packs w_hh per call and runs the same per-frame kernel: the convenience form and the kept-packed form agree)"""
     torch.manual_seed(h + b)
     gates = torch.randn(t, b, 4 * h, device=DEV)
     w_hh = torch.randn(4 * h, h, device=DEV) * 0.2
@@ -230,13 +231,63 @@ def test_lstm_recurrence_packed_is_bit_identical(b, t, h):
     assert torch.isfinite(out1).all() and torch.equal(out0, out1)
 
 
-def test_absmax_kernel():
-    x = torch.randn(3, 80, 252, device=DEV)
-    x[1] *= 1e-12
-    x[2, 7, 100] = -3.5e6
-    out = torch.full((3,), -1.0, device=DEV)
-    hip.absmax(x, out)
-    assert torch.equal(out.cpu(), x.abs().amax(dim=(1, 2)).cpu())
+@pytest.mark.parametrize('b,t,h', [(3, 7, 500), (17, 5, 36), (64, 3, 500), (2, 4, 12), (8, 250, 500), (33, 61, 500), (1, 1, 500), (16, 2, 512)])
+def test_lstm_recurrence_in_one_launch_is_bit_identical(b, t, h):
+    """All frames in one launch (w_hh resident, flag-synchronised steps) against one launch per frame: same h, bit for bit; the status
+    word stays clear (no wait timed out); the final cell state is left in cell_ws as the per-frame form leaves it."""
+    torch.manual_seed(h + b)
+    gates = torch.randn(t, b, 4 * h, device=DEV)
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.2
+    packed = hip.lstm_pack_whh(w_hh)
+    out0, out1 = torch.full((b, t, h), float('nan'), device=DEV), torch.full((b, t, h), float('nan'), device=DEV)
+    cell0, cell1 = torch.empty(b, h, device=DEV), torch.full((b, h), float('nan'), device=DEV)
+    hip.lstm_recurrence_packed(gates, packed, cell0, out0)
+    ws = hip.lstm_seq_workspace(b, h, DEV)
+    assert ws is not None
+    hip.lstm_recurrence_seq(gates, packed, cell1, out1, ws)
+    hip.lstm_seq_status(ws)
+    assert torch.isfinite(out1).all() and torch.equal(out0, out1)
+    assert torch.equal(cell0, cell1)
+
+
+def test_lstm_recurrence_in_one_launch_under_uneven_load():
+    """The hand-off of h between workgroups must not depend on placement or timing: repeat the production shape while a second stream
+    keeps part of the chip busy with node kernels (so workgroups start late, run at different speeds and find warm L1s), re-using ONE
+    workspace (flags and images are reset by every call), and compare every word every time."""
+    torch.manual_seed(77)
+    b, t, h = 64, 120, 500
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.2
+    packed = hip.lstm_pack_whh(w_hh)
+    ws = hip.lstm_seq_workspace(b, h, DEV)
+    cell = torch.empty(b, h, device=DEV)
+    c, frames = 600, 1000
+    xb = torch.randn(16, c, frames, device=DEV)
+    yb = torch.empty_like(xb)
+    wb, bb = torch.randn(c, c // 100, 5, device=DEV) * 0.1, torch.zeros(c, device=DEV)
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        gates = torch.randn(t, b, 4 * h, device=DEV)
+        want = torch.empty(b, t, h, device=DEV)
+        hip.lstm_recurrence_packed(gates, packed, cell, want)
+        got = torch.full((b, t, h), float('nan'), device=DEV)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            for _ in range(4 + 3 * rep):
+                hip.grouped_conv1d_node(xb, wb, bb, [], yb, frames, 100, 5, 1)
+        hip.lstm_recurrence_seq(gates, packed, cell, got, ws)
+        hip.lstm_seq_status(ws)
+        torch.cuda.synchronize()
+        assert torch.equal(want, got), rep
+
+
+def test_lstm_recurrence_in_one_launch_limits():
+    assert hip.lstm_seq_workspace(65, 500, DEV) is None          # 5 tiles x 63 slices > 256 resident workgroups
+    assert hip.lstm_seq_workspace(8, 516, DEV) is None           # K does not fit one round of the 8 waves
+    gates = torch.randn(2, 65, 2000, device=DEV)
+    packed = hip.lstm_pack_whh(torch.randn(2000, 500, device=DEV))
+    with pytest.raises(hip.HipError, match='does not apply'):
+        hip.lstm_recurrence_seq(gates, packed, torch.empty(65, 500, device=DEV), torch.empty(65, 2, 500, device=DEV),
+                                torch.empty(1 << 20, dtype=torch.uint8, device=DEV))
 
 
 def test_layernorm_absmax_by_product():

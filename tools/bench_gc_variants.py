@@ -47,7 +47,7 @@ def main():
             wp = hip.pack_grouped_weights(w, 100)
             bias = torch.randn(c, device=dev) * 0.1
             stats = torch.empty(a.batch, 2, ld, device=dev)
-            hip.channel_stats_v(x, stats, t, 1e-3)
+            hip.channel_stats(x, stats, t, 1e-3)
             ln = (stats, torch.ones(c, device=dev), torch.zeros(c, device=dev))
             ws = hip.grouped_stats_workspace(a.batch, ld, 100, dev)
             flavours = {'plain': dict(skips=[], ln=None, on_x=False, ws=None),

@@ -35,7 +35,7 @@ for B in args.batches:
         for b_ in bufs:
             b_[:, :, t:] = 0
         stats = torch.empty(B, 2, ld, device=dev)
-        hip.channel_stats_v(bufs[0], stats, t, 1e-3)
+        hip.channel_stats(bufs[0], stats, t, 1e-3)
         gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
         for flavour, n_skips in (('plain', 0), ('plain', 1), ('lnx', 1)) + ((('lnx', 0),) if args.lnx0 else ()):
             ln = (stats, gamma, beta) if flavour == 'lnx' else None

@@ -42,7 +42,7 @@ for blk, (c, stride) in enumerate(zip((600, 800, 1000, 1200), (1, 1, 2, 2))):
     w = torch.randn(c, c // 100, 5, device=dev) * 0.2
     bias = torch.randn(c, device=dev) * 0.1
     stats = torch.empty(B, 2, ld, device=dev)
-    hip.channel_stats_v(sets[0][0], stats, t, 1e-3)
+    hip.channel_stats(sets[0][0], stats, t, 1e-3)
     gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
     ln = hip.DeferredLN(stats.data_ptr(), gamma.data_ptr(), beta.data_ptr())
     ws = hip.grouped_stats_workspace(B, ld, 100, dev)

@@ -41,7 +41,7 @@ for B in args.batches:
             for b_ in bufs:
                 b_[:, :, t:] = 0
             stats = torch.empty(B, 2, ld, device=dev)
-            hip.channel_stats_v(bufs[0], stats, t, 1e-3)
+            hip.channel_stats(bufs[0], stats, t, 1e-3)
             gamma, beta = torch.ones(c, device=dev), torch.zeros(c, device=dev)
             ws = hip.grouped_stats_workspace(B, ld, 100, dev)
             for flavour in ('plain', 'skip', 'lnx', 'lnx+skip', 'stats0', 'stats'):
