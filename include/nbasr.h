@@ -257,6 +257,23 @@ int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, i
                              const float* w2, const float* b2, int k2, int d2, int skip_mask, void* y,
                              int batch, int channels, int frames, int ld, int groups,
                              const nbasr_deferred_ln* ln, float* stats_ws, int dtype, nbasr_stream_t stream);
+/* The same cell for the bf16 storage path on the MATRIX cores (grouped_cell_mfma.hip): every tensor of the bf16 model is a bfloat16
+ * tensor, so the products go to v_mfma_f32_16x16x32_bf16 unchanged -- exact bf16 x bf16 products, fp32 accumulation: the reference's
+ * arithmetic up to the order of the sums (NOT bit-identical to the vector-ALU kernels; within an fp32 rounding of them before the one
+ * bf16 rounding per tensor).  x0, y: bf16 (batch, channels, ld), ld % 8 == 0; the normalised cell input is rounded to bf16 like every
+ * other tensor (the reference's LayerNorm output is one).  Weights: the fp32 values of the bf16 parameters, re-laid-out once per
+ * weight version as MFMA fragments (nbasr_grouped_cell_mfma_weights_bytes / nbasr_grouped_cell_mfma_pack, one image per node).
+ * No statistics by-product.  nbasr_grouped_cell_mfma_fits: 0 = the row does not fit a workgroup (two bf16 tiles per group within
+ * 160 KiB of LDS), else the groups per workgroup. */
+size_t nbasr_grouped_cell_mfma_weights_bytes(int channels, int groups, int kernel);
+int nbasr_grouped_cell_mfma_pack(const float* w, void* packed, int channels, int groups, int kernel, nbasr_stream_t stream);
+int nbasr_grouped_cell_mfma_fits(int channels, int frames_ld, int groups);
+int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const float* b0, int k0, int d0,
+                            const void* wp1, const float* b1, int k1, int d1,
+                            const void* wp2, const float* b2, int k2, int d2, int skip_mask, void* y,
+                            int batch, int channels, int frames, int ld, int groups,
+                            const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+
 /* Node whose main op is `zero` (reference ops.py:67-68): y = 0 + skip0 + skip1 + skip2 (`dtype` tensors; `ln`: pending LayerNorm of
  * skip0 when ln_on_skip0). */
 int nbasr_skip_sum(const void* skip0, const void* skip1, const void* skip2, void* y, int batch, int channels, int frames,

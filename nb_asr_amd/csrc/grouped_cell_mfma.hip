@@ -1,0 +1,354 @@
+// bf16 storage path (BASELINE config 4): a whole SearchCell of three grouped convolutions in ONE launch on the MATRIX cores.
+//   x1 = op0(x0n) + s00 x0n;   x2 = op1(x1) + s10 x0n + s11 x1;   x3 = op2(x2) + s20 x0n + s21 x1 + s22 x2
+// (reference model.py:49-59 over model.py:13-22 and ops.py:24-30 on torch.bfloat16 tensors).
+//
+// Why a second cell kernel: with bf16 storage the bytes halve but the vector-ALU form (grouped_cell.hip) still issues one FMA per
+// product -- 2 per lane per instruction -- and is bound by that (0.31-0.51 of its roof at 32 x 1600).  Every tensor of the bf16 model
+// IS a bfloat16 tensor (the reference rounds each op's output once), so the products can go to v_mfma_f32_16x16x32_bf16 unchanged:
+// exact bf16 x bf16 products, fp32 accumulation -- the reference's arithmetic up to the order of the sums.
+//
+// Mapping (per group of CG = 6..12 channels; groups never mix):
+//   * the group's tensor lives in LDS FRAME-major, tile[frame][CP channels] bf16 with CP = 8 or 16 (pad channels are zero), 16 zero
+//     frames either side: a frame's channels are 16 (or 2 x 16) contiguous, 16-byte aligned bytes;
+//   * one MFMA = 16 output channels (M; CG used) x 16 frames (N) x 32 (tap, channel) pairs (K): K runs over 4 taps x 8 channels
+//     (CP = 8) or 2 taps x 16 channels (CP = 16).  The B operand of lane (n, kb) is ONE aligned ds_read_b128 -- the 8 channels of
+//     frame f0 + n + tap * dilation - left_pad -- so dilation and padding are address arithmetic; the A operand is the weights,
+//     pre-packed per (node, group, K step, lane) and held in registers for the node (<= 16 registers);
+//   * a wave owns 256 frames = 16 column blocks; per block 2-4 MFMAs (taps padded to 8 / 6 / 8 with zero weights; a padded tap reads
+//     the lane's tap-0 window, so a NaN there surfaces at this frame as it does through the real tap 0), then the node's epilogue on the accumulator fragment -- lane =
+//     (frame, 4 channels): bias is the accumulator's initial value, relu + clamp, the skips in python's sum order, tail mask, ONE
+//     rounding to bf16 -- written as 8 bytes into the OTHER tile (ping-pong: x0n in A, x1 in B, x2 in A, x3 in B), so a node needs one
+//     barrier, not two.  Skip inputs are read at the lane's own position (x0n for the last node is carried in registers);
+//   * x0 comes in and x3 goes out channel-major (the tensors' layout in HBM) through a lane = (channel pair, 8-frame chunk) map:
+//     16-byte global accesses, 4-byte LDS accesses.
+// No statistics by-product (the bf16 executor's cell LayerNorm is consumed by the next convolution's image writer, which computes
+// them on the way); a cell whose consumer wants them runs on grouped_cell.hip.
+#include "common.h"
+#include "storage.h"
+
+#include <type_traits>
+
+namespace nbasr {
+
+typedef __bf16 cm_bf8 __attribute__((ext_vector_type(8)));
+typedef float cm_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned cm_u4 __attribute__((ext_vector_type(4)));
+
+constexpr int CM_PADL = 16, CM_PADR = 16;       // zero frames either side of a tile (taps reach <= 12 frames back, <= 14 ahead)
+constexpr int CM_NB = 16;                       // 16-frame column blocks per wave
+constexpr int CM_WAVE_FRAMES = 16 * CM_NB;
+
+struct CellMDims {
+    int channels, frames, ld, groups, batch, cg;
+    int k[3], d[3], lpad[3], nstep[3];          // taps, dilation, left padding, MFMAs per column block of each node
+    int skips;                                  // bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22
+    int nt;                                     // 256-frame wave tiles per row
+};
+
+__device__ __forceinline__ cm_f4 cm_unpack4(u2v p) { return cm_f4{bf16_lo(p.x), bf16_hi(p.x), bf16_lo(p.y), bf16_hi(p.y)}; }
+
+template <int CP, int GPW>
+__global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
+    const bf16_t* __restrict__ x0, bf16_t* __restrict__ y,
+    const cm_u4* __restrict__ wp0, const cm_u4* __restrict__ wp1, const cm_u4* __restrict__ wp2,
+    const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
+    const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, const CellMDims a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    const int nt = a.nt;
+    const int rows = nt * CM_WAVE_FRAMES + CM_PADL + CM_PADR;        // frames of a tile, pads included
+    const int tile_bytes = rows * CP * 2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int gi = wave / nt, ti = wave - gi * nt;
+    unsigned char* const tile_a = cm_lds + gi * 2 * tile_bytes;      // x0n, then x2
+    unsigned char* const tile_b = tile_a + tile_bytes;               // x1, then x3
+    const int g = blockIdx.x * GPW + gi, b = blockIdx.y;             // (GPW divides the group count: host check)
+    const int fb = ti * CM_WAVE_FRAMES;
+
+    // ---- zero pads of every tile ---------------------------------------------------------------------------------------------------
+    {
+        const int units = (CM_PADL + CM_PADR) * CP * 2 / 16;         // 16-byte units per tile
+        for (int i = threadIdx.x; i < GPW * 2 * units; i += blockDim.x) {
+            const int t = i / units, u = i - t * units;
+            const int byte = u * 16 < CM_PADL * CP * 2 ? u * 16 : (rows - CM_PADR) * CP * 2 + (u * 16 - CM_PADL * CP * 2);
+            *reinterpret_cast<cm_u4*>(cm_lds + t * tile_bytes + byte) = cm_u4{0u, 0u, 0u, 0u};
+        }
+    }
+
+    // ---- x0 -> tile A, normalised (pending LayerNorm) and rounded: lane = (channel pair, 8-frame chunk) ------------------------------
+    constexpr int PAIRS = CP / 2, CPI = 64 / PAIRS;                  // channel pairs of a tile row; chunks per wave instruction
+    const int cp = lane % PAIRS, chl = lane / PAIRS;
+    const size_t group_row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * a.cg) * a.ld;
+    const bool pair_ok = 2 * cp < a.cg;
+    {
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x0 + group_row0), 0, a.cg * a.ld * 2, 0x00020000);
+        const bool has_ln = ln_stats != nullptr;
+        const int c0 = min(2 * cp, a.cg - 2);
+        float gam0 = 1.f, bet0 = 0.f, gam1 = 1.f, bet1 = 0.f;
+        if (has_ln) {
+            gam0 = ln_gamma[g * a.cg + c0]; bet0 = ln_beta[g * a.cg + c0];
+            gam1 = ln_gamma[g * a.cg + c0 + 1]; bet1 = ln_beta[g * a.cg + c0 + 1];
+        }
+        const float* mrow = ln_stats + static_cast<size_t>(b) * 2 * a.ld;
+#pragma unroll
+        for (int it = 0; it < 32 / CPI; ++it) {
+            const int chunk = ti * 32 + it * CPI + chl, f0 = chunk * 8;
+            const bool ok = pair_ok && f0 < a.ld;
+            const int off = ok ? (2 * cp * a.ld + f0) * 2 : 0x7ffffff0;              // out of range: the buffer load returns zeros
+            const cm_u4 r0 = __builtin_bit_cast(cm_u4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+            const cm_u4 r1 = __builtin_bit_cast(cm_u4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? off + a.ld * 2 : off, 0, 0));
+            float v0[8], v1[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v0[2 * j] = bf16_lo(r0[j]); v0[2 * j + 1] = bf16_hi(r0[j]); v1[2 * j] = bf16_lo(r1[j]); v1[2 * j + 1] = bf16_hi(r1[j]); }
+            if (has_ln) {                                            // (workgroup-uniform)
+                float mean[8], rstd[8];
+                const int fs = f0 < a.ld ? f0 : 0;                   // (beyond the row: any valid address; the values are zeros anyway)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 m4 = *reinterpret_cast<const float4*>(mrow + fs + 4 * h);
+                    const float4 r4 = *reinterpret_cast<const float4*>(mrow + a.ld + fs + 4 * h);
+                    mean[4 * h] = m4.x; mean[4 * h + 1] = m4.y; mean[4 * h + 2] = m4.z; mean[4 * h + 3] = m4.w;
+                    rstd[4 * h] = r4.x; rstd[4 * h + 1] = r4.y; rstd[4 * h + 2] = r4.z; rstd[4 * h + 3] = r4.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v0[j] = ok ? ln_apply(v0[j], mean[j], rstd[j], gam0, bet0) : 0.f;
+                    v1[j] = ok ? ln_apply(v1[j], mean[j], rstd[j], gam1, bet1) : 0.f;
+                }
+            }
+            unsigned char* dst = tile_a + ((f0 + CM_PADL) * CP + 2 * cp) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(dst + j * CP * 2) = pack_bf16x2(v0[j], v1[j]);
+        }
+    }
+    __syncthreads();
+
+    // ---- the three nodes -------------------------------------------------------------------------------------------------------------
+    const int n16 = lane & 15, kb = lane >> 4;                       // MFMA fragment coordinates: column / row-in-tile, 8-deep k block
+    const int q4 = kb * 4;                                           // first of this lane's 4 output channels in the accumulator fragment
+    const bool q_ok = q4 < CP;                                       // (CP = 8: the fragment's rows 8-15 do not exist)
+    const int own = ((fb + n16 + CM_PADL) * CP + (q_ok ? q4 : 0)) * 2;   // this lane's (frame, 4 channels) of column block 0, bytes
+    constexpr int NB_STRIDE = 16 * CP * 2;                           // bytes between column blocks
+    u2v keep0[CM_NB];                                                // x0n at the lane's positions, for the last node's skip
+
+    constexpr int NSMAX = CP == 8 ? 2 : 4;                           // K steps per column block: CP = 8: 8 taps (2); CP = 16: 6 or 8 taps (3 or 4)
+    auto node = [&](auto idx, const cm_u4* __restrict__ wp, const float* __restrict__ bias, const unsigned char* src, unsigned char* dst) {
+        constexpr int NODE = decltype(idx)::value;
+        const int K = a.k[NODE], D = a.d[NODE], LP = a.lpad[NODE], ns = a.nstep[NODE];
+        const bool four = NSMAX == 4 && ns == 4;                     // (wave-uniform)
+        cm_bf8 aw[NSMAX];
+        int off[NSMAX];
+#pragma unroll
+        for (int s = 0; s < NSMAX; ++s) {
+            const int tap = CP == 8 ? s * 4 + kb : s * 2 + (kb >> 1);
+            const int chb = CP == 8 ? 0 : (kb & 1);
+            // a padded tap (tap >= K) has zero weights; its B operand is the lane's tap-0 window (finite wherever the data are)
+            off[s] = ((fb + n16 + (tap < K ? tap * D - LP : -LP) + CM_PADL) * CP + chb * 8) * 2;
+            aw[s] = __builtin_bit_cast(cm_bf8, wp[(static_cast<size_t>(g) * ns + (s < ns ? s : 0)) * 64 + lane]);
+        }
+        cm_f4 bv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (q4 + r < a.cg) ? bias[g * a.cg + q4 + r] : 0.f;
+        cm_u4 nxt[NSMAX];
+        auto fetch = [&](int nb) {
+#pragma unroll
+            for (int s = 0; s < NSMAX; ++s)
+                if (s < 3 || four) nxt[s] = *reinterpret_cast<const cm_u4*>(src + off[s] + nb * NB_STRIDE);
+        };
+        fetch(0);
+#pragma unroll
+        for (int nb = 0; nb < CM_NB; ++nb) {
+            cm_u4 cur[NSMAX];
+#pragma unroll
+            for (int s = 0; s < NSMAX; ++s) cur[s] = nxt[s];
+            if (nb + 1 < CM_NB) fetch(nb + 1);                       // the next block's operands are in flight behind this block's MFMAs
+            cm_f4 acc = bv;
+#pragma unroll
+            for (int s = 0; s < NSMAX; ++s)
+                if (s < 3 || four) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[s], __builtin_bit_cast(cm_bf8, cur[s]), acc, 0, 0, 0);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[r]);
+            if (q_ok) {
+                const int pos = own + nb * NB_STRIDE;
+                auto add = [&](u2v p) { const cm_f4 v = cm_unpack4(p); o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3]; };
+                if constexpr (NODE == 0) {
+                    if (a.skips & 1) add(*reinterpret_cast<const u2v*>(tile_a + pos));
+                } else if constexpr (NODE == 1) {
+                    if (a.skips & (2 | 8)) {
+                        const u2v x0n = *reinterpret_cast<const u2v*>(tile_a + pos);
+                        keep0[nb] = x0n;
+                        if (a.skips & 2) add(x0n);
+                    }
+                    if (a.skips & 4) add(*reinterpret_cast<const u2v*>(tile_b + pos));
+                } else {
+                    if (a.skips & 8) add(keep0[nb]);
+                    if (a.skips & 16) add(*reinterpret_cast<const u2v*>(tile_b + pos));
+                    if (a.skips & 32) add(*reinterpret_cast<const u2v*>(tile_a + pos));
+                }
+                if (fb + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+                *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            }
+        }
+        __syncthreads();
+    };
+    node(std::integral_constant<int, 0>{}, wp0, b0, tile_a, tile_b);
+    node(std::integral_constant<int, 1>{}, wp1, b1, tile_b, tile_a);
+    node(std::integral_constant<int, 2>{}, wp2, b2, tile_a, tile_b);
+
+    // ---- x3 (tile B) -> y, channel-major: lane = (channel pair, 8-frame chunk) -------------------------------------------------------
+    {
+        const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + group_row0, 0, a.cg * a.ld * 2, 0x00020000);
+#pragma unroll
+        for (int it = 0; it < 32 / CPI; ++it) {
+            const int chunk = ti * 32 + it * CPI + chl, f0 = chunk * 8;
+            const unsigned char* srcp = tile_b + ((f0 + CM_PADL) * CP + 2 * cp) * 2;
+            unsigned dd[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dd[j] = *reinterpret_cast<const unsigned*>(srcp + j * CP * 2);
+            cm_u4 r0, r1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r0[j] = __builtin_amdgcn_perm(dd[2 * j + 1], dd[2 * j], 0x05040100u);       // channel 2 cp:     frames 2j, 2j + 1
+                r1[j] = __builtin_amdgcn_perm(dd[2 * j + 1], dd[2 * j], 0x07060302u);       // channel 2 cp + 1
+            }
+            const bool ok = pair_ok && f0 < a.ld;
+            const int off = ok ? (2 * cp * a.ld + f0) * 2 : 0x7ffffff0;                      // out of range: the store is dropped
+            __builtin_amdgcn_raw_buffer_store_b128(r0, yr, off, 0, 2);
+            __builtin_amdgcn_raw_buffer_store_b128(r1, yr, ok ? off + a.ld * 2 : off, 0, 2);
+        }
+    }
+}
+
+static size_t cellm_lds_bytes(int cp, int nt, int gpw)
+{
+    return static_cast<size_t>(gpw) * 2 * (nt * CM_WAVE_FRAMES + CM_PADL + CM_PADR) * cp * 2;
+}
+static int cellm_cp(int cg) { return cg <= 8 ? 8 : 16; }
+// groups per workgroup: as many as fit 160 KiB of LDS and 16 waves, from {4, 2, 1}; 0 = the row does not fit at all
+static int cellm_gpw(int cg, int nt, int groups)
+{
+    for (int gpw = 4; gpw >= 1; gpw >>= 1)
+        if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw) <= 160 * 1024) return gpw;
+    return 0;
+}
+static int cellm_nstep(int cp, int kernel) { return cp == 8 ? (kernel + 3) / 4 : (kernel + 1) / 2; }
+
+template <int CP, int GPW>
+static int launch_cellm(const bf16_t* x0, bf16_t* y, const void* const* wp, const float* const* bias, const LnRef& l, const CellMDims& a, hipStream_t stream)
+{
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_mfma_kernel<CP, GPW>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr != hipSuccess) {
+        set_error("nbasr_grouped_cell_mfma: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
+        return static_cast<int>(attr);
+    }
+    hipLaunchKernelGGL((grouped_cell_mfma_kernel<CP, GPW>), dim3(a.groups / GPW, a.batch), dim3(64 * GPW * a.nt), cellm_lds_bytes(CP, a.nt, GPW), stream,
+                       x0, y, static_cast<const cm_u4*>(wp[0]), static_cast<const cm_u4*>(wp[1]), static_cast<const cm_u4*>(wp[2]),
+                       bias[0], bias[1], bias[2], l.stats, l.gamma, l.beta, a);
+    return launch_status("nbasr_grouped_cell_mfma");
+}
+
+// w (channels, cg, kernel) fp32 -> [group][K step][lane] x 8 bf16: the A fragments of the node's MFMAs (zero outside the group's
+// cg x cg x kernel block).  Lane (m = out channel, kb): CP = 8: tap = 4 s + kb, channels 0..7; CP = 16: tap = 2 s + (kb >> 1),
+// channels 8 (kb & 1) .. + 7.
+__global__ __launch_bounds__(256) void pack_cell_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int groups, int cg,
+                                                                int kernel, int cp, int nstep)
+{
+    const int total = groups * nstep * 64 * 8;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int e = i;
+        const int j = e % 8; e /= 8;
+        const int lane = e % 64; e /= 64;
+        const int s = e % nstep; e /= nstep;
+        const int g = e, m = lane & 15, kb = lane >> 4;
+        const int tap = cp == 8 ? s * 4 + kb : s * 2 + (kb >> 1);
+        const int c = cp == 8 ? j : (kb & 1) * 8 + j;
+        float v = 0.f;
+        if (m < cg && c < cg && tap < kernel) v = w[((static_cast<size_t>(g) * cg + m) * cg + c) * kernel + tap];
+        packed[i] = static_cast<unsigned short>(pack_bf16x2(v, 0.f) & 0xffffu);
+    }
+}
+
+}  // namespace nbasr
+
+using namespace nbasr;
+
+extern "C" size_t nbasr_grouped_cell_mfma_weights_bytes(int channels, int groups, int kernel)
+{
+    if (channels <= 0 || groups <= 0 || channels % groups || (kernel != 5 && kernel != 7)) return 0;
+    const int cg = channels / groups;
+    if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
+    return static_cast<size_t>(groups) * cellm_nstep(cellm_cp(cg), kernel) * 64 * 16;
+}
+
+extern "C" int nbasr_grouped_cell_mfma_pack(const float* w, void* packed, int channels, int groups, int kernel, nbasr_stream_t stream)
+{
+    clear_error();
+    const size_t bytes = nbasr_grouped_cell_mfma_weights_bytes(channels, groups, kernel);
+    NBASR_REQUIRE(bytes != 0, NBASR_EINVAL, "nbasr_grouped_cell_mfma_pack: channels=%d groups=%d kernel=%d unsupported (channels/groups in {6, 8, 10, 12}, kernel in {5, 7})",
+                  channels, groups, kernel);
+    NBASR_REQUIRE(w && packed, NBASR_ENULL, "nbasr_grouped_cell_mfma_pack: NULL pointer");
+    NBASR_REQUIRE(aligned16(packed), NBASR_EALIGN, "nbasr_grouped_cell_mfma_pack: packed must be 16-byte aligned");
+    const int cg = channels / groups, cp = cellm_cp(cg);
+    hipLaunchKernelGGL(pack_cell_weights_kernel, dim3(256), dim3(256), 0, as_stream(stream), w, static_cast<unsigned short*>(packed), groups, cg, kernel,
+                       cp, cellm_nstep(cp, kernel));
+    return launch_status("nbasr_grouped_cell_mfma_pack");
+}
+
+extern "C" int nbasr_grouped_cell_mfma_fits(int channels, int frames_ld, int groups)
+{
+    if (channels <= 0 || groups <= 0 || channels % groups || frames_ld <= 0 || frames_ld % 8) return 0;
+    const int cg = channels / groups;
+    if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
+    const int nt = (frames_ld + CM_WAVE_FRAMES - 1) / CM_WAVE_FRAMES;
+    return cellm_gpw(cg, nt, groups);
+}
+
+extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const float* b0, int k0, int d0,
+                                       const void* wp1, const float* b1, int k1, int d1,
+                                       const void* wp2, const float* b2, int k2, int d2, int skip_mask, void* y,
+                                       int batch, int channels, int frames, int ld, int groups,
+                                       const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && channels > 0 && frames >= 0 && groups > 0 && channels % groups == 0, NBASR_EINVAL,
+                  "nbasr_grouped_cell_mfma: bad sizes batch=%d channels=%d frames=%d groups=%d", batch, channels, frames, groups);
+    if (batch == 0 || ld == 0) return NBASR_OK;
+    NBASR_REQUIRE(x0 && wp0 && b0 && wp1 && b1 && wp2 && b2 && y, NBASR_ENULL, "nbasr_grouped_cell_mfma: NULL pointer");
+    NBASR_REQUIRE(ld >= frames && ld % 8 == 0 && aligned16(x0) && aligned16(y) && aligned16(wp0) && aligned16(wp1) && aligned16(wp2), NBASR_EALIGN,
+                  "nbasr_grouped_cell_mfma: ld=%d must be >= frames=%d and a multiple of 8; x0, y and the packed weights 16-byte aligned", ld, frames);
+    NBASR_REQUIRE(batch <= 65535 && skip_mask >= 0 && skip_mask < 64, NBASR_EINVAL, "nbasr_grouped_cell_mfma: bad batch / skip mask");
+    NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
+                  "nbasr_grouped_cell_mfma: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
+    const int gpw = nbasr_grouped_cell_mfma_fits(channels, ld, groups);
+    NBASR_REQUIRE(gpw != 0, NBASR_EINVAL,
+                  "nbasr_grouped_cell_mfma: a row of %d frames x %d channels per group does not fit one workgroup (channels/groups in {6, 8, 10, 12}, "
+                  "two bf16 tiles per group within 160 KiB of LDS); use nbasr_grouped_cell_fused or the per-node launches", ld, channels / groups);
+    const int ks[3] = {k0, k1, k2}, ds[3] = {d0, d1, d2};
+    CellMDims a{};
+    a.channels = channels; a.frames = frames; a.ld = ld; a.groups = groups; a.batch = batch; a.cg = channels / groups;
+    const int cp = cellm_cp(a.cg);
+    for (int i = 0; i < 3; ++i) {
+        NBASR_REQUIRE((ks[i] == 5 || ks[i] == 7) && (ds[i] == 1 || ds[i] == 2), NBASR_EINVAL,
+                      "nbasr_grouped_cell_mfma: node %d has (kernel=%d, dilation=%d); the search space has k in {5, 7}, d in {1, 2}", i, ks[i], ds[i]);
+        a.k[i] = ks[i]; a.d[i] = ds[i]; a.lpad[i] = pad_left(ks[i], ds[i], 1); a.nstep[i] = cellm_nstep(cp, ks[i]);
+    }
+    a.skips = skip_mask;
+    a.nt = (ld + CM_WAVE_FRAMES - 1) / CM_WAVE_FRAMES;
+    const void* const wp[3] = {wp0, wp1, wp2};
+    const float* const bias[3] = {b0, b1, b2};
+    const LnRef l = ln_ref(ln, true);
+    const bf16_t* xin = static_cast<const bf16_t*>(x0);
+    bf16_t* yout = static_cast<bf16_t*>(y);
+    hipStream_t s = as_stream(stream);
+    if (cp == 8) {
+        if (gpw == 4) return launch_cellm<8, 4>(xin, yout, wp, bias, l, a, s);
+        if (gpw == 2) return launch_cellm<8, 2>(xin, yout, wp, bias, l, a, s);
+        return launch_cellm<8, 1>(xin, yout, wp, bias, l, a, s);
+    }
+    if (gpw == 4) return launch_cellm<16, 4>(xin, yout, wp, bias, l, a, s);
+    if (gpw == 2) return launch_cellm<16, 2>(xin, yout, wp, bias, l, a, s);
+    return launch_cellm<16, 1>(xin, yout, wp, bias, l, a, s);
+}

@@ -187,7 +187,11 @@ class ForwardPlan:
         # cells whose three nodes are grouped convs run as ONE launch where a row fits a workgroup (<= 1024 frames): x1 and x2 never
         # touch HBM and the cell's LayerNorm statistics come out of the same launch (grouped_cell.hip, round 3).  Bit-identical to
         # the three node launches; NBASR_CELL_FUSION=0 turns it off (A/B)
-        self.cell_fusion = os.environ.get('NBASR_CELL_FUSION', '1') != '0'
+        _cf = os.environ.get('NBASR_CELL_FUSION', '1')
+        if _cf not in ('1', '0', 'valu'):
+            raise ValueError(f"NBASR_CELL_FUSION={_cf!r}: expected '1', '0' or 'valu'")
+        self.cell_fusion = _cf != '0'
+        self.cell_mfma = _cf == '1'          # bf16 storage: the matrix-core cell kernel ('valu': the vector-ALU one, as for fp32)
         # the LSTM recurrence in ONE launch (w_hh resident in registers; nbasr.h: nbasr_lstm_recurrence_seq): 'auto' = in the plain forward
         # (latency: 4.2 instead of 5.6 us per frame), not in a pipelined tail, whose resident grid would hold CUs the next batch's
         # encoder needs (measured: -3...-8 % utterances/s at 8-64 utterances); '0' = one launch per frame everywhere; '1' = wherever
@@ -909,7 +913,14 @@ class ForwardPlan:
                         n_sk = [sum(isinstance(br, Identity) for br in n.branch_ops) for n in layer.nodes]
                         meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_sk), act_frames, 0)
                         src, ln0, cell_ws = act, pending, (self.stats_ws if epilogue_stats else None)
-                        self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0, cell_ws))
+                        if self.cell_mfma and not epilogue_stats and hip.grouped_cell_mfma_fits(layer.filters, act.shape[2], last_op.groups):
+                            # every tensor of the bf16 model is a bfloat16 tensor: the products go to the matrix cores unchanged (grouped_cell_mfma.hip)
+                            groups = last_op.groups
+                            mspecs = [(self._cached(n.op.conv.weight, 'cell_mfma', (lambda w=n.op.conv.weight: hip.grouped_cell_mfma_pack(self._f32(w), groups))),
+                                       sp[1], sp[2], sp[3]) for n, sp in zip(layer.nodes, specs)]
+                            self._timed('grouped_cell', meta, lambda: hip.grouped_cell_mfma(src, mspecs, mask, view, act_frames, groups, ln0))
+                        else:
+                            self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0, cell_ws))
                         outs = [act, None, None, view]
                     for j, (node, dst) in enumerate(zip(layer.nodes, free) if not cell_gpp else ()):
                         if len(outs) != len(node.branch_ops):

@@ -45,6 +45,11 @@ SIGNATURES = {
     'nbasr_grouped_cell_fits': (_c_int, [_c_int] * 3),
     'nbasr_grouped_cell_fused': (_c_int, [_c_float_p, _c_float_p, _c_float_p, _c_int, _c_int, _c_float_p, _c_float_p, _c_int, _c_int,
                                           _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_float_p, _c_int, _c_stream]),
+    'nbasr_grouped_cell_mfma_weights_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_grouped_cell_mfma_pack': (_c_int, [_c_float_p] * 2 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_grouped_cell_mfma_fits': (_c_int, [_c_int] * 3),
+    'nbasr_grouped_cell_mfma': (_c_int, [_c_float_p, _c_float_p, _c_float_p, _c_int, _c_int, _c_float_p, _c_float_p, _c_int, _c_int,
+                                         _c_float_p, _c_float_p, _c_int, _c_int, _c_int, _c_float_p] + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_skip_sum': (_c_int, [_c_float_p] * 4 + [_c_int] * 4 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_repitch': (_c_int, [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
     'nbasr_convert': (_c_int, [_c_float_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_stream]),
@@ -106,7 +111,7 @@ SIGNATURES = {
 
 # entry points that only answer on the host (never recorded on a launch tape); every other one enqueues work on a stream
 _HOST_ONLY = frozenset({'nbasr_version', 'nbasr_build_id', 'nbasr_last_error', 'nbasr_pad_amounts', 'nbasr_output_frames',
-                        'nbasr_grouped_cell_fits'})
+                        'nbasr_grouped_cell_fits', 'nbasr_grouped_cell_mfma_fits'})
 _ENQUEUES = frozenset(name for name in SIGNATURES if name not in _HOST_ONLY and not name.endswith('_bytes')
                       and '_bytes_' not in name)
 
@@ -296,6 +301,36 @@ def grouped_cell_fused(x0, nodes, skip_mask, y, frames, groups, ln=None, stats_w
     dtype = x0.dtype
     _check(load_library().nbasr_grouped_cell_fused(_act(x0, 'x0', dtype), *args, skip_mask, _act(y, 'y', dtype), b, c, frames, ld, groups,
                                                    _ln(ln), _opt(stats_ws, 'stats_ws'), dtype_code(dtype), _stream(x0)), 'nbasr_grouped_cell_fused')
+    return y
+
+
+def grouped_cell_mfma_fits(channels, ld, groups):
+    """0 when a bf16 (channels, ld, groups) cell cannot run as one matrix-core launch, else its groups per workgroup."""
+    return int(load_library().nbasr_grouped_cell_mfma_fits(channels, ld, groups))
+
+
+def grouped_cell_mfma_pack(weight, groups):
+    """(C, C/groups, k) fp32 weight (the values of a bf16 parameter) -> the MFMA fragment image grouped_cell_mfma takes for that node."""
+    c, _, k = weight.shape
+    nbytes = load_library().nbasr_grouped_cell_mfma_weights_bytes(c, groups, k)
+    if nbytes == 0:
+        raise HipError(f'grouped_cell_mfma_pack: weight shape {tuple(weight.shape)} with {groups} groups is not a node op of the search space')
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=weight.device)
+    _check(load_library().nbasr_grouped_cell_mfma_pack(_dev(weight, 'weight'), packed.data_ptr(), c, groups, k, _stream(weight)),
+           'nbasr_grouped_cell_mfma_pack')
+    return packed
+
+
+def grouped_cell_mfma(x0, nodes, skip_mask, y, frames, groups, ln=None):
+    """The bf16 cell on the matrix cores.  nodes: three (packed weight from grouped_cell_mfma_pack, fp32 bias, kernel, dilation)."""
+    b, c, ld = x0.shape
+    args = []
+    for packed, bias, k, d in nodes:
+        if not packed.is_cuda or packed.dtype != torch.uint8 or packed.numel() != load_library().nbasr_grouped_cell_mfma_weights_bytes(c, groups, k):
+            raise HipError('grouped_cell_mfma: node weights must be the uint8 tensors of grouped_cell_mfma_pack for this (channels, groups, kernel)')
+        args += [packed.data_ptr(), _dev(bias, 'bias'), k, d]
+    _check(load_library().nbasr_grouped_cell_mfma(_act(x0, 'x0', torch.bfloat16), *args, skip_mask, _act(y, 'y', torch.bfloat16), b, c, frames, ld,
+                                                  groups, _ln(ln), _stream(x0)), 'nbasr_grouped_cell_mfma')
     return y
 
 

@@ -290,3 +290,66 @@ def test_fused_cell_either_storage_type_equals_three_node_launches(dtype, c, gro
         assert torch.equal(st_cell[:, :, :t], st_node[:, :, :t])
     else:
         assert torch.allclose(st_cell[:, :, :t], st_node[:, :, :t], rtol=2e-6, atol=1e-6)
+
+
+def _bf16_round(v):
+    return v.to(torch.float32).to(BF).to(torch.float64)
+
+
+@pytest.mark.parametrize('c,groups,t', [(600, 100, 1600), (800, 100, 1000), (1000, 100, 800), (1200, 100, 400), (40, 5, 801), (32, 4, 2048), (36, 6, 77), (48, 4, 8)])
+@pytest.mark.parametrize('kds,mask,with_ln', [(((7, 1), (7, 2), (5, 2)), 63, True), (((5, 1), (5, 1), (5, 1)), 0, True), (((5, 2), (7, 2), (7, 1)), 0b010110, False),
+                                              (((7, 2), (5, 1), (7, 2)), 0b101001, True)])
+def test_bf16_cell_on_the_matrix_cores(c, groups, t, kds, mask, with_ln):
+    """nbasr_grouped_cell_mfma (bf16 storage, v_mfma_f32_16x16x32_bf16) against a float64 restatement of what the reference computes on
+    torch.bfloat16 tensors: every tensor -- the normalised cell input, x1, x2, x3 -- is rounded to bfloat16 ONCE, products and sums in
+    between are exact / wide.  The kernel accumulates in fp32, so an element may land on the other side of a rounding boundary: at most
+    one bf16 step off, and rarely.  Also: the pitch columns stay zero, and the vector-ALU cell (which keeps the normalised input in
+    fp32) agrees to bf16 resolution."""
+    torch.manual_seed(c + t + mask)
+    b = 2
+    x = (torch.randn(b, c, t) * 1.5 + 0.3).to(BF).float()
+    xp = pitched(x, BF)
+    ld = xp.shape[2]
+    ln = None
+    xn = x.double()
+    if with_ln:
+        stats = torch.empty(b, 2, ld, device=DEV)
+        hip.channel_stats(xp, stats, t, 1e-3)
+        gamma, beta = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+        ln = (stats, gamma.to(DEV), beta.to(DEV))
+        mean, rstd = stats[:, 0, :t].cpu().double(), stats[:, 1, :t].cpu().double()
+        xn = (x.double() - mean[:, None, :]) * rstd[:, None, :] * gamma.double()[None, :, None] + beta.double()[None, :, None]
+    xn = _bf16_round(xn)
+    ws = [((torch.randn(c, c // groups, k) * 0.3).to(BF).float(), (torch.randn(c) * 0.2).to(BF).float(), k, d) for k, d in kds]
+    s = [bool(mask >> i & 1) for i in range(6)]
+
+    def op(v, w, bias, k, d):
+        return oracle.pad_conv_relu(v, w.double(), bias.double(), d, 1, groups)
+    x1 = _bf16_round(op(xn, *ws[0]) + (xn if s[0] else 0))
+    x2 = _bf16_round(op(x1, *ws[1]) + (xn if s[1] else 0) + (x1 if s[2] else 0))
+    want = _bf16_round(op(x2, *ws[2]) + (xn if s[3] else 0) + (x1 if s[4] else 0) + (x2 if s[5] else 0))
+    assert hip.grouped_cell_mfma_fits(c, ld, groups) in (1, 2, 4)
+    nodes = [(hip.grouped_cell_mfma_pack(w.to(DEV), groups), bias.to(DEV), k, d) for w, bias, k, d in ws]
+    got = torch.full_like(xp, 7.0)
+    hip.grouped_cell_mfma(xp, nodes, mask, got, t, groups, ln)
+    assert torch.all(got[:, :, t:] == 0)
+    g = got[:, :, :t].float().cpu().double()
+    step = torch.clamp(want.abs() * 2.0 ** -7, min=1e-5)              # >= one bf16 step at this magnitude (floor: sign flips of a ~0 pre-activation)
+    off = (g - want).abs()
+    # (an element of x1 / x2 that rounds the other way moves its ~84 consumers by a fraction of a step: two steps are the rare worst case)
+    assert bool((off <= 2 * step).all()), float((off / step).max())
+    assert float((off > step).double().mean()) < 1e-3, float((off > step).double().mean())
+    assert float((off > 0).double().mean()) < 0.02, float((off > 0).double().mean())
+    valu = torch.full_like(xp, 7.0)
+    hip.grouped_cell_fused(xp, [(w.to(DEV), bias.to(DEV), k, d) for w, bias, k, d in ws], mask, valu, t, groups, ln, None)
+    v = valu[:, :, :t].float().cpu().double()
+    assert float((v - g).abs().max()) <= 0.05 * max(1.0, float(want.abs().max()))
+
+
+def test_bf16_cell_on_the_matrix_cores_limits():
+    assert hip.grouped_cell_mfma_fits(1200, 4096, 100) == 0                  # two 32-byte-per-frame tiles of 4096 frames exceed 160 KiB
+    assert hip.grouped_cell_mfma_fits(700, 1000, 100) == 0                   # 7 channels per group is not in the search space
+    assert hip.grouped_cell_mfma_fits(1200, 1600, 100) == 1 and hip.grouped_cell_mfma_fits(600, 1600, 100) == 2
+    assert hip.grouped_cell_mfma_fits(800, 1000, 100) == 4
+    with pytest.raises(hip.HipError, match='not a node op'):
+        hip.grouped_cell_mfma_pack(torch.randn(700, 7, 5, device=DEV), 100)
