@@ -131,6 +131,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     const int own = ((fb + n16 + CM_PADL) * CP + (q_ok ? q4 : 0)) * 2;   // this lane's (frame, 4 channels) of column block 0, bytes
     constexpr int NB_STRIDE = 16 * CP * 2;                           // bytes between column blocks
     u2v keep0[CM_NB];                                                // x0n at the lane's positions, for the last node's skip
+    const bool tail = fb + CM_WAVE_FRAMES > a.frames;                // (wave-uniform) only the wave tile that holds the row's end masks frames
 
     constexpr int NSMAX = CP == 8 ? 2 : 4;                           // K steps per column block: CP = 8: 8 taps (2); CP = 16: 6 or 8 taps (3 or 4)
     auto node = [&](auto idx, const cm_u4* __restrict__ wp, const float* __restrict__ bias, const unsigned char* src, unsigned char* dst) {
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
                     if (a.skips & 16) add(*reinterpret_cast<const u2v*>(tile_b + pos));
                     if (a.skips & 32) add(*reinterpret_cast<const u2v*>(tile_a + pos));
                 }
-                if (fb + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+                if (tail && fb + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
                 *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             }
         }
@@ -229,8 +230,11 @@ static int cellm_cp(int cg) { return cg <= 8 ? 8 : 16; }
 // groups per workgroup: as many as fit 160 KiB of LDS and 16 waves, from {4, 2, 1}; 0 = the row does not fit at all
 static int cellm_gpw(int cg, int nt, int groups)
 {
-    for (int gpw = 4; gpw >= 1; gpw >>= 1)
-        if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw) <= 160 * 1024) return gpw;
+    // two workgroups per CU where a group's tiles allow it (<= 80 KiB per workgroup): their barriers and load phases then interleave;
+    // within that, as many groups per workgroup as fit (waves per barrier domain)
+    for (int budget = 80; budget <= 160; budget += 80)
+        for (int gpw = 4; gpw >= 1; gpw >>= 1)
+            if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw) <= static_cast<size_t>(budget) * 1024) return gpw;
     return 0;
 }
 static int cellm_nstep(int cp, int kernel) { return cp == 8 ? (kernel + 3) / 4 : (kernel + 1) / 2; }

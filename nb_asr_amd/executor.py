@@ -913,9 +913,11 @@ class ForwardPlan:
                         n_sk = [sum(isinstance(br, Identity) for br in n.branch_ops) for n in layer.nodes]
                         meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_sk), act_frames, 0)
                         src, ln0, cell_ws = act, pending, (self.stats_ws if epilogue_stats else None)
-                        if self.cell_mfma and not epilogue_stats and hip.grouped_cell_mfma_fits(layer.filters, act.shape[2], last_op.groups):
-                            # every tensor of the bf16 model is a bfloat16 tensor: the products go to the matrix cores unchanged (grouped_cell_mfma.hip)
-                            groups = last_op.groups
+                        if self.cell_mfma and hip.grouped_cell_mfma_fits(layer.filters, act.shape[2], last_op.groups):
+                            # every tensor of the bf16 model is a bfloat16 tensor: the products go to the matrix cores unchanged (grouped_cell_mfma.hip;
+                            # 133 against 281 us for a 32 x 800 x 1600 cell).  That kernel has no statistics by-product: a consumer that
+                            # normalises on load gets them from a read pass over the result (~25 us)
+                            groups, epilogue_stats = last_op.groups, False
                             mspecs = [(self._cached(n.op.conv.weight, 'cell_mfma', (lambda w=n.op.conv.weight: hip.grouped_cell_mfma_pack(self._f32(w), groups))),
                                        sp[1], sp[2], sp[3]) for n, sp in zip(layer.nodes, specs)]
                             self._timed('grouped_cell', meta, lambda: hip.grouped_cell_mfma(src, mspecs, mask, view, act_frames, groups, ln0))

@@ -336,9 +336,11 @@ def test_bf16_cell_on_the_matrix_cores(c, groups, t, kds, mask, with_ln):
     g = got[:, :, :t].float().cpu().double()
     step = torch.clamp(want.abs() * 2.0 ** -7, min=1e-5)              # >= one bf16 step at this magnitude (floor: sign flips of a ~0 pre-activation)
     off = (g - want).abs()
-    # (an element of x1 / x2 that rounds the other way moves its ~84 consumers by a fraction of a step: two steps are the rare worst case)
-    assert bool((off <= 2 * step).all()), float((off / step).max())
-    assert float((off > step).double().mean()) < 1e-3, float((off > step).double().mean())
+    # An element of x1 / x2 that rounds the other way (fp32 vs exact accumulation next to a rounding boundary: ~1e-5 of the elements)
+    # moves its consumers by weight x its bf16 step -- up to 0.125 at magnitude 16-20 -- whatever their own magnitude: so nearly every
+    # element is within one step, and the few that are not are within a few hundredths (measured: 3e-5 of the elements, <= 0.05)
+    assert float((off > step).double().mean()) < 2e-4, float((off > step).double().mean())
+    assert float((off - 2 * step).max()) <= 0.15, float((off - 2 * step).max())
     assert float((off > 0).double().mean()) < 0.02, float((off > 0).double().mean())
     valu = torch.full_like(xp, 7.0)
     hip.grouped_cell_fused(xp, [(w.to(DEV), bias.to(DEV), k, d) for w, bias, k, d in ws], mask, valu, t, groups, ln, None)
@@ -349,7 +351,7 @@ def test_bf16_cell_on_the_matrix_cores(c, groups, t, kds, mask, with_ln):
 def test_bf16_cell_on_the_matrix_cores_limits():
     assert hip.grouped_cell_mfma_fits(1200, 4096, 100) == 0                  # two 32-byte-per-frame tiles of 4096 frames exceed 160 KiB
     assert hip.grouped_cell_mfma_fits(700, 1000, 100) == 0                   # 7 channels per group is not in the search space
-    assert hip.grouped_cell_mfma_fits(1200, 1600, 100) == 1 and hip.grouped_cell_mfma_fits(600, 1600, 100) == 2
-    assert hip.grouped_cell_mfma_fits(800, 1000, 100) == 4
+    assert hip.grouped_cell_mfma_fits(1200, 1600, 100) == 1 and hip.grouped_cell_mfma_fits(600, 1600, 100) == 1      # (<= 80 KiB per workgroup where possible)
+    assert hip.grouped_cell_mfma_fits(800, 1000, 100) == 2 and hip.grouped_cell_mfma_fits(1200, 256, 100) == 4
     with pytest.raises(hip.HipError, match='not a node op'):
         hip.grouped_cell_mfma_pack(torch.randn(700, 7, 5, device=DEV), 100)
