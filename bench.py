@@ -353,12 +353,15 @@ def roofline_leg(model, x, args):
         # and crosses it for the wide, skip-free launches (those must not be priced against HBM)
         fl = (sum(grouped_conv_flops(args.batch, c, frames, kj) for kj in ks) if kind == 'grouped_cell'
               else grouped_conv_flops(args.batch, c, frames, k))
-        t_hbm, t_alu = b / (HBM_PEAK_GBS * 1e9), fl / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+        # (a bf16 cell on the matrix-core kernel is priced against the dense bf16 MFMA peak: it is HBM-bound everywhere)
+        on_mfma = kind == 'grouped_cell' and args.dtype == 'bf16' and getattr(plan, 'cell_mfma', False)
+        flop_peak = BF16_MFMA_PEAK_TFLOPS if on_mfma else FP32_MFMA_PEAK_TFLOPS
+        t_hbm, t_alu = b / (HBM_PEAK_GBS * 1e9), fl / (flop_peak * 1e12)
         tot_attain_s += max(t_hbm, t_alu) * n
         alu_bound_s += (max(t_hbm, t_alu) * n) if t_alu > t_hbm else 0.0
         tot_flops_gc += fl * n
         e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}_s{n_skips if kind == "grouped_conv" else "x"}_{kind}',
-                                 {'bytes_per_launch': b, 'flops_per_launch': fl, 'ms': 0.0, 'n': 0})
+                                 {'bytes_per_launch': b, 'flops_per_launch': fl, 'ms': 0.0, 'n': 0, 'flop_peak': flop_peak})
         e['ms'] += ms
         e['n'] += n
     if launches:
@@ -371,9 +374,11 @@ def roofline_leg(model, x, args):
         def block_entry(v):
             ai = v['flops_per_launch'] / v['bytes_per_launch']
             t_us = 1e3 * v['ms'] / v['n']
-            roof_us = 1e6 * max(v['bytes_per_launch'] / (HBM_PEAK_GBS * 1e9), v['flops_per_launch'] / (FP32_MFMA_PEAK_TFLOPS * 1e12))
+            roof_us = 1e6 * max(v['bytes_per_launch'] / (HBM_PEAK_GBS * 1e9), v['flops_per_launch'] / (v['flop_peak'] * 1e12))
+            ridge_v = v['flop_peak'] * 1e12 / (HBM_PEAK_GBS * 1e9)
             return {'GBps': v['bytes_per_launch'] / t_us / 1e3, 'TFLOPs': v['flops_per_launch'] / t_us / 1e6, 'us_per_launch': t_us,
-                    'bytes_per_launch': v['bytes_per_launch'], 'flop_per_byte': ai, 'bound': 'hbm' if ai < ridge else 'fp32-alu',
+                    'bytes_per_launch': v['bytes_per_launch'], 'flop_per_byte': ai,
+                    'bound': 'hbm' if ai < ridge_v else ('bf16-mfma' if v['flop_peak'] != FP32_MFMA_PEAK_TFLOPS else 'fp32-alu'),
                     'attainable_us': roof_us, 'frac_of_attainable': roof_us / t_us}
         compute_bound = alu_bound_s > 0.5 * tot_attain_s
         head = ({'bound': 'mfma', 'achieved': tot_flops_gc / (tot_ms * 1e-3) / 1e12, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -385,7 +390,8 @@ def roofline_leg(model, x, args):
                       'three node ops of a cell, x1 / x2 never leave the CU, LayerNorm statistics as a by-product: credited with the algorithmic '
                       'bytes of those three ops); otherwise grouped_conv_f32_{ring_,pipe_,osplit_,}kernel<CG,K,D,..> (variant per launch from '
                       'gc_variant_table.json; bf16: grouped_conv_kernel<bf16_t,..>): fused pad + grouped Conv1d + bias + ReLU + clamp + skip sum '
-                      '[+ LayerNorm on load]',
+                      '[+ LayerNorm on load]; bf16 storage: grouped_cell_mfma_kernel<CP,GPW> (the same cell on v_mfma_f32_16x16x32_bf16, no '
+                      'statistics by-product)',
             **head, 'frac': (tot_attain_s / (tot_ms * 1e-3)) if compute_bound else achieved / HBM_PEAK_GBS,
             'frac_of_attainable': tot_attain_s / (tot_ms * 1e-3), 'hbm_GBps': achieved, 'frac_of_hbm_peak': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,

@@ -556,6 +556,39 @@ def test_model_bf16_golden(bf16_fx, tag, arch, use_rnn, mode, b, t):
             f'{tag} layer {idx}: rms err vs fp64 {hip_err:.3e}, reference bf16 {ref_err:.3e}, layer rms {rms[idx, 1]:.3e}'
 
 
+def test_bf16_cells_on_the_matrix_cores_or_the_vector_alu(bf16_fx, monkeypatch):
+    """NBASR_CELL_FUSION for the bf16 storage path: '1' (default) runs conv-only cells on the matrix-core cell kernel, 'valu' on the
+    vector-ALU cell kernel, '0' as three node launches.  Different accumulation orders and (matrix cores) a bf16-rounded normalised
+    cell input, like the reference's: each route is as close to fp64 as the reference's own bf16 arithmetic, and the routes are really
+    taken (spied on the library wrappers)."""
+    from nb_asr_amd import hip
+    tag, arch, use_rnn, mode, b, t = next(c for c in cases.BF16_CASES if c[1] == cases.ARCH_D)
+    m = build_bf16(arch, use_rnn, mode)
+    x = keyed_input(b, t, seed=0).to(torch.bfloat16).to(DEV)
+    ref, truth = torch.from_numpy(bf16_fx[f'{tag}/logits']).double(), torch.from_numpy(bf16_fx[f'{tag}/logits_f64'])
+    e_ref = cases._rms(ref - truth)
+    calls = []
+    for name in ('grouped_cell_mfma', 'grouped_cell_fused', 'grouped_conv1d_node'):
+        original = getattr(hip, name)
+        monkeypatch.setattr(hip, name, (lambda orig, tag_: lambda *a, **k: (calls.append(tag_), orig(*a, **k))[1])(original, name))
+    routes = {'1': 'grouped_cell_mfma', 'valu': 'grouped_cell_fused', '0': 'grouped_conv1d_node'}
+    outs = {}
+    for mode_, wrapper in routes.items():
+        monkeypatch.setenv('NBASR_CELL_FUSION', mode_)
+        monkeypatch.setenv('NBASR_TAPE', '0')
+        m._plans.clear()
+        calls.clear()
+        with torch.no_grad():
+            outs[mode_] = m(x).double().cpu()
+        assert wrapper in calls and not (set(routes.values()) - {wrapper}) & set(calls), (mode_, set(calls))
+        assert cases._rms(outs[mode_] - truth) <= 1.25 * e_ref, (mode_, cases._rms(outs[mode_] - truth), e_ref)
+    assert cases._rms(outs['valu'] - outs['0']) <= 0.1 * e_ref     # (the vector-ALU cell is bit-identical to its node launches; statistics per quad / pair: to rounding)
+    monkeypatch.setenv('NBASR_CELL_FUSION', 'maybe')
+    m._plans.clear()
+    with pytest.raises(ValueError, match='NBASR_CELL_FUSION'):
+        m(x)
+
+
 def test_bf16_needs_matching_dtypes():
     m = build_bf16(cases.ARCH_D, True, 'lively')
     with pytest.raises(nb.hip.HipError, match='parameters are torch.bfloat16'):
