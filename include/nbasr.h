@@ -175,13 +175,14 @@ int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* packed_whh, 
                                  int batch, int frames, int hidden, nbasr_stream_t stream);
 /* The same recurrence, all frames in ONE launch (reference model.py:100,118-121: the LSTM's time loop): the grid of the per-frame
  * kernel stays resident, every workgroup keeps its slice of w_hh in registers and its cell state in registers, h_t is exchanged
- * through a double-buffered image in `seq_ws` with one flag per (hidden slice, utterance tile) and step (write-through stores,
- * agent-scope flag, L1-bypassing loads); utterance tiles never synchronise with each other.  Bit-identical h_out to
- * nbasr_lstm_recurrence_packed.  For the single forward (latency) and for small batches; a pipelined caller whose next encoder
- * needs the CUs keeps the per-frame launches.  nbasr_lstm_seq_workspace_bytes returns 0 where the form does not apply
+ * through a double-buffered image in `seq_ws` whose 16-byte granules carry their own step tag (bit 30 of every fp32 -- free because
+ * |h| <= 1 -- written write-through, polled with L1-bypassing loads; no flags, no drains); utterance tiles never synchronise with each
+ * other.  Bit-identical h_out to nbasr_lstm_recurrence_packed.  For the single forward (latency); a pipelined caller whose next
+ * encoder needs the CUs keeps the per-frame launches.  nbasr_lstm_seq_workspace_bytes returns 0 where the form does not apply
  * (hidden > 512, or more than 256 workgroups = ceil(hidden / 8) * ceil(batch / 16): every workgroup must be resident).
  * Every wait is bounded (1 s): on a timeout the kernel raises the status word in seq_ws and fills the rest of h_out with NaN;
- * nbasr_lstm_seq_status (synchronises `stream`) returns NBASR_EINVAL then. */
+ * nbasr_lstm_seq_status (synchronises `stream`) returns NBASR_EINVAL then.  Launches from different streams of one process are
+ * chained by an event; a stream under graph capture is refused (use the per-frame form there). */
 size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden);
 int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
                               int batch, int frames, int hidden, nbasr_stream_t stream);

@@ -216,18 +216,22 @@ __global__ __launch_bounds__(256) void head_kernel(
 //     its cell state kept in registers;
 //   * h_t is exchanged through a double-buffered image in fragment order, hx[t & 1][k quad][utterance] (float4 = 4 consecutive k),
 //     so that a wave's operand load is 1 KiB contiguous.  Utterance tiles are independent: only the (<= 64) slices of ONE tile
-//     synchronise, each step, through one flag word per slice;
-//   * hand-off (the write-through form of the programming guide's inter-workgroup recipe; placement-independent): the two epilogue
-//     waves store their 16 x 16-byte pieces of the image `sc1`, drain them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier,
-//     ONE lane stores the flag (= frames done) `sc1`; a consumer's wave 0 polls the tile's flags with ONE relaxed agent-scope load
-//     per lane, the workgroup meets at a barrier, then every load of the image is a 16-byte `sc1` buffer load (never L1-served).
-//     Two buffers suffice: a workgroup can only start step t + 1 (and overwrite image (t + 1) & 1) after every slice has published
-//     step t, i.e. has finished reading image (t - 1) & 1;
+//     depend on each other;
+//   * hand-off WITHOUT flags: the payload carries its own tag.  |h| <= 1, so bit 30 of every exchanged fp32 is zero: the producer sets
+//     it to the tag of the step (lstm_tag: it flips every time a slot is rewritten, and the zeroed workspace never matches the first
+//     one), in EVERY dword of the 16-byte granule, and stores the granule write-through (`sc1`, one store instruction per 16 bytes).
+//     A consumer wave polls ITS OWN four operand granules with 16-byte `sc1` buffer loads (never served by the CU's L1) until every dword
+//     of every lane shows the wanted tag -- a torn or stale granule fails the test in at least one dword -- then clears the bit and
+//     multiplies.  No drain of the producer's stores, no flag store, no poll of a second location, no barrier around the loads: one
+//     fabric round trip per step when the data are there (the flag form this replaces needed three: 4.2 us per frame).  A value that
+//     cannot be an LSTM output (|h| >= 2, Inf, NaN) travels as the marker 1.5 and is decoded as NaN, so a diverged input stays visible.
+//     Two images suffice: a workgroup can only publish step t + 1 (overwriting image (t + 1) & 1) after it has consumed every slice's
+//     step t, which each slice published after consuming everybody's step t - 1;
+//   * one workgroup barrier per step (the K partials of the 8 waves, double-buffered by step parity);
 //   * every spin is bounded (1 s of the constant 100 MHz clock): on a timeout the workgroup raises the status word, fills the rest of
 //     its h rows with NaN and leaves; nbasr_lstm_seq_status reports it.
 // Same MFMA sequence per wave, same order of the eight wave partials and the same gate arithmetic as lstm_step_packed_kernel:
 // bit-identical h.  Needs hidden <= 512 (all of K in ONE round of the 8 waves' 4 chunks) and <= 256 workgroups (co-residency).
-constexpr int LSTMS_FLAGS = 64;                              // flag words per utterance tile (one per slice)
 constexpr int LSTMS_QUADS = LSTM_WAVES * LSTM_CHUNKS * 4;    // k quads of an exchange image (128: hidden <= 512)
 constexpr int LSTMS_IMAGE_FLOATS = LSTMS_QUADS * 16 * 4;     // one image of one tile (32 KiB)
 constexpr int LSTMS_HEADER_WORDS = 64;                       // [0] status
@@ -235,18 +239,22 @@ constexpr unsigned long long LSTMS_TIMEOUT_TICKS = 100000000ull;
 
 typedef unsigned lstm_u4 __attribute__((ext_vector_type(4)));
 
+// bit 30 of every dword of an exchanged granule carries the tag of its step: |h| <= 1 leaves that bit of an fp32 zero.  A slot of the
+// double-buffered image is rewritten every second step, and the tag flips each time (the zeroed workspace never matches the first one)
+__device__ __forceinline__ unsigned lstm_tag(int t) { return (static_cast<unsigned>((t >> 1) + 1) & 1u) << 30; }
+
 __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
     const float* __restrict__ gates_in,   // (frames, batch, 4*hidden)
     const float4* __restrict__ wp,        // packed w_hh
-    float* __restrict__ cell, float* __restrict__ h_out, unsigned* status, unsigned* flags, float* hx,
+    float* __restrict__ cell, float* __restrict__ h_out, unsigned* status, float* hx,
     int batch, int frames, int hidden, int kchunks_p)
 {
-    __shared__ float4 red[LSTM_WAVES][2][64];    // [wave][row tile][lane] -> the lane's 4 accumulator registers (= gates)
+    __shared__ float4 red[2][LSTM_WAVES][2][64];  // [step parity][wave][row tile][lane] -> the lane's 4 accumulator registers (= gates)
     __shared__ int stop;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
-    const int slice = blockIdx.x, tile = blockIdx.y, nslices = gridDim.x;
+    const int slice = blockIdx.x, tile = blockIdx.y;
     const int b0 = tile * 16;
     if (threadIdx.x == 0) stop = 0;
 
@@ -272,7 +280,11 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
 
     float* const image = hx + static_cast<size_t>(tile) * 2 * LSTMS_IMAGE_FLOATS;
     const __amdgpu_buffer_rsrc_t hxr = __builtin_amdgcn_make_buffer_rsrc(image, 0, 2 * LSTMS_IMAGE_FLOATS * 4, 0x00020000);
-    unsigned* const tflags = flags + tile * LSTMS_FLAGS;
+    // the granules this lane consumes: utterance i16 of the tile, k quads (wave * 4 + c) * 4 + kq; those outside the batch / the layer
+    // are never written and read as zeros
+    bool live[LSTM_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < LSTM_CHUNKS; ++c) live[c] = eb < batch && ((wave * LSTM_CHUNKS + c) * 4 + kq) * 4 < hidden;
     __syncthreads();
 
     int t = 0;
@@ -285,32 +297,47 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
         }
         floatx4 acc[2] = {floatx4{0.f, 0.f, 0.f, 0.f}, floatx4{0.f, 0.f, 0.f, 0.f}};
         if (t > 0) {
-            if (wave == 0) {                      // every slice of this tile has published h_(t-1): its flag reads >= t
-                const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-                bool ok = false;
-                for (;;) {
-                    const unsigned v = lane < nslices ? __hip_atomic_load(tflags + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-                    ok = __all(v >= static_cast<unsigned>(t));
-                    if (ok || __builtin_amdgcn_s_memrealtime() - t_start > LSTMS_TIMEOUT_TICKS) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                if (!ok && lane == 0) { stop = 1; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-            __syncthreads();
-            if (stop) break;                      // (LDS, read behind the barrier; workgroup-uniform)
+            // every wave polls ITS OWN operand granules of h_(t-1) until each dword carries that step's tag: no flag, no drain on the
+            // producer's side, one fabric round trip per step when the data are already there
             const int img = ((t - 1) & 1) * LSTMS_QUADS;
+            const unsigned want = lstm_tag(t - 1);
             floatx4 hr[LSTM_CHUNKS];
+            const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+            bool ok = false;
+            for (;;) {
 #pragma unroll
-            for (int c = 0; c < LSTM_CHUNKS; ++c) {
-                const int k4 = (wave * LSTM_CHUNKS + c) * 4 + kq;
-                // (bit_cast of the builtin's own result type: assigned to an `unsigned` ext-vector it degrades to ONE dword, splatted)
-                hr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(hxr, ((img + k4) * 16 + i16) * 16, 0, 16));   // aux 16 = sc1
+                for (int c = 0; c < LSTM_CHUNKS; ++c) {
+                    const int k4 = (wave * LSTM_CHUNKS + c) * 4 + kq;
+                    // (bit_cast of the builtin's own result type: assigned to an `unsigned` ext-vector it degrades to ONE dword, splatted)
+                    hr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(hxr, ((img + k4) * 16 + i16) * 16, 0, 16));   // aux 16 = sc1
+                }
+                // all four loads in flight together (left alone, hipcc issues load / wait / 8 MFMAs four times over)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]));
+                bool mine = true;
+#pragma unroll
+                for (int c = 0; c < LSTM_CHUNKS; ++c) {
+                    unsigned tags = 0x40000000u;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) tags &= __builtin_bit_cast(unsigned, hr[c][e]) ^ ~want;       // bit 30 stays set while every dword's tag == want
+                    mine = mine && (!live[c] || (tags & 0x40000000u) != 0);
+                }
+                ok = __all(mine);
+                if (ok || __builtin_amdgcn_s_memrealtime() - t_start > LSTMS_TIMEOUT_TICKS) break;
+                __builtin_amdgcn_s_sleep(1);
             }
-            // all four loads in flight together (left alone, hipcc issues load / wait / 8 MFMAs four times over: 4 round trips per step)
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]));
+            if (!ok && lane == 0) { stop = 1; __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             float4 hv[LSTM_CHUNKS];
 #pragma unroll
-            for (int c = 0; c < LSTM_CHUNKS; ++c) hv[c] = make_float4(hr[c][0], hr[c][1], hr[c][2], hr[c][3]);
+            for (int c = 0; c < LSTM_CHUNKS; ++c) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned u = __builtin_bit_cast(unsigned, hr[c][e]) & ~0x40000000u;
+                    if ((u & 0x7fffffffu) == 0x3fc00000u) u = 0x7fc00000u;                  // the marker of a non-finite h
+                    d[e] = live[c] ? __builtin_bit_cast(float, u) : 0.f;
+                }
+                hv[c] = make_float4(d[0], d[1], d[2], d[3]);
+            }
 #pragma unroll
             for (int c = 0; c < LSTM_CHUNKS; ++c) {
 #pragma unroll
@@ -323,13 +350,17 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
                 for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[c][m].w, hv[c].w, acc[m], 0, 0, 0);
             }
         }
+        const int par = t & 1;
 #pragma unroll
-        for (int m = 0; m < 2; ++m) red[wave][m][lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        for (int m = 0; m < 2; ++m) red[par][wave][m][lane] = make_float4(acc[m][0], acc[m][1], acc[m][2], acc[m][3]);
+        // ONE barrier per step.  The partials are double-buffered by step parity: a wave can only write those of step t + 2 after the
+        // barrier of step t + 1, which the epilogue waves reach after they have read those of step t
         __syncthreads();
+        if (stop) break;                          // (LDS, read behind the barrier; workgroup-uniform: a wave that timed out still came here)
         if (wave < 2) {
-            float4 s = red[0][wave][lane];
+            float4 s = red[par][0][wave][lane];
 #pragma unroll
-            for (int w = 1; w < LSTM_WAVES; ++w) { const float4 r = red[w][wave][lane]; s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w; }
+            for (int w = 1; w < LSTM_WAVES; ++w) { const float4 r = red[par][w][wave][lane]; s.x += r.x; s.y += r.y; s.z += r.z; s.w += r.w; }
             pre[0] += s.x; pre[1] += s.y; pre[2] += s.z; pre[3] += s.w;
             const float c_new = sigmoidf_(pre[1]) * c_state + sigmoidf_(pre[0]) * tanhf(pre[2]);
             const float h_new = sigmoidf_(pre[3]) * tanhf(c_new);
@@ -337,14 +368,17 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
             const float4 hq = make_float4(__shfl(h_new, i16), __shfl(h_new, i16 + 16), __shfl(h_new, i16 + 32), __shfl(h_new, i16 + 48));
             if (q_ok) {
                 *reinterpret_cast<float4*>(h_out + (static_cast<size_t>(eb) * frames + t) * hidden + quad * 4) = hq;
-                const lstm_u4 bits = {__builtin_bit_cast(unsigned, hq.x), __builtin_bit_cast(unsigned, hq.y), __builtin_bit_cast(unsigned, hq.z),
-                                      __builtin_bit_cast(unsigned, hq.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(bits, hxr, (((t & 1) * LSTMS_QUADS + quad) * 16 + i16) * 16, 0, 16);   // write-through
+                const unsigned tag = lstm_tag(t);
+                lstm_u4 bits = {__builtin_bit_cast(unsigned, hq.x), __builtin_bit_cast(unsigned, hq.y), __builtin_bit_cast(unsigned, hq.z),
+                                __builtin_bit_cast(unsigned, hq.w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (bits[e] & 0x40000000u) bits[e] = (bits[e] & 0x80000000u) | 0x3fc00000u;   // |h| >= 2, Inf, NaN cannot be an LSTM output: marker 1.5
+                    bits[e] |= tag;
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(bits, hxr, (((t & 1) * LSTMS_QUADS + quad) * 16 + i16) * 16, 0, 16);   // write-through, 16 bytes at once
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();                          // both storing waves have drained their stores
-        if (threadIdx.x == 0) __hip_atomic_store(tflags + slice, static_cast<unsigned>(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (t < frames) {                             // timed out: make the failure visible in the output too
         if (wave < 2 && q_ok) {
@@ -421,7 +455,7 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
 static bool lstm_seq_fits(int batch, int hidden)
 {
     if (batch <= 0 || hidden <= 0 || hidden % 4) return false;
-    if (lstm_kchunks_p(hidden) > LSTM_WAVES * LSTM_CHUNKS || lstm_slices(hidden) > LSTMS_FLAGS) return false;
+    if (lstm_kchunks_p(hidden) > LSTM_WAVES * LSTM_CHUNKS) return false;
     return static_cast<long>(lstm_slices(hidden)) * ((batch + 15) / 16) <= 256;      // every workgroup resident: one per CU
 }
 
@@ -429,7 +463,7 @@ extern "C" size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden)
 {
     if (!lstm_seq_fits(batch, hidden)) return 0;
     const size_t tiles = (batch + 15) / 16;
-    return (LSTMS_HEADER_WORDS + tiles * LSTMS_FLAGS) * sizeof(unsigned) + tiles * 2 * LSTMS_IMAGE_FLOATS * sizeof(float);
+    return LSTMS_HEADER_WORDS * sizeof(unsigned) + tiles * 2 * LSTMS_IMAGE_FLOATS * sizeof(float);
 }
 
 extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
@@ -447,7 +481,7 @@ extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* pack
                   "<= 256 workgroups); use nbasr_lstm_recurrence_packed", batch, hidden);
     const size_t tiles = (batch + 15) / 16;
     unsigned* const words = static_cast<unsigned*>(seq_ws);
-    float* const hx = reinterpret_cast<float*>(words + LSTMS_HEADER_WORDS + tiles * LSTMS_FLAGS);
+    float* const hx = reinterpret_cast<float*>(words + LSTMS_HEADER_WORDS);
     // Two of these grids fit the chip together, three do not, and a grid whose workgroups are only partly resident waits for peers that
     // cannot start: launches of this kernel from different streams of the process are therefore chained, stream-ordered (each waits for
     // the event behind the previous one; no host synchronisation).  A stream under capture cannot take part in that chain.
@@ -467,7 +501,7 @@ extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* pack
     if (e == hipSuccess) e = hipMemsetAsync(seq_ws, 0, nbasr_lstm_seq_workspace_bytes(batch, hidden), as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: %s", hipGetErrorString(e)); return static_cast<int>(e); }
     hipLaunchKernelGGL(lstm_seq_kernel, dim3(lstm_slices(hidden), static_cast<unsigned>(tiles)), dim3(64 * LSTM_WAVES), 0, as_stream(stream),
-                       gates_ws, static_cast<const float4*>(packed_whh), cell_ws, h_out, words, words + LSTMS_HEADER_WORDS, hx, batch, frames, hidden,
+                       gates_ws, static_cast<const float4*>(packed_whh), cell_ws, h_out, words, hx, batch, frames, hidden,
                        lstm_kchunks_p(hidden));
     e = hipEventRecord(done, as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: hipEventRecord: %s", hipGetErrorString(e)); return static_cast<int>(e); }

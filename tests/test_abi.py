@@ -80,7 +80,7 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.nbasr_pointwise_packed_weights_bytes(2000, 1200) == 16 * 38 * 16384 + 2 * 16 * 128 * 4
     assert lib.nbasr_packed_dense_weights_bytes(1, 800, 600, 8, 128) == 7 * 38 * 2 * 8 * 128 * 16 * 2 + 2 * 7 * 128 * 4
     assert lib.nbasr_packed_dense_weights_bytes(9, 800, 600, 8, 128) == 0 and lib.nbasr_lstm_seq_workspace_bytes(65, 500) == 0
-    assert lib.nbasr_lstm_seq_workspace_bytes(64, 500) == (64 + 4 * 64) * 4 + 4 * 2 * 128 * 16 * 16
+    assert lib.nbasr_lstm_seq_workspace_bytes(64, 500) == 64 * 4 + 4 * 2 * 128 * 16 * 16       # status words + two images per utterance tile
 
 
 def test_missing_library_fails_loudly(tmp_path):
