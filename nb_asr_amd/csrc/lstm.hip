@@ -305,20 +305,23 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
             const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
             bool ok = false;
             for (;;) {
+                // The loads are inline assembly: a spin must really re-load every time (nothing for the optimiser to hoist or merge).
+                // (Elements are taken with __float_as_uint: __builtin_bit_cast(unsigned, v[e]) of an ext-vector ELEMENT reads element 0
+                // whatever e is -- hipcc, ROCm 7.2; tools/ubench/x3/bit_cast_of_vector_element.hip.)
 #pragma unroll
                 for (int c = 0; c < LSTM_CHUNKS; ++c) {
                     const int k4 = (wave * LSTM_CHUNKS + c) * 4 + kq;
-                    // (bit_cast of the builtin's own result type: assigned to an `unsigned` ext-vector it degrades to ONE dword, splatted)
-                    hr[c] = __builtin_bit_cast(floatx4, __builtin_amdgcn_raw_buffer_load_b128(hxr, ((img + k4) * 16 + i16) * 16, 0, 16));   // aux 16 = sc1
+                    const float* gp = image + ((img + k4) * 16 + i16) * 4;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(hr[c]) : "v"(gp) : "memory");     // sc1: never served by this CU's L1
                 }
-                // all four loads in flight together (left alone, hipcc issues load / wait / 8 MFMAs four times over)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]));
+                // all four loads in flight together, then ONE wait
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hr[0]), "+v"(hr[1]), "+v"(hr[2]), "+v"(hr[3]) :: "memory");
                 bool mine = true;
 #pragma unroll
                 for (int c = 0; c < LSTM_CHUNKS; ++c) {
                     unsigned tags = 0x40000000u;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) tags &= __builtin_bit_cast(unsigned, hr[c][e]) ^ ~want;       // bit 30 stays set while every dword's tag == want
+                    for (int e = 0; e < 4; ++e) tags &= __float_as_uint(hr[c][e]) ^ ~want;       // bit 30 stays set while every dword's tag == want
                     mine = mine && (!live[c] || (tags & 0x40000000u) != 0);
                 }
                 ok = __all(mine);
@@ -332,7 +335,7 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
                 float d[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    unsigned u = __builtin_bit_cast(unsigned, hr[c][e]) & ~0x40000000u;
+                    unsigned u = __float_as_uint(hr[c][e]) & ~0x40000000u;
                     if ((u & 0x7fffffffu) == 0x3fc00000u) u = 0x7fc00000u;                  // the marker of a non-finite h
                     d[e] = live[c] ? __builtin_bit_cast(float, u) : 0.f;
                 }
