@@ -32,37 +32,56 @@ __global__ __launch_bounds__(256) void pack_grouped_weights_kernel(const float* 
     }
 }
 
-// merge the per-quad partial statistics: stats (batch, 2, ld) <- (mean, rstd) per frame, 0 in the pitch columns
-__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                             int batch, int frames, int ld, int groups, int cg, int gpp, float eps)
+// merge the partial statistics: stats (batch, 2, ld) <- (mean, rstd) per frame, 0 in the pitch columns.
+// A workgroup = 32 frames x 8 part lanes: lane p merges the partials p, p + 8, ... (all its loads issued together: one round trip),
+// then one thread per frame merges the 8 lane results from LDS.  The first version walked all 25-50 partials of a frame in ONE
+// thread, five at a time: 5-10 dependent round trips = 10-12 us per launch whatever the batch, 15 launches per forward
+// (0.18 ms: 10 % of a step at 8 utterances per GPU).  Chan's merge throughout; the order is fixed, so results are reproducible.
+constexpr int SF_FRAMES = 32, SF_LANES = 8, SF_MAX_PER_LANE = 8;       // <= 64 partials per frame
+__global__ __launch_bounds__(SF_FRAMES * SF_LANES) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                                int batch, int frames, int ld, int groups, int cg, int gpp, float eps)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ float s_cnt[SF_LANES][SF_FRAMES], s_mean[SF_LANES][SF_FRAMES], s_m2[SF_LANES][SF_FRAMES];
+    const int tf = threadIdx.x & (SF_FRAMES - 1), pl = threadIdx.x / SF_FRAMES;      // frames fastest: a wave reads 128 contiguous bytes per partial row
+    const int t = blockIdx.x * SF_FRAMES + tf;
     const int b = blockIdx.y;
-    if (t >= ld) return;
-    float* srow = stats + static_cast<size_t>(b) * 2 * ld;
-    if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
-    const int nquads = (groups + gpp - 1) / gpp;          // partials per frame: one per `gpp` groups (4: node kernels; 2: some fused cells)
+    const int nparts = (groups + gpp - 1) / gpp;          // partials per frame: one per `gpp` groups (4: node kernels; 2: some fused cells)
     float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    // the partials are loaded five at a time BEFORE they are merged: the merge is a serial chain, the loads need not be
-    // (25 partials per frame at 100 groups: 5 round trips to memory instead of 25; same merge order, same result)
-    for (int k0 = 0; k0 < nquads; k0 += 5) {
-        float pm[5], pq[5];
+    if (t < frames) {
+        float pm[SF_MAX_PER_LANE], pq[SF_MAX_PER_LANE];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = min(k0 + u, nquads - 1);
+        for (int u = 0; u < SF_MAX_PER_LANE; ++u) {
+            const int k = min(pl + u * SF_LANES, nparts - 1);
             const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld;
             pm[u] = prow[t];
             pq[u] = prow[ld + t];
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int k = k0 + u;
-            if (k >= nquads) break;
-            const float nb = static_cast<float>(cg * min(gpp, groups - gpp * k));
+        for (int u = 0; u < SF_MAX_PER_LANE; ++u) {
+            const int k = pl + u * SF_LANES;
+            if (k < nparts) {
+                const float nb = static_cast<float>(cg * min(gpp, groups - gpp * k));
+                const float tot = cnt + nb;
+                const float delta = pm[u] - mean;
+                mean += delta * (nb / tot);
+                m2 += pq[u] + delta * delta * (cnt * nb / tot);
+                cnt = tot;
+            }
+        }
+    }
+    s_cnt[pl][tf] = cnt; s_mean[pl][tf] = mean; s_m2[pl][tf] = m2;
+    __syncthreads();
+    if (pl != 0 || t >= ld) return;
+    float* srow = stats + static_cast<size_t>(b) * 2 * ld;
+    if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
+#pragma unroll
+    for (int p = 1; p < SF_LANES; ++p) {
+        const float nb = s_cnt[p][tf];
+        if (nb > 0.f) {
             const float tot = cnt + nb;
-            const float delta = pm[u] - mean;
+            const float delta = s_mean[p][tf] - mean;
             mean += delta * (nb / tot);
-            m2 += pq[u] + delta * delta * (cnt * nb / tot);
+            m2 += s_m2[p][tf] + delta * delta * (cnt * nb / tot);
             cnt = tot;
         }
     }
@@ -427,7 +446,9 @@ extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_
     NBASR_REQUIRE(groups_per_part == 4 || groups_per_part == 2, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4 or 2)", groups_per_part);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + 255) / 256, batch), dim3(256), 0, as_stream(stream), stats_ws, stats_out,
+    NBASR_REQUIRE((groups + groups_per_part - 1) / groups_per_part <= SF_LANES * SF_MAX_PER_LANE, NBASR_EINVAL,
+                  "nbasr_grouped_stats_finalize: %d groups in parts of %d are more than %d partials per frame", groups, groups_per_part, SF_LANES * SF_MAX_PER_LANE);
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + SF_FRAMES - 1) / SF_FRAMES, batch), dim3(SF_FRAMES * SF_LANES), 0, as_stream(stream), stats_ws, stats_out,
                        batch, frames, ld, groups, channels / groups, groups_per_part, eps);
     return launch_status("nbasr_grouped_stats_finalize");
 }
