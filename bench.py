@@ -189,6 +189,9 @@ def main():
             worst = float(((out_s.double() - out.double()).abs() / (1e-5 + 1e-4 * out.double().abs())).max())
             strict = {'value': args.batch * world * args.steps / elapsed_strict, 'ms_per_step': 1e3 * elapsed_strict / args.steps,
                       'worst_err_over_tol_vs_default_path': worst}
+            if rank == 0 and not args.no_roofline:
+                # the dense convs of THIS leg against the fp32 MFMA peak (v_mfma_f32_32x32x2_f32, no operand splitting)
+                strict['roofline_mfma'] = roofline_leg(model, x, args).get('roofline_mfma')
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -237,6 +240,7 @@ def main():
         'value_strict_f32': strict['value'] if strict else None,
         'ms_per_step_strict_f32': strict['ms_per_step'] if strict else None,
         'strict_f32_vs_default_worst_err_over_tol': strict['worst_err_over_tol_vs_default_path'] if strict else None,
+        'roofline_mfma_strict_f32': strict.get('roofline_mfma') if strict else None,
         'value_strong': strong['value'] if strong else (args.batch * world * args.steps / elapsed if world == 1 or args.scaling == 'strong' else None),
         'ms_per_step_strong': strong['ms_per_step'] if strong else (1e3 * elapsed / args.steps if world == 1 or args.scaling == 'strong' else None),
         'strong': strong,
@@ -360,7 +364,8 @@ def roofline_leg(model, x, args):
         tot_attain_s += max(t_hbm, t_alu) * n
         alu_bound_s += (max(t_hbm, t_alu) * n) if t_alu > t_hbm else 0.0
         tot_flops_gc += fl * n
-        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}_s{n_skips if kind == "grouped_conv" else "x"}_{kind}',
+        skip_tag = n_skips if kind == 'grouped_conv' else '-'.join(str(v) for v in skips)      # per node of the cell
+        e = per_block.setdefault(f'block{blk}_C{c}_T{frames}_k{k}_s{skip_tag}_{kind}',
                                  {'bytes_per_launch': b, 'flops_per_launch': fl, 'ms': 0.0, 'n': 0, 'flop_peak': flop_peak})
         e['ms'] += ms
         e['n'] += n
@@ -395,6 +400,10 @@ def roofline_leg(model, x, args):
             **head, 'frac': (tot_attain_s / (tot_ms * 1e-3)) if compute_bound else achieved / HBM_PEAK_GBS,
             'frac_of_attainable': tot_attain_s / (tot_ms * 1e-3), 'hbm_GBps': achieved, 'frac_of_hbm_peak': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,
+            # what actually crosses the HBM pins (PMC) over the measured time, and the vector-ALU side of the same launches: a fused cell
+            # moves ~0.37 x the algorithmic bytes of its three node ops and is bound by vector issue (profiles/r03_pmc_valu_issue.csv)
+            'traffic_GBps': (traffic / (1e3 * tot_ms / launches) / 1e3) if traffic else None,
+            'fp32_TFLOPs': tot_flops_gc / (tot_ms * 1e-3) / 1e12, 'frac_of_fp32_vector_peak': tot_flops_gc / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             'bytes_per_launch_avg': tot_bytes / launches, 'us_per_launch_avg': 1e3 * tot_ms / launches,
             'launches_per_forward': launches // args.steps,
             'per_block': {k: block_entry(v) for k, v in sorted(per_block.items())},
