@@ -238,6 +238,8 @@ class ForwardPlan:
     def _recurrence(self, gates, packed_hh, hidden, pipe, capturing=False):
         """The LSTM recurrence into ``self.h_out``: all frames in one launch where that form applies and pays, else one launch per frame."""
         # (launches of the resident grid are chained across the process's streams by an event, which a graph capture cannot hold)
+        if not capturing and torch.cuda.is_current_stream_capturing():       # a caller's own torch.cuda.graph(...) around model(x)
+            capturing = True
         use = self.lstm_seq_mode != '0' and not capturing and (self.lstm_seq_mode == '1' or not pipe)
         nbytes = hip.load_library().nbasr_lstm_seq_workspace_bytes(self.batch, hidden) if use else 0
         if nbytes:
