@@ -45,6 +45,16 @@ __device__ __forceinline__ void tile_statistics(const T* x, int channels, int ld
             ++n;
         };
         int c = row;
+        // A lane walks channels / 16 rows: with four rows in flight that is 12 dependent round trips at 800 channels -- ~35 us whatever the
+        // bytes (bf16 rows: 1.7 TB/s; few workgroups per CU, so nothing else hides them).  Eight in flight halve the trips; the folds stay
+        // in channel order, so the sums are the same bit for bit.
+        for (; c + 7 * LN_ROWS < channels; c += 8 * LN_ROWS) {
+            float e[8][FR];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load_frames<FR>(x + base + static_cast<size_t>(c + u * LN_ROWS) * ld, e[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fold(e[u]);
+        }
         for (; c + 3 * LN_ROWS < channels; c += 4 * LN_ROWS) {       // four loads issued, then four folds (same order as one by one)
             float e[4][FR];
 #pragma unroll
