@@ -157,41 +157,56 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
             for (int s = 0; s < NSMAX; ++s)
                 if (s < 3 || four) nxt[s] = *reinterpret_cast<const cm_u4*>(src + off[s] + nb * NB_STRIDE);
         };
-        fetch(0);
+        // The node's skip inputs as 0 / 1 factors (wave-uniform): the column-block loop below has NO branch on them, so the sixteen
+        // blocks are one straight line and the scheduler overlaps one block's epilogue with the next block's MFMAs and LDS reads (with a
+        // branch per skip a block cost ~430 cycles of mostly dependent latency at 3.5 waves per SIMD).  fma(1, v, o) = o + v exactly;
+        // fma(0, v, o) = o for the finite values a tile holds.  A node without skips takes the loop without the reads.
+        const int sk = a.skips;
+        const float m_a = (NODE == 0 ? (sk & 1) : NODE == 1 ? (sk & 2) : (sk & 32)) ? 1.f : 0.f;      // x0n (nodes 0, 1) / x2 (node 2) from tile A
+        const float m_b = (NODE == 1 ? (sk & 4) : NODE == 2 ? (sk & 16) : 0) ? 1.f : 0.f;               // x1 from tile B
+        const float m_k = (NODE == 2 && (sk & 8)) ? 1.f : 0.f;                                          // x0n carried in registers
+        const bool any = NODE == 0 ? (sk & 1) != 0 : NODE == 1 ? (sk & (2 | 4 | 8)) != 0 : (sk & (8 | 16 | 32)) != 0;
+        auto blocks = [&](auto with_skips) {
+            constexpr bool SK = decltype(with_skips)::value;
+            fetch(0);
 #pragma unroll
-        for (int nb = 0; nb < CM_NB; ++nb) {
-            cm_u4 cur[NSMAX];
+            for (int nb = 0; nb < CM_NB; ++nb) {
+                cm_u4 cur[NSMAX];
 #pragma unroll
-            for (int s = 0; s < NSMAX; ++s) cur[s] = nxt[s];
-            if (nb + 1 < CM_NB) fetch(nb + 1);                       // the next block's operands are in flight behind this block's MFMAs
-            cm_f4 acc = bv;
+                for (int s = 0; s < NSMAX; ++s) cur[s] = nxt[s];
+                if (nb + 1 < CM_NB) fetch(nb + 1);                   // the next block's operands are in flight behind this block's MFMAs
+                cm_f4 acc = bv;
 #pragma unroll
-            for (int s = 0; s < NSMAX; ++s)
-                if (s < 3 || four) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[s], __builtin_bit_cast(cm_bf8, cur[s]), acc, 0, 0, 0);
-            float o[4];
+                for (int s = 0; s < NSMAX; ++s)
+                    if (s < 3 || four) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[s], __builtin_bit_cast(cm_bf8, cur[s]), acc, 0, 0, 0);
+                float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[r]);
-            if (q_ok) {
-                const int pos = own + nb * NB_STRIDE;
-                auto add = [&](u2v p) { const cm_f4 v = cm_unpack4(p); o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3]; };
-                if constexpr (NODE == 0) {
-                    if (a.skips & 1) add(*reinterpret_cast<const u2v*>(tile_a + pos));
-                } else if constexpr (NODE == 1) {
-                    if (a.skips & (2 | 8)) {
-                        const u2v x0n = *reinterpret_cast<const u2v*>(tile_a + pos);
-                        keep0[nb] = x0n;
-                        if (a.skips & 2) add(x0n);
+                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[r]);
+                const int pos = own + nb * NB_STRIDE;                // (lanes of fragment rows that do not exist: position of rows 0-3, nothing stored)
+                if constexpr (SK) {
+                    auto add = [&](float m, u2v p) {
+                        const cm_f4 v = cm_unpack4(p);
+                        o[0] = __builtin_fmaf(m, v[0], o[0]); o[1] = __builtin_fmaf(m, v[1], o[1]);
+                        o[2] = __builtin_fmaf(m, v[2], o[2]); o[3] = __builtin_fmaf(m, v[3], o[3]);
+                    };
+                    const u2v ta = *reinterpret_cast<const u2v*>(tile_a + pos);
+                    if constexpr (NODE == 0) {
+                        add(m_a, ta);
+                    } else if constexpr (NODE == 1) {
+                        keep0[nb] = ta;
+                        add(m_a, ta);
+                        add(m_b, *reinterpret_cast<const u2v*>(tile_b + pos));
+                    } else {
+                        add(m_k, keep0[nb]);
+                        add(m_b, *reinterpret_cast<const u2v*>(tile_b + pos));
+                        add(m_a, ta);
                     }
-                    if (a.skips & 4) add(*reinterpret_cast<const u2v*>(tile_b + pos));
-                } else {
-                    if (a.skips & 8) add(keep0[nb]);
-                    if (a.skips & 16) add(*reinterpret_cast<const u2v*>(tile_b + pos));
-                    if (a.skips & 32) add(*reinterpret_cast<const u2v*>(tile_a + pos));
                 }
                 if (tail && fb + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
-                *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                if (q_ok) *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             }
-        }
+        };
+        if (any) blocks(std::true_type{}); else blocks(std::false_type{});
         __syncthreads();
     };
     node(std::integral_constant<int, 0>{}, wp0, b0, tile_a, tile_b);
