@@ -335,7 +335,7 @@ def roofline_leg(model, x, args):
         a[1] += 1
     out = {}
     # fused grouped Conv1d (HBM-bound)
-    tot_bytes = tot_ms = tot_attain_s = alu_bound_s = tot_flops_gc = 0.0
+    tot_bytes = tot_ms = tot_attain_s = alu_bound_s = tot_flops_gc = fused_min_bytes = fused_attain_s = 0.0
     per_block, launches = {}, 0
     for (kind, meta), (ms, n) in agg.items():
         if kind == 'grouped_conv':
@@ -362,6 +362,12 @@ def roofline_leg(model, x, args):
         flop_peak = BF16_MFMA_PEAK_TFLOPS if on_mfma else FP32_MFMA_PEAK_TFLOPS
         t_hbm, t_alu = b / (HBM_PEAK_GBS * 1e9), fl / (flop_peak * 1e12)
         tot_attain_s += max(t_hbm, t_alu) * n
+        # the same launch under ITS OWN roofline: a fused cell has to move x0 and y once (+ weights), whatever the three node ops it
+        # replaces would have moved, and has to do their flops
+        elem_b = 2 if args.dtype == 'bf16' else 4
+        b_min = (2.0 * elem_b * args.batch * c * frames + 4.0 * sum(c * (c // 100) * kj + c for kj in ks)) if kind == 'grouped_cell' else b
+        fused_min_bytes += b_min * n
+        fused_attain_s += max(b_min / (HBM_PEAK_GBS * 1e9), t_alu) * n
         alu_bound_s += (max(t_hbm, t_alu) * n) if t_alu > t_hbm else 0.0
         tot_flops_gc += fl * n
         skip_tag = n_skips if kind == 'grouped_conv' else '-'.join(str(v) for v in skips)      # per node of the cell
@@ -403,6 +409,12 @@ def roofline_leg(model, x, args):
             # what actually crosses the HBM pins (PMC) over the measured time, and the vector-ALU side of the same launches: a fused cell
             # moves ~0.37 x the algorithmic bytes of its three node ops and is bound by vector issue (profiles/r03_pmc_valu_issue.csv)
             'traffic_GBps': (traffic / (1e3 * tot_ms / launches) / 1e3) if traffic else None,
+            # `achieved` / `frac` above credit a fused-cell launch with the algorithmic bytes of the three node operations it performs (SURVEY.md
+            # 8(d): per-call bytes x the calls one launch replaces) -- per block that can exceed 1, because the unfused ops' bytes are not a
+            # bound for the fused launch.  `own_roofline`: the same launches priced as what they are -- x0 in, y out, weights, and the flops of
+            # the three convolutions at the pipe they run on: attainable = max(bytes / 8 TB/s, flops / peak)
+            'own_roofline': {'min_bytes_per_launch_avg': fused_min_bytes / launches, 'attainable_us_per_launch_avg': 1e6 * fused_attain_s / launches,
+                             'frac': fused_attain_s / (tot_ms * 1e-3)},
             'fp32_TFLOPs': tot_flops_gc / (tot_ms * 1e-3) / 1e12, 'frac_of_fp32_vector_peak': tot_flops_gc / (tot_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             'bytes_per_launch_avg': tot_bytes / launches, 'us_per_launch_avg': 1e3 * tot_ms / launches,
             'launches_per_forward': launches // args.steps,

@@ -10,11 +10,14 @@
 // Mapping (per group of CG = 6..12 channels; groups never mix):
 //   * the group's tensor lives in LDS FRAME-major, tile[frame][CP channels] bf16 with CP = 8 or 16 (pad channels are zero), 16 zero
 //     frames either side: a frame's channels are 16 (or 2 x 16) contiguous, 16-byte aligned bytes;
-//   * one MFMA = 16 output channels (M; CG used) x 16 frames (N) x 32 (tap, channel) pairs (K): K runs over 4 taps x 8 channels
-//     (CP = 8) or 2 taps x 16 channels (CP = 16).  The B operand of lane (n, kb) is ONE aligned ds_read_b128 -- the 8 channels of
-//     frame f0 + n + tap * dilation - left_pad -- so dilation and padding are address arithmetic; the A operand is the weights,
-//     pre-packed per (node, group, K step, lane) and held in registers for the node (<= 16 registers);
-//   * a wave owns 256 frames = 16 column blocks; per block 2-4 MFMAs (taps padded to 8 / 6 / 8 with zero weights; a padded tap reads
+//   * one MFMA = 16 fragment rows (M) x 16 frames (N) x 32 (tap, channel) pairs (K), always 2 taps per K step.  CP = 16: the rows are
+//     the group's 16 (padded) channels, K = 2 taps x 16 channels.  CP = 8: only 8 rows exist, so ONE MFMA serves TWO column blocks 128
+//     frames apart -- rows 0-7 x K slots 0-15 (2 taps x 8 channels of block nb), rows 8-15 x K slots 16-31 (the same taps of block
+//     nb + 8), weights packed block-diagonally -- and every lane of the accumulator fragment holds real outputs.  The B operand of lane
+//     (n, kb) is ONE aligned ds_read_b128 -- the 8 channels of frame f0 + n + tap * dilation - left_pad -- so dilation and padding are
+//     address arithmetic; the A operand is the weights, pre-packed per (node, group, K step, lane) and held in registers for the node
+//     (<= 16 registers);
+//   * a wave owns 256 frames = 16 column blocks; per block (CP = 8: per pair of blocks) 3-4 MFMAs (taps padded to 6 / 8 with zero weights; a padded tap reads
 //     the lane's tap-0 window, so a NaN there surfaces at this frame as it does through the real tap 0), then the node's epilogue on the accumulator fragment -- lane =
 //     (frame, 4 channels): bias is the accumulator's initial value, relu + clamp, the skips in python's sum order, tail mask, ONE
 //     rounding to bf16 -- written as 8 bytes into the OTHER tile (ping-pong: x0n in A, x1 in B, x2 in A, x3 in B), so a node needs one
@@ -126,14 +129,19 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 
     // ---- the three nodes -------------------------------------------------------------------------------------------------------------
     const int n16 = lane & 15, kb = lane >> 4;                       // MFMA fragment coordinates: column / row-in-tile, 8-deep k block
-    const int q4 = kb * 4;                                           // first of this lane's 4 output channels in the accumulator fragment
-    const bool q_ok = q4 < CP;                                       // (CP = 8: the fragment's rows 8-15 do not exist)
-    const int own = ((fb + n16 + CM_PADL) * CP + (q_ok ? q4 : 0)) * 2;   // this lane's (frame, 4 channels) of column block 0, bytes
+    // CP = 16: the fragment's 16 rows are the group's (padded) 16 channels; a K step is 2 taps x 16 channels; 16 column blocks per wave.
+    // CP = 8: only 8 rows exist, so ONE MFMA serves TWO column blocks 128 frames apart: rows 0-7 x K slots 0-15 (2 taps x 8 channels of
+    // block nb), rows 8-15 x K slots 16-31 (the same 2 taps of block nb + 8) -- the weights are packed block-diagonally.  Same MFMA count
+    // as 4 taps x 8 channels per step, but every lane of the accumulator fragment holds real outputs: half the epilogue instructions.
+    constexpr int NBW = CP == 8 ? CM_NB / 2 : CM_NB;                 // column-block iterations per wave
+    const int fblk = CP == 8 ? (kb >> 1) * (CM_WAVE_FRAMES / 2) : 0; // this lane's frame offset within the wave tile (second block of the pair)
+    const int q4 = CP == 8 ? (kb & 1) * 4 : kb * 4;                  // first of this lane's 4 output channels in the accumulator fragment
+    const int own = ((fb + fblk + n16 + CM_PADL) * CP + q4) * 2;     // this lane's (frame, 4 channels) of column block 0, bytes
     constexpr int NB_STRIDE = 16 * CP * 2;                           // bytes between column blocks
-    u2v keep0[CM_NB];                                                // x0n at the lane's positions, for the last node's skip
+    u2v keep0[NBW];                                                  // x0n at the lane's positions, for the last node's skip
     const bool tail = fb + CM_WAVE_FRAMES > a.frames;                // (wave-uniform) only the wave tile that holds the row's end masks frames
 
-    constexpr int NSMAX = CP == 8 ? 2 : 4;                           // K steps per column block: CP = 8: 8 taps (2); CP = 16: 6 or 8 taps (3 or 4)
+    constexpr int NSMAX = 4;                                         // K steps per column block: 2 taps each, 6 or 8 taps (3 or 4 steps)
     auto node = [&](auto idx, const cm_u4* __restrict__ wp, const float* __restrict__ bias, const unsigned char* src, unsigned char* dst) {
         constexpr int NODE = decltype(idx)::value;
         const int K = a.k[NODE], D = a.d[NODE], LP = a.lpad[NODE], ns = a.nstep[NODE];
@@ -142,10 +150,10 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
         int off[NSMAX];
 #pragma unroll
         for (int s = 0; s < NSMAX; ++s) {
-            const int tap = CP == 8 ? s * 4 + kb : s * 2 + (kb >> 1);
+            const int tap = CP == 8 ? s * 2 + (kb & 1) : s * 2 + (kb >> 1);
             const int chb = CP == 8 ? 0 : (kb & 1);
             // a padded tap (tap >= K) has zero weights; its B operand is the lane's tap-0 window (finite wherever the data are)
-            off[s] = ((fb + n16 + (tap < K ? tap * D - LP : -LP) + CM_PADL) * CP + chb * 8) * 2;
+            off[s] = ((fb + fblk + n16 + (tap < K ? tap * D - LP : -LP) + CM_PADL) * CP + chb * 8) * 2;
             aw[s] = __builtin_bit_cast(cm_bf8, wp[(static_cast<size_t>(g) * ns + (s < ns ? s : 0)) * 64 + lane]);
         }
         cm_f4 bv;
@@ -170,11 +178,11 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
             constexpr bool SK = decltype(with_skips)::value;
             fetch(0);
 #pragma unroll
-            for (int nb = 0; nb < CM_NB; ++nb) {
+            for (int nb = 0; nb < NBW; ++nb) {
                 cm_u4 cur[NSMAX];
 #pragma unroll
                 for (int s = 0; s < NSMAX; ++s) cur[s] = nxt[s];
-                if (nb + 1 < CM_NB) fetch(nb + 1);                   // the next block's operands are in flight behind this block's MFMAs
+                if (nb + 1 < NBW) fetch(nb + 1);                     // the next block's operands are in flight behind this block's MFMAs
                 cm_f4 acc = bv;
 #pragma unroll
                 for (int s = 0; s < NSMAX; ++s)
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[r]);
-                const int pos = own + nb * NB_STRIDE;                // (lanes of fragment rows that do not exist: position of rows 0-3, nothing stored)
+                const int pos = own + nb * NB_STRIDE;
                 if constexpr (SK) {
                     auto add = [&](float m, u2v p) {
                         const cm_f4 v = cm_unpack4(p);
@@ -202,8 +210,8 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
                         add(m_a, ta);
                     }
                 }
-                if (tail && fb + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
-                if (q_ok) *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                if (tail && fb + fblk + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
+                *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             }
         };
         if (any) blocks(std::true_type{}); else blocks(std::false_type{});
@@ -252,7 +260,7 @@ static int cellm_gpw(int cg, int nt, int groups)
             if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw) <= static_cast<size_t>(budget) * 1024) return gpw;
     return 0;
 }
-static int cellm_nstep(int cp, int kernel) { return cp == 8 ? (kernel + 3) / 4 : (kernel + 1) / 2; }
+static int cellm_nstep(int /*cp*/, int kernel) { return (kernel + 1) / 2; }      // 2 taps per K step either way
 
 template <int CP, int GPW>
 static int launch_cellm(const bf16_t* x0, bf16_t* y, const void* const* wp, const float* const* bias, const LnRef& l, const CellMDims& a, hipStream_t stream)
@@ -270,8 +278,9 @@ static int launch_cellm(const bf16_t* x0, bf16_t* y, const void* const* wp, cons
 }
 
 // w (channels, cg, kernel) fp32 -> [group][K step][lane] x 8 bf16: the A fragments of the node's MFMAs (zero outside the group's
-// cg x cg x kernel block).  Lane (m = out channel, kb): CP = 8: tap = 4 s + kb, channels 0..7; CP = 16: tap = 2 s + (kb >> 1),
-// channels 8 (kb & 1) .. + 7.
+// cg x cg x kernel block).  Lane (m = fragment row, kb): CP = 16: out channel m, tap = 2 s + (kb >> 1), channels 8 (kb & 1) .. + 7;
+// CP = 8: out channel m & 7, tap = 2 s + (kb & 1), channels 0..7, and ZERO unless (m >> 3) == (kb >> 1): rows 0-7 multiply the K slots of
+// the first column block of a pair, rows 8-15 those of the second.
 __global__ __launch_bounds__(256) void pack_cell_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ packed, int groups, int cg,
                                                                 int kernel, int cp, int nstep)
 {
@@ -282,10 +291,12 @@ __global__ __launch_bounds__(256) void pack_cell_weights_kernel(const float* __r
         const int lane = e % 64; e /= 64;
         const int s = e % nstep; e /= nstep;
         const int g = e, m = lane & 15, kb = lane >> 4;
-        const int tap = cp == 8 ? s * 4 + kb : s * 2 + (kb >> 1);
+        const int tap = cp == 8 ? s * 2 + (kb & 1) : s * 2 + (kb >> 1);
         const int c = cp == 8 ? j : (kb & 1) * 8 + j;
+        const int co = cp == 8 ? (m & 7) : m;
+        const bool mine = cp != 8 || (m >> 3) == (kb >> 1);
         float v = 0.f;
-        if (m < cg && c < cg && tap < kernel) v = w[((static_cast<size_t>(g) * cg + m) * cg + c) * kernel + tap];
+        if (mine && co < cg && c < cg && tap < kernel) v = w[((static_cast<size_t>(g) * cg + co) * cg + c) * kernel + tap];
         packed[i] = static_cast<unsigned short>(pack_bf16x2(v, 0.f) & 0xffffu);
     }
 }
