@@ -336,7 +336,7 @@ def roofline_leg(model, x, args):
     out = {}
     # fused grouped Conv1d (HBM-bound)
     tot_bytes = tot_ms = tot_attain_s = alu_bound_s = tot_flops_gc = fused_min_bytes = fused_attain_s = 0.0
-    per_block, launches = {}, 0
+    per_block, launches, any_on_mfma = {}, 0, False
     for (kind, meta), (ms, n) in agg.items():
         if kind == 'grouped_conv':
             blk, c, _, k, frames, n_skips = meta
@@ -359,6 +359,7 @@ def roofline_leg(model, x, args):
               else grouped_conv_flops(args.batch, c, frames, k))
         # (a bf16 cell on the matrix-core kernel is priced against the dense bf16 MFMA peak: it is HBM-bound everywhere)
         on_mfma = kind == 'grouped_cell' and args.dtype == 'bf16' and getattr(plan, 'cell_mfma', False)
+        any_on_mfma = any_on_mfma or on_mfma
         flop_peak = BF16_MFMA_PEAK_TFLOPS if on_mfma else FP32_MFMA_PEAK_TFLOPS
         t_hbm, t_alu = b / (HBM_PEAK_GBS * 1e9), fl / (flop_peak * 1e12)
         tot_attain_s += max(t_hbm, t_alu) * n
@@ -404,6 +405,10 @@ def roofline_leg(model, x, args):
                       '[+ LayerNorm on load]; bf16 storage: grouped_cell_mfma_kernel<CP,GPW> (the same cell on v_mfma_f32_16x16x32_bf16, no '
                       'statistics by-product)',
             **head, 'frac': (tot_attain_s / (tot_ms * 1e-3)) if compute_bound else achieved / HBM_PEAK_GBS,
+            **({'achieved': fused_min_bytes / (tot_ms * 1e-3) / 1e9, 'frac': fused_attain_s / (tot_ms * 1e-3),
+                'frac_note': 'matrix-core bf16 cells: priced under their own roofline (x0 in, y out, weights; flops at the bf16 MFMA peak); '
+                             'crediting them with the bytes of the three node ops they replace gives frac_credited_node_ops, which can exceed 1',
+                'frac_credited_node_ops': achieved / HBM_PEAK_GBS} if any_on_mfma else {}),
             'frac_of_attainable': tot_attain_s / (tot_ms * 1e-3), 'hbm_GBps': achieved, 'frac_of_hbm_peak': achieved / HBM_PEAK_GBS,
             'traffic': traffic, 'traffic_source': traffic_src,
             # what actually crosses the HBM pins (PMC) over the measured time, and the vector-ALU side of the same launches: a fused cell

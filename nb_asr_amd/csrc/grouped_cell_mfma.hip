@@ -17,7 +17,7 @@
 //     (n, kb) is ONE aligned ds_read_b128 -- the 8 channels of frame f0 + n + tap * dilation - left_pad -- so dilation and padding are
 //     address arithmetic; the A operand is the weights, pre-packed per (node, group, K step, lane) and held in registers for the node
 //     (<= 16 registers);
-//   * a wave owns 256 frames = 16 column blocks; per block (CP = 8: per pair of blocks) 3-4 MFMAs (taps padded to 6 / 8 with zero weights; a padded tap reads
+//   * a wave owns 256 frames = 16 column blocks (128 = 8 for rows of <= 1024 frames: twice the waves); per block (CP = 8: per pair of blocks) 3-4 MFMAs (taps padded to 6 / 8 with zero weights; a padded tap reads
 //     the lane's tap-0 window, so a NaN there surfaces at this frame as it does through the real tap 0), then the node's epilogue on the accumulator fragment -- lane =
 //     (frame, 4 channels): bias is the accumulator's initial value, relu + clamp, the skips in python's sum order, tail mask, ONE
 //     rounding to bf16 -- written as 8 bytes into the OTHER tile (ping-pong: x0n in A, x1 in B, x2 in A, x3 in B), so a node needs one
@@ -38,8 +38,11 @@ typedef float cm_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned cm_u4 __attribute__((ext_vector_type(4)));
 
 constexpr int CM_PADL = 16, CM_PADR = 16;       // zero frames either side of a tile (taps reach <= 12 frames back, <= 14 ahead)
-constexpr int CM_NB = 16;                       // 16-frame column blocks per wave
-constexpr int CM_WAVE_FRAMES = 16 * CM_NB;
+// NBT = 16-frame column blocks per wave (template): 16 (256 frames per wave), or 8 (128) for the 16-channel-slot groups at rows of <= 1024
+// frames, where 256-frame tiles leave a CU with 8 waves (two workgroups of 400 / 800-frame rows) -- too few to hide a block's dependent
+// latency (106 / 62 -> 88 / 49 us per cell at 32 x 800 / 400).  8-slot groups at 1000 frames already have 16 waves per CU and lose 10 % to the
+// extra per-wave overhead.
+static inline int cellm_nbt(int ld, int cp) { return (cp == 16 && ld <= 1024) ? 8 : 16; }
 
 struct CellMDims {
     int channels, frames, ld, groups, batch, cg;
@@ -50,7 +53,7 @@ struct CellMDims {
 
 __device__ __forceinline__ cm_f4 cm_unpack4(u2v p) { return cm_f4{bf16_lo(p.x), bf16_hi(p.x), bf16_lo(p.y), bf16_hi(p.y)}; }
 
-template <int CP, int GPW>
+template <int CP, int GPW, int NBT>
 __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     const bf16_t* __restrict__ x0, bf16_t* __restrict__ y,
     const cm_u4* __restrict__ wp0, const cm_u4* __restrict__ wp1, const cm_u4* __restrict__ wp2,
@@ -58,6 +61,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, const CellMDims a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
+    constexpr int CM_NB = NBT, CM_WAVE_FRAMES = 16 * NBT;
     const int nt = a.nt;
     const int rows = nt * CM_WAVE_FRAMES + CM_PADL + CM_PADR;        // frames of a tile, pads included
     const int tile_bytes = rows * CP * 2;
@@ -95,8 +99,8 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
         }
         const float* mrow = ln_stats + static_cast<size_t>(b) * 2 * a.ld;
 #pragma unroll
-        for (int it = 0; it < 32 / CPI; ++it) {
-            const int chunk = ti * 32 + it * CPI + chl, f0 = chunk * 8;
+        for (int it = 0; it < (2 * NBT) / CPI; ++it) {
+            const int chunk = ti * (2 * NBT) + it * CPI + chl, f0 = chunk * 8;
             const bool ok = pair_ok && f0 < a.ld;
             const int off = ok ? (2 * cp * a.ld + f0) * 2 : 0x7ffffff0;              // out of range: the buffer load returns zeros
             const cm_u4 r0 = __builtin_bit_cast(cm_u4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
@@ -225,8 +229,8 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     {
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + group_row0, 0, a.cg * a.ld * 2, 0x00020000);
 #pragma unroll
-        for (int it = 0; it < 32 / CPI; ++it) {
-            const int chunk = ti * 32 + it * CPI + chl, f0 = chunk * 8;
+        for (int it = 0; it < (2 * NBT) / CPI; ++it) {
+            const int chunk = ti * (2 * NBT) + it * CPI + chl, f0 = chunk * 8;
             const unsigned char* srcp = tile_b + ((f0 + CM_PADL) * CP + 2 * cp) * 2;
             unsigned dd[8];
 #pragma unroll
@@ -245,33 +249,33 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     }
 }
 
-static size_t cellm_lds_bytes(int cp, int nt, int gpw)
+static size_t cellm_lds_bytes(int cp, int nt, int gpw, int nbt)
 {
-    return static_cast<size_t>(gpw) * 2 * (nt * CM_WAVE_FRAMES + CM_PADL + CM_PADR) * cp * 2;
+    return static_cast<size_t>(gpw) * 2 * (nt * 16 * nbt + CM_PADL + CM_PADR) * cp * 2;
 }
 static int cellm_cp(int cg) { return cg <= 8 ? 8 : 16; }
 // groups per workgroup: as many as fit 160 KiB of LDS and 16 waves, from {4, 2, 1}; 0 = the row does not fit at all
-static int cellm_gpw(int cg, int nt, int groups)
+static int cellm_gpw(int cg, int nt, int groups, int nbt)
 {
     // two workgroups per CU where a group's tiles allow it (<= 80 KiB per workgroup): their barriers and load phases then interleave;
     // within that, as many groups per workgroup as fit (waves per barrier domain)
     for (int budget = 80; budget <= 160; budget += 80)
         for (int gpw = 4; gpw >= 1; gpw >>= 1)
-            if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw) <= static_cast<size_t>(budget) * 1024) return gpw;
+            if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw, nbt) <= static_cast<size_t>(budget) * 1024) return gpw;
     return 0;
 }
 static int cellm_nstep(int /*cp*/, int kernel) { return (kernel + 1) / 2; }      // 2 taps per K step either way
 
-template <int CP, int GPW>
+template <int CP, int GPW, int NBT>
 static int launch_cellm(const bf16_t* x0, bf16_t* y, const void* const* wp, const float* const* bias, const LnRef& l, const CellMDims& a, hipStream_t stream)
 {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_mfma_kernel<CP, GPW>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_mfma_kernel<CP, GPW, NBT>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) {
         set_error("nbasr_grouped_cell_mfma: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
-    hipLaunchKernelGGL((grouped_cell_mfma_kernel<CP, GPW>), dim3(a.groups / GPW, a.batch), dim3(64 * GPW * a.nt), cellm_lds_bytes(CP, a.nt, GPW), stream,
+    hipLaunchKernelGGL((grouped_cell_mfma_kernel<CP, GPW, NBT>), dim3(a.groups / GPW, a.batch), dim3(64 * GPW * a.nt), cellm_lds_bytes(CP, a.nt, GPW, NBT), stream,
                        x0, y, static_cast<const cm_u4*>(wp[0]), static_cast<const cm_u4*>(wp[1]), static_cast<const cm_u4*>(wp[2]),
                        bias[0], bias[1], bias[2], l.stats, l.gamma, l.beta, a);
     return launch_status("nbasr_grouped_cell_mfma");
@@ -332,8 +336,8 @@ extern "C" int nbasr_grouped_cell_mfma_fits(int channels, int frames_ld, int gro
     if (channels <= 0 || groups <= 0 || channels % groups || frames_ld <= 0 || frames_ld % 8) return 0;
     const int cg = channels / groups;
     if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
-    const int nt = (frames_ld + CM_WAVE_FRAMES - 1) / CM_WAVE_FRAMES;
-    return cellm_gpw(cg, nt, groups);
+    const int nbt = cellm_nbt(frames_ld, cellm_cp(cg)), nt = (frames_ld + 16 * nbt - 1) / (16 * nbt);
+    return cellm_gpw(cg, nt, groups, nbt);
 }
 
 extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const float* b0, int k0, int d0,
@@ -366,19 +370,25 @@ extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const fl
         a.k[i] = ks[i]; a.d[i] = ds[i]; a.lpad[i] = pad_left(ks[i], ds[i], 1); a.nstep[i] = cellm_nstep(cp, ks[i]);
     }
     a.skips = skip_mask;
-    a.nt = (ld + CM_WAVE_FRAMES - 1) / CM_WAVE_FRAMES;
+    const int nbt = cellm_nbt(ld, cellm_cp(channels / groups));
+    a.nt = (ld + 16 * nbt - 1) / (16 * nbt);
     const void* const wp[3] = {wp0, wp1, wp2};
     const float* const bias[3] = {b0, b1, b2};
     const LnRef l = ln_ref(ln, true);
     const bf16_t* xin = static_cast<const bf16_t*>(x0);
     bf16_t* yout = static_cast<bf16_t*>(y);
     hipStream_t s = as_stream(stream);
+#define NBASR_CELLM_LAUNCH(CP_, NBT_)                                                            \
+    do {                                                                                        \
+        if (gpw == 4) return launch_cellm<CP_, 4, NBT_>(xin, yout, wp, bias, l, a, s);          \
+        if (gpw == 2) return launch_cellm<CP_, 2, NBT_>(xin, yout, wp, bias, l, a, s);          \
+        return launch_cellm<CP_, 1, NBT_>(xin, yout, wp, bias, l, a, s);                        \
+    } while (0)
     if (cp == 8) {
-        if (gpw == 4) return launch_cellm<8, 4>(xin, yout, wp, bias, l, a, s);
-        if (gpw == 2) return launch_cellm<8, 2>(xin, yout, wp, bias, l, a, s);
-        return launch_cellm<8, 1>(xin, yout, wp, bias, l, a, s);
+        if (nbt == 8) NBASR_CELLM_LAUNCH(8, 8);
+        NBASR_CELLM_LAUNCH(8, 16);
     }
-    if (gpw == 4) return launch_cellm<16, 4>(xin, yout, wp, bias, l, a, s);
-    if (gpw == 2) return launch_cellm<16, 2>(xin, yout, wp, bias, l, a, s);
-    return launch_cellm<16, 1>(xin, yout, wp, bias, l, a, s);
+    if (nbt == 8) NBASR_CELLM_LAUNCH(16, 8);
+    NBASR_CELLM_LAUNCH(16, 16);
+#undef NBASR_CELLM_LAUNCH
 }
