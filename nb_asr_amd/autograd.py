@@ -74,7 +74,7 @@ class _LayerNormChannels(torch.autograd.Function):
 
 class _DensePadConvRelu(torch.autograd.Function):
     """Dense k = 8 downsample conv (stride 1 | 2) or the per-frame `linear` op (k = 1) with ReLU and clamp; forward of the k = 8 convs on the
-    split 16-bit GEMMs (NBASR_TRAIN_GEMM = f16x2 (default) | bf16x3 | f32: the exact-fp32 MFMA GEMM), backward through hip.dense_conv1d_backward."""
+    split 16-bit GEMMs (NBASR_DENSE_MODE = auto (default: two-term fp16 split) | bf16x3 | f32: the exact-fp32 MFMA GEMM), backward through hip.dense_conv1d_backward."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, normalized_input=False):

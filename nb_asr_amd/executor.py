@@ -180,7 +180,7 @@ class ForwardPlan:
             raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
         # (round 3: the A/B switches of rounds 1-2 whose alternatives lost everywhere are gone -- NBASR_IMAGE_MODE, NBASR_ROW_TILE,
         # NBASR_LN_MODE, NBASR_EPILOGUE_STATS, NBASR_LSTM_UNPACKED, NBASR_GC_TABLE, NBASR_GC_BF16_VARIANT, NBASR_GC_BF16_MFMA; what is
-        # left: NBASR_DENSE_MODE, NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_TAPE here, NBASR_TRAIN_GEMM in autograd.py)
+        # left: NBASR_DENSE_MODE (also read by autograd.py), NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_LSTM_SEQ, NBASR_TAPE)
         self._act_image = None
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
