@@ -903,7 +903,7 @@ def dense_conv1d_backward(x, weight, y, dy, frames_in, stride, need_dx=True, nee
     Correctness-first.  Weight and bias gradients: ONE (C_out, B * T') x (B * T', C_in * k + 1) GEMM on a materialised
     column matrix.  Input gradient of the k = 8 convs: ONE (C_in * 8, C_out) x (C_out, B * T') GEMM, then a fold of the 8 tap rows onto
     the input frames (nbasr_conv_fold).  Both GEMMs run on the fp16 matrix cores with the fp32-accurate two-term split;
-    ``NBASR_TRAIN_GEMM=f32`` keeps every product on the exact-fp32 MFMA GEMMs of the forward (there the input gradient is a stride-1 conv
+    ``NBASR_DENSE_MODE=f32`` keeps every product on the exact-fp32 MFMA GEMMs of the forward (there the input gradient is a stride-1 conv
     of the zero-stuffed, masked output gradient with the flipped, channel-transposed kernel)."""
     lib = load_library()
     b, c_in, ld_in = x.shape
@@ -985,7 +985,7 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
 
     Correctness first: gate pre-activations of all frames are recomputed from the saved h by ONE GEMM, a serial
     scan restores the cell states, the reverse recurrence is T launches of a step kernel that forms w_hh^T . dpre of the next frame in place, and the weight / input gradients
-    are batched GEMMs -- on the fp16 matrix cores with the fp32-accurate two-term split (``NBASR_TRAIN_GEMM=f32``: the exact-fp32 MFMA GEMM
+    are batched GEMMs -- on the fp16 matrix cores with the fp32-accurate two-term split (``NBASR_DENSE_MODE=f32``: the exact-fp32 MFMA GEMM
     nbasr_pointwise_linear); tensor re-layouts are torch copies."""
     lib = load_library()
     b, c, _ = xp.shape
