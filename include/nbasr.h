@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NBASR_ABI_VERSION 3
+#define NBASR_ABI_VERSION 4
 
 #define NBASR_OK 0
 #define NBASR_EINVAL (-1)   /* bad size / unsupported shape */
@@ -179,13 +179,19 @@ int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* packed_whh, 
  * |h| <= 1 -- written write-through, polled with L1-bypassing loads; no flags, no drains); utterance tiles never synchronise with each
  * other.  Bit-identical h_out to nbasr_lstm_recurrence_packed.  For the single forward (latency); a pipelined caller whose next
  * encoder needs the CUs keeps the per-frame launches.  nbasr_lstm_seq_workspace_bytes returns 0 where the form does not apply
- * (hidden > 512, or more than 256 workgroups = ceil(hidden / 8) * ceil(batch / 16): every workgroup must be resident).
- * Every wait is bounded (1 s): on a timeout the kernel raises the status word in seq_ws and fills the rest of h_out with NaN;
- * nbasr_lstm_seq_status (synchronises `stream`) returns NBASR_EINVAL then.  Launches from different streams of one process are
- * chained by an event; a stream under graph capture is refused (use the per-frame form there). */
+ * (hidden > 512, or more workgroups = ceil(hidden / 8) * ceil(batch / 16) than the CURRENT device holds at once -- its compute units x
+ * the kernel's occupancy, at most 256: every workgroup must be resident).  The launch is cooperative where the device offers it
+ * (ABI 4): a grid the device cannot hold at once is refused with an error instead of started in part.
+ * Every wait is bounded (1 s): on a timeout (compute units taken by another process) the kernel raises the status word -- the first
+ * 32-bit word of seq_ws -- and fills the rest of h_out with NaN; nbasr_lstm_seq_status (synchronises `stream`) returns NBASR_EINVAL
+ * then, and a caller that must not block copies that word back asynchronously and looks at it later (what nb_asr_amd's executor does
+ * behind every launch: a timed-out forward raises at the next call, and the one-launch form is switched off for the plan).
+ * Launches from different streams of one process are chained by an event; a stream under graph capture is refused (use the
+ * per-frame form there).  flags: 0, or NBASR_LSTM_SEQ_INJECT_FAULT (tests: one workgroup per tile never starts). */
+#define NBASR_LSTM_SEQ_INJECT_FAULT 1
 size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden);
 int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
-                              int batch, int frames, int hidden, nbasr_stream_t stream);
+                              int batch, int frames, int hidden, int flags, nbasr_stream_t stream);
 int nbasr_lstm_seq_status(const void* seq_ws, nbasr_stream_t stream);
 
 /* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
@@ -249,6 +255,8 @@ int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int 
  * LayerNorm statistics of x3, exactly as nbasr_grouped_conv1d_node does for a cell's last node (merge: nbasr_grouped_stats_finalize).
  * `dtype` = NBASR_F32 | NBASR_BF16: storage type of x0 and y (weights, biases, statistics, gamma / beta are fp32 either way; with
  * bf16 storage x1 and x2 are rounded to bfloat16 exactly where the three-launch form stores them).
+ * w0, w1, w2 (ABI 4): the [group][ci][tap][co] copies made by nbasr_pack_grouped_weights -- a packed FMA of the kernel covers two
+ * output channels of one frame, its weight operand is a scalar-register pair loaded from two adjacent floats.
  * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup -- <= 2048 frames (<= 8 waves per group row),
  * channels / groups in {6, 8, 10, 12}, the group tiles within 160 KiB of LDS: 0 = no, else the number of groups one statistics partial
  * covers (4 or 2: the groups_per_part of nbasr_grouped_stats_finalize). */

@@ -48,18 +48,12 @@ __device__ __forceinline__ float ln_apply(float x, float mean, float rstd, float
     return rstd != 0.f ? __builtin_fmaf((x - mean) * rstd, gamma, beta) : 0.f;
 }
 
-// min(relu(v), 20): v_med3_f32 (fminf(fmaxf(v, 0), 20) costs an extra canonicalising v_max).  v_med3 alone maps NaN to 0
-// (it returns min3 of its operands when one is NaN), which would turn a diverged checkpoint or a corrupt input into
-// finite-looking logits; the reference's relu / clamp_max_ (ops.py:27-28) propagate NaN.  fma(v, 0, med3) restores that for
-// one more (packable) instruction: v * 0 is +-0 for finite v -- the sum is then exactly med3 -- and NaN for NaN.  It is NaN
-// for +-Inf too, where the reference gives 20 / 0: an overflowed pre-activation comes out LOUDER here, never quieter.
-// NBASR_NAN_QUIET=1 (compile time) restores the bare v_med3 for A/B timing.
-#ifndef NBASR_NAN_QUIET
-#define NBASR_NAN_QUIET 0
-#endif
+// min(relu(v), 20) with the reference's treatment of non-finite values (ops.py:27-28: relu, then clamp_max_): NaN stays NaN,
+// +Inf -> 20, -Inf -> 0.  gfx950 has the IEEE-754-2019 minimum / maximum (v_maximum3_f32 / v_minimum3_f32: NaN-propagating), so this
+// is two instructions -- as many as rounds 1-3's v_med3 + fma(v, 0, .), which turned +-Inf into NaN (v_med3 alone turns NaN into 0,
+// v_max / v_min return the other operand).
 __device__ __forceinline__ float relu_clamp(float v) {
-    const float m = __builtin_amdgcn_fmed3f(v, 0.0f, kClamp);
-    return NBASR_NAN_QUIET ? m : __builtin_fmaf(v, 0.0f, m);
+    return __builtin_elementwise_minimum(__builtin_elementwise_maximum(v, 0.0f), kClamp);
 }
 // |v| if it is finite, else 0: range statistics (max|x| per utterance) must not be hijacked by an Inf / NaN sample --
 // the scaled fp16 GEMM would otherwise flush every finite sample of that utterance to zero

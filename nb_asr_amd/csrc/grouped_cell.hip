@@ -23,9 +23,25 @@
 //    element once per window chunk;
 //  * the window of input channel ci + 1 is read from LDS while channel ci multiplies.
 //
-// Algorithmic bytes credited per launch (bench.py): those of the three node operations it replaces.
+// Round 4 -- the vector stream is the FMAs and little else (41-48 % of the vector instructions were v_pk_fma_f32,
+// 16-21 % v_readlane / v_writelane of spilled scalar registers, 14-21 % moves):
+//  * a packed FMA covers TWO OUTPUT CHANNELS of one frame (round 3: two frames of one channel).  Its weight operand is then a scalar
+//    register PAIR -- the weights arrive as [group][ci][tap][co] (nbasr_pack_grouped_weights), so the CG weights of a (ci, tap) are
+//    one wide scalar load -- and its x operand ONE window register broadcast to both halves by op_sel: any register of the window
+//    is addressable (no alignment, no shifted copies; hipcc only folds a splat of an EVEN register, hence the inline assembly);
+//  * one input channel per trip: its CG K scalars (30-84) are the only weights alive -- nothing spills --, requested together with
+//    the channel's window (ds_read_b128) and waited for once; the other waves of the SIMD cover that wait;
+//  * the same sums in the same order as before (bias, then ci-major, tap-minor, one fma each): still bit-identical to the node kernels.
+//
+// Algorithmic bytes credited per launch (bench.py): x0 in, y out, the weights once (round 3 credited the three node operations).
 #include "storage.h"
 
+#include <cstddef>
+#include <cstdlib>
+
+#ifndef NBASR_CELL_STAMPS
+#define NBASR_CELL_STAMPS 0
+#endif
 #include <type_traits>
 
 namespace nbasr {
@@ -47,6 +63,9 @@ struct CellDims {
     int kd0, kd1, kd2;          // 0: k5 d1, 1: k5 d2, 2: k7 d1, 3: k7 d2
     int skips;                  // bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22
     int nt;                     // 64-chunk tiles (waves) per row
+#if NBASR_CELL_STAMPS
+    unsigned long long* stamps; // [workgroup][16]: HW_ID, XCC_ID, then the 100 MHz clock at the phase boundaries of wave 0
+#endif
 };
 
 typedef float cell_f4 __attribute__((ext_vector_type(4)));
@@ -89,43 +108,129 @@ template <typename T> __device__ __forceinline__ void cell_round(float (&o)[4])
     }
 }
 
+typedef float cell_f2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) float* cell_cptr;      // wave-uniform read-only data: scalar loads
+__device__ __forceinline__ cell_cptr cell_const(const float* p) { return (cell_cptr)p; }
+
+// N (even, <= 40) consecutive floats at a wave-uniform address -> scalar registers, by ONE statement that also waits for them.
+// hipcc, left to place the scalar loads of a weight batch itself, schedules for the scalar-register pressure it sees BEFORE register
+// allocation (the kernel's ~50 long-lived scalars count in full) and fetched eight weights at a time with a full wait after each: 7-11
+// exposed scalar-cache round trips per input channel.  Written out, the batch is requested at once and waited for once, and the
+// allocator moves long-lived scalars out of the way around the loop (a few v_writelane / v_readlane per node, none inside).
+typedef float cell_f8 __attribute__((ext_vector_type(8)));
+typedef float cell_f16 __attribute__((ext_vector_type(16)));
+template <int N>
+struct WeightBatch {
+    static_assert(N % 2 == 0 && N >= 2 && N <= 46, "an even number of scalars, at most 2 x 16 + 8 + 4 + 2");
+    static constexpr int N16 = N / 16, N8 = (N % 16) / 8, N4 = (N % 8) / 4, N2 = (N % 4) / 2;
+    cell_f16 q0, q1; cell_f8 o; cell_f4 f; cell_f2 t;
+    __device__ __forceinline__ cell_f2 pair(int i) const     // scalars (2i, 2i + 1); i is a constant after unrolling
+    {
+        int e = 2 * i;
+        if (e < 16 * N16) return e < 16 ? cell_f2{q0[e & 15], q0[(e & 15) + 1]} : cell_f2{q1[e & 15], q1[(e & 15) + 1]};
+        e -= 16 * N16;
+        if (N8 && e < 8) return cell_f2{o[e & 7], o[(e & 7) + 1]};
+        e -= 8 * N8;
+        if (N4 && e < 4) return cell_f2{f[e & 3], f[(e & 3) + 1]};
+        return t;
+    }
+    __device__ __forceinline__ void load(cell_cptr p)
+    {
+        constexpr int O8 = 64 * N16, O4 = O8 + 32 * N8, O2 = O4 + 16 * N4;      // byte offsets of the 8- / 4- / 2-dword pieces
+#define NBASR_WB_CASE(n16, n8, n4, n2, text, ...)                                                    \
+        if constexpr (N16 == n16 && N8 == n8 && N4 == n4 && N2 == n2)                                \
+            asm volatile(text "\n\ts_waitcnt lgkmcnt(0)" : __VA_ARGS__ : [p] "s"(p), [o8] "n"(O8), [o4] "n"(O4), [o2] "n"(O2));
+#define L16A "s_load_dwordx16 %[q0], %[p], 0x0"
+#define L16B "\n\ts_load_dwordx16 %[q1], %[p], 0x40"
+#define L8 "\n\ts_load_dwordx8 %[o], %[p], %[o8]"
+#define L4 "\n\ts_load_dwordx4 %[f], %[p], %[o4]"
+#define L2 "\n\ts_load_dwordx2 %[t], %[p], %[o2]"
+#define Q0 [q0] "=&s"(q0)
+#define Q1 [q1] "=&s"(q1)
+#define O_ [o] "=&s"(o)
+#define F_ [f] "=&s"(f)
+#define T_ [t] "=&s"(t)
+        NBASR_WB_CASE(0, 1, 1, 0, "s_load_dwordx8 %[o], %[p], 0x0" L4, O_, F_)                       // 12
+        NBASR_WB_CASE(1, 0, 0, 0, L16A, Q0)                                                            // 16
+        NBASR_WB_CASE(1, 0, 0, 1, L16A L2, Q0, T_)                                                     // 18
+        NBASR_WB_CASE(1, 0, 1, 0, L16A L4, Q0, F_)                                                     // 20
+        NBASR_WB_CASE(1, 1, 0, 0, L16A L8, Q0, O_)                                                     // 24
+        NBASR_WB_CASE(1, 1, 1, 1, L16A L8 L4 L2, Q0, O_, F_, T_)                                       // 30
+        NBASR_WB_CASE(2, 0, 0, 0, L16A L16B, Q0, Q1)                                                   // 32
+        NBASR_WB_CASE(2, 0, 1, 0, L16A L16B L4, Q0, Q1, F_)                                            // 36
+        NBASR_WB_CASE(2, 1, 0, 0, L16A L16B L8, Q0, Q1, O_)                                            // 40
+        static_assert(N == 12 || N == 16 || N == 18 || N == 20 || N == 24 || N == 30 || N == 32 || N == 36 || N == 40, "batch size without a load pattern");
+#undef NBASR_WB_CASE
+#undef L16A
+#undef L16B
+#undef L8
+#undef L4
+#undef L2
+#undef Q0
+#undef Q1
+#undef O_
+#undef F_
+#undef T_
+    }
+};
+
+// taps J0 .. J0 + NT - 1 of one input channel: its NT * CG weights (wt: [tap][co]) in one batch, then the FMAs.  One packed FMA: the
+// weight pair from scalar registers, x = word (e & 1) of the aligned register pair that holds window element e (after unrolling e
+// is a constant and one of the two statements remains)
+template <int CG, int K, int D, int J0, int NT>
+__device__ __forceinline__ void conv_taps(cell_f2 (&acc)[CG / 2][4], cell_cptr wt, const cell_f4 (&xq)[Win<K, D>::NCH])
+{
+    using W = Win<K, D>;
+    WeightBatch<NT * CG> wb;
+    wb.load(wt);
+#pragma unroll
+    for (int j = J0; j < J0 + NT; ++j) {
+#pragma unroll
+        for (int p = 0; p < CG / 2; ++p) {
+            const cell_f2 wv = wb.pair((j - J0) * (CG / 2) + p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = W::BASE + r + j * D;
+                const cell_f2 xp = {xq[e / 4][(e & 3) & ~1], xq[e / 4][(e & 3) | 1]};
+                if (e & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc[p][r]) : "s"(wv), "v"(xp));
+                else       asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc[p][r]) : "s"(wv), "v"(xp));
+            }
+        }
+    }
+}
+
 // acc = bias + conv over one group's CG input channels, the input read from this group's LDS tile (row pitch rl floats; a lane's own
-// chunk of channel ci at row[ci * rl + 4 * col]); the window of channel ci + 1 is requested before the FMAs of channel ci
+// chunk of channel ci at row[ci * rl + 4 * col]).  acc[p][r] = output channels (2p, 2p + 1) at the lane's frame r;
+// wg = this group's weights as [ci][tap][co]
 template <int CG, int K, int D>
-__device__ __forceinline__ void conv_from_tile(float (&acc)[CG][4], const float* __restrict__ wg, const float* __restrict__ bg,
-                                               const float* tile, int rl, int col)
+__device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CG / 2][4], cell_cptr wg, cell_cptr bg, const float* tile, int rl, int col)
 {
     using W = Win<K, D>;
 #pragma unroll
-    for (int co = 0; co < CG; ++co) {
-        const float bv = bg[co];
+    for (int p = 0; p < CG / 2; ++p) {
+        const cell_f2 bv = {bg[2 * p], bg[2 * p + 1]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[co][r] = bv;
+        for (int r = 0; r < 4; ++r) acc[p][r] = bv;
     }
     const float* win = tile + 4 * (col - W::QL);
-    cell_f4 nxt[W::NCH];
-#pragma unroll
-    for (int c = 0; c < W::NCH; ++c) nxt[c] = *reinterpret_cast<const cell_f4*>(win + 4 * c);
-    // two channels per trip where their 2 CG K scalar weights fit the scalar registers: one `lgkmcnt(0)` stall (scalar loads return out
-    // of order, so hipcc never counts them) per TWO channels' FMAs
-    constexpr int UNROLL = (2 * CG * K <= 84) ? 2 : 1;
-#pragma unroll UNROLL
+    // the weights of an input channel in batches of TB taps, each at most 40 scalars: what is alive beside the kernel's own
+    // scalars (pointers, sizes) then fits the 102 scalar registers
+    constexpr int NB = (K * CG + 39) / 40, TB = (K + NB - 1) / NB;
+    static_assert(NB <= 3, "at most three weight batches per input channel");
+#pragma unroll 1
     for (int ci = 0; ci < CG; ++ci) {
-        float xw[W::NCH * 4];
+        cell_f4 xq[W::NCH];
 #pragma unroll
-        for (int c = 0; c < W::NCH; ++c) { xw[4 * c + 0] = nxt[c][0]; xw[4 * c + 1] = nxt[c][1]; xw[4 * c + 2] = nxt[c][2]; xw[4 * c + 3] = nxt[c][3]; }
-        const float* nwin = win + (ci + 1 < CG ? ci + 1 : ci) * rl;            // (last round: a redundant re-read instead of a branch)
-#pragma unroll
-        for (int c = 0; c < W::NCH; ++c) nxt[c] = *reinterpret_cast<const cell_f4*>(nwin + 4 * c);
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-#pragma unroll
-            for (int co = 0; co < CG; ++co) {
-                const float wv = wg[(co * CG + ci) * K + j];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[co][r] = __builtin_fmaf(wv, xw[W::BASE + r + j * D], acc[co][r]);
-            }
+        for (int c = 0; c < W::NCH; ++c) xq[c] = *reinterpret_cast<const cell_f4*>(win + ci * rl + 4 * c);
+        const cell_cptr wc = wg + ci * (K * CG);
+        conv_taps<CG, K, D, 0, (TB < K ? TB : K)>(acc, wc, xq);
+        if constexpr (NB >= 2) {
+            __builtin_amdgcn_sched_barrier(0);      // (this batch's loads stay behind the previous batch's FMAs)
+            conv_taps<CG, K, D, TB, (2 * TB < K ? TB : K - TB)>(acc, wc + TB * CG, xq);
+        }
+        if constexpr (NB >= 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            conv_taps<CG, K, D, 2 * TB, K - 2 * TB>(acc, wc + 2 * TB * CG, xq);
         }
     }
 }
@@ -138,15 +243,36 @@ __device__ __forceinline__ void conv_from_tile(float (&acc)[CG][4], const float*
 // 64 * GPW * NTB-thread workgroup (128 registers at 1024 threads; the narrower forms may use more)
 // T: storage type of the cell input and output (float, or bf16_t: the bf16 path -- x1 and x2 are then rounded to bfloat16 exactly
 // where the three-launch form stores them, the statistics describe x3 before its rounding)
+// The kernel's arguments as ONE by-value struct (the kernarg segment).  Pointers that are needed only late in the kernel -- the
+// weights and biases of nodes 1 and 2, y, the LayerNorm vectors, the partials -- are NOT read through it: kept alive across the three
+// convolution loops they left the loops ~16 scalar registers for weights, and hipcc, scheduling for that pressure, fetched the
+// weights eight at a time with a full wait after each.  cell_arg<>() re-reads such a pointer from the kernarg segment where it is used.
+template <typename T>
+struct CellArgs {
+    const T* x0; T* y;
+    const float* w0; const float* w1; const float* w2;
+    const float* b0; const float* b1; const float* b2;
+    const float* ln_stats; const float* ln_gamma; const float* ln_beta;
+    float* part;
+    CellDims a;
+};
+// (an asm result counts as divergent and a re-read pointer as generic: hipcc would fetch the weights behind it by flat vector loads.
+// v_readfirstlane makes it uniform again; the users cast it to the constant address space, i.e. to scalar loads)
+#define NBASR_CELL_ARG(T_, field) reinterpret_cast<decltype(CellArgs<T_>::field)>(cell_arg<offsetof(CellArgs<T_>, field)>())
+template <int OFFSET>
+__device__ __forceinline__ uintptr_t cell_arg()
+{
+    uint64_t p;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(p) : "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(OFFSET));
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(p)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(p >> 32));
+    return (static_cast<uint64_t>(hi) << 32) | lo;
+}
+
 template <typename T, int CG, bool KEEP1, int NTB, int GPW>
-__global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
-    const T* __restrict__ x0, T* __restrict__ y,
-    const float* __restrict__ w0, const float* __restrict__ w1, const float* __restrict__ w2,
-    const float* __restrict__ b0, const float* __restrict__ b1, const float* __restrict__ b2,
-    const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta,
-    float* __restrict__ part, const CellDims a)
+__global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const CellArgs<T> A)
 {
     extern __shared__ __attribute__((aligned(16))) float cell_tiles[];
+    const CellDims& a = A.a;
     const int nt = a.nt;
     const int rl = (nt * 64 + CELL_PADL + CELL_PADR) * 4;    // tile row length in floats
     const int lane = threadIdx.x & 63;
@@ -163,9 +289,25 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     const bool in_row = q < nq;
     const int t0 = q * 4;
     const size_t row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG) * a.ld;
-    const T* __restrict__ xg = x0 + row0;
-    const bool has_ln = ln_stats != nullptr;
+    const bool has_ln = A.ln_stats != nullptr;
 
+    // -DNBASR_CELL_STAMPS=1 (NBASR_EXTRA_CXXFLAGS; tools/gpu/cell_stamps.py): wave 0 of every workgroup records the 100 MHz clock at its
+    // phase boundaries -- how round 4 found that a workgroup spends half of its life outside the convolution loops
+#if NBASR_CELL_STAMPS
+    unsigned long long* const stamp_row = a.stamps ? a.stamps + (static_cast<size_t>(blockIdx.x) + static_cast<size_t>(gridDim.x) * blockIdx.y) * 16 : nullptr;
+    int stamp_i = 2;
+    auto stamp = [&]() {
+        if (stamp_row && threadIdx.x == 0) stamp_row[stamp_i] = wall_clock64();
+        ++stamp_i;
+    };
+    if (stamp_row && threadIdx.x == 0) {
+        stamp_row[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_ID
+        stamp_row[1] = __builtin_amdgcn_s_getreg(20 | (31 << 11));      // XCC_ID
+    }
+#else
+    auto stamp = []() {};
+#endif
+    stamp();
     // the zero pads of every tile row (never written again)
     for (int i = threadIdx.x; i < GPW * CG * (CELL_PADL + CELL_PADR); i += blockDim.x) {
         const int row = i / (CELL_PADL + CELL_PADR), p = i - row * (CELL_PADL + CELL_PADR);
@@ -177,19 +319,20 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     // statistics of this lane's own 4 frames (pending LayerNorm of the cell input); beyond the row rstd = 0, i.e. normalised = 0
     float4 sm = make_float4(0.f, 0.f, 0.f, 0.f), sr = sm;
     if (has_ln) {                                   // (workgroup-uniform)
-        const float* mrow = ln_stats + static_cast<size_t>(b) * 2 * a.ld;
+        const float* mrow = A.ln_stats + static_cast<size_t>(b) * 2 * a.ld;
         sm = cell_load4(mrow, row_bytes, boff);
         sr = cell_load4(mrow + a.ld, row_bytes, boff);
     }
-    auto normalise = [&](float4 v, int co) -> float4 {
+    // (gamma / beta / the input rows through pointers handed in: the late users pass freshly re-read ones)
+    auto normalise = [&](float4 v, int co, const float* gamma, const float* beta) -> float4 {
         if (has_ln) {
-            const float gam = ln_gamma[g * CG + co], bet = ln_beta[g * CG + co];
+            const float gam = cell_const(gamma)[g * CG + co], bet = cell_const(beta)[g * CG + co];
             v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
             v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
         }
         return v;
     };
-    auto x0_raw = [&](int co) -> float4 {           // the cell input at this lane's frames, channel co, from HBM (zeros beyond the row)
+    auto x0_raw = [&](const T* __restrict__ xg, int co) -> float4 {   // the cell input at this lane's frames, channel co, from HBM (zeros beyond the row)
         return cell_load_frames(xg + static_cast<size_t>(co) * a.ld, a.ld, q);
     };
     auto tile_own = [&](int co) -> float4 {         // this lane's chunk of the tensor the tile holds
@@ -197,7 +340,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         return make_float4(v[0], v[1], v[2], v[3]);
     };
     // only the wave tile that holds the row's end has frames to zero: a wave-uniform branch saves the other waves 4 selects per output
-    // channel and node (33 of a node's ~900 vector instructions)
+    // channel and node
     const bool tail_wave = (ti + 1) * 256 > a.frames;
     auto mask_tail = [&](float (&o)[4]) {
         if (tail_wave) {
@@ -213,117 +356,149 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
-    float acc[CG][4];
+    cell_f2 acc[CG / 2][4];                         // the convolution's accumulators: output channels (2p, 2p + 1) at frame r
+    float out[CG][4];                               // a node's finished output (after the epilogue): channel co at frame r
     float keep1[KEEP1 ? CG : 1][4];
 
     // ---- the cell input: own chunks of all CG channels (all loads in flight together), normalised once, into the tile ------------
+    {
+        const T* __restrict__ xg = A.x0 + row0;
 #pragma unroll
-    for (int ci = 0; ci < CG; ++ci) {
-        const float4 v = x0_raw(ci);
-        acc[ci][0] = v.x; acc[ci][1] = v.y; acc[ci][2] = v.z; acc[ci][3] = v.w;
-    }
+        for (int ci = 0; ci < CG; ++ci) {
+            const float4 v = x0_raw(xg, ci);
+            out[ci][0] = v.x; out[ci][1] = v.y; out[ci][2] = v.z; out[ci][3] = v.w;
+        }
 #pragma unroll
-    for (int ci = 0; ci < CG; ++ci) {
-        const float4 v = normalise(make_float4(acc[ci][0], acc[ci][1], acc[ci][2], acc[ci][3]), ci);      // (rstd = 0 beyond the row: zeros)
-        *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{v.x, v.y, v.z, v.w};
+        for (int ci = 0; ci < CG; ++ci) {
+            const float4 v = normalise(make_float4(out[ci][0], out[ci][1], out[ci][2], out[ci][3]), ci, A.ln_gamma, A.ln_beta);      // (rstd = 0 beyond the row: zeros)
+            *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{v.x, v.y, v.z, v.w};
+        }
     }
+    stamp();
     __syncthreads();                                // (also orders the zero pads, which other waves wrote)
+    stamp();
 
     using I5 = std::integral_constant<int, 5>; using I7 = std::integral_constant<int, 7>;
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    auto conv = [&](auto kc, auto dc, const float* __restrict__ w, const float* __restrict__ bias) {
+    auto conv = [&](auto kc, auto dc, const float* w, const float* bias) {
         constexpr int K = decltype(kc)::value, D = decltype(dc)::value;
-        conv_from_tile<CG, K, D>(acc, w + static_cast<size_t>(g) * (CG * CG * K), bias + g * CG, tile, rl, col);
+        conv_from_tile<CG, K, D>(acc, cell_const(w) + static_cast<size_t>(g) * (CG * CG * K), cell_const(bias) + g * CG, tile, rl, col);
     };
 #define NBASR_KD_SWITCH(kd, W_, B_)                                                                    \
     switch (kd) {                                                                                      \
         case 0: conv(I5{}, I1{}, W_, B_); break; case 1: conv(I5{}, I2{}, W_, B_); break;              \
         case 2: conv(I7{}, I1{}, W_, B_); break; default: conv(I7{}, I2{}, W_, B_); break;             \
     }
-    auto tile_write = [&]() {                       // the node output in `acc` becomes the next node's input
+    auto tile_write = [&]() {                       // the node output in `out` becomes the next node's input
 #pragma unroll
         for (int co = 0; co < CG; ++co)
-            *reinterpret_cast<cell_f4*>(tile + co * rl + 4 * col) = cell_f4{acc[co][0], acc[co][1], acc[co][2], acc[co][3]};
+            *reinterpret_cast<cell_f4*>(tile + co * rl + 4 * col) = cell_f4{out[co][0], out[co][1], out[co][2], out[co][3]};
     };
 
     // ---- node 0: x1 = op0(x0n) + s00 x0n (x0n read back from the tile) -------------------------------------------------------------
-    NBASR_KD_SWITCH(a.kd0, w0, b0)
+    NBASR_KD_SWITCH(a.kd0, A.w0, A.b0)
+    stamp();
 #pragma unroll
     for (int co = 0; co < CG; ++co) {
         float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
+        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co >> 1][r][co & 1]);
         if (a.skips & 1) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         mask_tail(o);
         cell_round<T>(o);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { acc[co][r] = o[r]; if (KEEP1) keep1[KEEP1 ? co : 0][r] = o[r]; }
+        for (int r = 0; r < 4; ++r) { out[co][r] = o[r]; if (KEEP1) keep1[KEEP1 ? co : 0][r] = o[r]; }
     }
     phase_sync();                                   // every read of x0n is done
     tile_write();
     phase_sync();
+    stamp();
 
     // ---- node 1: x2 = op1(x1) + s10 x0n + s11 x1 --------------------------------------------------------------------------------------
-    NBASR_KD_SWITCH(a.kd1, w1, b1)
-    // (the skip input x0n comes back from HBM: its four-channel groups are requested together behind ONE wave-uniform branch each)
+    {
+        const float* __restrict__ w1 = NBASR_CELL_ARG(T, w1);
+        const float* __restrict__ b1 = NBASR_CELL_ARG(T, b1);
+        NBASR_KD_SWITCH(a.kd1, w1, b1)
+    }
+    stamp();
+    {
+        // (the skip input x0n comes back from HBM: its four-channel groups are requested together behind ONE wave-uniform branch each)
+        const bool s10 = a.skips & 2;
+        const T* __restrict__ xg = nullptr; const float* __restrict__ gamma = nullptr; const float* __restrict__ beta = nullptr;
+        if (s10) { xg = NBASR_CELL_ARG(T, x0) + row0; if (has_ln) { gamma = NBASR_CELL_ARG(T, ln_gamma); beta = NBASR_CELL_ARG(T, ln_beta); } }
 #pragma unroll
-    for (int c0 = 0; c0 < CG; c0 += 4) {
-        float4 u[4];
-        if (a.skips & 2) {
+        for (int c0 = 0; c0 < CG; c0 += 4) {
+            float4 u[4];
+            if (s10) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(c0 + c);
-        }
+                for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(xg, c0 + c);
+            }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int co = c0 + c;
-            if (co >= CG) break;
-            float o[4];
+            for (int c = 0; c < 4; ++c) {
+                const int co = c0 + c;
+                if (co >= CG) break;
+                float o[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-            if (a.skips & 2) { const float4 v = normalise(u[c], co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-            if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-            mask_tail(o);
-            cell_round<T>(o);
+                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co >> 1][r][co & 1]);
+                if (s10) { const float4 v = normalise(u[c], co, gamma, beta); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+                if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+                mask_tail(o);
+                cell_round<T>(o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];
+                for (int r = 0; r < 4; ++r) out[co][r] = o[r];
+            }
         }
     }
     phase_sync();
     tile_write();
     phase_sync();
+    stamp();
 
     // ---- node 2: x3 = op2(x2) + s20 x0n + s21 x1 + s22 x2 -> HBM ------------------------------------------------------------------------
-    NBASR_KD_SWITCH(a.kd2, w2, b2)
+    {
+        const float* __restrict__ w2 = NBASR_CELL_ARG(T, w2);
+        const float* __restrict__ b2 = NBASR_CELL_ARG(T, b2);
+        NBASR_KD_SWITCH(a.kd2, w2, b2)
+    }
 #undef NBASR_KD_SWITCH
-    const int store_len = g_ok ? a.ld : 0;          // a surplus wave's stores are dropped by the bounds check
+    stamp();
+    {
+        const int store_len = g_ok ? a.ld : 0;      // a surplus wave's stores are dropped by the bounds check
+        const bool s20 = a.skips & 8;
+        T* __restrict__ yg = NBASR_CELL_ARG(T, y) + row0;
+        const T* __restrict__ xg = nullptr; const float* __restrict__ gamma = nullptr; const float* __restrict__ beta = nullptr;
+        if (s20) { xg = NBASR_CELL_ARG(T, x0) + row0; if (has_ln) { gamma = NBASR_CELL_ARG(T, ln_gamma); beta = NBASR_CELL_ARG(T, ln_beta); } }
 #pragma unroll
-    for (int c0 = 0; c0 < CG; c0 += 4) {
-        float4 u[4];
-        if (a.skips & 8) {
+        for (int c0 = 0; c0 < CG; c0 += 4) {
+            float4 u[4];
+            if (s20) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(c0 + c);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int co = c0 + c;
-            if (co >= CG) break;
-            float o[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co][r]);
-            if (a.skips & 8) { const float4 v = normalise(u[c], co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-            if (KEEP1) {
-                if (a.skips & 16) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? co : 0][r];
-                }
+                for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(xg, c0 + c);
             }
-            if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
-            mask_tail(o);
-            cell_store_frames(y + row0 + static_cast<size_t>(co) * a.ld, store_len, q, o);        // (no predicate: lanes beyond the row store nothing)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[co][r] = o[r];    // the final values, for the statistics
+            for (int c = 0; c < 4; ++c) {
+                const int co = c0 + c;
+                if (co >= CG) break;
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co >> 1][r][co & 1]);
+                if (s20) { const float4 v = normalise(u[c], co, gamma, beta); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+                if (KEEP1) {
+                    if (a.skips & 16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? co : 0][r];
+                    }
+                }
+                if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+                mask_tail(o);
+                cell_store_frames(yg + static_cast<size_t>(co) * a.ld, store_len, q, o);        // (no predicate: lanes beyond the row store nothing)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[co][r] = o[r];    // the final values, for the statistics
+            }
         }
     }
+    stamp();
+    float* __restrict__ part = NBASR_CELL_ARG(T, part);
     if (part == nullptr) return;                    // (workgroup-uniform)
 
     // ---- LayerNorm statistics of x3: per lane (mean, M2) over this group's CG channels, exact two-pass in registers; the wave of the
@@ -333,11 +508,11 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
     for (int r = 0; r < 4; ++r) {
         float sum = 0.f;
 #pragma unroll
-        for (int co = 0; co < CG; ++co) sum += acc[co][r];
+        for (int co = 0; co < CG; ++co) sum += out[co][r];
         pm[r] = sum * (1.0f / CG);
         float m2 = 0.f;
 #pragma unroll
-        for (int co = 0; co < CG; ++co) { const float d = acc[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
+        for (int co = 0; co < CG; ++co) { const float d = out[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
         p2[r] = m2;
     }
     __syncthreads();                                // every read of x2 is done: the tiles become the exchange buffer [GPW][nt][8][64]
@@ -364,20 +539,15 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(
         *reinterpret_cast<float4*>(prow) = make_float4(om[0], om[1], om[2], om[3]);
         *reinterpret_cast<float4*>(prow + a.ld) = make_float4(o2[0], o2[1], o2[2], o2[3]);
     }
+    stamp();
 }
 
 static size_t cell_lds_bytes(int cg, int nt, int gpw) { return static_cast<size_t>(gpw) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
 // groups per workgroup: 4 while at least two such workgroups fit a CU's 160 KiB and the workgroup its 16 waves, else 2
 static int cell_gpw(int cg, int nt) { return (nt <= 4 && 2 * cell_lds_bytes(cg, nt, 4) <= 160 * 1024) ? 4 : 2; }
 
-template <typename T>
-struct CellPtrs {
-    const T* x0; T* y; const float* w0; const float* w1; const float* w2; const float* b0; const float* b1; const float* b2;
-    const float* ln_stats; const float* ln_gamma; const float* ln_beta; float* part;
-};
-
 template <typename T, int CG, bool KEEP1, int NTB, int GPW>
-static int launch_cell_kernel(const CellPtrs<T>& p, const CellDims& a, hipStream_t stream)
+static int launch_cell_kernel(const CellArgs<T>& p, hipStream_t stream)
 {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -385,30 +555,31 @@ static int launch_cell_kernel(const CellPtrs<T>& p, const CellDims& a, hipStream
         set_error("nbasr_grouped_cell_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
+    const CellDims& a = p.a;
     const size_t lds = cell_lds_bytes(CG, a.nt, GPW);
-    hipLaunchKernelGGL((grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream,
-                       p.x0, p.y, p.w0, p.w1, p.w2, p.b0, p.b1, p.b2, p.ln_stats, p.ln_gamma, p.ln_beta, p.part, a);
+    hipLaunchKernelGGL((grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream, p);
     return launch_status("nbasr_grouped_cell_fused");
 }
 
 template <typename T, int CG, bool KEEP1>
-static int launch_cell_nt(const CellPtrs<T>& p, const CellDims& a, hipStream_t stream)
+static int launch_cell_nt(const CellArgs<T>& p, hipStream_t stream)
 {
+    const CellDims& a = p.a;
     if (cell_gpw(CG, a.nt) == 4) {
-        if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 4>(p, a, stream);
-        if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 4>(p, a, stream);
-        return launch_cell_kernel<T, CG, KEEP1, 4, 4>(p, a, stream);
+        if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 4>(p, stream);
+        if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 4>(p, stream);
+        return launch_cell_kernel<T, CG, KEEP1, 4, 4>(p, stream);
     }
-    if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 2>(p, a, stream);
-    if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 2>(p, a, stream);
-    if (a.nt <= 4) return launch_cell_kernel<T, CG, KEEP1, 4, 2>(p, a, stream);
-    return launch_cell_kernel<T, CG, KEEP1, 8, 2>(p, a, stream);
+    if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 2>(p, stream);
+    if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 2>(p, stream);
+    if (a.nt <= 4) return launch_cell_kernel<T, CG, KEEP1, 4, 2>(p, stream);
+    return launch_cell_kernel<T, CG, KEEP1, 8, 2>(p, stream);
 }
 
 template <typename T, int CG>
-static int launch_cell(const CellPtrs<T>& p, const CellDims& a, hipStream_t stream)
+static int launch_cell(const CellArgs<T>& p, hipStream_t stream)
 {
-    return (a.skips & 16) ? launch_cell_nt<T, CG, true>(p, a, stream) : launch_cell_nt<T, CG, false>(p, a, stream);
+    return (p.a.skips & 16) ? launch_cell_nt<T, CG, true>(p, stream) : launch_cell_nt<T, CG, false>(p, stream);
 }
 
 static int kd_code(int kernel, int dilation)
@@ -425,12 +596,12 @@ static int cell_fused_impl(const T* x0, const float* w0, const float* b0, const 
                            T* y, const CellDims& a, const nbasr_deferred_ln* ln, float* stats_ws, hipStream_t s)
 {
     const LnRef l = ln_ref(ln, true);
-    const CellPtrs<T> p{x0, y, w0, w1, w2, b0, b1, b2, l.stats, l.gamma, l.beta, stats_ws};
+    const CellArgs<T> p{x0, y, w0, w1, w2, b0, b1, b2, l.stats, l.gamma, l.beta, stats_ws, a};
     switch (a.channels / a.groups) {
-        case 6:  return launch_cell<T, 6>(p, a, s);
-        case 8:  return launch_cell<T, 8>(p, a, s);
-        case 10: return launch_cell<T, 10>(p, a, s);
-        default: return launch_cell<T, 12>(p, a, s);
+        case 6:  return launch_cell<T, 6>(p, s);
+        case 8:  return launch_cell<T, 8>(p, s);
+        case 10: return launch_cell<T, 10>(p, s);
+        default: return launch_cell<T, 12>(p, s);
     }
 }
 
@@ -477,6 +648,9 @@ extern "C" int nbasr_grouped_cell_fused(const void* x0, const float* w0, const f
                   "nbasr_grouped_cell_fused: node ops must be conv5 / conv5d2 / conv7 / conv7d2 (got k=%d,%d,%d d=%d,%d,%d)", k0, k1, k2, d0, d1, d2);
     a.skips = skip_mask;
     a.nt = (ld / 4 + 63) / 64;
+#if NBASR_CELL_STAMPS
+    { const char* e = getenv("NBASR_CELL_STAMPS"); a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
     hipStream_t s = as_stream(stream);
     if (dtype == NBASR_F32)
         return cell_fused_impl<float>(static_cast<const float*>(x0), w0, b0, w1, b1, w2, b2, static_cast<float*>(y), a, ln, stats_ws, s);

@@ -247,10 +247,13 @@ __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_seq_kernel(
     const float* __restrict__ gates_in,   // (frames, batch, 4*hidden)
     const float4* __restrict__ wp,        // packed w_hh
     float* __restrict__ cell, float* __restrict__ h_out, unsigned* status, float* hx,
-    int batch, int frames, int hidden, int kchunks_p)
+    int batch, int frames, int hidden, int kchunks_p, int flags)
 {
     __shared__ float4 red[2][LSTM_WAVES][2][64];  // [step parity][wave][row tile][lane] -> the lane's 4 accumulator registers (= gates)
     __shared__ int stop;
+    // NBASR_LSTM_SEQ_INJECT_FAULT (tests): the first slice of every tile never starts -- exactly what a grid that is not co-resident
+    // looks like to the other slices, which time out, raise the status word and leave
+    if ((flags & NBASR_LSTM_SEQ_INJECT_FAULT) && blockIdx.x == 0) return;
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, kq = lane >> 4;
@@ -455,11 +458,35 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     return launch_status("nbasr_lstm_recurrence_packed");
 }
 
+// Workgroups of lstm_seq_kernel the CURRENT device holds at once (not a constant -- a partitioned (CPX) or CU-masked
+// MI355X, or a smaller part, holds fewer than 256): compute units x the kernel's occupancy per unit, asked once per device.
+// Without a device (host-only callers: tests of the size functions) the full part's 256.
+static long lstm_seq_resident_workgroups()
+{
+    static std::mutex m;
+    static long cached[NBASR_MAX_DEVICES] = {};
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= NBASR_MAX_DEVICES) { (void)hipGetLastError(); return 256; }
+    std::lock_guard<std::mutex> lock(m);
+    if (cached[device] == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_kernel, 64 * LSTM_WAVES, 0) != hipSuccess || cus <= 0 || per_cu <= 0) {
+            (void)hipGetLastError();
+            return 256;
+        }
+        cached[device] = static_cast<long>(cus) * per_cu;
+    }
+    return cached[device];
+}
+
 static bool lstm_seq_fits(int batch, int hidden)
 {
     if (batch <= 0 || hidden <= 0 || hidden % 4) return false;
     if (lstm_kchunks_p(hidden) > LSTM_WAVES * LSTM_CHUNKS) return false;
-    return static_cast<long>(lstm_slices(hidden)) * ((batch + 15) / 16) <= 256;      // every workgroup resident: one per CU
+    // every workgroup resident at once; never more than one per CU of a full part (two such grids are chained, see below)
+    const long grid = static_cast<long>(lstm_slices(hidden)) * ((batch + 15) / 16);
+    return grid <= 256 && grid <= lstm_seq_resident_workgroups();
 }
 
 extern "C" size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden)
@@ -470,7 +497,7 @@ extern "C" size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden)
 }
 
 extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
-                                         int batch, int frames, int hidden, nbasr_stream_t stream)
+                                         int batch, int frames, int hidden, int flags, nbasr_stream_t stream)
 {
     clear_error();
     const int rc = lstm_check("nbasr_lstm_recurrence_seq", batch, 4, frames, frames, hidden);
@@ -503,9 +530,31 @@ extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* pack
     else e = hipStreamWaitEvent(as_stream(stream), done, 0);
     if (e == hipSuccess) e = hipMemsetAsync(seq_ws, 0, nbasr_lstm_seq_workspace_bytes(batch, hidden), as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-    hipLaunchKernelGGL(lstm_seq_kernel, dim3(lstm_slices(hidden), static_cast<unsigned>(tiles)), dim3(64 * LSTM_WAVES), 0, as_stream(stream),
-                       gates_ws, static_cast<const float4*>(packed_whh), cell_ws, h_out, words, hx, batch, frames, hidden,
-                       lstm_kchunks_p(hidden));
+    // A COOPERATIVE launch where the device offers it: the runtime then refuses a grid it cannot hold at once (instead of starting part
+    // of it) and dispatches it as a unit.  What neither form can promise is that ANOTHER process leaves the compute units alone -- that
+    // is what the bounded waits and the status word are for, and the executor reads the word behind every such launch (executor.py).
+    static int coop[NBASR_MAX_DEVICES] = {};         // 0 unknown, 1 cooperative, -1 plain
+    if (coop[device] == 0) {
+        int ok = 0;
+        coop[device] = (hipDeviceGetAttribute(&ok, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && ok) ? 1 : -1;
+    }
+    const dim3 grid(lstm_slices(hidden), static_cast<unsigned>(tiles)), block(64 * LSTM_WAVES);
+    if (coop[device] > 0) {
+        const float4* pw = static_cast<const float4*>(packed_whh);
+        int kchunks = lstm_kchunks_p(hidden);
+        unsigned* words_arg = words; float* hx_arg = hx;
+        void* kargs[] = {&gates_ws, &pw, &cell_ws, &h_out, &words_arg, &hx_arg, &batch, &frames, &hidden, &kchunks, &flags};
+        e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(lstm_seq_kernel), grid, block, kargs, 0, as_stream(stream));
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("nbasr_lstm_recurrence_seq: cooperative launch of %u x %u workgroups refused: %s (use nbasr_lstm_recurrence_packed)",
+                      grid.x, grid.y, hipGetErrorString(e));
+            return static_cast<int>(e);
+        }
+    } else {
+        hipLaunchKernelGGL(lstm_seq_kernel, grid, block, 0, as_stream(stream), gates_ws, static_cast<const float4*>(packed_whh), cell_ws, h_out,
+                           words, hx, batch, frames, hidden, lstm_kchunks_p(hidden), flags);
+    }
     e = hipEventRecord(done, as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: hipEventRecord: %s", hipGetErrorString(e)); return static_cast<int>(e); }
     return launch_status("nbasr_lstm_recurrence_seq");

@@ -199,6 +199,8 @@ class ForwardPlan:
         self.lstm_seq_mode = os.environ.get('NBASR_LSTM_SEQ', 'auto')
         if self.lstm_seq_mode not in ('auto', '0', '1'):
             raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', '0' or '1'")
+        self._seq_host, self._seq_pending = None, None      # pinned copy of the status word / event behind the copy (check_seq)
+        self._seq_flags = hip.LSTM_SEQ_INJECT_FAULT if os.environ.get('NBASR_LSTM_SEQ_FAULT') == '1' else 0     # tests: force a timeout
         # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_F32_VARIANT=<bits> forces one (0: the
         # default kernel everywhere)
         self.gc_table = _GC_TABLE
@@ -244,8 +246,48 @@ class ForwardPlan:
         nbytes = hip.load_library().nbasr_lstm_seq_workspace_bytes(self.batch, hidden) if use else 0
         if nbytes:
             ws = self._buf('lstm_seq', nbytes, torch.uint8)
-            return hip.lstm_recurrence_seq(gates, packed_hh, self.cell_ws, self.h_out, ws)
+            try:
+                out = hip.lstm_recurrence_seq(gates, packed_hh, self.cell_ws, self.h_out, ws, self._seq_flags)
+            except hip.HipError:
+                # the device refused the cooperative grid (a partition / CU mask smaller than the occupancy query said): per-frame from now on
+                self.lstm_seq_mode = '0'
+                self._tapes.clear()
+                return hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out)
+            self._host(lambda: self._seq_status_readback(ws))
+            return out
         return hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out)
+
+    def _seq_status_readback(self, ws):
+        """Behind every one-launch recurrence: its status word travels to pinned host memory, stream-ordered and without a host
+        synchronisation; `check_seq` looks at it once the copy has landed (ADVICE r3 / VERDICT r3 next 6: the word used to be read by
+        nobody, and a grid that lost its compute units to another process returned NaN logits without an error)."""
+        if self._seq_host is None:
+            self._seq_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._seq_host.copy_(ws.view(torch.int32)[:1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._seq_pending = ev
+
+    def check_seq(self, wait=False):
+        """Raise if the last one-launch recurrence enqueued through this plan timed out (its forward's logits hold NaN rows); the
+        one-launch form is switched off for this plan then, so the caller's retry runs the per-frame launches.  ``wait``: block until
+        that launch has finished (tests, `ASRModel.check`); otherwise only a finished launch is looked at -- called at the start of
+        every forward, so a failure surfaces at the next call at the latest."""
+        ev = self._seq_pending
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        self._seq_pending = None
+        if int(self._seq_host[0]) != 0:
+            self._seq_host[0] = 0
+            self.lstm_seq_mode = '0'
+            self._tapes.clear()
+            raise hip.HipError('the one-launch LSTM recurrence of the PREVIOUS forward timed out waiting for its peer workgroups (the grid was '
+                               'not co-resident: compute units taken by another process or stream); that forward\'s logits are invalid. '
+                               'The plan now uses one launch per frame (as NBASR_LSTM_SEQ=0): run the forward again')
 
     def wait_tails(self):
         """Make the current stream wait for every pipelined LSTM tail enqueued through this plan (a plain
@@ -343,6 +385,11 @@ class ForwardPlan:
         """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""
         w = linear.weight if hasattr(linear, 'weight') else linear
         return self._cached(w, 'pointwise', lambda: hip.pack_pointwise_weights(w.detach()))
+
+    def _packed_grouped(self, op):
+        """[group][ci][tap][co] copy of a grouped conv's weights (what the fused cell's scalar loads read), rebuilt whenever the parameter changes."""
+        w = op.conv.weight
+        return self._cached(w, 'gc_wperm', lambda: hip.pack_grouped_weights(self._f32(w).contiguous(), op.groups))
 
     def _packed_whh(self, w):
         """Fragment-ordered copy of the LSTM's recurrent weight, rebuilt whenever the parameter changes."""
@@ -594,6 +641,7 @@ class ForwardPlan:
         a ``PendingLogits`` is returned."""
         if x.device != self.device:
             raise hip.HipError(f'input on {x.device}, plan on {self.device}')
+        self.check_seq()
         wdtype = model.model[0].conv.weight.dtype          # (not model.parameters(): a DataParallel replica has none)
         if x.dtype != wdtype:
             raise hip.HipError(f'input is {x.dtype} but the model\'s parameters are {wdtype}: cast one of them '
@@ -719,7 +767,7 @@ class ForwardPlan:
                         if type(layer.nodes[j].branch_ops[i]).__name__ == 'Identity':
                             mask |= 1 << bit
                     view = self._view(free[2], layer.filters, act_frames)
-                    specs = [(n.op.conv.weight.detach(), n.op.conv.bias.detach(), n.op.kernel_size, n.op.dilation) for n in layer.nodes]
+                    specs = [(self._packed_grouped(n.op), n.op.conv.bias.detach(), n.op.kernel_size, n.op.dilation) for n in layer.nodes]
                     n_skips = [sum(type(br).__name__ == 'Identity' for br in n.branch_ops) for n in layer.nodes]
                     meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_skips), act_frames, 0)
                     src, ln0 = act, pending
@@ -911,7 +959,7 @@ class ForwardPlan:
                             if isinstance(layer.nodes[j].branch_ops[i], Identity):
                                 mask |= 1 << bit
                         view = self._view16(free[2], layer.filters, act_frames)
-                        specs = [(self._f32(n.op.conv.weight), self._f32(n.op.conv.bias), n.op.kernel_size, n.op.dilation) for n in layer.nodes]
+                        specs = [(None, self._f32(n.op.conv.bias), n.op.kernel_size, n.op.dilation) for n in layer.nodes]
                         n_sk = [sum(isinstance(br, Identity) for br in n.branch_ops) for n in layer.nodes]
                         meta = (blk, layer.filters, tuple(sp[2] for sp in specs), tuple(n_sk), act_frames, 0)
                         src, ln0, cell_ws = act, pending, (self.stats_ws if epilogue_stats else None)
@@ -922,9 +970,10 @@ class ForwardPlan:
                             groups, epilogue_stats = last_op.groups, False
                             mspecs = [(self._cached(n.op.conv.weight, 'cell_mfma', (lambda w=n.op.conv.weight: hip.grouped_cell_mfma_pack(self._f32(w), groups))),
                                        sp[1], sp[2], sp[3]) for n, sp in zip(layer.nodes, specs)]
-                            self._timed('grouped_cell', meta, lambda: hip.grouped_cell_mfma(src, mspecs, mask, view, act_frames, groups, ln0))
+                            self._timed('grouped_cell_mfma', meta, lambda: hip.grouped_cell_mfma(src, mspecs, mask, view, act_frames, groups, ln0))
                         else:
-                            self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, specs, mask, view, act_frames, last_op.groups, ln0, cell_ws))
+                            vspecs = [(self._packed_grouped(n.op), sp[1], sp[2], sp[3]) for n, sp in zip(layer.nodes, specs)]
+                            self._timed('grouped_cell', meta, lambda: hip.grouped_cell_fused(src, vspecs, mask, view, act_frames, last_op.groups, ln0, cell_ws))
                         outs = [act, None, None, view]
                     for j, (node, dst) in enumerate(zip(layer.nodes, free) if not cell_gpp else ()):
                         if len(outs) != len(node.branch_ops):

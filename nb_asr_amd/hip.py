@@ -15,7 +15,7 @@ import pathlib
 import torch
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libnbasr_hip.so'
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
 _c_int = ctypes.c_int
@@ -77,7 +77,7 @@ SIGNATURES = {
     'nbasr_lstm_pack_whh': (_c_int, [_c_float_p] * 2 + [_c_int, _c_stream]),
     'nbasr_lstm_recurrence_packed': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_lstm_seq_workspace_bytes': (ctypes.c_size_t, [_c_int] * 2),
-    'nbasr_lstm_recurrence_seq': (_c_int, [_c_float_p] * 5 + [_c_int] * 3 + [_c_stream]),
+    'nbasr_lstm_recurrence_seq': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
     'nbasr_lstm_seq_status': (_c_int, [_c_float_p, _c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
@@ -292,7 +292,8 @@ def grouped_cell_fits(channels, ld, groups):
 
 
 def grouped_cell_fused(x0, nodes, skip_mask, y, frames, groups, ln=None, stats_ws=None):
-    """nodes: three (weight, bias, kernel, dilation); skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.
+    """nodes: three (weight, bias, kernel, dilation), ``weight`` = the [group][ci][tap][co] copy of ``pack_grouped_weights`` (ABI 4);
+    skip_mask: bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22.
     ``stats_ws`` (grouped_stats_workspace): also emit the partial LayerNorm statistics of the result (merge: grouped_stats_finalize)."""
     b, c, ld = x0.shape
     args = []
@@ -558,8 +559,12 @@ def lstm_seq_workspace(batch, hidden, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
 
 
-def lstm_recurrence_seq(gates_ws, packed_whh, cell_ws, h_out, seq_ws):
-    """lstm_recurrence_packed with all frames in ONE launch (w_hh resident in registers, flag-synchronised steps); same h_out, bit for bit."""
+LSTM_SEQ_INJECT_FAULT = 1       # NBASR_LSTM_SEQ_INJECT_FAULT of nbasr_lstm_recurrence_seq (tests)
+
+
+def lstm_recurrence_seq(gates_ws, packed_whh, cell_ws, h_out, seq_ws, flags=0):
+    """lstm_recurrence_packed with all frames in ONE (cooperative) launch: w_hh resident in registers, h exchanged in payload-tagged
+    granules; same h_out, bit for bit.  The first int32 of ``seq_ws`` is the status word (non-zero: a step timed out, h_out holds NaN)."""
     b, frames, hidden = h_out.shape
     lib = load_library()
     if not packed_whh.is_cuda or packed_whh.dtype != torch.uint8 or packed_whh.numel() != lib.nbasr_lstm_packed_whh_bytes(hidden):
@@ -569,7 +574,7 @@ def lstm_recurrence_seq(gates_ws, packed_whh, cell_ws, h_out, seq_ws):
         raise HipError(f'lstm_recurrence_seq: batch={b} hidden={hidden} needs a uint8 device workspace of {need} bytes from lstm_seq_workspace '
                        '(0 = this form does not apply)')
     _check(lib.nbasr_lstm_recurrence_seq(_dev(gates_ws, 'gates_ws'), packed_whh.data_ptr(), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
-                                         seq_ws.data_ptr(), b, frames, hidden, _stream(h_out)), 'nbasr_lstm_recurrence_seq')
+                                         seq_ws.data_ptr(), b, frames, hidden, int(flags), _stream(h_out)), 'nbasr_lstm_recurrence_seq')
     return h_out
 
 

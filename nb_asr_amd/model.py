@@ -181,6 +181,13 @@ class ASRModel(nn.Module):
         finally:
             self._plans.release(plan)
 
+    def check(self):
+        """Wait for the forwards enqueued so far and raise ``hip.HipError`` if one of them ran the LSTM recurrence as one resident launch
+        that timed out (compute units taken away by another process: its logits hold NaN rows).  A plain ``model(x)`` checks the
+        PREVIOUS call without waiting; ``check()`` is for a caller that wants the answer for the call it has just made."""
+        for plan in self._plans.values():
+            plan.check_seq(wait=True)
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state['_plans'] = PlanPool()          # never pickle / deepcopy workspaces

@@ -280,7 +280,8 @@ def test_fused_cell_either_storage_type_equals_three_node_launches(dtype, c, gro
                             *nodes[2][2:], ln if s[3] else None, False, ln is not None and s[3], ws_node, 0)
     got = torch.full_like(xp, 7.0)
     ws_cell = hip.grouped_stats_workspace(b, ld, groups, DEV)
-    hip.grouped_cell_fused(xp, nodes, mask, got, t, groups, ln, ws_cell)
+    packed = [(hip.pack_grouped_weights(w, groups), bias, k, d) for w, bias, k, d in nodes]     # [group][ci][tap][co] (ABI 4)
+    hip.grouped_cell_fused(xp, packed, mask, got, t, groups, ln, ws_cell)
     assert torch.equal(got, x3), float((got.float() - x3.float()).abs().max())
     assert torch.all(got[:, :, t:] == 0)
     st_cell, st_node = torch.empty(b, 2, ld, device=DEV), torch.empty(b, 2, ld, device=DEV)
@@ -343,7 +344,7 @@ def test_bf16_cell_on_the_matrix_cores(c, groups, t, kds, mask, with_ln):
     assert float((off - 2 * step).max()) <= 0.15, float((off - 2 * step).max())
     assert float((off > 0).double().mean()) < 0.02, float((off > 0).double().mean())
     valu = torch.full_like(xp, 7.0)
-    hip.grouped_cell_fused(xp, [(w.to(DEV), bias.to(DEV), k, d) for w, bias, k, d in ws], mask, valu, t, groups, ln, None)
+    hip.grouped_cell_fused(xp, [(hip.pack_grouped_weights(w.to(DEV), groups), bias.to(DEV), k, d) for w, bias, k, d in ws], mask, valu, t, groups, ln, None)
     v = valu[:, :, :t].float().cpu().double()
     assert float((v - g).abs().max()) <= 0.05 * max(1.0, float(want.abs().max()))
 
