@@ -356,6 +356,23 @@ int nbasr_linear_fused_packed(const float* x, void* ws, const void* packed_w, co
 int nbasr_lstm_input_projection_packed(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
                                        const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
                                        int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+/* The same two maps for the bf16 storage path (reference ops.py:42-50 and model.py:100,118-121 under model.to(torch.bfloat16)) on the
+ * bf16 matrix cores, ONE v_mfma_f32_16x16x32_bf16 per 32 products (round 4): x, y, skips are bf16 (batch, channels, ld) rows, ld % 8
+ * == 0; the weights are the fp32 values of the bf16 parameter, packed once per version (nbasr_pointwise_bf16_weights_bytes /
+ * nbasr_pack_pointwise_weights_bf16); `ws` (nbasr_pointwise_bf16_workspace_bytes; scratch) takes the operand image -- x, with its
+ * pending LayerNorm applied and rounded to bf16 as the reference's LayerNorm module rounds, in the GEMM's LDS order.  Exact bf16 x bf16
+ * products, fp32 accumulation, bias, relu / min(20), the skips added in fp32 in python's sum order, ONE rounding of the node's output;
+ * the LSTM gates stay fp32, (frames, batch, 4 hidden). */
+size_t nbasr_pointwise_bf16_weights_bytes(int c_out, int c_in);
+size_t nbasr_pointwise_bf16_workspace_bytes(int batch, int c_in, int ld);
+int nbasr_pack_pointwise_weights_bf16(const float* w, void* packed, int c_out, int c_in, nbasr_stream_t stream);
+int nbasr_linear_fused_bf16(const void* x, void* ws, const void* packed_w, const float* bias,
+                            const void* skip0, const void* skip1, const void* skip2, void* y,
+                            int batch, int channels_in, int frames, int ld, int channels_out,
+                            const nbasr_deferred_ln* ln, int ln_on_x, int ln_on_skip0, nbasr_stream_t stream);
+int nbasr_lstm_input_projection_bf16(const void* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                     const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                     int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream);
 
 /* ---- feature front-end (reference training/torch/timit.py:78-97) --------------------------------------
  * torchaudio MelSpectrogram(16 kHz, n_fft = win = 400, hop 160, 80 mels, power 2, centred reflect-padded frames, periodic

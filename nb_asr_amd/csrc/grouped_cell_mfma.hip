@@ -169,14 +169,15 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
             for (int s = 0; s < NSMAX; ++s)
                 if (s < 3 || four) nxt[s] = *reinterpret_cast<const cm_u4*>(src + off[s] + nb * NB_STRIDE);
         };
-        // The node's skip inputs as 0 / 1 factors (wave-uniform): the column-block loop below has NO branch on them, so the sixteen
-        // blocks are one straight line and the scheduler overlaps one block's epilogue with the next block's MFMAs and LDS reads (with a
-        // branch per skip a block cost ~430 cycles of mostly dependent latency at 3.5 waves per SIMD).  fma(1, v, o) = o + v exactly;
-        // fma(0, v, o) = o for the finite values a tile holds.  A node without skips takes the loop without the reads.
+        // The node's skip inputs as all-ones / all-zeros MASKS on the packed bf16 pairs (wave-uniform): the column-block loop below has NO
+        // branch on them, so the sixteen blocks are one straight line and the scheduler overlaps one block's epilogue with the next
+        // block's MFMAs and LDS reads (with a branch per skip a block cost ~430 cycles of mostly dependent latency at 3.5 waves per SIMD).
+        // An absent skip contributes an exact +0 whatever the tensor holds there (round 3 multiplied by a 0 / 1 factor: 0 x Inf = NaN
+        // where the reference never reads the tensor).  A node without skips takes the loop without the reads.
         const int sk = a.skips;
-        const float m_a = (NODE == 0 ? (sk & 1) : NODE == 1 ? (sk & 2) : (sk & 32)) ? 1.f : 0.f;      // x0n (nodes 0, 1) / x2 (node 2) from tile A
-        const float m_b = (NODE == 1 ? (sk & 4) : NODE == 2 ? (sk & 16) : 0) ? 1.f : 0.f;               // x1 from tile B
-        const float m_k = (NODE == 2 && (sk & 8)) ? 1.f : 0.f;                                          // x0n carried in registers
+        const unsigned m_a = (NODE == 0 ? (sk & 1) : NODE == 1 ? (sk & 2) : (sk & 32)) ? 0xffffffffu : 0u;      // x0n (nodes 0, 1) / x2 (node 2) from tile A
+        const unsigned m_b = (NODE == 1 ? (sk & 4) : NODE == 2 ? (sk & 16) : 0) ? 0xffffffffu : 0u;               // x1 from tile B
+        const unsigned m_k = (NODE == 2 && (sk & 8)) ? 0xffffffffu : 0u;                                          // x0n carried in registers
         const bool any = NODE == 0 ? (sk & 1) != 0 : NODE == 1 ? (sk & (2 | 4 | 8)) != 0 : (sk & (8 | 16 | 32)) != 0;
         auto blocks = [&](auto with_skips) {
             constexpr bool SK = decltype(with_skips)::value;
@@ -196,10 +197,9 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
                 for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[r]);
                 const int pos = own + nb * NB_STRIDE;
                 if constexpr (SK) {
-                    auto add = [&](float m, u2v p) {
-                        const cm_f4 v = cm_unpack4(p);
-                        o[0] = __builtin_fmaf(m, v[0], o[0]); o[1] = __builtin_fmaf(m, v[1], o[1]);
-                        o[2] = __builtin_fmaf(m, v[2], o[2]); o[3] = __builtin_fmaf(m, v[3], o[3]);
+                    auto add = [&](unsigned m, u2v p) {
+                        const cm_f4 v = cm_unpack4(u2v{p.x & m, p.y & m});
+                        o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
                     };
                     const u2v ta = *reinterpret_cast<const u2v*>(tile_a + pos);
                     if constexpr (NODE == 0) {

@@ -154,12 +154,36 @@ class LaunchTape:
         return logits
 
 
+# Environment switches of earlier rounds that no longer exist: a script that still sets one gets ONE warning instead of silence
+_REMOVED_SWITCHES = {
+    'NBASR_TRAIN_GEMM': 'folded into NBASR_DENSE_MODE (f32 = every GEMM on the exact-fp32 MFMA)',
+    'NBASR_IMAGE_MODE': None, 'NBASR_ROW_TILE': None, 'NBASR_LN_MODE': None, 'NBASR_EPILOGUE_STATS': None, 'NBASR_LSTM_UNPACKED': None,
+    'NBASR_GC_TABLE': 'NBASR_GC_F32_VARIANT=0 runs the default node kernel everywhere', 'NBASR_GC_BF16_VARIANT': None,
+    'NBASR_GC_BF16_MFMA': 'NBASR_CELL_FUSION=1|valu|0 chooses the bf16 cell kernel', 'NBASR_MFMA_SPLITS': None,
+    'NBASR_DENSE_EPILOGUE': None, 'NBASR_FORCE_DIST': None, 'NBASR_PW_ORDER': None,
+}
+_warned_removed = [False]
+
+
+def _warn_removed_switches():
+    if _warned_removed[0]:
+        return
+    _warned_removed[0] = True
+    stale = [k for k in _REMOVED_SWITCHES if k in os.environ]
+    if stale:
+        import warnings
+        notes = '; '.join(f'{k} ({_REMOVED_SWITCHES[k]})' if _REMOVED_SWITCHES[k] else k for k in stale)
+        warnings.warn(f'nb_asr_amd: these environment switches were removed and are IGNORED: {notes}.  The current ones: NBASR_DENSE_MODE, '
+                      f'NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_LSTM_SEQ, NBASR_TAPE (DESIGN.md 5)', stacklevel=3)
+
+
 class ForwardPlan:
     """Workspaces + launch sequence for one device.  Shape-independent: every buffer is flat, grows on demand
     (never shrinks) and is viewed per call; at most one forward is being ENQUEUED through a plan at a time
     (``PlanPool`` hands a plan to one thread at a time), while pipelined tails of earlier calls may still be in flight."""
 
     def __init__(self, device):
+        _warn_removed_switches()
         self.device = torch.device(device)
         self.batch = self.frames = self.out_frames = 0
         self.block_frames = []
@@ -945,7 +969,8 @@ class ForwardPlan:
                         raise NotImplementedError(f'cells with {len(layer.nodes)} nodes need a larger buffer pool')
                     last_op = layer.nodes[-1].op
                     norm = layer.norm_layer if layer.use_norm else None
-                    epilogue_stats = (norm is not None and self._cheap_consumer(nxt)
+                    after_cell = model.model[idx + 2] if isinstance(nxt, nn.Dropout) and idx + 2 < n_layers else nxt
+                    epilogue_stats = (norm is not None and (self._cheap_consumer(nxt) or isinstance(after_cell, nn.LSTM))
                                       and isinstance(last_op, PadConvRelu) and last_op.groups > 1)
                     outs = [act]
                     # three grouped convs: ONE launch where a row fits a workgroup (grouped_cell.hip; x1 and x2 rounded to bf16 exactly
@@ -994,32 +1019,14 @@ class ForwardPlan:
                         elif isinstance(op, Zero):
                             self._timed('skip_sum', meta, lambda: hip.skip_sum(skips, view, act_frames, ln if on_s0 else None, on_s0))
                         elif isinstance(op, Linear):
-                            # no bf16 GEMM for the per-frame linear map yet (BASELINE config 4 does not use the op): bridge through
-                            # the fp32 one.  x -> fp32 (its pending LayerNorm applied on the way), the fp16-split GEMM, the op's
-                            # output rounded to bf16 as the reference's bf16 module does, then the skip sum in bf16 storage.
+                            # round 4: one bf16 MFMA per product on a bf16 operand image (gemm_pointwise_bf16.hip); rounds 2-3 bridged the op
+                            # through the fp32 split GEMM (x -> fp32, two fp16 terms, three MFMAs, y -> bf16, a separate skip sum)
                             b_, c_, ld_ = last.shape
-                            n = b_ * c_ * ld_
-                            x32 = self._buf('bridge_x32', n)[:n].view(b_, c_, ld_)
-                            y32 = self._buf('bridge_y32', n)[:n].view(b_, c_, ld_)
-                            if on_x:
-                                hip.layernorm_channels(last, ln[1], ln[2], x32, act_frames, LN_EPS)
-                            else:
-                                hip.convert(last, x32)
                             wl = op.linear.weight
-                            packed = self._cached(wl, 'pointwise', lambda: hip.pack_pointwise_weights(self._f32(wl)))
-                            self._timed('linear_op', meta, lambda: hip.linear_fused_packed(
-                                x32, act_frames, packed, op.linear.out_features, self._f32(op.linear.bias), (), y32, self._pointwise_ws(c_, ld_)))
-                            if not skips:
-                                hip.convert(y32, view)
-                            else:
-                                op16 = self._buf('bridge_op16', n, bf16)[:n].view(b_, c_, ld_)
-                                hip.convert(y32, op16)
-                                if len(skips) <= 2:
-                                    hip.skip_sum(skips + [op16], view, act_frames, ln if on_s0 else None, on_s0)
-                                else:
-                                    part = self._buf('bridge_sum16', n, bf16)[:n].view(b_, c_, ld_)
-                                    hip.skip_sum(skips, part, act_frames, ln if on_s0 else None, on_s0)
-                                    hip.skip_sum([op16, part], view, act_frames)
+                            packed = self._cached(wl, 'pointwise_bf16', lambda: hip.pack_pointwise_weights_bf16(self._f32(wl)))
+                            ws16 = self._buf('pointwise_bf16_ws', max(lib.nbasr_pointwise_bf16_workspace_bytes(b_, c_, ld_), 16), torch.uint8)
+                            self._timed('linear_op', meta, lambda: hip.linear_fused_bf16(
+                                last, act_frames, packed, op.linear.out_features, self._f32(op.linear.bias), skips, view, ws16, ln, on_x, on_s0))
                         else:
                             raise TypeError(f'unsupported node operation {type(op).__name__}')
                         outs.append(view)
@@ -1029,8 +1036,32 @@ class ForwardPlan:
                     if act.dim() != 3 or pending is not None:
                         raise RuntimeError('LayerNorm in an unexpected position of the layer list')
                 feeds_tail = isinstance(nxt, (nn.Dropout, nn.LSTM, nn.Linear))
+                after = model.model[idx + 2] if isinstance(nxt, nn.Dropout) and idx + 2 < n_layers else nxt
                 meta = (blk, act.shape[1], act.shape[1], 0, act_frames, 0)
-                if feeds_tail:
+                if feeds_tail and isinstance(after, nn.LSTM):
+                    # the LSTM's input projection takes the bf16 encoder output itself (round 4: bf16 operand image, one MFMA per
+                    # product) and applies a pending LayerNorm while writing that image: statistics only, no fp32 copy of the tensor
+                    if pipe:
+                        pipe_k, _ = self._pipeline_buffers(act.shape[1], act.shape[2], need_enc=False)
+                    if norm is not None:
+                        g32, b32 = self._f32(norm.weight), self._f32(norm.bias)
+                        self._stat_turn ^= 1
+                        b, c, ld = act.shape
+                        stats = self.stats[self._stat_turn][: b * 2 * ld].view(b, 2, ld)
+                        src = act
+                        if epilogue_stats:
+                            self._timed('stats_finalize', meta, lambda: hip.grouped_stats_finalize(self.stats_ws, stats, c, act_frames,
+                                                                                                 last_op.groups, norm.eps, cell_gpp or 4))
+                        else:
+                            self._timed('channel_stats', meta, lambda: hip.channel_stats(src, stats, act_frames, norm.eps))
+                        pending = (stats, g32, b32)
+                        if taps is not None:                 # parity debugging: materialise a copy, the flow stays deferred
+                            copy = torch.empty_like(act)
+                            hip.layernorm_channels(act, g32, b32, copy, act_frames, norm.eps)
+                            taps[idx] = copy[:, :, :act_frames].clone()
+                    elif taps is not None:
+                        taps[idx] = act[:, :, :act_frames].clone()
+                elif feeds_tail:
                     # hand-over to the fp32 tail (LSTM projection / head): the last LayerNorm writes fp32
                     b, c, ld = act.shape
                     if pipe:
@@ -1082,16 +1113,22 @@ class ForwardPlan:
                 if taps is not None:
                     taps[idx] = taps[idx - 1]
             elif isinstance(layer, nn.LSTM):
-                if not act_is_f32:
-                    raise RuntimeError('the LSTM expects the fp32 hand-over of the encoder output')
                 src, src_frames = act, act_frames
                 b_ih, b_hh = self._f32(layer.bias_ih_l0), self._f32(layer.bias_hh_l0)
                 gates = self.gates_pipe[pipe_k] if pipe else self.gates_ws
                 w_ih32, w_hh32 = self._f32(layer.weight_ih_l0), self._f32(layer.weight_hh_l0)
-                packed_ih = self._cached(layer.weight_ih_l0, 'pointwise', lambda: hip.pack_pointwise_weights(w_ih32))
-                ws = self._pointwise_ws(src.shape[1], src.shape[2])
-                self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: hip.lstm_input_projection_packed(src, src_frames, packed_ih, b_ih, b_hh, gates, layer.hidden_size, ws, None))
+                if act_is_f32:
+                    # (an fp32 hand-over copy of the encoder output, should a caller have made one: the fp16-split GEMM of rounds 2-3)
+                    packed_ih = self._cached(layer.weight_ih_l0, 'pointwise', lambda: hip.pack_pointwise_weights(w_ih32))
+                    ws = self._pointwise_ws(src.shape[1], src.shape[2])
+                    self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_input_projection_packed(src, src_frames, packed_ih, b_ih, b_hh, gates, layer.hidden_size, ws, None))
+                else:
+                    packed_ih = self._cached(layer.weight_ih_l0, 'pointwise_bf16', lambda: hip.pack_pointwise_weights_bf16(w_ih32))
+                    ws16 = self._buf('pointwise_bf16_ws', max(lib.nbasr_pointwise_bf16_workspace_bytes(B, src.shape[1], src.shape[2]), 16), torch.uint8)
+                    ln_x, pending = pending, None
+                    self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_input_projection_bf16(src, src_frames, packed_ih, b_ih, b_hh, gates, layer.hidden_size, ws16, ln_x))
                 if pipe:
                     self._to_side_stream()
                     tail_ctx = torch.cuda.stream(self.side_stream)

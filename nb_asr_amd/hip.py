@@ -73,6 +73,11 @@ SIGNATURES = {
     # LSTM + head
     'nbasr_lstm_input_projection': (_c_int, [_c_float_p] * 5 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_input_projection_packed': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    'nbasr_pointwise_bf16_weights_bytes': (ctypes.c_size_t, [_c_int] * 2),
+    'nbasr_pointwise_bf16_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
+    'nbasr_pack_pointwise_weights_bf16': (_c_int, [_c_float_p] * 2 + [_c_int] * 2 + [_c_stream]),
+    'nbasr_linear_fused_bf16': (_c_int, [_c_float_p] * 8 + [_c_int] * 5 + [_c_ln_p, _c_int, _c_int, _c_stream]),
+    'nbasr_lstm_input_projection_bf16': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_packed_whh_bytes': (ctypes.c_size_t, [_c_int]),
     'nbasr_lstm_pack_whh': (_c_int, [_c_float_p] * 2 + [_c_int, _c_stream]),
     'nbasr_lstm_recurrence_packed': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
@@ -630,6 +635,50 @@ def lstm_input_projection_packed(x, frames, packed_w_ih, b_ih, b_hh, gates_ws, h
     _check(load_library().nbasr_lstm_input_projection_packed(
         _dev(x, 'x'), ws.data_ptr(), packed_w_ih.data_ptr(), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
         b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_input_projection_packed')
+    return gates_ws
+
+
+def pack_pointwise_weights_bf16(weight):
+    """(c_out, c_in) fp32 values of a bf16 weight -> opaque uint8 tensor (bf16, LDS-image order) for the bf16 per-frame maps."""
+    c_out, c_in = weight.shape
+    packed = torch.empty(load_library().nbasr_pointwise_bf16_weights_bytes(c_out, c_in), dtype=torch.uint8, device=weight.device)
+    _check(load_library().nbasr_pack_pointwise_weights_bf16(_dev(weight, 'weight'), packed.data_ptr(), c_out, c_in, _stream(weight)),
+           'nbasr_pack_pointwise_weights_bf16')
+    return packed
+
+
+def pointwise_bf16_workspace(batch, c_in, ld, device):
+    return torch.empty(max(load_library().nbasr_pointwise_bf16_workspace_bytes(batch, c_in, ld), 16), dtype=torch.uint8, device=device)
+
+
+def _check_pointwise_bf16(packed, ws, c_out, c_in, batch, ld):
+    lib = load_library()
+    if not packed.is_cuda or packed.dtype != torch.uint8 or packed.numel() != lib.nbasr_pointwise_bf16_weights_bytes(c_out, c_in):
+        raise HipError(f'packed weights are not the pack_pointwise_weights_bf16 image of a ({c_out}, {c_in}) weight')
+    if not ws.is_cuda or ws.dtype != torch.uint8 or ws.numel() < lib.nbasr_pointwise_bf16_workspace_bytes(batch, c_in, ld):
+        raise HipError('workspace too small: allocate it with pointwise_bf16_workspace(batch, c_in, ld, device)')
+
+
+def linear_fused_bf16(x, frames, packed, c_out, bias, skips, y, ws, ln=None, ln_on_x=False, ln_on_skip0=False):
+    """The `linear` node op on bf16 rows, one bf16 MFMA per product: y = bf16(min(relu(W x + b), 20) + skips) (see nbasr.h)."""
+    b, c_in, ld = x.shape
+    bf = torch.bfloat16
+    _check_pointwise_bf16(packed, ws, c_out, c_in, b, ld)
+    s = list(skips) + [None] * (3 - len(skips))
+    _check(load_library().nbasr_linear_fused_bf16(
+        _act(x, 'x', bf), ws.data_ptr(), packed.data_ptr(), _dev(bias, 'bias'), _act_opt(s[0], 'skip0', bf), _act_opt(s[1], 'skip1', bf),
+        _act_opt(s[2], 'skip2', bf), _act(y, 'y', bf), b, c_in, frames, ld, c_out, _ln(ln), int(ln_on_x), int(ln_on_skip0), _stream(x)),
+        'nbasr_linear_fused_bf16')
+    return y
+
+
+def lstm_input_projection_bf16(x, frames, packed_w_ih, b_ih, b_hh, gates_ws, hidden, ws, ln=None):
+    """gates (frames, batch, 4 hidden) fp32 from the bf16 encoder output x (batch, c_in, ld), its pending LayerNorm applied on the way."""
+    b, c_in, ld = x.shape
+    _check_pointwise_bf16(packed_w_ih, ws, 4 * hidden, c_in, b, ld)
+    _check(load_library().nbasr_lstm_input_projection_bf16(
+        _act(x, 'x', torch.bfloat16), ws.data_ptr(), packed_w_ih.data_ptr(), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
+        b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_input_projection_bf16')
     return gates_ws
 
 

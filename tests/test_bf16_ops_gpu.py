@@ -356,3 +356,78 @@ def test_bf16_cell_on_the_matrix_cores_limits():
     assert hip.grouped_cell_mfma_fits(800, 1000, 100) == 2 and hip.grouped_cell_mfma_fits(1200, 256, 100) == 4
     with pytest.raises(hip.HipError, match='not a node op'):
         hip.grouped_cell_mfma_pack(torch.randn(700, 7, 5, device=DEV), 100)
+
+
+@pytest.mark.parametrize('c_in,c_out,t,b', [(600, 600, 300, 2), (1200, 1200, 77, 3), (40, 72, 1000, 1), (1000, 1000, 8, 2), (33, 130, 257, 2)])
+@pytest.mark.parametrize('n_skips,with_ln', [(0, False), (1, True), (3, True), (2, False)])
+def test_linear_op_on_the_bf16_matrix_cores(c_in, c_out, t, b, n_skips, with_ln):
+    """nbasr_linear_fused_bf16 (round 4): the `linear` node op (ops.py:42-50 + the node's skip sum) on bf16 rows, ONE bf16 MFMA per product --
+    exact bf16 x bf16 products, fp32 accumulation, skips added in fp32, one rounding.  Against a float64 evaluation of the same bf16-valued
+    operands: within one bf16 rounding of the exact result (2^-8 relative) plus the fp32 accumulation noise; pitch columns zero."""
+    if n_skips and c_in != c_out:
+        pytest.skip('a node op maps C -> C; skips need equal shapes')
+    torch.manual_seed(c_in + c_out + t + n_skips)
+    x = (torch.randn(b, c_in, t) * 1.3).to(BF)
+    w = (torch.randn(c_out, c_in) / c_in ** 0.5).to(BF)
+    bias = (torch.randn(c_out) * 0.2).to(BF)
+    skips = [(torch.randn(b, c_out, t)).to(BF) for _ in range(n_skips)]
+    xp = pitched(x.float(), BF)
+    ld = xp.shape[2]
+    sp = [pitched(s.float(), BF) for s in skips]
+    ln, xn64 = None, x.double()
+    s0_64 = skips[0].double() if skips else None
+    if with_ln:
+        stats = torch.empty(b, 2, ld, device=DEV)
+        hip.channel_stats(xp, stats, t, 1e-3)
+        gamma, beta = torch.rand(c_in, device=DEV) + 0.5, torch.randn(c_in, device=DEV) * 0.2
+        ln = (stats, gamma, beta)
+        # the pending LayerNorm of x (and of skip0, which inside a cell is the same tensor as x: use x itself as skip0 then)
+        mu, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+        xn64 = ((x.double() - mu) / (var + 1e-3).sqrt() * gamma.cpu().double()[None, :, None] + beta.cpu().double()[None, :, None])
+        if skips:
+            sp[0], s0_64 = xp, xn64                                  # skip0 = the cell input, un-normalised in storage
+        xn64 = xn64.float().to(BF).double()                          # the GEMM operand is the bf16 rounding of the normalised tensor
+    want = torch.einsum('oc,bct->bot', w.double(), xn64) + bias.double()[None, :, None]
+    want = want.clamp(min=0.0, max=20.0)
+    for i, s in enumerate(skips):
+        want = want + (s0_64 if i == 0 else s.double())
+    y = torch.full((b, c_out, ld), 7.0, dtype=BF, device=DEV)
+    ws = hip.pointwise_bf16_workspace(b, c_in, ld, DEV)
+    packed = hip.pack_pointwise_weights_bf16(w.float().to(DEV))
+    hip.linear_fused_bf16(xp, t, packed, c_out, bias.float().to(DEV), sp, y, ws, ln, with_ln, with_ln and bool(skips))
+    torch.cuda.synchronize()
+    assert torch.all(y[:, :, t:] == 0)
+    got = y[:, :, :t].float().cpu().double()
+    tol = 2.0 ** -8 * want.abs() + 2e-3
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())
+
+
+@pytest.mark.parametrize('c_in,hidden,t,b', [(1200, 500, 100, 3), (1200, 500, 1, 2), (72, 24, 300, 2)])
+@pytest.mark.parametrize('with_ln', [False, True])
+def test_lstm_projection_on_the_bf16_matrix_cores(c_in, hidden, t, b, with_ln):
+    """nbasr_lstm_input_projection_bf16: gates (frames, batch, 4 H) fp32 = W_ih xn + b_ih + b_hh with xn = the bf16 rounding of the (pending)
+    LayerNorm of the bf16 encoder output -- exact products, fp32 accumulation: against float64 to fp32 accumulation accuracy."""
+    torch.manual_seed(c_in + hidden + t)
+    x = (torch.randn(b, c_in, t) * 1.3).to(BF)
+    w = (torch.randn(4 * hidden, c_in) / c_in ** 0.5).to(BF)
+    b_ih, b_hh = (torch.randn(4 * hidden) * 0.2).to(BF), (torch.randn(4 * hidden) * 0.2).to(BF)
+    xp = pitched(x.float(), BF)
+    ld = xp.shape[2]
+    ln, xn64 = None, x.double()
+    if with_ln:
+        stats = torch.empty(b, 2, ld, device=DEV)
+        hip.channel_stats(xp, stats, t, 1e-3)
+        gamma, beta = torch.rand(c_in, device=DEV) + 0.5, torch.randn(c_in, device=DEV) * 0.2
+        ln = (stats, gamma, beta)
+        mu, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+        xn64 = ((x.double() - mu) / (var + 1e-3).sqrt() * gamma.cpu().double()[None, :, None] + beta.cpu().double()[None, :, None]).float().to(BF).double()
+    want = torch.einsum('oc,bct->tbo', w.double(), xn64) + (b_ih.double() + b_hh.double())[None, None, :]
+    gates = torch.full((t, b, 4 * hidden), 7.0, device=DEV)
+    ws = hip.pointwise_bf16_workspace(b, c_in, ld, DEV)
+    hip.lstm_input_projection_bf16(xp, t, hip.pack_pointwise_weights_bf16(w.float().to(DEV)), b_ih.float().to(DEV), b_hh.float().to(DEV), gates, hidden, ws, ln)
+    torch.cuda.synchronize()
+    got = gates.cpu().double()
+    # with a pending LayerNorm an element of xn next to a bf16 rounding boundary may round the other way than the float64 restatement
+    # (fp32 vs float64 normalisation): one bf16 step of one operand, |w| 2^-8 |xn| -- allow a few of those per output
+    tol = (3e-2 if with_ln else 1e-4) * (1.0 + want.abs())
+    assert bool(((got - want).abs() <= tol).all()), float(((got - want).abs() / tol).max())

@@ -144,3 +144,16 @@ def test_bench_reads_only_attributes_a_plan_has():
     plan = executor.ForwardPlan('cpu')
     for name in sorted(set(re.findall(r'\bplan\.([A-Za-z_]+)', (root / 'bench.py').read_text()))):
         assert hasattr(plan, name), f'bench.py reads plan.{name}, which ForwardPlan does not have'
+
+
+def test_removed_environment_switches_are_announced_once(monkeypatch):
+    """a script that still sets a switch of rounds 1-3 (NBASR_TRAIN_GEMM became NBASR_DENSE_MODE, ...) is told so, once."""
+    import warnings
+    from nb_asr_amd import executor
+    monkeypatch.setenv('NBASR_TRAIN_GEMM', 'f32')
+    monkeypatch.setattr(executor, '_warned_removed', [False])
+    with warnings.catch_warnings(record=True) as seen:
+        warnings.simplefilter('always')
+        executor._warn_removed_switches()
+        executor._warn_removed_switches()
+    assert len(seen) == 1 and 'NBASR_TRAIN_GEMM' in str(seen[0].message) and 'NBASR_DENSE_MODE' in str(seen[0].message)
