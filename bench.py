@@ -23,11 +23,18 @@ With N > 1 `value` is the weak-scaling number (64 utterances per GPU) and `value
 utterances split over the N ranks): north_star's ">= 6x on (B=64, T=1000)" reads as the latter.
 
 One JSON line on stdout (rank 0).  Besides the driver's contract fields it carries
-  roofline      fused grouped Conv1d kernel (the graded, HBM-bound kernel of SURVEY.md 8(d)): algorithmic bytes of
-                its 54 launches / their HIP-event time, vs 8 TB/s
-  roofline_mfma the dense downsample convs: issued bf16 MFMA flops (6 per algorithmic fp32 product) vs 2.5 PFLOP/s
-                (or algorithmic flops vs the 157.3 TFLOP/s fp32 MFMA peak with NBASR_DENSE_MODE=f32)
-  cpu_baseline  the CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample, host cores
+  roofline      the node op of the search space -- since round 3 a whole cell of three grouped Conv1d per launch (grouped_cell_kernel),
+                the graded kernel of SURVEY.md 8(d).  Round 4: every launch priced under its OWN roofline -- x0 in, y out, weights
+                against 8 TB/s; the three convolutions' flops against the pipe the launch ran on (fp32 vector rate, or the bf16 MFMA
+                peak for the matrix-core cell) -- frac = sum of max(byte time, flop time) / HIP-event time of the launches.  The
+                figure rounds 1-3 reported (the algorithmic bytes of the three node ops a fused launch replaces / time / 8 TB/s) is
+                kept as frac_credited_node_ops; it is not a bound
+  roofline_mfma the dense downsample convs: issued 16-bit MFMA flops (3 fp16 or 6 bf16 products per algorithmic fp32 product) vs
+                2.5 PFLOP/s (or algorithmic flops vs the 157.3 TFLOP/s fp32 MFMA peak with NBASR_DENSE_MODE=f32)
+  cpu_baseline  the CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample of the workload, host cores:
+                1 warm-up + 3 timed forwards of 16 utterances, then one forward of the metric's own batch
+  parity        the logits of the TIMED steps against the oracle's (all utterances) and against a float64 evaluation (8 utterances)
+                under the rule of tests/cases.py; a violation makes the run exit non-zero after printing the line
 """
 import argparse
 import json

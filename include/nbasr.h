@@ -219,8 +219,8 @@ int nbasr_channel_stats(const void* x, float* stats, int batch, int channels, in
 
 /* LayerNorm statistics of a node's output from the convolution's own epilogue (what nbasr_channel_stats(y) would give):
  * workgroups write per-part partial (mean, M2) to stats_ws (nbasr_grouped_stats_workspace_bytes), nbasr_grouped_stats_finalize
- * merges them into stats_out (batch, 2, ld).  A part covers `groups_per_part` groups: 4 (nbasr_grouped_conv1d_node, most
- * nbasr_grouped_cell_fused launches) or 2 (the value nbasr_grouped_cell_fits returns for the shape). */
+ * merges them into stats_out (batch, 2, ld).  A part covers `groups_per_part` groups: 4 (nbasr_grouped_conv1d_node,
+ * nbasr_grouped_cell_fused on rows of one wave), 2 or 1 (the value nbasr_grouped_cell_fits returns for the shape; <= 128 parts). */
 size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups);
 int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
                                  int groups, int groups_per_part, float eps, nbasr_stream_t stream);
@@ -259,7 +259,7 @@ int nbasr_pack_grouped_weights(const float* w, float* packed, int channels, int 
  * output channels of one frame, its weight operand is a scalar-register pair loaded from two adjacent floats.
  * nbasr_grouped_cell_fits tells whether a (channels, ld, groups) row fits one workgroup -- <= 2048 frames (<= 8 waves per group row),
  * channels / groups in {6, 8, 10, 12}, the group tiles within 160 KiB of LDS: 0 = no, else the number of groups one statistics partial
- * covers (4 or 2: the groups_per_part of nbasr_grouped_stats_finalize). */
+ * covers (4, 2 or 1: the groups_per_part of nbasr_grouped_stats_finalize; 1 = one group row per workgroup, rows of more than 256 frames). */
 int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups);
 int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, int k0, int d0,
                              const float* w1, const float* b1, int k1, int d1,

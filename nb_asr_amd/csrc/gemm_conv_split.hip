@@ -246,7 +246,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 {
     static_assert(!(XIMG && LNX) && !(XIMG && !has_image_path<P>()), "the image path: scaled fp16 scheme or plain bf16, no LayerNorm on load");
     static_assert(XIMG || P::NS > 1, "plain bf16 operands exist as an image only");
-    static_assert(MI == 4 || ((MI == 5 || MI == 2) && XIMG), "160- and 64-row tiles exist for the image path only");
+    static_assert(MI == 4 || ((MI == 5 || MI == 3 || MI == 2) && XIMG), "160-, 96- and 64-row tiles exist for the image path only");
     using G = GeoP<P, S, MI>;
     constexpr int PB_M = G::PBM, WROWS = 16 * MI;                // rows per tile, rows per wave
     using vec8 = typename P::vec8;
@@ -727,7 +727,7 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     return launch_status(P::NAME);
 }
 
-static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : (row_tile == 64 ? 2 : 0)); }
+static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : (row_tile == 96 ? 3 : (row_tile == 64 ? 2 : 0))); }
 
 // image-path kernel of scheme P at a given row tile (the only kernel the plain-bf16 scheme has)
 template <class P, int S, int MI>
@@ -763,7 +763,7 @@ static int pack_impl(const float* w, void* packed, int c_out, int c_in, int kern
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
-    NBASR_REQUIRE(mi != 0 && (mi == 4 || has_image_path<P>()), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 64 / 160 for the image-path schemes)", row_tile);
+    NBASR_REQUIRE(mi != 0 && (mi == 4 || has_image_path<P>()), NBASR_EINVAL, "nbasr_pack_dense_weights: row_tile=%d unsupported (128, or 64 / 96 / 160 for the image-path schemes)", row_tile);
     const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(c_out > 0 && c_in > 0, NBASR_EINVAL, "nbasr_pack_dense_weights: bad sizes");
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
@@ -791,8 +791,8 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
-    NBASR_REQUIRE(mi == 4 || ((mi == 5 || mi == 2) && x_is_image && P::SCALED), NBASR_EINVAL,
-                  "%s: row_tile=%d unsupported (128; 64 and 160 for the fp16 image path)", P::NAME, row_tile);
+    NBASR_REQUIRE(mi == 4 || ((mi == 5 || mi == 3 || mi == 2) && x_is_image && P::SCALED), NBASR_EINVAL,
+                  "%s: row_tile=%d unsupported (128; 64, 96 and 160 for the fp16 image path)", P::NAME, row_tile);
     const int PB_M = pb_rows(mi);
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
@@ -822,9 +822,12 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
                         + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * PB_M;
     }
     if (mi == 5) return stride == 1 ? launch_packed_rows160<P, 1>(a, as_stream(stream)) : launch_packed_rows160<P, 2>(a, as_stream(stream));
-    if (mi == 2) {
-        // 64-row tiles: twice the workgroups where a small batch leaves CUs without one (the executor's round count decides)
-        if constexpr (has_image_path<P>() && P::SCALED) return stride == 1 ? launch_image<P, 1, 2>(a, as_stream(stream)) : launch_image<P, 2, 2>(a, as_stream(stream));
+    if (mi == 2 || mi == 3) {
+        // 64- / 96-row tiles: more workgroups where a small batch leaves CUs without one (the executor's round count decides)
+        if constexpr (has_image_path<P>() && P::SCALED) {
+            if (mi == 3) return stride == 1 ? launch_image<P, 1, 3>(a, as_stream(stream)) : launch_image<P, 2, 3>(a, as_stream(stream));
+            return stride == 1 ? launch_image<P, 1, 2>(a, as_stream(stream)) : launch_image<P, 2, 2>(a, as_stream(stream));
+        }
     }
     return stride == 1 ? launch_packed<P, 1>(a, as_stream(stream)) : launch_packed<P, 2>(a, as_stream(stream));
 }

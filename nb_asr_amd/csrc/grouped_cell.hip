@@ -36,6 +36,7 @@
 // Algorithmic bytes credited per launch (bench.py): x0 in, y out, the weights once (round 3 credited the three node operations).
 #include "storage.h"
 
+#include <algorithm>
 #include <cstddef>
 #include <cstdlib>
 
@@ -56,13 +57,20 @@ struct Win {
     static constexpr int BASE = 4 * QL - LPAD;          // window index of (r = 0, tap = 0)
 };
 
-constexpr int CELL_PADL = 2, CELL_PADR = 2;             // zero chunks on either side of a tile row (QL <= 2, QR <= 1: the conv's padding)
+constexpr int CELL_PADL = 2, CELL_PADR = 1;             // the most zero chunks a tile row can need on either side (QL <= 2, QR <= 1: the conv's padding)
+// A tile row holds exactly the row's ld / 4 chunks plus the pad chunks THIS cell's three (taps, dilation) pairs reach (round 4; rounds
+// 2-3: 64 chunks per wave + 2 + 2).  At 1000 frames that is 251-253 chunks instead of 260 -- and five instead of four one-group
+// workgroups in a CU's 160 KiB at 8 channels per group (block 1), eight instead of seven at 10 (block 2)
+__host__ __device__ constexpr int cell_ql(int kd) { return kd == 0 ? Win<5, 1>::QL : kd == 1 ? Win<5, 2>::QL : kd == 2 ? Win<7, 1>::QL : Win<7, 2>::QL; }
+__host__ __device__ constexpr int cell_qr(int kd) { return kd == 0 ? Win<5, 1>::QR : kd == 1 ? Win<5, 2>::QR : kd == 2 ? Win<7, 1>::QR : Win<7, 2>::QR; }
 
 struct CellDims {
     int channels, frames, ld, groups, batch;
     int kd0, kd1, kd2;          // 0: k5 d1, 1: k5 d2, 2: k7 d1, 3: k7 d2
     int skips;                  // bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22
     int nt;                     // 64-chunk tiles (waves) per row
+    int padl, padr;             // zero chunks left / right of a tile row: the largest QL / QR of the three nodes
+    int rowq;                   // data chunks of a tile row
 #if NBASR_CELL_STAMPS
     unsigned long long* stamps; // [workgroup][16]: HW_ID, XCC_ID, then the 100 MHz clock at the phase boundaries of wave 0
 #endif
@@ -235,10 +243,10 @@ __device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CG / 2][4], cell_c
     }
 }
 
-// GPW: groups per workgroup -- 4 (the statistics partials are then the node kernel's group quads, bit for bit), or 2 where four group
-// tiles would leave room for only ONE workgroup per CU (its load, compute and store phases then do not overlap with anybody's:
-// measured 157 / 246 / 201 us per cell in blocks 0-2 against 183 / 254 / 185 for three node launches); the partials are then per
-// group PAIR, merged by stats_finalize_kernel with groups_per_part = 2 -- the same statistics to rounding, not bit for bit.
+// GPW: groups per workgroup -- 4 (one-wave rows: the statistics partials are then the node kernel's group quads, bit for bit), 2 (kept
+// for one-wave rows whose four tiles would not leave room for two workgroups per CU), or 1 (rows of several waves, round 4: see
+// cell_gpw); the partials are then per group pair / per group, merged by stats_finalize_kernel with groups_per_part = 2 / 1 -- the
+// same statistics to rounding, not bit for bit.
 // NTB: the largest number of tiles per row this instantiation is launched with (1, 2 or 4): its register budget is that of a
 // 64 * GPW * NTB-thread workgroup (128 registers at 1024 threads; the narrower forms may use more)
 // T: storage type of the cell input and output (float, or bf16_t: the bf16 path -- x1 and x2 are then rounded to bfloat16 exactly
@@ -274,7 +282,8 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     extern __shared__ __attribute__((aligned(16))) float cell_tiles[];
     const CellDims& a = A.a;
     const int nt = a.nt;
-    const int rl = (nt * 64 + CELL_PADL + CELL_PADR) * 4;    // tile row length in floats
+    const int nq = a.ld >> 2;                                // chunks of a row
+    const int rl = (a.rowq + a.padl + a.padr) * 4;           // tile row length in floats
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gi = wave / nt, ti = wave - gi * nt;           // group within the quad, tile within the row
@@ -284,8 +293,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     const bool g_ok = g_raw < a.groups;                       // a surplus wave of the last quad recomputes the last group, stores nothing
     const int g = g_ok ? g_raw : a.groups - 1;
     const int q = ti * 64 + lane;                            // chunk within the row
-    const int col = CELL_PADL + q;                           // its column (in chunks) in the tile row
-    const int nq = a.ld >> 2;
+    const int col = a.padl + q;                              // its column (in chunks) in the tile row
     const bool in_row = q < nq;
     const int t0 = q * 4;
     const size_t row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG) * a.ld;
@@ -309,9 +317,10 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
 #endif
     stamp();
     // the zero pads of every tile row (never written again)
-    for (int i = threadIdx.x; i < GPW * CG * (CELL_PADL + CELL_PADR); i += blockDim.x) {
-        const int row = i / (CELL_PADL + CELL_PADR), p = i - row * (CELL_PADL + CELL_PADR);
-        const int c = p < CELL_PADL ? p : nt * 64 + p;
+    const int npad = a.padl + a.padr;
+    for (int i = threadIdx.x; i < GPW * CG * npad; i += blockDim.x) {
+        const int row = i / npad, p = i - row * npad;
+        const int c = p < a.padl ? p : a.rowq + p;
         *reinterpret_cast<cell_f4*>(cell_tiles + row * rl + 4 * c) = cell_f4{0.f, 0.f, 0.f, 0.f};
     }
 
@@ -370,8 +379,8 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
         }
 #pragma unroll
         for (int ci = 0; ci < CG; ++ci) {
-            const float4 v = normalise(make_float4(out[ci][0], out[ci][1], out[ci][2], out[ci][3]), ci, A.ln_gamma, A.ln_beta);      // (rstd = 0 beyond the row: zeros)
-            *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{v.x, v.y, v.z, v.w};
+            const float4 v = normalise(make_float4(out[ci][0], out[ci][1], out[ci][2], out[ci][3]), ci, A.ln_gamma, A.ln_beta);
+            if (q < a.rowq) *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{v.x, v.y, v.z, v.w};        // (a tile row ends with the row's last chunk + pads)
         }
     }
     stamp();
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     auto tile_write = [&]() {                       // the node output in `out` becomes the next node's input
 #pragma unroll
         for (int co = 0; co < CG; ++co)
-            *reinterpret_cast<cell_f4*>(tile + co * rl + 4 * col) = cell_f4{out[co][0], out[co][1], out[co][2], out[co][3]};
+            if (q < a.rowq) *reinterpret_cast<cell_f4*>(tile + co * rl + 4 * col) = cell_f4{out[co][0], out[co][1], out[co][2], out[co][3]};
     };
 
     // ---- node 0: x1 = op0(x0n) + s00 x0n (x0n read back from the tile) -------------------------------------------------------------
@@ -515,6 +524,15 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
         for (int co = 0; co < CG; ++co) { const float d = out[co][r] - pm[r]; m2 = __builtin_fmaf(d, d, m2); }
         p2[r] = m2;
     }
+    if constexpr (GPW == 1) {                       // one group per workgroup: the lane's own (mean, M2) IS the partial -- no exchange, no barrier
+        if (in_row) {
+            float* prow = part + (static_cast<size_t>(blockIdx.x) * gridDim.y + b) * 2 * a.ld + t0;
+            *reinterpret_cast<float4*>(prow) = make_float4(pm[0], pm[1], pm[2], pm[3]);
+            *reinterpret_cast<float4*>(prow + a.ld) = make_float4(p2[0], p2[1], p2[2], p2[3]);
+        }
+        stamp();
+        return;
+    }
     __syncthreads();                                // every read of x2 is done: the tiles become the exchange buffer [GPW][nt][8][64]
     float* const sp = cell_tiles;
 #pragma unroll
@@ -542,9 +560,21 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     stamp();
 }
 
-static size_t cell_lds_bytes(int cg, int nt, int gpw) { return static_cast<size_t>(gpw) * cg * (nt * 64 + CELL_PADL + CELL_PADR) * 16; }
+// LDS of a workgroup: gpw tiles of cg rows of (chunks + pads) x 16 bytes (fits / groups-per-workgroup decisions: the widest pads)
+static size_t cell_lds_bytes(int cg, int chunks, int gpw, int pads = CELL_PADL + CELL_PADR) { return static_cast<size_t>(gpw) * cg * (chunks + pads) * 16; }
 // groups per workgroup: 4 while at least two such workgroups fit a CU's 160 KiB and the workgroup its 16 waves, else 2
-static int cell_gpw(int cg, int nt) { return (nt <= 4 && 2 * cell_lds_bytes(cg, nt, 4) <= 160 * 1024) ? 4 : 2; }
+// groups per workgroup.  Rows of ONE wave (<= 256 frames): 4 -- the waves of a workgroup never meet at a barrier and the partials are
+// the node kernel's group quads, bit for bit.  Longer rows (round 4): ONE -- a workgroup is the nt waves of one group row.  Phase stamps
+// showed a workgroup of 2 groups x 4 waves outside its convolution loops for half of its life, much of it at the barriers of its
+// node boundaries (the slowest of 8 waves) and in the statistics exchange (two more barriers, half of the waves idle); with one group
+// per workgroup a barrier joins 4 waves, twice as many workgroups interleave their phases on a CU, and the lane's own (mean, M2) IS
+// the partial: 95 / 162 / 140 -> 90 / 142 / 132 us per cell in blocks 0-2 at 64 x 1000.  Price: per-group partials (100 instead of
+// 50 rows per utterance for nbasr_grouped_stats_finalize: 0.17 -> 0.21 ms per forward); end to end +0.9 % (same-box A/B, twice).
+static int cell_gpw(int cg, int nt)
+{
+    if (nt >= 2) return 1;
+    return 2 * cell_lds_bytes(cg, nt * 64, 4) <= 160 * 1024 ? 4 : 2;
+}
 
 template <typename T, int CG, bool KEEP1, int NTB, int GPW>
 static int launch_cell_kernel(const CellArgs<T>& p, hipStream_t stream)
@@ -556,7 +586,8 @@ static int launch_cell_kernel(const CellArgs<T>& p, hipStream_t stream)
         return static_cast<int>(attr);
     }
     const CellDims& a = p.a;
-    const size_t lds = cell_lds_bytes(CG, a.nt, GPW);
+    // (the tiles double as the statistics exchange buffer [GPW][nt][8][64] floats of a multi-group workgroup)
+    const size_t lds = std::max(cell_lds_bytes(CG, a.rowq, GPW, a.padl + a.padr), GPW > 1 ? static_cast<size_t>(GPW) * a.nt * 8 * 64 * 4 : 0);
     hipLaunchKernelGGL((grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream, p);
     return launch_status("nbasr_grouped_cell_fused");
 }
@@ -565,6 +596,11 @@ template <typename T, int CG, bool KEEP1>
 static int launch_cell_nt(const CellArgs<T>& p, hipStream_t stream)
 {
     const CellDims& a = p.a;
+    if (cell_gpw(CG, a.nt) == 1) {
+        if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 1>(p, stream);
+        if (a.nt <= 4) return launch_cell_kernel<T, CG, KEEP1, 4, 1>(p, stream);
+        return launch_cell_kernel<T, CG, KEEP1, 8, 1>(p, stream);
+    }
     if (cell_gpw(CG, a.nt) == 4) {
         if (a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 4>(p, stream);
         if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 4>(p, stream);
@@ -617,7 +653,7 @@ extern "C" int nbasr_grouped_cell_fits(int channels, int frames_ld, int groups)
     const int nt = (frames_ld / 4 + 63) / 64;
     if (nt > 8) return 0;                                              // 2 groups x 8 waves = the 1024 threads of a workgroup
     const int gpw = cell_gpw(cg, nt);
-    return cell_lds_bytes(cg, nt, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize)
+    return cell_lds_bytes(cg, frames_ld / 4, gpw) <= 160 * 1024 ? gpw : 0;       // the groups per statistics partial (nbasr_grouped_stats_finalize)
 }
 
 extern "C" int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, int k0, int d0,
@@ -648,6 +684,9 @@ extern "C" int nbasr_grouped_cell_fused(const void* x0, const float* w0, const f
                   "nbasr_grouped_cell_fused: node ops must be conv5 / conv5d2 / conv7 / conv7d2 (got k=%d,%d,%d d=%d,%d,%d)", k0, k1, k2, d0, d1, d2);
     a.skips = skip_mask;
     a.nt = (ld / 4 + 63) / 64;
+    a.padl = std::max(cell_ql(a.kd0), std::max(cell_ql(a.kd1), cell_ql(a.kd2)));
+    a.padr = std::max(cell_qr(a.kd0), std::max(cell_qr(a.kd1), cell_qr(a.kd2)));
+    a.rowq = ld / 4;            // (same-box A/B against rows of 64 nt + 2 + 2 chunks: block 2 140 -> 132.5 us per cell at 64 x 1000, the others unchanged)
 #if NBASR_CELL_STAMPS
     { const char* e = getenv("NBASR_CELL_STAMPS"); a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
 #endif

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void pack_grouped_weights_kernel(const float* 
 // then one thread per frame merges the 8 lane results from LDS.  The first version walked all 25-50 partials of a frame in ONE
 // thread, five at a time: 5-10 dependent round trips = 10-12 us per launch whatever the batch, 15 launches per forward
 // (0.18 ms: 10 % of a step at 8 utterances per GPU).  Chan's merge throughout; the order is fixed, so results are reproducible.
-constexpr int SF_FRAMES = 32, SF_LANES = 8, SF_MAX_PER_LANE = 8;       // <= 64 partials per frame
+constexpr int SF_FRAMES = 32, SF_LANES = 8, SF_MAX_PER_LANE = 16;      // <= 128 partials per frame (per-group partials of a fused cell: 100)
 __global__ __launch_bounds__(SF_FRAMES * SF_LANES) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
                                                                                 int batch, int frames, int ld, int groups, int cg, int gpp, float eps)
 {
@@ -374,7 +374,7 @@ using namespace nbasr;
 extern "C" size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups)
 {
     if (batch <= 0 || ld <= 0 || groups <= 0) return 0;
-    return static_cast<size_t>((groups + 1) / 2) * batch * 2 * ld * sizeof(float);      // room for per-PAIR partials (fused cells); the node kernels use half
+    return static_cast<size_t>(groups) * batch * 2 * ld * sizeof(float);      // room for per-GROUP partials (fused cells of one group per workgroup); the node kernels use a quarter
 }
 
 // every flavour of the node op lands here: validation, then the variant's translation unit
@@ -443,7 +443,7 @@ extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && groups > 0 && channels % groups == 0 && frames >= 0 && ld >= frames, NBASR_EINVAL,
                   "nbasr_grouped_stats_finalize: bad sizes");
-    NBASR_REQUIRE(groups_per_part == 4 || groups_per_part == 2, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4 or 2)", groups_per_part);
+    NBASR_REQUIRE(groups_per_part == 4 || groups_per_part == 2 || groups_per_part == 1, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4, 2 or 1)", groups_per_part);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
     NBASR_REQUIRE((groups + groups_per_part - 1) / groups_per_part <= SF_LANES * SF_MAX_PER_LANE, NBASR_EINVAL,

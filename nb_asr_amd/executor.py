@@ -401,9 +401,15 @@ class ForwardPlan:
             wgs = -(-c_out // rows) * n_nt * self.batch
             return -(-wgs // 256) * rows
         rows = 160 if cost(160) < cost(128) else 128
-        # 64-row tiles where a small batch leaves CUs without a workgroup (8 utterances: 128 or 80 workgroups for convs 2 and 3)
-        # (a 64-row tile does less per operand byte staged: it has to win by a quarter, measured +4 % at 8 utterances, nothing to gain at 32)
-        return 64 if (allow_64 and 1.25 * cost(64) < cost(rows)) else rows
+        # smaller tiles where a small batch leaves CUs without a workgroup (8 utterances: 128 or 80 workgroups for convs 2 and 3).  A
+        # smaller tile does less per operand byte staged, so it has to win by a margin: 96 rows (round 4: 13 x 16 = 208 workgroups in ONE
+        # round for conv 3 at 16 utterances) by a tenth, 64 rows by a quarter (measured +4 % at 8 utterances, nothing to gain at 32)
+        score = float(cost(rows))
+        if allow_64:
+            for r, margin in ((96, 1.1), (64, 1.25)):
+                if margin * cost(r) < score:
+                    rows, score = r, margin * cost(r)
+        return rows
 
     def _packed_linear(self, linear):
         """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""

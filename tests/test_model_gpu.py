@@ -893,8 +893,10 @@ def test_one_launch_recurrence_beside_a_stream_that_hogs_the_chip():
 @pytest.mark.parametrize('arch,b,t', [(cases.ARCH_A, 2, 1000), (cases.ARCH_D, 3, 515), (cases.ARCH_D, 2, 250), ([[2, 0], [4, 1, 0], [1, 0, 1, 1]], 2, 1024)])
 def test_fused_cells_against_node_launches(monkeypatch, arch, b, t):
     """Cells of three grouped convs run as ONE launch by default (grouped_cell.hip); NBASR_CELL_FUSION=0 runs the three node launches.
-    The cell outputs are bit-identical; the cell LayerNorm's statistics are merged per group quad (bit-identical) or, for long wide
-    rows, per group pair (equal to rounding) -- so the logits agree far inside the tolerance, and exactly where every cell takes quads."""
+    The cell outputs are bit-identical; the cell LayerNorm's statistics are merged per group quad (rows of one wave: bit-identical) or
+    per group (round 4, rows of several waves: equal to rounding -- another order of the same fp32 merge) -- so the logits agree far
+    inside the tolerance (a quarter of it; 0.16 measured on the dense-skip architecture at 3 x 515), and exactly where every cell
+    takes quads."""
     from nb_asr_amd import hip
     m = build(arch, True, 'lively', seed=5)
     x = keyed_input(b, t, seed=3).to(DEV)
@@ -917,7 +919,7 @@ def test_fused_cells_against_node_launches(monkeypatch, arch, b, t):
         cases.assert_parity(fused, want, truth, 'fused cells')
         cases.assert_parity(unfused, want, truth, 'node launches')
     else:
-        assert r <= 0.15, r
+        assert r <= 0.25, r
     frames = t
     gpps = []
     for c, stride in zip((600, 800, 1000, 1200), (1, 1, 2, 2)):

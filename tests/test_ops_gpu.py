@@ -692,14 +692,15 @@ def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, m
     assert torch.equal(got2, x3) and torch.equal(x3b, x3)
     if gpp == 4:                                   # group quads, as the node kernel: the same partials bit for bit
         assert torch.equal(st_cell[:, :, :t], st_node[:, :, :t])
-    else:                                          # group pairs (long, wide rows): the same statistics to rounding
+    else:                                          # group pairs / single groups (rows of more than one wave): the same statistics to rounding
         assert torch.allclose(st_cell[:, :, :t], st_node[:, :, :t], rtol=2e-6, atol=1e-6)
 
 
 def test_fused_cell_limits():
     assert not hip.grouped_cell_fits(600, 2052, 100)          # > 2048 frames: more than eight 64-chunk waves per group row
-    assert hip.grouped_cell_fits(600, 1600, 100) == 2 and not hip.grouped_cell_fits(1200, 1600, 100)    # (2 x 12 x 1600 x 4 B of tiles > 160 KiB)
-    assert hip.grouped_cell_fits(1200, 1000, 100) == 2 and hip.grouped_cell_fits(1200, 252, 100) == 4      # groups per workgroup / statistics partial
+    # groups per workgroup = groups per statistics partial: 1 for rows of several waves (round 4), 4 for one-wave rows
+    assert hip.grouped_cell_fits(600, 1600, 100) == 1 and hip.grouped_cell_fits(1200, 1600, 100) == 1 and hip.grouped_cell_fits(1200, 2048, 100) == 1
+    assert hip.grouped_cell_fits(1200, 1000, 100) == 1 and hip.grouped_cell_fits(1200, 252, 100) == 4
     assert not hip.grouped_cell_fits(700, 1000, 100)          # 7 channels per group: not a model width
     assert hip.grouped_cell_fits(800, 1000, 100) and hip.grouped_cell_fits(600, 1000, 100) and hip.grouped_cell_fits(1200, 500, 100)
     x = torch.zeros(1, 24, 16, device=DEV)
@@ -751,6 +752,11 @@ def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     got64 = torch.full_like(want, float('nan'))
     packed64 = hip.pack_dense_weights(w, stride, 'f16x2', row_tile=64)
     hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed64, cout, 8, bias, got64, stride, row_tile=64)
+    # 96-row tiles (round 4: one round of 208 workgroups for conv 3 at 16 utterances): bit-identical like the others
+    got96 = torch.full_like(want, float('nan'))
+    packed96 = hip.pack_dense_weights(w, stride, 'f16x2', row_tile=96)
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed96, cout, 8, bias, got96, stride, row_tile=96)
+    assert torch.equal(got96, got)
     assert torch.equal(got64, got)
 
 
