@@ -43,6 +43,9 @@
 #ifndef NBASR_CELL_STAMPS
 #define NBASR_CELL_STAMPS 0
 #endif
+#ifndef NBASR_CELL_BATCH
+#define NBASR_CELL_BATCH 60          // most scalar weights requested (and waited for) at once
+#endif
 #include <type_traits>
 
 namespace nbasr {
@@ -129,13 +132,16 @@ typedef float cell_f8 __attribute__((ext_vector_type(8)));
 typedef float cell_f16 __attribute__((ext_vector_type(16)));
 template <int N>
 struct WeightBatch {
-    static_assert(N % 2 == 0 && N >= 2 && N <= 46, "an even number of scalars, at most 2 x 16 + 8 + 4 + 2");
+    static_assert(N % 2 == 0 && N >= 2 && N <= 62, "an even number of scalars, at most 3 x 16 + 8 + 4 + 2");
     static constexpr int N16 = N / 16, N8 = (N % 16) / 8, N4 = (N % 8) / 4, N2 = (N % 4) / 2;
-    cell_f16 q0, q1; cell_f8 o; cell_f4 f; cell_f2 t;
+    cell_f16 q0, q1, q2; cell_f8 o; cell_f4 f; cell_f2 t;
     __device__ __forceinline__ cell_f2 pair(int i) const     // scalars (2i, 2i + 1); i is a constant after unrolling
     {
         int e = 2 * i;
-        if (e < 16 * N16) return e < 16 ? cell_f2{q0[e & 15], q0[(e & 15) + 1]} : cell_f2{q1[e & 15], q1[(e & 15) + 1]};
+        if (e < 16 * N16) {
+            const int w = e & 15;
+            return e < 16 ? cell_f2{q0[w], q0[w + 1]} : e < 32 ? cell_f2{q1[w], q1[w + 1]} : cell_f2{q2[w], q2[w + 1]};
+        }
         e -= 16 * N16;
         if (N8 && e < 8) return cell_f2{o[e & 7], o[(e & 7) + 1]};
         e -= 8 * N8;
@@ -150,11 +156,13 @@ struct WeightBatch {
             asm volatile(text "\n\ts_waitcnt lgkmcnt(0)" : __VA_ARGS__ : [p] "s"(p), [o8] "n"(O8), [o4] "n"(O4), [o2] "n"(O2));
 #define L16A "s_load_dwordx16 %[q0], %[p], 0x0"
 #define L16B "\n\ts_load_dwordx16 %[q1], %[p], 0x40"
+#define L16C "\n\ts_load_dwordx16 %[q2], %[p], 0x80"
 #define L8 "\n\ts_load_dwordx8 %[o], %[p], %[o8]"
 #define L4 "\n\ts_load_dwordx4 %[f], %[p], %[o4]"
 #define L2 "\n\ts_load_dwordx2 %[t], %[p], %[o2]"
 #define Q0 [q0] "=&s"(q0)
 #define Q1 [q1] "=&s"(q1)
+#define Q2 [q2] "=&s"(q2)
 #define O_ [o] "=&s"(o)
 #define F_ [f] "=&s"(f)
 #define T_ [t] "=&s"(t)
@@ -167,15 +175,23 @@ struct WeightBatch {
         NBASR_WB_CASE(2, 0, 0, 0, L16A L16B, Q0, Q1)                                                   // 32
         NBASR_WB_CASE(2, 0, 1, 0, L16A L16B L4, Q0, Q1, F_)                                            // 36
         NBASR_WB_CASE(2, 1, 0, 0, L16A L16B L8, Q0, Q1, O_)                                            // 40
-        static_assert(N == 12 || N == 16 || N == 18 || N == 20 || N == 24 || N == 30 || N == 32 || N == 36 || N == 40, "batch size without a load pattern");
+        NBASR_WB_CASE(2, 1, 0, 1, L16A L16B L8 L2, Q0, Q1, O_, T_)                                     // 42
+        NBASR_WB_CASE(3, 0, 0, 0, L16A L16B L16C, Q0, Q1, Q2)                                          // 48
+        NBASR_WB_CASE(3, 0, 0, 1, L16A L16B L16C L2, Q0, Q1, Q2, T_)                                   // 50
+        NBASR_WB_CASE(3, 1, 0, 0, L16A L16B L16C L8, Q0, Q1, Q2, O_)                                   // 56
+        NBASR_WB_CASE(3, 1, 1, 0, L16A L16B L16C L8 L4, Q0, Q1, Q2, O_, F_)                            // 60
+        static_assert(N == 12 || N == 16 || N == 18 || N == 20 || N == 24 || N == 30 || N == 32 || N == 36 || N == 40 || N == 42 || N == 48 ||
+                      N == 50 || N == 56 || N == 60, "batch size without a load pattern");
 #undef NBASR_WB_CASE
 #undef L16A
 #undef L16B
+#undef L16C
 #undef L8
 #undef L4
 #undef L2
 #undef Q0
 #undef Q1
+#undef Q2
 #undef O_
 #undef F_
 #undef T_
@@ -223,7 +239,7 @@ __device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CG / 2][4], cell_c
     const float* win = tile + 4 * (col - W::QL);
     // the weights of an input channel in batches of TB taps, each at most 40 scalars: what is alive beside the kernel's own
     // scalars (pointers, sizes) then fits the 102 scalar registers
-    constexpr int NB = (K * CG + 39) / 40, TB = (K + NB - 1) / NB;
+    constexpr int NB = (K * CG + NBASR_CELL_BATCH - 1) / NBASR_CELL_BATCH, TB = (K + NB - 1) / NB;
     static_assert(NB <= 3, "at most three weight batches per input channel");
 #pragma unroll 1
     for (int ci = 0; ci < CG; ++ci) {
