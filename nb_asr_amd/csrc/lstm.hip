@@ -15,6 +15,7 @@
 // The recurrence is latency-bound (frames dependent steps).
 #include "common.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace nbasr {

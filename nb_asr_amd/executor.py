@@ -671,7 +671,8 @@ class ForwardPlan:
         a ``PendingLogits`` is returned."""
         if x.device != self.device:
             raise hip.HipError(f'input on {x.device}, plan on {self.device}')
-        self.check_seq()
+        if not _capturing and self._seq_pending is not None and not torch.cuda.is_current_stream_capturing():
+            self.check_seq()                           # (an event query is not a capturable operation)
         wdtype = model.model[0].conv.weight.dtype          # (not model.parameters(): a DataParallel replica has none)
         if x.dtype != wdtype:
             raise hip.HipError(f'input is {x.dtype} but the model\'s parameters are {wdtype}: cast one of them '
