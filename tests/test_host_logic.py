@@ -142,7 +142,9 @@ def test_row_tile_rule_counts_rounds_of_workgroups():
     plan.batch = 32
     assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 160]
     plan.batch = 8
-    assert [pick(600, 1000), pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [128, 128, 64, 64]   # under-filled launches: 64-row tiles
+    assert [pick(600, 1000), pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [96, 128, 64, 64]    # under-filled launches: 64- / 96-row tiles
+    plan.batch = 16
+    assert [pick(600, 1000), pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [160, 128, 128, 96]  # (round 4) conv 3: 13 x 16 = 208 workgroups, one round
     plan.batch = 2
     assert [pick(800, 1000), pick(1000, 500), pick(1200, 250)] == [64, 64, 64]        # a single round whatever the tile: the smallest
     assert ForwardPlan._row_tile(plan, 1200, 250, allow_64=False) == 128               # (the bf16 GEMM has no 64-row instance)
