@@ -184,9 +184,12 @@ __global__ __launch_bounds__(256) void grouped_conv_f32_kernel(
     if (!STATS && g >= groups) return;              // with STATS every wave must reach the workgroup barrier below
     const bool active = q < nq && g < groups;
 
-    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
-    const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
-    const float* __restrict__ bg = bias + g * CG;
+    // a surplus wave of the last group quad (STATS flavour, groups % 4 != 0) computes on the last group's weights and
+    // stores nothing: every address below stays inside the tensors
+    const int ga = g < groups ? g : groups - 1;
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(ga) * CG) * ld;
+    const float* __restrict__ wg = w + static_cast<size_t>(ga) * (CG * CG * K);
+    const float* __restrict__ bg = bias + ga * CG;
 
     float acc[CG][4];
 #pragma unroll
@@ -229,7 +232,7 @@ __global__ __launch_bounds__(256) void grouped_conv_f32_kernel(
             xw[4 * c + 0] = v.x; xw[4 * c + 1] = v.y; xw[4 * c + 2] = v.z; xw[4 * c + 3] = v.w;
         }
         if (LNX) {
-            const float gam = ln_x.gamma[g * CG + ci], bet = ln_x.beta[g * CG + ci];     // wave-uniform: scalar loads
+            const float gam = ln_x.gamma[ga * CG + ci], bet = ln_x.beta[ga * CG + ci];     // wave-uniform: scalar loads
             const f2 gam2 = f2{gam, gam}, bet2 = f2{bet, bet};
 #pragma unroll
             for (int p = 0; p < NCH * 2; ++p) {
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) void grouped_conv_f32_kernel(
         if (s0) {
             float4 v = *reinterpret_cast<const float4*>(s0 + off);
             if (ln_s0.stats) {
-                const float gam = ln_s0.gamma[g * CG + co], bet = ln_s0.beta[g * CG + co];
+                const float gam = ln_s0.gamma[ga * CG + co], bet = ln_s0.beta[ga * CG + co];
                 v.x = ln_apply(v.x, sm.x, sr.x, gam, bet); v.y = ln_apply(v.y, sm.y, sr.y, gam, bet);
                 v.z = ln_apply(v.z, sm.z, sr.z, gam, bet); v.w = ln_apply(v.w, sm.w, sr.w, gam, bet);
             }

@@ -45,9 +45,12 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
     const int b = FLAT ? (active ? item / nq : 0) : static_cast<int>(blockIdx.z);
     const int q = FLAT ? item - b * nq : item;
 
-    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(g) * CG) * ld;
-    const float* __restrict__ wg = w + static_cast<size_t>(g) * (CG * CG * K);
-    const float* __restrict__ bg = bias + g * CG;
+    // a surplus wave of the last group quad (STATS flavour, groups % 4 != 0) computes on the last group's weights and
+    // stores nothing: every address below stays inside the tensors
+    const int ga = g < groups ? g : groups - 1;
+    const size_t row0 = (static_cast<size_t>(b) * channels + static_cast<size_t>(ga) * CG) * ld;
+    const float* __restrict__ wg = w + static_cast<size_t>(ga) * (CG * CG * K);
+    const float* __restrict__ bg = bias + ga * CG;
 
     float acc[CG][FPL];
 #pragma unroll
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
             for (int e = 0; e < FPL; ++e) xw[FPL * c + e] = v[e];
         }
         if (LNX) {
-            const float gam = ln_x.gamma[g * CG + ci], bet = ln_x.beta[g * CG + ci];     // wave-uniform: scalar loads
+            const float gam = ln_x.gamma[ga * CG + ci], bet = ln_x.beta[ga * CG + ci];     // wave-uniform: scalar loads
             const f2 gam2 = f2{gam, gam}, bet2 = f2{bet, bet};
 #pragma unroll
             for (int p = 0; p < NCH * FPL / 2; ++p) {
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void grouped_conv_kernel(
             float v[FPL];
             load_frames<FPL>(s0 + off, v);
             if (ln_s0.stats) {
-                const float gam = ln_s0.gamma[g * CG + co], bet = ln_s0.beta[g * CG + co];
+                const float gam = ln_s0.gamma[ga * CG + co], bet = ln_s0.beta[ga * CG + co];
 #pragma unroll
                 for (int r = 0; r < FPL; ++r) v[r] = __builtin_fmaf((v[r] + sm[r]) * sr[r], gam, bet) * sk[r];    // == ln_apply for finite values
             }

@@ -696,6 +696,50 @@ def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, m
         assert torch.allclose(st_cell[:, :, :t], st_node[:, :, :t], rtol=2e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize('c,groups,t,k', [(30, 5, 257, 7), (42, 7, 130, 5), (24, 3, 64, 7)])
+def test_statistics_flavour_keeps_surplus_waves_inside_the_weights(c, groups, t, k):
+    """A group count that is not a multiple of 4 leaves surplus waves in the last workgroup of the statistics flavour (they
+    must reach its barrier).  Round 4 found them reading weights of groups that do not exist -- up to 3 groups past the end of
+    the tensor, a memory fault when the tensor ends its device allocation.  Here weights, bias, gamma and beta are the last
+    bytes of allocations of their own (>= 10 MiB requests get a segment of exactly their rounded size from the caching
+    allocator), and the surplus waves must change nothing."""
+    torch.manual_seed(c + t)
+    b, cg = 2, c // groups
+    seg = 12 << 20
+
+    def at_end(values):
+        buf = torch.empty(seg, dtype=torch.uint8, device=DEV)
+        view = buf[seg - values.numel() * 4:].view(torch.float32).view(values.shape)
+        view.copy_(values)
+        return buf, view
+
+    x = torch.randn(b, c, t) * 1.5 + 0.3
+    xp, _ = pitched(x)
+    stats = torch.empty(b, 2, xp.shape[2], device=DEV)
+    hip.channel_stats(xp, stats, t, 1e-3)
+    keep = [at_end(torch.randn(c, cg, k) * 0.3), at_end(torch.randn(c) * 0.2), at_end(torch.rand(c) + 0.5), at_end(torch.randn(c) * 0.2)]
+    (w, bias, gamma, beta) = (v for _, v in keep)
+    ln = (stats, gamma, beta)
+    want, got = torch.full_like(xp, float('nan')), torch.full_like(xp, float('nan'))
+    hip.grouped_conv1d_fused(xp, w, bias, [xp], want, t, groups, k, 1, ln, True, True)
+    ws = hip.grouped_stats_workspace(b, xp.shape[2], groups, DEV)
+    hip.grouped_conv1d_node(xp, w, bias, [xp], got, t, groups, k, 1, ln, True, True, ws, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(got, want)
+    # the templated kernel (here with pre-permuted weights) carries the same workgroup shape
+    keep.append(at_end(hip.pack_grouped_weights(w, groups)))
+    got_t, ws_t = torch.full_like(xp, float('nan')), hip.grouped_stats_workspace(b, xp.shape[2], groups, DEV)
+    hip.grouped_conv1d_node(xp, keep[-1][1], bias, [xp], got_t, t, groups, k, 1, ln, True, True, ws_t, hip.GC_WPERM)
+    torch.cuda.synchronize()
+    assert torch.equal(got_t, want)
+    st, st_want, st_t = (torch.empty(b, 2, xp.shape[2], device=DEV) for _ in range(3))
+    hip.grouped_stats_finalize(ws, st, c, t, groups, 1e-3)
+    hip.grouped_stats_finalize(ws_t, st_t, c, t, groups, 1e-3)
+    assert torch.equal(st_t, st)                              # the same partials (the workspace's unused tail is not compared)
+    hip.channel_stats(got, st_want, t, 1e-3)
+    close(st[:, :, :t], st_want[:, :, :t].cpu(), rtol=1e-5, atol=2e-6)
+
+
 def test_fused_cell_limits():
     assert not hip.grouped_cell_fits(600, 2052, 100)          # > 2048 frames: more than eight 64-chunk waves per group row
     # groups per workgroup = groups per statistics partial: 1 for rows of several waves (round 4), 4 for one-wave rows
