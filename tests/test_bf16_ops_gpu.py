@@ -349,6 +349,44 @@ def test_bf16_cell_on_the_matrix_cores(c, groups, t, kds, mask, with_ln):
     assert float((v - g).abs().max()) <= 0.05 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize('c,groups,t', [(600, 100, 1600), (1200, 100, 1600), (800, 100, 1000)])
+def test_bf16_cell_on_the_matrix_cores_contains_a_non_finite_input(c, groups, t):
+    """Accepted divergence, pinned: the matrix-core cell multiplies zero WEIGHTS with real window data -- taps padded
+    to an even count read the lane's tap-0 window, and with 8-channel slots one MFMA serves two column blocks 64 / 128 frames
+    apart through block-diagonal weights.  0 x Inf = NaN, so where the reference turns a +Inf pre-activation into 20 this kernel
+    may give NaN -- but only in the group that holds the Inf, within the cell's receptive field of that frame or of its partner
+    blocks.  Everything else is bit-identical to the same launch on a finite input, and no Inf ever leaves the cell (skips that are
+    switched off are masked, not multiplied by 0)."""
+    torch.manual_seed(c + t)
+    b, cg, f, reach = 2, c // groups, 700, 48            # three nodes of <= 12 frames back / 14 ahead each
+    x = (torch.randn(b, c, t) * 1.5 + 0.3).to(BF).float()
+    bad = x.clone()
+    g_bad = 3
+    bad[1, g_bad * cg + 2, f] = float('inf')
+    ws = [((torch.rand(c, cg, k) * 0.3 + 0.01).to(BF).float(), (torch.randn(c) * 0.2).to(BF).float(), k, d) for k, d in ((7, 1), (5, 2), (7, 2))]
+    nodes = [(hip.grouped_cell_mfma_pack(w.to(DEV), groups), bias.to(DEV), k, d) for w, bias, k, d in ws]
+    outs = []
+    for v in (x, bad):
+        xp = pitched(v, BF)
+        got = torch.full_like(xp, 7.0)
+        hip.grouped_cell_mfma(xp, nodes, 0b110100, got, t, groups, None)       # no skip from the cell input
+        outs.append(got.float().cpu())
+    clean, dirty = outs
+    assert torch.isfinite(clean).all()
+    assert not torch.isinf(dirty).any()
+    near = torch.zeros(t, dtype=torch.bool)
+    for centre in (f - 128, f - 64, f, f + 64, f + 128):
+        near[max(0, centre - reach):centre + reach + 1] = True
+    same = dirty == clean
+    rows = slice(g_bad * cg, (g_bad + 1) * cg)
+    assert same[0].all()                                                       # the other utterance
+    assert same[1, :g_bad * cg].all() and same[1, (g_bad + 1) * cg:].all()     # the other groups
+    assert same[1, rows, :t][:, ~near].all()                                   # this group, away from the frame
+    touched = dirty[1, rows, :t][:, near]
+    assert (torch.isnan(touched) | ((touched >= 0) & (touched <= 80))).all()
+    assert not same[1, rows, f].all()                                          # the Inf is felt where the reference feels it
+
+
 def test_bf16_cell_on_the_matrix_cores_limits():
     assert hip.grouped_cell_mfma_fits(1200, 4096, 100) == 0                  # two 32-byte-per-frame tiles of 4096 frames exceed 160 KiB
     assert hip.grouped_cell_mfma_fits(700, 1000, 100) == 0                   # 7 channels per group is not in the search space
