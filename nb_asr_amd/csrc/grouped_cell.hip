@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     const size_t row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * CG) * a.ld;
     const bool has_ln = A.ln_stats != nullptr;
 
-    // -DNBASR_CELL_STAMPS=1 (NBASR_EXTRA_CXXFLAGS; tools/cell_stamps.py): wave 0 of every workgroup records the 100 MHz clock at its
+    // -DNBASR_CELL_STAMPS=1 (NBASR_EXTRA_CXXFLAGS; tools/gpu/cell_stamps.py): wave 0 of every workgroup records the 100 MHz clock at its
     // phase boundaries -- how round 4 found that a workgroup spends half of its life outside the convolution loops
 #if NBASR_CELL_STAMPS
     unsigned long long* const stamp_row = a.stamps ? a.stamps + (static_cast<size_t>(blockIdx.x) + static_cast<size_t>(gridDim.x) * blockIdx.y) * 16 : nullptr;

@@ -3,13 +3,13 @@
 
 Needs a library built with the stamps compiled in:
     NBASR_EXTRA_CXXFLAGS=-DNBASR_CELL_STAMPS=1 python -c "import nb_asr_amd.build as b; b.build_library(force=True)"
-    python tools/cell_stamps.py [batch=64] [block=0..3]
+    python tools/gpu/cell_stamps.py [batch=64] [block=0..3]
 Wave 0 of every workgroup records the 100 MHz clock at its phase boundaries into the buffer whose address the launcher reads from
 NBASR_CELL_STAMPS.  The round-4 record is profiles/r04_cell_phase_stamps.txt."""
 import os, sys, pathlib
 import numpy as np
 import torch
-sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[1]))
+sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 from nb_asr_amd import hip
 DEV = 'cuda:0'
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
