@@ -65,9 +65,15 @@ __global__ __launch_bounds__(256) void lstm_pack_whh_kernel(const float* __restr
 __global__ __launch_bounds__(64 * LSTM_WAVES) void lstm_step_packed_kernel(
     const float* __restrict__ gates_in,   // (frames, batch, 4*hidden)
     const float4* __restrict__ wp,        // packed w_hh
-    float* __restrict__ cell, float* h_out, int batch, int frames, int hidden, int kchunks_p, int t)
+    float* __restrict__ cell, float* h_out, int batch, int frames, int hidden, int kchunks_p, int t, int prio)
 {
     __shared__ float red[LSTM_WAVES][2][4][64];    // [wave][row tile][reg = gate][lane]
+    // The per-frame chain runs on a side stream beside the next batch's encoder (executor.py): its waves share compute units with
+    // encoder waves, and every frame waits for the slowest of its workgroups.  At <= 32 utterances per GPU that chain is (close to)
+    // the critical path, so its waves take issue priority over whatever else the unit holds (round 4, same box, alternating runs:
+    // 4 467 -> 4 635 utterances/s at 8, 6 483 -> 7 115 at 16, 8 635 -> 8 861 at 32); at 64 the encoder is the critical path and the
+    // priority costs 0.8 %, so the launcher leaves it off there.  The one-launch recurrence gains nothing from it (measured).
+    if (prio) __builtin_amdgcn_s_setprio(3);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, kq = lane >> 4;
@@ -453,9 +459,10 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     NBASR_REQUIRE(gates_ws && packed_whh && cell_ws && h_out, NBASR_ENULL, "nbasr_lstm_recurrence_packed: NULL pointer");
     NBASR_REQUIRE(aligned16(packed_whh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence_packed: packed_whh, h_out must be 16-byte aligned");
     const dim3 grid(lstm_slices(hidden), (batch + 15) / 16);
+    const int prio = batch <= 32;          // issue priority for the chain's waves where the chain is the critical path (see the kernel)
     for (int t = 0; t < frames; ++t)
         hipLaunchKernelGGL(lstm_step_packed_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws,
-                           static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, lstm_kchunks_p(hidden), t);
+                           static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, lstm_kchunks_p(hidden), t, prio);
     return launch_status("nbasr_lstm_recurrence_packed");
 }
 

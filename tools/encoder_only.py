@@ -6,7 +6,8 @@ sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
 import nb_asr_amd as nb
 from nb_asr_amd.weights import keyed_fill_, keyed_input
 ARCH = [[1, 0], [1, 0, 0], [1, 0, 0, 0]]
-x = keyed_input(64, 1000, seed=0).to('cuda:0')
+BATCH = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+x = keyed_input(BATCH, 1000, seed=0).to('cuda:0')
 for use_rnn in (False, True):
     m = nb.get_model(ARCH, use_rnn=use_rnn, dropout_rate=0.0)
     keyed_fill_(m, seed=1235, mode='lively')
@@ -37,4 +38,4 @@ for use_rnn in (False, True):
             y = m.forward_async(x) if (mode == 'pipelined') else m(x)
             enq = (time.perf_counter() - t1) * 1e3
             torch.cuda.synchronize()
-            print(f'use_rnn={use_rnn} {mode}: {dt:.2f} ms/forward, enqueue of one forward {enq:.2f} ms', flush=True)
+            print(f'batch={BATCH} use_rnn={use_rnn} {mode}: {dt:.2f} ms/forward, enqueue of one forward {enq:.2f} ms', flush=True)
