@@ -862,6 +862,15 @@ def test_one_launch_recurrence_that_loses_its_peers_raises_and_falls_back(monkey
         with pytest.raises(hip.HipError, match='timed out'):
             m(x)
         assert torch.equal(m(x), want)
+        # a healthy forward enqueued right behind a failed one must not hide it: every launch has a pinned status word of its own
+        m._plans.clear()
+        m(x)                                                       # fails (about a second on the device)
+        plan = m._plans.values()[-1]
+        plan._seq_flags = 0
+        fine = m(x)                                                # enqueued at once; its own launch is healthy and clears the device word
+        with pytest.raises(hip.HipError, match='timed out'):
+            m.check()
+        assert torch.equal(fine, want) and torch.equal(m(x), want)
 
 
 def test_one_launch_recurrence_beside_a_stream_that_hogs_the_chip():
