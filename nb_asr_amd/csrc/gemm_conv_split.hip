@@ -160,7 +160,6 @@ struct PackedConvArgs {
     const float* x_range;
     int sel_want;
     int staged_epilogue;         // fp32 output through LDS in whole row segments (always 1; the direct stores were 1.2 % slower end to end)
-    int n_major;                 // tile order: 0 = row-tile major (an XCD keeps a row tile's weights in L2, streams the image), 1 = frame-tile major
 };
 
 // an utterance the scaled fp16 scheme must not take: non-finite samples, or a frame > 2^12 below the loudest sample (the unscaled
@@ -255,22 +254,16 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     unsigned char* const Abuf = smem;                       // [2][ASTEP]    weights of the current / next K-step
     unsigned char* const Xbase = smem + 2 * ASTEP;          // [2][X_BYTES]  input tile of the current / next channel group
 
-    // XCD-aware, m-major tile order (as gemm_conv.hip)
+    // XCD-aware tile order (the bijective remap of gemm_conv.hip), frame-tile major
     const int nwg = gridDim.x, id = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = id & 7;
     const int L = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (id >> 3);
     int mt_i, b, nt_i;
-    if (a.n_major) {                 // all row tiles of a frame tile next to each other: they share its operand image through L2
+    {                                // frame-tile major: all row tiles of a frame tile next to each other, they share its operand image through L2
         mt_i = L % a.n_mt;
         const int rest = L / a.n_mt;
         b = rest / a.n_nt;
         nt_i = rest - b * a.n_nt;
-    } else {
-        const int per_m = a.n_nt * a.batch;
-        mt_i = L / per_m;
-        const int rem = L - mt_i * per_m;
-        b = rem / a.n_nt;
-        nt_i = rem - b * a.n_nt;
     }
     const int m0 = mt_i * PB_M, n0 = nt_i * PB_N;
     if (a.x_range && a.sel_want >= 0 && static_cast<int>(range_is_extreme(a.x_range + 4 * b)) != a.sel_want) return;   // whole workgroup
@@ -659,33 +652,6 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 // 5-19 row tiles of one frame tile run next to each other on one XCD and share its image through L2 -- one pass over the image -- while
 // the weights (15-38 MB, every XCD wants all of them all the time) come from the last-level cache.  Same tiles, same sums; same-box
 // A/B at 64 x 1000: 9 434 / 9 501 against 9 328 / 9 411 utterances/s (+1 %), conv 3 692 -> 671 us.
-static int dense_order_n() { return 1; }
-
-// 160-row tiles: image-path fp16 kernel only
-template <class P, int S>
-static int launch_packed_rows160(PackedConvArgs a, hipStream_t stream)
-{
-    if constexpr (has_image_path<P>()) {
-        using G = GeoP<P, S, 5>;
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true, 5>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-        if (attr != hipSuccess) {
-            set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr));
-            return static_cast<int>(attr);
-        }
-        a.n_mt = (a.c_out + G::PBM - 1) / G::PBM;
-        a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
-        a.n_major = dense_order_n();
-    a.n_major = dense_order_n();
-        const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
-        NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
-        hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, 5>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
-        return launch_status(P::NAME);
-    } else {
-        set_error("%s: 160-row tiles exist for the image path only", P::NAME);
-        return NBASR_EINVAL;
-    }
-}
 
 template <class P, int S>
 static int launch_packed(PackedConvArgs a, hipStream_t stream)
@@ -705,21 +671,8 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     NBASR_REQUIRE(HAS_LNX || !a.ln_x.stats, NBASR_EINVAL, "%s: this scheme takes no deferred LayerNorm", P::NAME);
     a.n_mt = (a.c_out + PB_M - 1) / PB_M;
     a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
-    a.n_major = dense_order_n();
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
-    if constexpr (P::SCALED) {
-        if (a.x_is_image) {
-            static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true>),
-                                                                hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-            if (attr2 != hipSuccess) {
-                set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr2));
-                return static_cast<int>(attr2);
-            }
-            hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
-            return launch_status(P::NAME);
-        }
-    }
     if (a.ln_x.stats)
         hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, HAS_LNX>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
     else
@@ -742,7 +695,6 @@ static int launch_image(PackedConvArgs a, hipStream_t stream)
     }
     a.n_mt = (a.c_out + G::PBM - 1) / G::PBM;
     a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
-    a.n_major = dense_order_n();
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
     hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, MI>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
@@ -821,12 +773,17 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
         a.w_inv_scale = reinterpret_cast<const float*>(a.wp + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * a.n_groups * pb_group_bytes<P>(mi))
                         + static_cast<size_t>((c_out + PB_M - 1) / PB_M) * PB_M;
     }
-    if (mi == 5) return stride == 1 ? launch_packed_rows160<P, 1>(a, as_stream(stream)) : launch_packed_rows160<P, 2>(a, as_stream(stream));
-    if (mi == 2 || mi == 3) {
-        // 64- / 96-row tiles: more workgroups where a small batch leaves CUs without one (the executor's round count decides)
-        if constexpr (has_image_path<P>() && P::SCALED) {
-            if (mi == 3) return stride == 1 ? launch_image<P, 1, 3>(a, as_stream(stream)) : launch_image<P, 2, 3>(a, as_stream(stream));
-            return stride == 1 ? launch_image<P, 1, 2>(a, as_stream(stream)) : launch_image<P, 2, 2>(a, as_stream(stream));
+    if constexpr (has_image_path<P>() && P::SCALED) {
+        if (x_is_image) {
+            // 160-row tiles where 128 rows leave a mostly empty last row tile or a partial last round of workgroups; 64- / 96-row tiles:
+            // more workgroups where a small batch leaves CUs without one (the executor's round count decides)
+            hipStream_t s = as_stream(stream);
+            switch (mi) {
+                case 5: return stride == 1 ? launch_image<P, 1, 5>(a, s) : launch_image<P, 2, 5>(a, s);
+                case 3: return stride == 1 ? launch_image<P, 1, 3>(a, s) : launch_image<P, 2, 3>(a, s);
+                case 2: return stride == 1 ? launch_image<P, 1, 2>(a, s) : launch_image<P, 2, 2>(a, s);
+                default: return stride == 1 ? launch_image<P, 1, 4>(a, s) : launch_image<P, 2, 4>(a, s);
+            }
         }
     }
     return stride == 1 ? launch_packed<P, 1>(a, as_stream(stream)) : launch_packed<P, 2>(a, as_stream(stream));
