@@ -195,7 +195,7 @@ def main():
             elapsed_strict, out_s = timed(sequential if args.no_pipeline else pipelined)
             worst = float(((out_s.double() - out.double()).abs() / (1e-5 + 1e-4 * out.double().abs())).max())
             strict = {'value': args.batch * world * args.steps / elapsed_strict, 'ms_per_step': 1e3 * elapsed_strict / args.steps,
-                      'worst_err_over_tol_vs_default_path': worst}
+                      'worst_err_over_tol_vs_default_path': worst, 'logits': out_s.detach().clone()}
             if rank == 0 and not args.no_roofline:
                 # the dense convs of THIS leg against the fp32 MFMA peak (v_mfma_f32_32x32x2_f32, no operand splitting)
                 strict['roofline_mfma'] = roofline_leg(model, x, args).get('roofline_mfma')
@@ -238,6 +238,7 @@ def main():
         'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps,
         'p50_forward_ms': p50,
+        'value_b_over_p50': args.batch * world / (1e-3 * p50),          # SURVEY 8(d)'s definition: B / p50 of a single forward
         'value_sequential': args.batch * world * args.steps / elapsed_seq,
         'ms_per_step_sequential': 1e3 * elapsed_seq / args.steps,
         'higher_is_better': True,
@@ -277,8 +278,9 @@ def main():
     parity_failed = False
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # `out` = the logits of the timed steps (the pipelined leg's are asserted bit-equal to them above)
-        result['cpu_baseline'], result['parity'] = cpu_baseline_leg(model, args, x.detach().float().cpu(), out)
-        parity_failed = not result['parity']['ok']
+        result['cpu_baseline'], result['parity'], result['parity_strict_f32'] = cpu_baseline_leg(
+            model, args, x.detach().float().cpu(), out, strict['logits'] if strict else None)
+        parity_failed = not result['parity']['ok'] or not (result['parity_strict_f32'] or {'ok': True})['ok']
     runner.barrier()
     runner.close()
     # RCCL writes its version banner to the C-level stdout buffer, which would otherwise be flushed at exit, AFTER the result:
@@ -422,6 +424,8 @@ def roofline_leg(model, x, args):
             'hbm_GBps': tot_own_bytes / secs / 1e9, 'frac_of_hbm_peak': tot_own_bytes / secs / 1e9 / HBM_PEAK_GBS,
             'TFLOPs': tot_flops / secs / 1e12, 'frac_of_flop_peak': tot_flops / secs / 1e12 / flop_peak_head,
             'traffic': traffic, 'traffic_source': traffic_src,
+            'traffic_source_build': (f'committed PMC capture of the graded kernels at source hash {kernel_source_hash()} (= this build: a capture '
+                                     'on other sources is rejected)') if traffic else None,
             'traffic_GBps': (traffic / (1e3 * tot_ms / launches) / 1e3) if traffic else None,
             'own_bytes_per_launch_avg': tot_own_bytes / launches, 'attainable_us_per_launch_avg': 1e6 * tot_own_s / launches,
             'us_per_launch_avg': 1e3 * tot_ms / launches, 'launches_per_forward': launches // args.steps,
@@ -469,7 +473,7 @@ def roofline_leg(model, x, args):
     return out
 
 
-def cpu_baseline_leg(model, args, x_cpu, got):
+def cpu_baseline_leg(model, args, x_cpu, got, got_strict=None):
     """The CPU oracle (torch-CPU port of the reference's op sequence) on a bounded sample of the same workload -- and, from the same
     oracle runs, the PARITY of the timed workload: `got` = the logits the timed HIP steps produced for `x_cpu`.
 
@@ -506,23 +510,42 @@ def cpu_baseline_leg(model, args, x_cpu, got):
         p64 = {k: v.double() for k, v in params.items()} if dt == torch.float32 else {k: v.float().double() for k, v in params.items()}
         truth = oracle.asr_forward(p64, arch, x_cpu[:n64].float().double(), use_rnn=True, dtype=torch.float64)
     # ---- parity of the timed workload --------------------------------------------------------------------------------------------
-    g, w = got[:sample_b].detach().float().cpu().double(), want.float().double()
-    ratio_all = cases.worst_ratio(g, w, 1e-4, 1e-5)
-    g8, w8, t8 = g[:n64], w[:n64], truth.double()
+    w, t8 = want.float().double(), truth.double()
+    w8 = w[:n64]
     noise = cases.worst_ratio(w8, t8, 1e-4, 1e-5)
-    rms_ratio = cases._rms(g8 - t8) / max(cases._rms(w8 - t8), 1e-300)
-    max_ratio = float((g8 - t8).abs().max()) / max(float((w8 - t8).abs().max()), 1e-300)
-    if args.dtype == 'bf16':
-        leg, ok = 'bf16: rms <= 1.25 x, worst <= 1.5 x the reference bf16 forward (vs fp64)', rms_ratio <= 1.25 and max_ratio <= 1.5
-    elif noise < cases.QUIET:
-        leg, ok = 'quiet: north-star tolerance un-relaxed', cases.worst_ratio(g8, w8, 1e-4, 1e-5) <= 1.0 and ratio_all <= 1.0
-    else:
-        f_rms, f_max = cases.FACTORS['default']
-        leg = f'noisy: rms <= {f_rms} x, worst <= {f_max} x the fp32 reference (vs fp64)'
-        ok = rms_ratio <= f_rms and cases.worst_ratio(g8, t8, 1e-4, 1e-5) <= f_max * noise
-    parity = {'ok': bool(ok), 'leg': leg, 'ratio_vs_oracle': ratio_all, 'utterances_vs_oracle': sample_b,
-              'oracle_noise_vs_fp64': noise, 'rms_ratio': rms_ratio, 'worst_ratio_vs_fp64': max_ratio, 'utterances_vs_fp64': n64,
-              'tolerance': 'north star: |err| <= 1e-5 + 1e-4 |ref| (ratio_vs_oracle, oracle_noise_vs_fp64 in units of it); rule: tests/cases.py::assert_parity'}
+
+    def per_utterance_rms(e):
+        return e.pow(2).mean(dim=(1, 2)).sqrt()
+
+    def parity_of(got_logits, mode):
+        g = got_logits[:sample_b].detach().float().cpu().double()
+        ratio_all = cases.worst_ratio(g, w, 1e-4, 1e-5)
+        g8 = g[:n64]
+        rms_ratio = cases._rms(g8 - t8) / max(cases._rms(w8 - t8), 1e-300)
+        max_ratio = float((g8 - t8).abs().max()) / max(float((w8 - t8).abs().max()), 1e-300)
+        # every utterance gates: only the first 8 have an fp64 truth, so the others are held to the oracle through the
+        # spread the truth-checked ones show -- a tile or batch-index bug at b >= 8 is orders of magnitude, not a factor of two
+        dist = per_utterance_rms(g - w)
+        spread = float(dist.max()) / max(float(dist[:n64].max()), 1e-300)
+        batch_ok = spread <= 2.0
+        if args.dtype == 'bf16':
+            leg, ok = 'bf16: rms <= 1.25 x, worst <= 1.5 x the reference bf16 forward (vs fp64)', rms_ratio <= 1.25 and max_ratio <= 1.5
+        elif noise < cases.QUIET:
+            leg, ok = 'quiet: north-star tolerance un-relaxed', cases.worst_ratio(g8, w8, 1e-4, 1e-5) <= 1.0 and ratio_all <= 1.0
+        else:
+            f_rms, f_max = cases.FACTORS[mode]
+            leg = f'noisy: rms <= {f_rms} x, worst <= {f_max} x the fp32 reference (vs fp64)'
+            ok = rms_ratio <= f_rms and cases.worst_ratio(g8, t8, 1e-4, 1e-5) <= f_max * noise
+        return {'ok': bool(ok and batch_ok), 'leg': leg, 'ratio_vs_oracle': ratio_all, 'utterances_vs_oracle': sample_b,
+                'oracle_noise_vs_fp64': noise, 'rms_ratio': rms_ratio, 'worst_ratio_vs_fp64': max_ratio, 'utterances_vs_fp64': n64,
+                'worst_utterance_distance_to_oracle_over_worst_truth_checked': spread,
+                'whole_batch_rule': 'per-utterance RMS distance to the oracle, every utterance <= 2 x the largest among the fp64-checked ones',
+                'tolerance': 'north star: |err| <= 1e-5 + 1e-4 |ref| (ratio_vs_oracle, oracle_noise_vs_fp64 in units of it); rule: tests/cases.py::assert_parity'}
+
+    parity = parity_of(got, 'default')
+    # the exact-fp32 leg (every GEMM on v_mfma_f32_*_f32, no operand splitting) under the same rule: how far ANY fp32 evaluation in
+    # another summation order sits from the oracle on this workload
+    parity_strict = parity_of(got_strict, 'strict') if got_strict is not None else None
     base = {'value': sample_b / secs, 'unit': 'utterances/s', 'cores': torch.get_num_threads(), 'kind': 'port',
             'batch': sample_b, 'frames': args.frames, 'forwards_timed': 3 + (1 if sample_b != small_b else 0),
             'sample': f'oracle/asr_oracle.py (torch CPU ops, the reference\'s op sequence): 1 warm-up + 3 timed forwards of B={small_b}, T={args.frames} '
@@ -530,7 +553,7 @@ def cpu_baseline_leg(model, args, x_cpu, got):
                                                                       if sample_b != small_b else ' (value)') + f'; os.cpu_count()={os.cpu_count()}',
             'seconds_per_forward': secs, 'value_small_batch': small_b / small, 'small_batch': small_b,
             'seconds_small_batch': small_times}
-    return base, parity
+    return base, parity, parity_strict
 
 
 if __name__ == '__main__':

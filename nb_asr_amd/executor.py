@@ -69,13 +69,22 @@ class PendingLogits:
 
     def __init__(self, logits, event):
         self._logits, self._event = logits, event
+        self._seq = None             # (plan, event behind the status copy, ring slot) when this forward ran the one-launch recurrence
 
     def result(self):
+        """The logits, ordered behind the tail on the caller's current stream (no host wait) -- except for a forward whose LSTM
+        recurrence ran as ONE resident launch (NBASR_LSTM_SEQ=1 in pipelined mode): that launch can time out when another process
+        takes its compute units, so ``result()`` then waits for ITS status word and raises ``HipError`` instead of handing out the
+        NaN rows.  A plain ``model(x)`` returns a tensor, not a handle: it can only report at the next call or
+        through ``model.check()``."""
         if self._event is not None:
             cur = torch.cuda.current_stream(self._logits.device)
             cur.wait_event(self._event)
             self._logits.record_stream(cur)
             self._event = None
+        if self._seq is not None:
+            (plan, ev, slot), self._seq = self._seq, None
+            plan.check_seq_slot(ev, slot)
         return self._logits
 
 
@@ -226,6 +235,7 @@ class ForwardPlan:
             raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', '0' or '1'")
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
+        self._seq_last = None        # (event, slot) of the status copy the forward being enqueued has just added
         self._seq_flags = hip.LSTM_SEQ_INJECT_FAULT if os.environ.get('NBASR_LSTM_SEQ_FAULT') == '1' else 0     # tests: force a timeout
         # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_F32_VARIANT=<bits> forces one (0: the
         # default kernel everywhere)
@@ -269,15 +279,19 @@ class ForwardPlan:
         if not capturing and torch.cuda.is_current_stream_capturing():       # a caller's own torch.cuda.graph(...) around model(x)
             capturing = True
         use = self.lstm_seq_mode != '0' and not capturing and (self.lstm_seq_mode == '1' or not pipe)
-        nbytes = hip.load_library().nbasr_lstm_seq_workspace_bytes(self.batch, hidden) if use else 0
+        nbytes = hip.lstm_seq_workspace_bytes(self.batch, hidden, self.device) if use else 0
         if nbytes:
             ws = self._buf('lstm_seq', nbytes, torch.uint8)
             try:
                 out = hip.lstm_recurrence_seq(gates, packed_hh, self.cell_ws, self.h_out, ws, self._seq_flags)
-            except hip.HipError:
-                # the device refused the cooperative grid (a partition / CU mask smaller than the occupancy query said): per-frame from now on
+            except hip.HipError as e:
+                # ONLY the device refusing the cooperative grid (a partition / CU mask smaller than the occupancy query said) demotes the
+                # plan to per-frame launches; an argument, alignment or capture error is the caller's to see
+                if 'cooperative launch' not in str(e):
+                    raise
                 self.lstm_seq_mode = '0'
                 self._tapes.clear()
+                self._mutations += 1          # a tape being recorded right now holds the refused launch: it must not be kept
                 return hip.lstm_recurrence_packed(gates, packed_hh, self.cell_ws, self.h_out)
             self._host(lambda: self._seq_status_readback(ws))
             return out
@@ -302,6 +316,7 @@ class ForwardPlan:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._seq_pending.append((ev, slot))
+        self._seq_last = (ev, slot)
 
     _SEQ_RING = 256
 
@@ -326,6 +341,21 @@ class ForwardPlan:
             raise hip.HipError('the one-launch LSTM recurrence of an EARLIER forward timed out waiting for its peer workgroups (the grid was '
                                'not co-resident: compute units taken by another process or stream); that forward\'s logits are invalid. '
                                'The plan now uses one launch per frame (as NBASR_LSTM_SEQ=0): run the forward again')
+
+    def check_seq_slot(self, ev, slot):
+        """Wait for ONE one-launch recurrence (the status copy behind it) and raise if it timed out: what ``PendingLogits.result()``
+        does for the forward it belongs to."""
+        ev.synchronize()
+        try:
+            self._seq_pending.remove((ev, slot))              # reported here, not again at the next forward
+        except ValueError:
+            return                                             # check_seq has looked at it already (and raised if it had to)
+        if int(self._seq_host[slot]) != 0:
+            self.lstm_seq_mode = '0'
+            self._tapes.clear()
+            raise hip.HipError('the one-launch LSTM recurrence of THIS forward timed out waiting for its peer workgroups (the grid was not '
+                               'co-resident: compute units taken by another process or stream); its logits are invalid. The plan now '
+                               'uses one launch per frame (as NBASR_LSTM_SEQ=0): run the forward again')
 
     def wait_tails(self):
         """Make the current stream wait for every pipelined LSTM tail enqueued through this plan (a plain
@@ -564,6 +594,7 @@ class ForwardPlan:
             for _ in range(2):                                # static initialisers, packed weights, workspace growth
                 self.run(model, x_static)
             torch.cuda.synchronize(self.device)
+            self.check_seq(wait=True)                         # (the warm-up forwards may have run the one-launch recurrence; the capture never does)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 y_static = self.run(model, x_static, _capturing=True)
@@ -679,6 +710,14 @@ class ForwardPlan:
         return tuple(fp)
 
     def run(self, model, x, taps=None, pipelined=False, _capturing=False):
+        """``_enqueue`` + the hand-over of a one-launch recurrence's status slot to the handle a pipelined forward returns."""
+        self._seq_last = None
+        out = self._enqueue(model, x, taps, pipelined, _capturing)
+        if self._seq_last is not None and isinstance(out, PendingLogits):
+            out._seq = (self,) + self._seq_last
+        return out
+
+    def _enqueue(self, model, x, taps=None, pipelined=False, _capturing=False):
         """Enqueue one forward of ``model`` (its parameters are read now, so a DataParallel replica runs with its own).
         ``taps`` (a dict) receives a copy of every layer's output, keyed by the layer's index in ``model.model``, in the
         oracle's layouts ((B,C,T) for encoder layers and the LSTM).  ``pipelined``: LSTM + head go to the side stream and
@@ -1219,6 +1258,16 @@ class PlanPool:
     def release(self, plan):
         with self._lock:
             self._idle.setdefault(plan.device.index, []).append(plan)
+
+    def poll(self, device):
+        """Look (without waiting) at the status words of the one-launch recurrences enqueued through EVERY idle plan of ``device`` and
+        raise for a finished one that timed out: with several plans per device (concurrent callers) the failing plan may not be the
+        one the next forward is handed."""
+        device = torch.device(device)
+        with self._lock:
+            for plan in self._idle.get(device.index, ()):
+                if plan._seq_pending:
+                    plan.check_seq()
 
     def values(self):
         """Idle plans, most recently used last (bench.py / tests read the last run's bookkeeping from them)."""

@@ -125,7 +125,9 @@ GC_FPL8, GC_WPERM, GC_OSPLIT, GC_PIPE, GC_RING = 1, 2, 4, 8, 16         # NBASR_
 
 
 class HipError(RuntimeError):
-    pass
+    """``code``: the entry point's return value (a negative NBASR_E* argument error or a positive hipError_t), None for errors raised
+    on the python side."""
+    code = None
 
 
 
@@ -197,7 +199,9 @@ def build_id():
 def _check(rc, what):
     if rc != 0:
         msg = load_library().nbasr_last_error().decode('utf-8', 'replace')
-        raise HipError(f'{what} failed with code {rc}: {msg}')
+        err = HipError(f'{what} failed with code {rc}: {msg}')
+        err.code = int(rc)
+        raise err
 
 
 def _stream(t):
@@ -560,7 +564,7 @@ def lstm_recurrence_packed(gates_ws, packed_whh, cell_ws, h_out):
 
 def lstm_seq_workspace(batch, hidden, device):
     """Workspace of the one-launch recurrence (flags + the exchange images of h), or None where that form does not apply."""
-    nbytes = load_library().nbasr_lstm_seq_workspace_bytes(int(batch), int(hidden))
+    nbytes = lstm_seq_workspace_bytes(int(batch), int(hidden), device)
     return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
 
 
@@ -574,13 +578,20 @@ def lstm_recurrence_seq(gates_ws, packed_whh, cell_ws, h_out, seq_ws, flags=0):
     lib = load_library()
     if not packed_whh.is_cuda or packed_whh.dtype != torch.uint8 or packed_whh.numel() != lib.nbasr_lstm_packed_whh_bytes(hidden):
         raise HipError('packed_whh must be the uint8 device tensor returned by lstm_pack_whh for this hidden size')
-    need = lib.nbasr_lstm_seq_workspace_bytes(b, hidden)
+    need = lstm_seq_workspace_bytes(b, hidden, h_out.device)
     if need == 0 or seq_ws is None or not seq_ws.is_cuda or seq_ws.dtype != torch.uint8 or seq_ws.numel() < need:
         raise HipError(f'lstm_recurrence_seq: batch={b} hidden={hidden} needs a uint8 device workspace of {need} bytes from lstm_seq_workspace '
                        '(0 = this form does not apply)')
     _check(lib.nbasr_lstm_recurrence_seq(_dev(gates_ws, 'gates_ws'), packed_whh.data_ptr(), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
                                          seq_ws.data_ptr(), b, frames, hidden, int(flags), _stream(h_out)), 'nbasr_lstm_recurrence_seq')
     return h_out
+
+
+def lstm_seq_workspace_bytes(batch, hidden, device):
+    """Workspace of the one-launch recurrence on ``device`` (0: that form does not apply there).  The answer depends on how many
+    workgroups THAT device holds at once, and the C query asks the current device: it runs with ``device`` current."""
+    with torch.cuda.device(device):
+        return load_library().nbasr_lstm_seq_workspace_bytes(batch, hidden)
 
 
 def lstm_seq_status(seq_ws):

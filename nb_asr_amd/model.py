@@ -147,7 +147,14 @@ class ASRModel(nn.Module):
         return self.forward(input, _pipelined=True)
 
     def forward(self, input, _taps=None, _pipelined=False):
-        """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1)."""
+        """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1).
+
+        Error reporting of the one-launch LSTM recurrence (a resident cooperative grid; it can time out when ANOTHER process or
+        stream takes its compute units): the work is enqueued, not waited for, so a plain ``model(x)`` has already returned its
+        tensor when the launch fails -- that tensor then holds NaN rows (never quiet garbage), and ``HipError`` is raised by the
+        NEXT forward on this device (every idle plan's status words are polled), by ``model.check()`` (waits), or -- for the handle
+        of ``forward_async`` -- by that handle's own ``result()``.  A serving loop that must not consume a failed forward calls
+        ``check()`` before using the logits, or uses ``forward_async(x).result()``."""
         if not isinstance(input, torch.Tensor) or input.dim() != 3 or input.shape[1] != FEATURES:
             raise ValueError(f'expected a (batch, {FEATURES}, frames) tensor, got {tuple(getattr(input, "shape", ()))}')
         if not input.is_cuda:
@@ -175,6 +182,8 @@ class ASRModel(nn.Module):
         _check_dropout(self)                         # the fused inference executor has no dropout masks: eval() or p == 0
         # one plan per device, re-used for every batch shape (grow-only workspaces); a second plan only comes into being
         # when two threads are inside forward() on the same device at once
+        if not torch.cuda.is_current_stream_capturing():
+            self._plans.poll(input.device)
         plan = self._plans.acquire(input.device)
         try:
             return plan.run(self, input, _taps, _pipelined)

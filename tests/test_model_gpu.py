@@ -873,6 +873,22 @@ def test_one_launch_recurrence_that_loses_its_peers_raises_and_falls_back(monkey
             m.check()
         # (had the failed forward finished before the second call looked -- a second of device time -- that call itself would have raised)
         assert (fine is None or torch.equal(fine, want)) and torch.equal(m(x), want)
+        # a HANDLE checks its own launch -- `result()` of the failing pipelined forward itself raises (a plain model(x)
+        # returns a tensor and can only report at the next call / through check(), as above)
+        monkeypatch.setenv('NBASR_LSTM_SEQ', '1')                   # the one-launch form in pipelined mode too
+        m._plans.clear()
+        handle = m.forward_async(x)                                 # fails on the device; nothing has looked yet
+        with pytest.raises(hip.HipError, match='THIS forward timed out|of THIS forward'):
+            handle.result()
+        plan = m._plans.values()[-1]
+        assert plan.lstm_seq_mode == '0'
+        m.check()                                                   # reported once, by the handle
+        assert torch.equal(m.forward_async(x).result(), want)       # the retry runs one launch per frame
+        # a healthy one-launch forward: result() waits for its status word and returns the logits
+        monkeypatch.delenv('NBASR_LSTM_SEQ_FAULT')
+        m._plans.clear()
+        assert torch.equal(m.forward_async(x).result(), want)
+        assert m._plans.values()[-1].lstm_seq_mode == '1'
 
 
 def test_one_launch_recurrence_beside_a_stream_that_hogs_the_chip():
