@@ -130,7 +130,16 @@ int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
  * EXTREME when it holds a non-finite sample or a frame more than 2^12 below its loudest sample: the scaled fp16 scheme would then
  * lose precision in (or, for Inf, flush) the quiet part.  The two schemes are launched back to back on the same output with the same
  * x_range: NBASR_DENSE_F16X2 computes the ordinary utterances (scale from range[4 b]) and skips the extreme ones,
- * NBASR_DENSE_BF16X3 computes exactly those.  No host synchronisation. */
+ * NBASR_DENSE_BF16X3 computes exactly those.  No host synchronisation.
+ *
+ * stats_part (may be NULL; fp32 schemes, no skips; ABI 5): the launch also emits the partial LayerNorm statistics of y from its own
+ * epilogue -- per frame the (mean, M2) over every 16 output channels, part[16-channel unit][batch][2][ld_out] floats (16-byte aligned,
+ * NBASR_DENSE_STATS_UNIT = 16; ceil(c_out / 16) * batch * 2 * ld_out floats) -- which nbasr_grouped_stats_finalize(stats_part, stats,
+ * batch, c_out, frames_out, ld_out, groups = c_out, groups_per_part = 16, eps) merges into (mean, rstd) rows: what nbasr_channel_stats(y)
+ * computes in a pass of its own over y (model.py:92, 125-128: the block LayerNorm behind every downsample convolution).  The unit does
+ * not depend on row_tile: the statistics are the same arithmetic whatever tile the launch runs with.  With x_range routing both
+ * launches take the same stats_part (each writes the utterances it computes). */
+#define NBASR_DENSE_STATS_UNIT 16
 #define NBASR_DENSE_BF16X3 0
 #define NBASR_DENSE_F16X2 1
 #define NBASR_DENSE_BF16 2
@@ -141,7 +150,7 @@ int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_image, const f
                               const void* packed_w, const float* bias,
                               const float* skip0, const float* skip1, const float* skip2, void* y,
                               int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                              int row_tile, const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+                              int row_tile, const nbasr_deferred_ln* ln, float* stats_part, nbasr_stream_t stream);
 int nbasr_input_range(const float* x, float* range, int batch, int channels, int frames, int ld, nbasr_stream_t stream);
 
 /* The operand images of the fp16 scheme.  nbasr_layernorm_split_image normalises x (batch, channels, ld) and writes it as the
@@ -220,7 +229,8 @@ int nbasr_channel_stats(const void* x, float* stats, int batch, int channels, in
 /* LayerNorm statistics of a node's output from the convolution's own epilogue (what nbasr_channel_stats(y) would give):
  * workgroups write per-part partial (mean, M2) to stats_ws (nbasr_grouped_stats_workspace_bytes), nbasr_grouped_stats_finalize
  * merges them into stats_out (batch, 2, ld).  A part covers `groups_per_part` groups: 4 (nbasr_grouped_conv1d_node,
- * nbasr_grouped_cell_fused on rows of one wave), 2 or 1 (the value nbasr_grouped_cell_fits returns for the shape; <= 128 parts). */
+ * nbasr_grouped_cell_fused on rows of one wave), 2 or 1 (the value nbasr_grouped_cell_fits returns for the shape), or -- for the partials
+ * of nbasr_dense_conv1d_packed(stats_part), whose "groups" are single channels -- NBASR_DENSE_STATS_UNIT; <= 128 parts either way. */
 size_t nbasr_grouped_stats_workspace_bytes(int batch, int ld, int groups);
 int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_out, int batch, int channels, int frames, int ld,
                                  int groups, int groups_per_part, float eps, nbasr_stream_t stream);

@@ -160,6 +160,8 @@ struct PackedConvArgs {
     const float* x_range;
     int sel_want;
     int staged_epilogue;         // fp32 output through LDS in whole row segments (always 1; the direct stores were 1.2 % slower end to end)
+    float* part;                 // fp32 output, no skips: also emit the partial LayerNorm statistics of y -- per frame the (mean, M2) over every
+                                 // 16 channels -- to part[16-channel unit][batch][2][ld_out] (merged by stats_finalize_kernel); NULL: none
 };
 
 // an utterance the scaled fp16 scheme must not take: non-finite samples, or a frame > 2^12 below the loudest sample (the unscaled
@@ -583,6 +585,14 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         static_assert(8 * 32 * TS * 4 <= G::LDS_BYTES, "output staging must fit the operand buffers");
         if (!wave_active) return;
         const int nc = n0 + wn * 64 + (lane & 15) * 4;
+        // Statistics by-product (round 5; a.part != NULL): per frame the (mean, M2) over each 16-ROW UNIT of the output -- one MFMA row
+        // tile, 16 channels aligned to 16 -- written to part[unit][batch][2][ld_out]; stats_finalize_kernel merges the units in ascending
+        // order.  The unit, not the workgroup's row tile, is the granule: its sums are the same arithmetic whatever row tile (64 ... 160,
+        // chosen per batch size) the launch runs with, so the statistics -- like y -- do not depend on the batch an utterance sits in.
+        // A lane takes ONE frame of the staged tile and walks down its column (ds_read_b32, consecutive lanes on consecutive banks):
+        // shifted sums n, S1 = sum (v - c), S2 = sum (v - c)^2 with c = the unit's first row, so nothing cancels; no cross-lane step.
+        const bool want_stats = a.part != nullptr;          // (kernel-uniform)
+        const int ncol = n0 + wn * 64 + lane;               // this lane's frame in the statistics pass
 #pragma unroll
         for (int i0 = 0; i0 < MI; i0 += 2) {
 #pragma unroll
@@ -614,6 +624,28 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                 if (ml < rows_pass && m < a.c_out && nc < a.ld_out) {
                     const floatx4 t = *reinterpret_cast<const floatx4*>(T + ml * TS + (lane & 15) * 4);
                     *reinterpret_cast<floatx4*>(a.y + (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + nc) = t;
+                }
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int mu = m0 + wm * WROWS + (i0 + u) * 16;          // the unit's first channel (a multiple of 16)
+                    if (i0 + u >= MI || mu >= a.c_out) break;                // (wave-uniform)
+                    const int nrows = min(16, a.c_out - mu);
+                    const float c = T[(u * 16) * TS + lane];
+                    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) {
+                        const float d = (r < nrows) ? T[(u * 16 + r) * TS + lane] - c : 0.f;
+                        s1 += d;
+                        s2 = __builtin_fmaf(d, d, s2);
+                    }
+                    if (ncol < a.ld_out) {
+                        const float inv = 1.0f / static_cast<float>(nrows);
+                        float* prow = a.part + (static_cast<size_t>(mu >> 4) * a.batch + b) * 2 * a.ld_out + ncol;
+                        prow[0] = c + s1 * inv;
+                        prow[a.ld_out] = s2 - s1 * s1 * inv;
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next pass overwrites the tile
@@ -739,7 +771,7 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
                              const float* skip1, const float* skip2, float* y, int batch, int c_in,
                              int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
                              const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream, bool x_is_image = false,
-                             int row_tile = 128, const float* x_range = nullptr, int sel_want = -1)
+                             int row_tile = 128, const float* x_range = nullptr, int sel_want = -1, float* stats_part = nullptr)
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
@@ -766,6 +798,9 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
     a.x_range = x_range;
     a.sel_want = x_range ? sel_want : -1;
     a.staged_epilogue = 1;
+    NBASR_REQUIRE(!stats_part || (!skip0 && !skip1 && !skip2 && aligned16(stats_part)), NBASR_EINVAL,
+                  "%s: the statistics by-product exists for the skip-free convolution only (stats_part 16-byte aligned)", P::NAME);
+    a.part = stats_part;
     if (P::SCALED) {
         NBASR_REQUIRE(x_absmax || x_range, NBASR_ENULL, "%s: x_absmax (per-utterance bound of |x|) must be non-NULL", P::NAME);
         a.x_absmax = x_absmax;
@@ -858,7 +893,7 @@ extern "C" int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_ima
                                          const void* packed_w, const float* bias, const float* skip0, const float* skip1,
                                          const float* skip2, void* y, int batch, int c_in, int frames_in, int ld_in, int c_out,
                                          int ld_out, int kernel, int stride, int row_tile, const nbasr_deferred_ln* ln,
-                                         nbasr_stream_t stream)
+                                         float* stats_part, nbasr_stream_t stream)
 {
     clear_error();
     const float* xf = static_cast<const float*>(x);
@@ -869,16 +904,16 @@ extern "C" int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_ima
             NBASR_REQUIRE(!image && !x_absmax, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the bf16x3 scheme reads a plain fp32 tensor and takes no bound");
             // with x_range: only the EXTREME utterances (the fp16 leg computes the others on the same output)
             return dense_packed_impl<SplitBf16x3>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                                  kernel, stride, ln, nullptr, stream, false, row_tile, x_range, 1);
+                                                  kernel, stride, ln, nullptr, stream, false, row_tile, x_range, 1, stats_part);
         case NBASR_DENSE_F16X2:
             NBASR_REQUIRE(!ln, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the fp16x2 scheme takes no pending LayerNorm (nbasr_layernorm_split_image writes its operand)");
             NBASR_REQUIRE(!(image && (skip0 || skip1 || skip2)), NBASR_EINVAL, "nbasr_dense_conv1d_packed: the image path takes no skips");
             NBASR_REQUIRE(!(x_absmax && x_range), NBASR_EINVAL, "nbasr_dense_conv1d_packed: give x_absmax or x_range, not both");
             return dense_packed_impl<SplitF16x2>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                                 kernel, stride, nullptr, x_absmax, stream, image, row_tile, x_range, 0);
+                                                 kernel, stride, nullptr, x_absmax, stream, image, row_tile, x_range, 0, stats_part);
         case NBASR_DENSE_BF16:
-            NBASR_REQUIRE(image && !x_absmax && !x_range && !ln && !skip0 && !skip1 && !skip2, NBASR_EINVAL,
-                          "nbasr_dense_conv1d_packed: the bf16 scheme reads nbasr_bf16_image's operand image only (no bound, range, LayerNorm or skips)");
+            NBASR_REQUIRE(image && !x_absmax && !x_range && !ln && !skip0 && !skip1 && !skip2 && !stats_part, NBASR_EINVAL,
+                          "nbasr_dense_conv1d_packed: the bf16 scheme reads nbasr_bf16_image's operand image only (no bound, range, LayerNorm, skips or statistics)");
             return dense_bf16_image_impl(x, packed_w, bias, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, stream);
         default: break;
     }

@@ -446,7 +446,7 @@ extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_
     clear_error();
     NBASR_REQUIRE(batch >= 0 && channels > 0 && groups > 0 && channels % groups == 0 && frames >= 0 && ld >= frames, NBASR_EINVAL,
                   "nbasr_grouped_stats_finalize: bad sizes");
-    NBASR_REQUIRE(groups_per_part == 4 || groups_per_part == 2 || groups_per_part == 1, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4, 2 or 1)", groups_per_part);
+    NBASR_REQUIRE(groups_per_part >= 1, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4, 2 or 1 for grouped convolutions, the row tile for a dense one)", groups_per_part);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
     NBASR_REQUIRE((groups + groups_per_part - 1) / groups_per_part <= SF_LANES * SF_MAX_PER_LANE, NBASR_EINVAL,

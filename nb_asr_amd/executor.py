@@ -184,7 +184,7 @@ def _warn_removed_switches():
         import warnings
         notes = '; '.join(f'{k} ({_REMOVED_SWITCHES[k]})' if _REMOVED_SWITCHES[k] else k for k in stale)
         warnings.warn(f'nb_asr_amd: these environment switches were removed and are IGNORED: {notes}.  The current ones: NBASR_DENSE_MODE, '
-                      f'NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_LSTM_SEQ, NBASR_TAPE (DESIGN.md 5)', stacklevel=3)
+                      f'NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_LSTM_SEQ, NBASR_TAPE, NBASR_CONV_STATS (DESIGN.md 5)', stacklevel=3)
 
 
 class ForwardPlan:
@@ -214,7 +214,7 @@ class ForwardPlan:
             raise ValueError(f'NBASR_LINEAR_MODE must be f16x2 or f32, got {self.linear_mode!r}')
         # (round 3: the A/B switches of rounds 1-2 whose alternatives lost everywhere are gone -- NBASR_IMAGE_MODE, NBASR_ROW_TILE,
         # NBASR_LN_MODE, NBASR_EPILOGUE_STATS, NBASR_LSTM_UNPACKED, NBASR_GC_TABLE, NBASR_GC_BF16_VARIANT, NBASR_GC_BF16_MFMA; what is
-        # left: NBASR_DENSE_MODE (also read by autograd.py), NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_LSTM_SEQ, NBASR_TAPE)
+        # left: NBASR_DENSE_MODE (also read by autograd.py), NBASR_LINEAR_MODE, NBASR_CELL_FUSION, NBASR_GC_F32_VARIANT, NBASR_LSTM_SEQ, NBASR_TAPE, NBASR_CONV_STATS)
         self._act_image = None
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
@@ -236,6 +236,9 @@ class ForwardPlan:
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
         self._seq_last = None        # (event, slot) of the status copy the forward being enqueued has just added
+        # statistics of a downsample convolution's output from its own epilogue (round 5); NBASR_CONV_STATS=0: a pass over the output
+        self.conv_stats = os.environ.get('NBASR_CONV_STATS', '1') != '0'
+        self._conv_part = None       # partials the dense convolution just enqueued left for the LayerNorm behind it
         self._seq_flags = hip.LSTM_SEQ_INJECT_FAULT if os.environ.get('NBASR_LSTM_SEQ_FAULT') == '1' else 0     # tests: force a timeout
         # fp32 node kernel variant per launch from the measured table (_gc_variant); NBASR_GC_F32_VARIANT=<bits> forces one (0: the
         # default kernel everywhere)
@@ -473,16 +476,26 @@ class ForwardPlan:
         need = hip.load_library().nbasr_pointwise_workspace_bytes(self.batch, c_in, ld)
         return self._buf('pointwise_ws', max(need, 16), torch.uint8)
 
-    def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None, image=None):
+    def _dense_part(self, c_out, ld_out):
+        """Workspace for the statistics partials a dense convolution emits from its epilogue (one row pair per 16 channels)."""
+        n = hip.dense_stats_part_floats(self.batch, c_out, ld_out)
+        return self._buf('dense_part', n)[:n]
+
+    def _dense(self, layer, act, act_frames, out, ln, absmax=None, blk=None, image=None, want_stats=False):
         """``absmax``: (B,) device bounds of max|act[b]| when `act` was just written by the LayerNorm kernel, else None.
-        ``image`` = (image, bound): the LayerNorm of `act` was written as the pre-split operand image instead."""
+        ``image`` = (image, bound): the LayerNorm of `act` was written as the pre-split operand image instead.
+        ``want_stats``: the block LayerNorm behind this convolution is deferred -- the image-path kernel then emits its statistics
+        partials itself (``self._conv_part``; merged in ``_norm``) instead of a statistics pass over the output."""
         if image is not None:
             self.dense_schemes[blk] = 'f16x2-image'
             b, c, ld = act.shape
             rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, (act_frames + layer.strides - 1) // layer.strides)
+            part = None
+            if want_stats:
+                part = self._conv_part = self._dense_part(layer.conv.out_channels, out.shape[2])
             return hip.dense_conv1d_fused_packed_f16_img(image[0], image[1], b, c, act_frames, ld,
                                                          self._packed_weights(layer, 'f16x2', rows), layer.conv.out_channels,
-                                                         layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, rows)
+                                                         layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, rows, part)
         if self.dense_mode != 'f32' and layer.kernel_size == 8:
             scheme = 'f16x2' if self.dense_mode == 'auto' and absmax is not None and ln is None else 'bf16x3'
             self.dense_schemes[blk] = scheme
@@ -533,7 +546,13 @@ class ForwardPlan:
         self._stat_turn ^= 1
         b, _, ld = act.shape
         stats = self.stats[self._stat_turn][: b * 2 * ld].view(b, 2, ld)
-        self._timed('channel_stats', kind_meta, lambda: hip.channel_stats(act, stats, act_frames, norm.eps))
+        conv_part, self._conv_part = self._conv_part, None
+        if conv_part is not None:
+            # the convolution that wrote `act` left per-row-tile partials: merge them (a few rows per utterance) -- no pass over `act`
+            c = act.shape[1]
+            self._timed('stats_finalize', kind_meta, lambda: hip.grouped_stats_finalize(conv_part, stats, c, act_frames, c, norm.eps, hip.DENSE_STATS_UNIT))
+        else:
+            self._timed('channel_stats', kind_meta, lambda: hip.channel_stats(act, stats, act_frames, norm.eps))
         if taps is not None:                         # parity debugging: materialise a copy, the flow stays deferred
             copy = torch.empty_like(act)
             hip.layernorm_channels(act, norm.weight.detach(), norm.bias.detach(), copy, act_frames, norm.eps)
@@ -800,6 +819,13 @@ class ForwardPlan:
                 out = self._view(dst, layer.conv.out_channels, t_out)
                 ln, src, src_frames, amax, blk_now, img = pending, act, act_frames, self._act_absmax, blk, self._act_image
                 meta = (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0)
+                # the block LayerNorm behind this convolution is deferred into the next cell's load: its statistics then come out of
+                # the convolution's own epilogue (round 5) instead of a pass over the output
+                nxt1 = model.model[idx + 1] if idx + 1 < n_layers else None
+                nxt2 = model.model[idx + 2] if idx + 2 < n_layers else None
+                want_stats = (taps is None and self.conv_stats and isinstance(nxt1, nn.LayerNorm) and self._cheap_consumer(nxt2)
+                              and layer.kernel_size == 8)
+                self._conv_part = None
                 if input_range is not None and layer.kernel_size == 8 and ln is None and img is None:
                     rng, input_range = input_range, None
                     # fp16 split with per-utterance fall-back to bf16x3 (extreme / non-finite input); image path: one split
@@ -809,12 +835,15 @@ class ForwardPlan:
                     rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out)
                     self.dense_schemes[blk] = 'f16x2' if image is None else 'f16x2-image'
                     w16 = self._packed_weights(layer, 'f16x2', rows) if image is not None else self._packed_weights(layer, 'f16x2')
+                    part = None
+                    if want_stats:                         # (both legs -- fp16 image, bf16x3 for extreme utterances -- write their utterances' partials)
+                        part = self._conv_part = self._dense_part(layer.conv.out_channels, out.shape[2])
                     self._timed('dense_conv', meta, lambda: hip.dense_conv1d_first_ranged(
                         src, src_frames, rng, w16, self._packed_weights(layer, 'bf16x3'),
-                        layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, image, rows))
+                        layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, image, rows, part))
                 else:
                     input_range = None
-                    self._timed('dense_conv', meta, lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now, img))
+                    self._timed('dense_conv', meta, lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now, img, want_stats))
                 act, act_frames, cur, pending, self._act_absmax, self._act_image = out, t_out, dst, None, None, None
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)

@@ -57,7 +57,7 @@ SIGNATURES = {
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 5),
     'nbasr_pack_dense_weights': (_c_int, [_c_int] + [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
-    'nbasr_dense_conv1d_packed': (_c_int, [_c_int, _c_float_p, _c_int] + [_c_float_p] * 8 + [_c_int] * 9 + [_c_ln_p, _c_stream]),
+    'nbasr_dense_conv1d_packed': (_c_int, [_c_int, _c_float_p, _c_int] + [_c_float_p] * 8 + [_c_int] * 9 + [_c_ln_p, _c_float_p, _c_stream]),
     'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_split_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_layernorm_split_image': (_c_int, [_c_float_p] * 6 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
@@ -407,13 +407,14 @@ def layernorm_split_image(x, gamma, beta, stats, bound, image, frames, eps):
 
 
 def dense_conv1d_fused_packed_f16_img(image, bound, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride,
-                                      row_tile=128):
-    """The fp16x2 convolution on the pre-split operand image (layernorm_split_image): LDS-DMA-only GEMM."""
+                                      row_tile=128, stats_part=None):
+    """The fp16x2 convolution on the pre-split operand image (layernorm_split_image): LDS-DMA-only GEMM.  ``stats_part``: also emit
+    the partial LayerNorm statistics of y (dense_stats_part_floats)."""
     _check_packed(packed, 'f16x2', c_out, c_in, kernel, row_tile)
     if image.numel() < load_library().nbasr_split_image_bytes(batch, c_in, ld_in):
         raise HipError('image buffer too small for (batch, c_in, ld_in)')
     return _dense_packed('f16x2', image.data_ptr(), True, bound, None, packed, bias, (None, None, None), y, _dev(y, 'y'), batch, c_in,
-                         frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y))
+                         frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y), stats_part)
 
 
 def input_range(x, frames, out):
@@ -425,7 +426,8 @@ def input_range(x, frames, out):
     return out
 
 
-def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride, image=None, row_tile=128):
+def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride, image=None, row_tile=128,
+                              stats_part=None):
     """The model's first dense conv with per-utterance routing on the device: ordinary utterances on the 2-way fp16 split,
     extreme ones (non-finite samples, > 2^12 dynamic range between frames) on the 3-way bf16 split; same output tensor.
     ``image``: uint8 workspace of ``nbasr_split_image_bytes`` -- the fp16 leg then runs on the image path (one split pass over
@@ -440,13 +442,14 @@ def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, 
             raise HipError('dense_conv1d_first_ranged: image workspace too small (nbasr_split_image_bytes)')
         _check(lib.nbasr_split_image_ranged(_dev(x, 'x'), _dev(x_range, 'x_range'), image.data_ptr(), b, c_in, frames_in, ld_in, stream),
                'nbasr_split_image_ranged')
+    if image is not None:
         _dense_packed('f16x2', image.data_ptr(), True, None, x_range, packed_f16, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in, ld_in,
-                      c_out, kernel, stride, row_tile, None, stream)
+                      c_out, kernel, stride, row_tile, None, stream, stats_part)
     else:
         _dense_packed('f16x2', _dev(x, 'x'), False, None, x_range, packed_f16, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in, ld_in,
-                      c_out, kernel, stride, 128, None, stream)
+                      c_out, kernel, stride, 128, None, stream, stats_part)
     return _dense_packed('bf16x3', _dev(x, 'x'), False, None, x_range, packed_bf16x3, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in,
-                         ld_in, c_out, kernel, stride, 128, None, stream)
+                         ld_in, c_out, kernel, stride, 128, None, stream, stats_part)
 
 
 def dense_conv1d_fused(x, frames_in, weight, bias, skips, y, stride, ln=None, ln_on_x=False, ln_on_skip0=False):
@@ -494,13 +497,24 @@ def pack_dense_weights(weight, stride, scheme='bf16x3', row_tile=128):
 
 
 def _dense_packed(scheme, x_ptr, image, x_absmax, x_range, packed, bias, s, y, y_ptr, b, c_in, frames_in, ld_in, c_out, kernel, stride,
-                  row_tile, ln, stream):
+                  row_tile, ln, stream, stats_part=None):
     """The one C entry point of the packed k = 8 convolution (nbasr.h: nbasr_dense_conv1d_packed)."""
+    if stats_part is not None and stats_part.numel() < dense_stats_part_floats(b, c_out, y.shape[2]):
+        raise HipError('stats_part too small: ceil(c_out / 16) * batch * 2 * ld_out floats (dense_stats_part_floats)')
     _check(load_library().nbasr_dense_conv1d_packed(
         _scheme_code(scheme), x_ptr, int(image), _opt(x_absmax, 'x_absmax'), _opt(x_range, 'x_range'), packed.data_ptr(),
         _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'), y_ptr, b, c_in, frames_in, ld_in, c_out,
-        y.shape[2], kernel, stride, row_tile, _ln(ln), stream), 'nbasr_dense_conv1d_packed')
+        y.shape[2], kernel, stride, row_tile, _ln(ln), _opt(stats_part, 'stats_part'), stream), 'nbasr_dense_conv1d_packed')
     return y
+
+
+DENSE_STATS_UNIT = 16         # nbasr.h: NBASR_DENSE_STATS_UNIT
+
+
+def dense_stats_part_floats(batch, c_out, ld_out):
+    """Floats of the statistics partials a dense convolution emits with ``stats_part``: one (mean, M2) row pair per 16 output channels
+    (merge: grouped_stats_finalize(part, stats, c_out, frames_out, c_out, eps, DENSE_STATS_UNIT))."""
+    return -(-c_out // DENSE_STATS_UNIT) * batch * 2 * ld_out
 
 
 def _check_packed(packed, scheme, c_out, c_in, kernel, row_tile=128):

@@ -917,6 +917,32 @@ def test_one_launch_recurrence_beside_a_stream_that_hogs_the_chip():
         torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize('arch,b,t', [(cases.ARCH_D, 3, 515), (cases.ARCH_D, 70, 250), ([[2, 0], [4, 1, 0], [1, 0, 1, 1]], 2, 1024)])
+def test_block_layernorm_statistics_from_the_convolution(monkeypatch, arch, b, t):
+    """Round 5: the statistics of a block LayerNorm whose consumer normalises on load come out of the downsample convolution's own
+    epilogue (NBASR_CONV_STATS=1, the default: per-row-tile partials + the merge kernel); NBASR_CONV_STATS=0 runs the statistics pass
+    over the convolution's output as rounds 1-4 did.  Same statistics to rounding -- the logits agree far inside the tolerance -- and the
+    default forward launches no channel_stats kernel behind a convolution."""
+    from nb_asr_amd import hip
+    m = build(arch, True, 'lively', seed=7)
+    x = keyed_input(b, t, seed=11).to(DEV)
+    monkeypatch.setenv('NBASR_TAPE', '0')
+    calls = []
+    real = hip.channel_stats
+    monkeypatch.setattr(hip, 'channel_stats', lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    m._plans.clear()
+    with torch.no_grad():
+        fused = m(x).clone()
+    assert m._plans.values()[-1].conv_stats and not calls
+    monkeypatch.setenv('NBASR_CONV_STATS', '0')
+    m._plans.clear()
+    with torch.no_grad():
+        passes = m(x).clone()
+    assert len(calls) == 4                                   # one statistics pass per downsample convolution
+    assert torch.isfinite(fused).all()
+    assert cases.worst_ratio(fused, passes, 1e-4, 1e-5) <= 0.25
+
+
 @pytest.mark.parametrize('arch,b,t', [(cases.ARCH_A, 2, 1000), (cases.ARCH_D, 3, 515), (cases.ARCH_D, 2, 250), ([[2, 0], [4, 1, 0], [1, 0, 1, 1]], 2, 1024)])
 def test_fused_cells_against_node_launches(monkeypatch, arch, b, t):
     """Cells of three grouped convs run as ONE launch by default (grouped_cell.hip); NBASR_CELL_FUSION=0 runs the three node launches.

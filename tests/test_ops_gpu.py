@@ -804,6 +804,56 @@ def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     assert torch.equal(got64, got)
 
 
+@pytest.mark.parametrize('c,cout,t,stride,b,rows', [(600, 800, 1000, 1, 2, 160), (96, 600, 301, 1, 3, 128), (112, 1000, 517, 2, 2, 128),
+                                                    (64, 1200, 250, 2, 3, 160), (48, 200, 75, 2, 2, 64), (32, 161, 130, 1, 2, 96)])
+def test_dense_conv_emits_the_statistics_of_its_output(c, cout, t, stride, b, rows):
+    """Round 5: the image-path convolution leaves partial (mean, M2) of its output per 16 channels (stats_part), merged by
+    grouped_stats_finalize with 16 as the part size: the (mean, rstd) rows that channel_stats computes in a pass of its own
+    over y (the block LayerNorm behind every downsample convolution, reference model.py:92) -- and y itself is untouched."""
+    torch.manual_seed(cout + t)
+    x = torch.randn(b, c, t) * 1.5 + 0.2
+    g, be = torch.rand(c) + 0.5, torch.randn(c) * 0.2
+    xp, _ = pitched(x)
+    ld = xp.shape[2]
+    stats_in, bound = torch.empty(b, 2, ld, device=DEV), torch.empty(b, device=DEV)
+    image = hip.split_image(b, c, ld, DEV)
+    hip.layernorm_split_image(xp, g.to(DEV), be.to(DEV), stats_in, bound, image, t, 1e-3)
+    w, bias = torch.randn(cout, c, 8, device=DEV) * (2.0 / (c * 8)) ** 0.5, torch.randn(cout, device=DEV) * 0.3
+    bias[: cout // 3] -= 30.0                                     # a third of the channels sit at exactly 0 behind the ReLU
+    t_out = (t + stride - 1) // stride
+    ld_out = hip.round_up4(t_out)
+    plain = torch.full((b, cout, ld_out), float('nan'), device=DEV)
+    withp = torch.full_like(plain, float('nan'))
+    packed = hip.pack_dense_weights(w, stride, 'f16x2', row_tile=rows)
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed, cout, 8, bias, plain, stride, row_tile=rows)
+    part = torch.full((hip.dense_stats_part_floats(b, cout, ld_out),), float('nan'), device=DEV)
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed, cout, 8, bias, withp, stride, row_tile=rows, stats_part=part)
+    assert torch.equal(withp, plain)
+    got = torch.full((b, 2, ld_out), float('nan'), device=DEV)
+    hip.grouped_stats_finalize(part, got, cout, t_out, cout, 1e-3, hip.DENSE_STATS_UNIT)
+    want = torch.empty_like(got)
+    hip.channel_stats(plain, want, t_out, 1e-3)
+    y64 = plain[:, :, :t_out].double().cpu()
+    mean64, var64 = y64.mean(dim=1), y64.var(dim=1, unbiased=False)
+    rstd64 = 1.0 / (var64 + 1e-3).sqrt()
+    for name, col, truth in (('mean', 0, mean64), ('rstd', 1, rstd64)):
+        e_got = float((got[:, col, :t_out].double().cpu() - truth).abs().max() / truth.abs().max())
+        e_ref = float((want[:, col, :t_out].double().cpu() - truth).abs().max() / truth.abs().max())
+        assert e_got <= max(4.0 * e_ref, 1e-6), (name, e_got, e_ref)
+    assert torch.all(got[:, :, t_out:] == 0)
+    # the 16-channel unit, not the row tile, is the granule of the partials: another tiling leaves the same bits (batch invariance of
+    # the statistics: the executor picks the row tile by batch size)
+    other = 128 if rows != 128 else 160
+    part2 = torch.full_like(part, float('nan'))
+    hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, hip.pack_dense_weights(w, stride, 'f16x2', row_tile=other), cout, 8, bias,
+                                          withp, stride, row_tile=other, stats_part=part2)
+    assert torch.equal(withp, plain)
+    live = part.view(-1, b, 2, ld_out)[:, :, :, :t_out]
+    assert torch.equal(part2.view(-1, b, 2, ld_out)[:, :, :, :t_out], live) and bool(torch.isfinite(live).all())
+    with pytest.raises(hip.HipError, match='too small'):
+        hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed, cout, 8, bias, withp, stride, row_tile=rows, stats_part=part[:-4])
+
+
 @pytest.mark.parametrize('c,cout,t,b,rows', [(80, 600, 300, 4, 128), (80, 600, 1000, 2, 160), (40, 72, 7, 3, 128), (24, 161, 64, 2, 128)])
 def test_first_conv_image_leg_equals_the_in_kernel_split(c, cout, t, b, rows):
     """Conv 0 on the image path (one split pass over the model input, GEMM copies operands by LDS-DMA) == conv 0 splitting the
