@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NBASR_ABI_VERSION 4
+#define NBASR_ABI_VERSION 5
 
 #define NBASR_OK 0
 #define NBASR_EINVAL (-1)   /* bad size / unsupported shape */

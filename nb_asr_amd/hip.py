@@ -15,7 +15,7 @@ import pathlib
 import torch
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libnbasr_hip.so'
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
 _c_int = ctypes.c_int
