@@ -454,6 +454,7 @@ def roofline_leg(model, x, args):
                     per_layer[f'conv_{meta[0]}_{meta[1]}x{meta[2]}_T{meta[4]}']['scheme'] = scheme
                     if meta[0] in plan.dense_row_tiles:
                         per_layer[f'conv_{meta[0]}_{meta[1]}x{meta[2]}_T{meta[4]}']['row_tile'] = plan.dense_row_tiles[meta[0]]
+                        per_layer[f'conv_{meta[0]}_{meta[1]}x{meta[2]}_T{meta[4]}']['frame_tile'] = plan.dense_frame_tiles.get(meta[0], 256)
                     issued_flops += (1.0 if scheme == 'bf16' else 3.0 if scheme.startswith('f16x2') else 6.0) * dense_conv_flops(args.batch, meta[1], meta[2], meta[3], meta[4]) * n
             issued = issued_flops / (tot_ms * 1e-3) / 1e12
             out['roofline_mfma'] = {'kernel': 'gemm_conv_split_kernel<P,S> (dense k=8 conv on v_mfma_f32_16x16x32_{f16,bf16}: 3 fp16 or 6 bf16 products per fp32 product)',

@@ -119,7 +119,9 @@ int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
  *       nbasr_split_image_bytes(batch, channels, ld) bytes),
  *     which the GEMM gathers by LDS-DMA (no vector work in the GEMM).  row_tile = output channels per workgroup: 160 pays where 128
  *     leaves a mostly empty last row tile (c_out = 800: 7 tiles, the last a quarter full, vs 5 full ones) or a partial last round of
- *     workgroups; 64 doubles the workgroups of a small batch.  Results are bit-identical between row tiles.
+ *     workgroups; 64 doubles the workgroups of a small batch.  frame_tile = output frames per workgroup: 256, or (ABI 5; image path
+ *     only) 128 -- twice the workgroups, half the matrix work per K-step, where a small batch would leave most compute units without a
+ *     workgroup.  Results are bit-identical between tiles: the K order of every output is the same.
  * NBASR_DENSE_BF16    the bf16 storage path (BASELINE config 4): ONE v_mfma_f32_16x16x32_bf16 per 32 products, fp32 accumulation,
  *     bias + relu + min(20) in fp32, one rounding to the bf16 output y (ld_out % 8 == 0).  x: nbasr_bf16_image's operand image
  *     (x_is_image = 1); weights: the fp32 values of the bf16 parameter; row_tile 128 or 160; no bound, range, LayerNorm or skips.
@@ -150,7 +152,7 @@ int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_image, const f
                               const void* packed_w, const float* bias,
                               const float* skip0, const float* skip1, const float* skip2, void* y,
                               int batch, int c_in, int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
-                              int row_tile, const nbasr_deferred_ln* ln, float* stats_part, nbasr_stream_t stream);
+                              int row_tile, int frame_tile, const nbasr_deferred_ln* ln, float* stats_part, nbasr_stream_t stream);
 int nbasr_input_range(const float* x, float* range, int batch, int channels, int frames, int ld, nbasr_stream_t stream);
 
 /* The operand images of the fp16 scheme.  nbasr_layernorm_split_image normalises x (batch, channels, ld) and writes it as the

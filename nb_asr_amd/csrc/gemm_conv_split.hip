@@ -58,7 +58,11 @@ namespace nbasr {
 
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
-constexpr int PB_N = 256, PB_CI = 16, PB_TAPS = 8;   // frames per tile, channels per group, conv taps
+constexpr int PB_CI = 16, PB_TAPS = 8;               // channels per group, conv taps
+// frames per tile = 64 * NJ: NJ = 4 (256 frames; every kernel) or 2 (128 frames; the image-path fp16 kernel only, where a small batch
+// leaves most compute units without a workgroup -- twice the workgroups, half the matrix work per K-step: VERDICT r4 next 5b).  A wave owns
+// 16 MI rows x 16 NJ frames; the K order of every output is the same whatever the tile, so results are bit-identical.
+constexpr int pb_frames(int nj) { return 64 * nj; }
 // rows per tile = 32 * MI: MI = 4 (128 rows; every kernel) or 5 (160 rows; the image-path fp16 kernel only, for layers whose
 // 128-row tiling leaves a mostly empty last row tile or a partial last round of workgroups -- C_out = 800 and 1200)
 constexpr int pb_rows(int mi) { return 32 * mi; }
@@ -123,13 +127,14 @@ template <class P> constexpr bool has_image_path() { return P::SCALED || P::NS =
 
 template <class P> constexpr size_t pb_group_bytes(int mi) { return static_cast<size_t>(P::NS) * PB_TAPS * pb_rows(mi) * PB_CI * 2; }   // packed weights of one (row tile, channel group)
 
-template <class P, int S, int MI = 4>
+template <class P, int S, int MI = 4, int NJ = 4>
 struct GeoP {
     static constexpr int PBM = pb_rows(MI);                      // rows per tile; a wave owns 16 * MI of them
+    static constexpr int PBN = pb_frames(NJ);                    // frames per tile; a wave owns 16 * NJ of them
     static constexpr int TP = P::taps_per_step(S);               // taps per K-step
     static constexpr int QSTEPS = PB_TAPS / TP;                  // K-steps per channel group
     static constexpr int A_STEP_BYTES = P::NS * TP * PBM * PB_CI * 2;
-    static constexpr int XR = (PB_N - 1) * S + PB_TAPS;          // input frames needed per channel
+    static constexpr int XR = (PBN - 1) * S + PB_TAPS;           // input frames needed per channel
     static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
     static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
     static constexpr int X_BYTES = P::NS * ROWS * PB_CI * 2;
@@ -242,14 +247,16 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
 // XIMG: x is not the fp32 activation but its pre-split fp16 image written by the normalise-and-split LayerNorm kernel
 // (layernorm.hip): [b][16-channel group][split][8-channel half][1 + ld_in rows][8 ch], row 0 all zero, frame t at row t + 1,
 // already scaled by 2^kx[b].  The input tile then needs no vector work at all: it is gathered by LDS-DMA like the weights.
-template <class P, int S, bool LNX, bool XIMG = false, int MI = 4>
+template <class P, int S, bool LNX, bool XIMG = false, int MI = 4, int NJ = 4>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const PackedConvArgs a)
 {
+    static_assert(NJ == 4 || (NJ == 2 && XIMG && P::NS == 2), "128-frame tiles exist for the fp16 image path only");
     static_assert(!(XIMG && LNX) && !(XIMG && !has_image_path<P>()), "the image path: scaled fp16 scheme or plain bf16, no LayerNorm on load");
     static_assert(XIMG || P::NS > 1, "plain bf16 operands exist as an image only");
     static_assert(MI == 4 || ((MI == 5 || MI == 3 || MI == 2) && XIMG), "160-, 96- and 64-row tiles exist for the image path only");
-    using G = GeoP<P, S, MI>;
+    using G = GeoP<P, S, MI, NJ>;
     constexpr int PB_M = G::PBM, WROWS = 16 * MI;                // rows per tile, rows per wave
+    constexpr int PB_N = G::PBN, WCOLS = 16 * NJ;                // frames per tile, frames per wave
     using vec8 = typename P::vec8;
     constexpr int TP = G::TP, QS = G::QSTEPS, ASTEP = G::A_STEP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -287,15 +294,15 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     const unsigned char* __restrict__ wtile = a.wp + static_cast<size_t>(mt_i) * a.n_groups * pb_group_bytes<P>(MI);
 
     // a wave whose whole tile is out of range issues no MFMAs
-    const bool wave_active = (m0 + wm * WROWS) < a.c_out && (n0 + wn * 64) < a.ld_out;
+    const bool wave_active = (m0 + wm * WROWS) < a.c_out && (n0 + wn * WCOLS) < a.ld_out;
 
     // two accumulator sets, a two-level BLOCKED sum: `acc` takes every product of ONE channel group (smallest terms first) starting
     // from zero, `tot` takes acc once per group (flush_group).  One-term operands (NS == 1) use `acc` alone.
-    floatx4 acc[MI][4], tot[MI][4];                   // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
+    floatx4 acc[MI][NJ], tot[MI][NJ];                 // 16 x 16 tiles: row (lane >> 4) * 4 + r, column lane & 15
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { acc[i][j][r] = 0.f; tot[i][j][r] = 0.f; }
     auto flush_group = [&]() {
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { tot[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
         }
@@ -421,7 +428,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         const unsigned char* A = Abuf + abuf * ASTEP + a_lane;
         const unsigned char* X = Xbase + xbuf * G::X_BYTES + x_lane;
         auto read_b = [&](int pp, int j, vec8 (&f)[P::NS]) {
-            const int row = G::rowmap((wn * 64 + j * 16 + l15) * S + q * TP + 2 * pp + (kq >> 1));
+            const int row = G::rowmap((wn * WCOLS + j * 16 + l15) * S + q * TP + 2 * pp + (kq >> 1));
 #pragma unroll
             for (int k = 0; k < P::NS; ++k) f[k] = *reinterpret_cast<const vec8*>(X + (k * 2 * G::ROWS + row) * 16);
         };
@@ -443,9 +450,9 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             acc[i][j] = P::mfma(af[0], bf[0], c);   // hi * hi
         };
         if constexpr (PIPE) {
-            vec8 bfr[4][P::NS], af[2][P::NS];
+            vec8 bfr[NJ][P::NS], af[2][P::NS];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) read_b(0, j, bfr[j]);
+            for (int j = 0; j < NJ; ++j) read_b(0, j, bfr[j]);
             read_a(0, 0, af[0]);
 #pragma unroll
             for (int pp = 0; pp < TP / 2; ++pp) {
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                     const int cur = (pp * MI + i) & 1;
                     const bool more_a = i < MI - 1 || pp + 1 < TP / 2;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
+                    for (int j = 0; j < NJ; ++j) {
                         __builtin_amdgcn_sched_barrier(0);
                         block(i, j, af[cur], bfr[j]);
                         __builtin_amdgcn_sched_barrier(0);
@@ -469,15 +476,15 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         } else {
 #pragma unroll 1
             for (int pp = 0; pp < TP / 2; ++pp) {
-                vec8 bfr[4][P::NS];
+                vec8 bfr[NJ][P::NS];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) read_b(pp, j, bfr[j]);
+                for (int j = 0; j < NJ; ++j) read_b(pp, j, bfr[j]);
 #pragma unroll
                 for (int i = 0; i < MI; ++i) {
                     vec8 af[P::NS];
                     read_a(pp, i, af);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) block(i, j, af, bfr[j]);
+                    for (int j = 0; j < NJ; ++j) block(i, j, af, bfr[j]);
                 }
             }
         }
@@ -580,19 +587,22 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     // per wave: 32 rows x 64 frames fp32 (row stride 68 floats: the four row groups of a fragment land 2-way instead of 4-way on the
     // banks) = 8.5 KiB of the staging buffers, which nobody reads any more (the last K-step ended with a barrier).
     if (!a.s0 && !a.s1 && !a.s2 && a.staged_epilogue) {
-        constexpr int TS = 68;
+        constexpr int TS = WCOLS + 4;                       // (64 + 4: the four row groups of a fragment land 2-way instead of 4-way on the banks)
+        constexpr int FQ = WCOLS / 4, RI = 64 / FQ, NIT = 32 / RI;   // frame quads per staged row; rows per copy-out instruction; instructions per pass
         float* const T = reinterpret_cast<float*>(smem) + wave * (32 * TS);
         static_assert(8 * 32 * TS * 4 <= G::LDS_BYTES, "output staging must fit the operand buffers");
         if (!wave_active) return;
-        const int nc = n0 + wn * 64 + (lane & 15) * 4;
+        const int nc = n0 + wn * WCOLS + (lane % FQ) * 4;
         // Statistics by-product (round 5; a.part != NULL): per frame the (mean, M2) over each 16-ROW UNIT of the output -- one MFMA row
         // tile, 16 channels aligned to 16 -- written to part[unit][batch][2][ld_out]; stats_finalize_kernel merges the units in ascending
-        // order.  The unit, not the workgroup's row tile, is the granule: its sums are the same arithmetic whatever row tile (64 ... 160,
-        // chosen per batch size) the launch runs with, so the statistics -- like y -- do not depend on the batch an utterance sits in.
-        // A lane takes ONE frame of the staged tile and walks down its column (ds_read_b32, consecutive lanes on consecutive banks):
-        // shifted sums n, S1 = sum (v - c), S2 = sum (v - c)^2 with c = the unit's first row, so nothing cancels; no cross-lane step.
+        // order.  The unit, not the workgroup's tile, is the granule: its sums are the same arithmetic whatever tile (64 ... 160 rows, 128 or
+        // 256 frames, chosen per batch size) the launch runs with, so the statistics -- like y -- do not depend on the batch an utterance
+        // sits in.  A lane takes ONE frame of the staged tile and walks down its column (ds_read_b32, consecutive lanes on consecutive
+        // banks): shifted sums S1 = sum (v - c), S2 = sum (v - c)^2 with c = the unit's first row, so nothing cancels; no cross-lane step.
+        // (128-frame tiles: the two halves of the wave take the pass's two units side by side.)
         const bool want_stats = a.part != nullptr;          // (kernel-uniform)
-        const int ncol = n0 + wn * 64 + lane;               // this lane's frame in the statistics pass
+        const int scol = lane % WCOLS, usel = lane / WCOLS; // this lane's frame (and first unit) in the statistics pass
+        const int ncol = n0 + wn * WCOLS + scol;
 #pragma unroll
         for (int i0 = 0; i0 < MI; i0 += 2) {
 #pragma unroll
@@ -600,8 +610,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                 const int i = i0 + ii;
                 if (i >= MI) break;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool live = n0 + wn * 64 + j * 16 + l15 < a.frames_out;
+                for (int j = 0; j < NJ; ++j) {
+                    const bool live = n0 + wn * WCOLS + j * 16 + l15 < a.frames_out;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int m = m0 + wm * WROWS + i * 16 + kq * 4 + r;
@@ -618,33 +628,35 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private tile: this wave's writes are done
             const int rows_pass = (MI - i0 >= 2) ? 32 : 16;
 #pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int ml = it * 4 + (lane >> 4);
+            for (int it = 0; it < NIT; ++it) {
+                const int ml = it * RI + lane / FQ;
                 const int m = m0 + wm * WROWS + i0 * 16 + ml;
                 if (ml < rows_pass && m < a.c_out && nc < a.ld_out) {
-                    const floatx4 t = *reinterpret_cast<const floatx4*>(T + ml * TS + (lane & 15) * 4);
+                    const floatx4 t = *reinterpret_cast<const floatx4*>(T + ml * TS + (lane % FQ) * 4);
                     *reinterpret_cast<floatx4*>(a.y + (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + nc) = t;
                 }
             }
             if (want_stats) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u0 = 0; u0 < 2; u0 += 64 / WCOLS) {
+                    const int u = u0 + usel;
                     const int mu = m0 + wm * WROWS + (i0 + u) * 16;          // the unit's first channel (a multiple of 16)
-                    if (i0 + u >= MI || mu >= a.c_out) break;                // (wave-uniform)
-                    const int nrows = min(16, a.c_out - mu);
-                    const float c = T[(u * 16) * TS + lane];
-                    float s1 = 0.f, s2 = 0.f;
+                    if (i0 + u < MI && mu < a.c_out) {
+                        const int nrows = min(16, a.c_out - mu);
+                        const float c = T[(u * 16) * TS + scol];
+                        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) {
-                        const float d = (r < nrows) ? T[(u * 16 + r) * TS + lane] - c : 0.f;
-                        s1 += d;
-                        s2 = __builtin_fmaf(d, d, s2);
-                    }
-                    if (ncol < a.ld_out) {
-                        const float inv = 1.0f / static_cast<float>(nrows);
-                        float* prow = a.part + (static_cast<size_t>(mu >> 4) * a.batch + b) * 2 * a.ld_out + ncol;
-                        prow[0] = c + s1 * inv;
-                        prow[a.ld_out] = s2 - s1 * s1 * inv;
+                        for (int r = 1; r < 16; ++r) {
+                            const float d = (r < nrows) ? T[(u * 16 + r) * TS + scol] - c : 0.f;
+                            s1 += d;
+                            s2 = __builtin_fmaf(d, d, s2);
+                        }
+                        if (ncol < a.ld_out) {
+                            const float inv = 1.0f / static_cast<float>(nrows);
+                            float* prow = a.part + (static_cast<size_t>(mu >> 4) * a.batch + b) * 2 * a.ld_out + ncol;
+                            prow[0] = c + s1 * inv;
+                            prow[a.ld_out] = s2 - s1 * s1 * inv;
+                        }
                     }
                 }
             }
@@ -657,8 +669,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + l15;
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * WCOLS + j * 16 + l15;
             if (n >= a.ld_out) continue;
             const bool live = n < a.frames_out;
 #pragma unroll
@@ -702,7 +714,7 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
     }
     NBASR_REQUIRE(HAS_LNX || !a.ln_x.stats, NBASR_EINVAL, "%s: this scheme takes no deferred LayerNorm", P::NAME);
     a.n_mt = (a.c_out + PB_M - 1) / PB_M;
-    a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
+    a.n_nt = (a.ld_out + G::PBN - 1) / G::PBN;
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
     if (a.ln_x.stats)
@@ -715,21 +727,21 @@ static int launch_packed(PackedConvArgs a, hipStream_t stream)
 static inline int rows_to_mi(int row_tile) { return row_tile == 128 ? 4 : (row_tile == 160 ? 5 : (row_tile == 96 ? 3 : (row_tile == 64 ? 2 : 0))); }
 
 // image-path kernel of scheme P at a given row tile (the only kernel the plain-bf16 scheme has)
-template <class P, int S, int MI>
+template <class P, int S, int MI, int NJ = 4>
 static int launch_image(PackedConvArgs a, hipStream_t stream)
 {
-    using G = GeoP<P, S, MI>;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true, MI>),
+    using G = GeoP<P, S, MI, NJ>;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_conv_split_kernel<P, S, false, true, MI, NJ>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     if (attr != hipSuccess) {
         set_error("%s: cannot reserve %d bytes of LDS: %s", P::NAME, G::LDS_BYTES, hipGetErrorString(attr));
         return static_cast<int>(attr);
     }
     a.n_mt = (a.c_out + G::PBM - 1) / G::PBM;
-    a.n_nt = (a.ld_out + PB_N - 1) / PB_N;
+    a.n_nt = (a.ld_out + G::PBN - 1) / G::PBN;
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", P::NAME, nwg);
-    hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, MI>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
+    hipLaunchKernelGGL((gemm_conv_split_kernel<P, S, false, true, MI, NJ>), dim3(static_cast<unsigned>(nwg)), dim3(PB_THREADS), G::LDS_BYTES, stream, a);
     return launch_status(P::NAME);
 }
 
@@ -771,13 +783,16 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
                              const float* skip1, const float* skip2, float* y, int batch, int c_in,
                              int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride,
                              const nbasr_deferred_ln* ln, const float* x_absmax, nbasr_stream_t stream, bool x_is_image = false,
-                             int row_tile = 128, const float* x_range = nullptr, int sel_want = -1, float* stats_part = nullptr)
+                             int row_tile = 128, const float* x_range = nullptr, int sel_want = -1, float* stats_part = nullptr,
+                             int frame_tile = 256)
 {
     clear_error();
     const int mi = rows_to_mi(row_tile);
     NBASR_REQUIRE(mi == 4 || ((mi == 5 || mi == 3 || mi == 2) && x_is_image && P::SCALED), NBASR_EINVAL,
                   "%s: row_tile=%d unsupported (128; 64, 96 and 160 for the fp16 image path)", P::NAME, row_tile);
     const int PB_M = pb_rows(mi);
+    NBASR_REQUIRE(frame_tile == 256 || (frame_tile == 128 && x_is_image && P::SCALED), NBASR_EINVAL,
+                  "%s: frame_tile=%d unsupported (256; 128 for the fp16 image path)", P::NAME, frame_tile);
     NBASR_REQUIRE(batch >= 0 && c_in > 0 && c_out > 0 && frames_in >= 0, NBASR_EINVAL, "%s: bad sizes", P::NAME);
     NBASR_REQUIRE(kernel == PB_TAPS && (stride == 1 || stride == 2), NBASR_EINVAL,
                   "%s: (kernel=%d, stride=%d) unsupported; packed path covers k=8, s in {1,2}", P::NAME, kernel, stride);
@@ -813,6 +828,15 @@ static int dense_packed_impl(const float* x, const void* packed_w, const float* 
             // 160-row tiles where 128 rows leave a mostly empty last row tile or a partial last round of workgroups; 64- / 96-row tiles:
             // more workgroups where a small batch leaves CUs without one (the executor's round count decides)
             hipStream_t s = as_stream(stream);
+            if (frame_tile == 128) {
+                // 128-frame tiles (round 5): twice the workgroups where a small batch leaves compute units without one
+                switch (mi) {
+                    case 5: return stride == 1 ? launch_image<P, 1, 5, 2>(a, s) : launch_image<P, 2, 5, 2>(a, s);
+                    case 3: return stride == 1 ? launch_image<P, 1, 3, 2>(a, s) : launch_image<P, 2, 3, 2>(a, s);
+                    case 2: return stride == 1 ? launch_image<P, 1, 2, 2>(a, s) : launch_image<P, 2, 2, 2>(a, s);
+                    default: return stride == 1 ? launch_image<P, 1, 4, 2>(a, s) : launch_image<P, 2, 4, 2>(a, s);
+                }
+            }
             switch (mi) {
                 case 5: return stride == 1 ? launch_image<P, 1, 5>(a, s) : launch_image<P, 2, 5>(a, s);
                 case 3: return stride == 1 ? launch_image<P, 1, 3>(a, s) : launch_image<P, 2, 3>(a, s);
@@ -892,7 +916,7 @@ static int dense_bf16_image_impl(const void* x_image, const void* packed_w, cons
 extern "C" int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_image, const float* x_absmax, const float* x_range,
                                          const void* packed_w, const float* bias, const float* skip0, const float* skip1,
                                          const float* skip2, void* y, int batch, int c_in, int frames_in, int ld_in, int c_out,
-                                         int ld_out, int kernel, int stride, int row_tile, const nbasr_deferred_ln* ln,
+                                         int ld_out, int kernel, int stride, int row_tile, int frame_tile, const nbasr_deferred_ln* ln,
                                          float* stats_part, nbasr_stream_t stream)
 {
     clear_error();
@@ -904,14 +928,15 @@ extern "C" int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_ima
             NBASR_REQUIRE(!image && !x_absmax, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the bf16x3 scheme reads a plain fp32 tensor and takes no bound");
             // with x_range: only the EXTREME utterances (the fp16 leg computes the others on the same output)
             return dense_packed_impl<SplitBf16x3>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                                  kernel, stride, ln, nullptr, stream, false, row_tile, x_range, 1, stats_part);
+                                                  kernel, stride, ln, nullptr, stream, false, row_tile, x_range, 1, stats_part, frame_tile);
         case NBASR_DENSE_F16X2:
             NBASR_REQUIRE(!ln, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the fp16x2 scheme takes no pending LayerNorm (nbasr_layernorm_split_image writes its operand)");
             NBASR_REQUIRE(!(image && (skip0 || skip1 || skip2)), NBASR_EINVAL, "nbasr_dense_conv1d_packed: the image path takes no skips");
             NBASR_REQUIRE(!(x_absmax && x_range), NBASR_EINVAL, "nbasr_dense_conv1d_packed: give x_absmax or x_range, not both");
             return dense_packed_impl<SplitF16x2>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
-                                                 kernel, stride, nullptr, x_absmax, stream, image, row_tile, x_range, 0, stats_part);
+                                                 kernel, stride, nullptr, x_absmax, stream, image, row_tile, x_range, 0, stats_part, frame_tile);
         case NBASR_DENSE_BF16:
+            NBASR_REQUIRE(frame_tile == 256, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the bf16 scheme has 256-frame tiles only");
             NBASR_REQUIRE(image && !x_absmax && !x_range && !ln && !skip0 && !skip1 && !skip2 && !stats_part, NBASR_EINVAL,
                           "nbasr_dense_conv1d_packed: the bf16 scheme reads nbasr_bf16_image's operand image only (no bound, range, LayerNorm, skips or statistics)");
             return dense_bf16_image_impl(x, packed_w, bias, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, stream);

@@ -382,6 +382,17 @@ __global__ __launch_bounds__(256) void normalize_split_kernel(const float* __res
     }
 }
 
+// workgroups that share one (64-quad tile, utterance) of normalize_split_kernel, each taking every z-th set of 4 channel octets: 4 at the
+// benchmark batch (1 024 workgroups); up to 16 where a small batch would otherwise leave most compute units without one (8 utterances x
+// 1000 frames: 128 workgroups -> 512; the same bytes in half the time, the kernel is three launches of a forward)
+static int split_grid_z(int tiles, int batch)
+{
+    const long long wgs = static_cast<long long>(tiles) * batch;
+    int z = 4;
+    while (z < 16 && wgs * z < 512) z *= 2;
+    return z;
+}
+
 extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, const float* beta, float* stats, float* bound,
                                            void* image, int batch, int channels, int frames, int ld, float eps,
                                            nbasr_stream_t stream)
@@ -398,7 +409,7 @@ extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, c
     const int nq = ld / 4;
     hipLaunchKernelGGL(channel_stats_bound_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
                        x, gamma, beta, stats, reinterpret_cast<unsigned*>(bound), channels, frames, ld, eps);
-    hipLaunchKernelGGL(normalize_split_kernel<true>, dim3((nq + 63) / 64, batch, 4), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(normalize_split_kernel<true>, dim3((nq + 63) / 64, batch, split_grid_z((nq + 63) / 64, batch)), dim3(256), 0, as_stream(stream),
                        x, stats, gamma, beta, bound, static_cast<unsigned char*>(image), channels, frames, ld, 1);
     return launch_status("nbasr_layernorm_split_image");
 }
@@ -497,7 +508,7 @@ extern "C" int nbasr_split_image_ranged(const float* x, const float* x_range, vo
     NBASR_REQUIRE(aligned16(x) && aligned16(image), NBASR_EALIGN, "nbasr_split_image_ranged: x, image must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_split_image_ranged: batch %d > 65535", batch);
     const int nq = ld / 4;
-    hipLaunchKernelGGL(normalize_split_kernel<false>, dim3((nq + 63) / 64, batch, 4), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(normalize_split_kernel<false>, dim3((nq + 63) / 64, batch, split_grid_z((nq + 63) / 64, batch)), dim3(256), 0, as_stream(stream),
                        x, static_cast<const float*>(nullptr), static_cast<const float*>(nullptr), static_cast<const float*>(nullptr),
                        x_range, static_cast<unsigned char*>(image), channels, frames, ld, 4);
     return launch_status("nbasr_split_image_ranged");

@@ -16,6 +16,7 @@ same memory), and the model is passed to every call, so ``torch.nn.DataParallel`
 the module that share the plan pool) each run with their own parameters.
 """
 import collections
+import math
 import os
 import threading
 import weakref
@@ -96,6 +97,22 @@ def _load_gc_table():
 
 
 _GC_TABLE = _load_gc_table()
+
+
+def _load_dense_tile_table():
+    """Measured us per launch of the image-path dense convolution per (row tile, frame tile): nb_asr_amd/dense_tile_table.json
+    (tools/ubench/dense_tiles.py -> tools/make_dense_tile_table.py), {(c_in, c_out, stride, frames_out): {batch: {(rows, frames): us}}}."""
+    import json
+    import pathlib
+    path = pathlib.Path(__file__).with_name('dense_tile_table.json')
+    if not path.exists():
+        return {}
+    raw = json.loads(path.read_text())['table']
+    return {tuple(int(v) for v in k.split(',')): {int(b): {tuple(int(v) for v in t.split('x')): us for t, us in row.items()} for b, row in by_b.items()}
+            for k, by_b in raw.items()}
+
+
+_DENSE_TILES = _load_dense_tile_table()
 
 
 # Any submodule or parameter (re-)registered on any module bumps this counter: a launch tape recorded before is not replayed
@@ -218,6 +235,7 @@ class ForwardPlan:
         self._act_image = None
         self.dense_schemes = {}      # block -> scheme used by the last run (read by bench.py)
         self.dense_row_tiles = {}    # block -> rows per workgroup of the image-path GEMM in the last run
+        self.dense_frame_tiles = {}  # block -> frames per workgroup (256, or 128 where the measured table says so)
         # cells whose three nodes are grouped convs run as ONE launch where a row fits a workgroup (<= 1024 frames): x1 and x2 never
         # touch HBM and the cell's LayerNorm statistics come out of the same launch (grouped_cell.hip, round 3).  Bit-identical to
         # the three node launches; NBASR_CELL_FUSION=0 turns it off (A/B)
@@ -458,6 +476,29 @@ class ForwardPlan:
                     rows, score = r, margin * cost(r)
         return rows
 
+    def _dense_tile(self, layer, frames_out):
+        """(row tile, frame tile) of the image-path fp16 GEMM for this launch.  Every tiling computes the same sums in the same order
+        (results are bit-identical), so the choice is speed only: `_row_tile`'s whole-rounds model, overruled by the measured table
+        (dense_tile_table.json: every tiling at 4 ... 64 utterances x 1000 frames) where that knows the shape and a tiling beat the
+        model's choice by more than 3 % -- 128-frame tiles and 64-row tiles at small batches (one round of workgroups: conv 3 at 8
+        utterances 185 -> 168 us), 64-row tiles for conv 0 at every batch (two workgroups per CU: its ten K-steps are mostly prologue
+        and epilogue)."""
+        conv = layer.conv
+        rows = self._row_tile(conv.out_channels, frames_out)
+        best = (rows, 256)
+        for (c_in, c_out, stride, t_ref), by_batch in _DENSE_TILES.items():
+            if (c_in, c_out, stride) != (conv.in_channels, conv.out_channels, layer.strides) or not 0.75 * t_ref <= frames_out <= 1.34 * t_ref:
+                continue
+            b_ref = min(by_batch, key=lambda b: abs(math.log2(max(self.batch, 1) / b)))
+            if not 0.7 * b_ref <= self.batch <= 1.42 * b_ref:
+                break
+            row = by_batch[b_ref]
+            cand = min(row, key=row.get)
+            if row[cand] < 0.97 * row.get(best, float('inf')):
+                best = cand
+            break
+        return best
+
     def _packed_linear(self, linear):
         """Packed (fp16 split) copy of an nn.Linear-like weight (c_out, c_in), rebuilt whenever the parameter changes."""
         w = linear.weight if hasattr(linear, 'weight') else linear
@@ -489,19 +530,23 @@ class ForwardPlan:
         if image is not None:
             self.dense_schemes[blk] = 'f16x2-image'
             b, c, ld = act.shape
-            rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, (act_frames + layer.strides - 1) // layer.strides)
+            rows, ftile = self._dense_tile(layer, (act_frames + layer.strides - 1) // layer.strides)
+            self.dense_row_tiles[blk], self.dense_frame_tiles[blk] = rows, ftile
             part = None
             if want_stats:
                 part = self._conv_part = self._dense_part(layer.conv.out_channels, out.shape[2])
             return hip.dense_conv1d_fused_packed_f16_img(image[0], image[1], b, c, act_frames, ld,
                                                          self._packed_weights(layer, 'f16x2', rows), layer.conv.out_channels,
-                                                         layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, rows, part)
+                                                         layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, rows, part, ftile)
         if self.dense_mode != 'f32' and layer.kernel_size == 8:
             scheme = 'f16x2' if self.dense_mode == 'auto' and absmax is not None and ln is None else 'bf16x3'
             self.dense_schemes[blk] = scheme
+            part = None
+            if want_stats:                             # (the same 16-channel partials as the image path: the statistics do not depend on the route)
+                part = self._conv_part = self._dense_part(layer.conv.out_channels, out.shape[2])
             return hip.dense_conv1d_fused_packed(act, act_frames, self._packed_weights(layer, scheme), layer.conv.out_channels,
                                                  layer.kernel_size, layer.conv.bias.detach(), (), out, layer.strides, ln, scheme,
-                                                 absmax if scheme == 'f16x2' else None)
+                                                 absmax if scheme == 'f16x2' else None, part)
         self.dense_schemes[blk] = 'f32'
         return hip.dense_conv1d_fused(act, act_frames, layer.conv.weight.detach(), layer.conv.bias.detach(), (), out,
                                       layer.strides, ln, ln is not None, False)
@@ -823,8 +868,7 @@ class ForwardPlan:
                 # the convolution's own epilogue (round 5) instead of a pass over the output
                 nxt1 = model.model[idx + 1] if idx + 1 < n_layers else None
                 nxt2 = model.model[idx + 2] if idx + 2 < n_layers else None
-                want_stats = (taps is None and self.conv_stats and isinstance(nxt1, nn.LayerNorm) and self._cheap_consumer(nxt2)
-                              and layer.kernel_size == 8)
+                want_stats = self.conv_stats and isinstance(nxt1, nn.LayerNorm) and self._cheap_consumer(nxt2) and layer.kernel_size == 8
                 self._conv_part = None
                 if input_range is not None and layer.kernel_size == 8 and ln is None and img is None:
                     rng, input_range = input_range, None
@@ -832,7 +876,8 @@ class ForwardPlan:
                     # pass over the input, then the same DMA-only GEMM as convs 1-3
                     bi, ci, ldi = src.shape
                     image = self._buf('input_image', max(hip.load_library().nbasr_split_image_bytes(bi, ci, ldi), 16), torch.uint8)
-                    rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out)
+                    rows, ftile = self._dense_tile(layer, t_out)
+                    self.dense_row_tiles[blk], self.dense_frame_tiles[blk] = rows, ftile
                     self.dense_schemes[blk] = 'f16x2' if image is None else 'f16x2-image'
                     w16 = self._packed_weights(layer, 'f16x2', rows) if image is not None else self._packed_weights(layer, 'f16x2')
                     part = None
@@ -840,7 +885,7 @@ class ForwardPlan:
                         part = self._conv_part = self._dense_part(layer.conv.out_channels, out.shape[2])
                     self._timed('dense_conv', meta, lambda: hip.dense_conv1d_first_ranged(
                         src, src_frames, rng, w16, self._packed_weights(layer, 'bf16x3'),
-                        layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, image, rows, part))
+                        layer.conv.out_channels, layer.kernel_size, layer.conv.bias.detach(), out, layer.strides, image, rows, part, ftile))
                 else:
                     input_range = None
                     self._timed('dense_conv', meta, lambda: self._dense(layer, src, src_frames, out, ln, amax, blk_now, img, want_stats))

@@ -57,7 +57,7 @@ SIGNATURES = {
     'nbasr_dense_conv1d_fused': (_c_int, [_c_float_p] * 7 + [_c_int] * 8 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_packed_dense_weights_bytes': (ctypes.c_size_t, [_c_int] * 5),
     'nbasr_pack_dense_weights': (_c_int, [_c_int] + [_c_float_p] * 2 + [_c_int] * 5 + [_c_stream]),
-    'nbasr_dense_conv1d_packed': (_c_int, [_c_int, _c_float_p, _c_int] + [_c_float_p] * 8 + [_c_int] * 9 + [_c_ln_p, _c_float_p, _c_stream]),
+    'nbasr_dense_conv1d_packed': (_c_int, [_c_int, _c_float_p, _c_int] + [_c_float_p] * 8 + [_c_int] * 10 + [_c_ln_p, _c_float_p, _c_stream]),
     'nbasr_input_range': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [_c_stream]),
     'nbasr_split_image_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_layernorm_split_image': (_c_int, [_c_float_p] * 6 + [_c_int] * 4 + [ctypes.c_float, _c_stream]),
@@ -407,14 +407,14 @@ def layernorm_split_image(x, gamma, beta, stats, bound, image, frames, eps):
 
 
 def dense_conv1d_fused_packed_f16_img(image, bound, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride,
-                                      row_tile=128, stats_part=None):
+                                      row_tile=128, stats_part=None, frame_tile=256):
     """The fp16x2 convolution on the pre-split operand image (layernorm_split_image): LDS-DMA-only GEMM.  ``stats_part``: also emit
     the partial LayerNorm statistics of y (dense_stats_part_floats)."""
     _check_packed(packed, 'f16x2', c_out, c_in, kernel, row_tile)
     if image.numel() < load_library().nbasr_split_image_bytes(batch, c_in, ld_in):
         raise HipError('image buffer too small for (batch, c_in, ld_in)')
     return _dense_packed('f16x2', image.data_ptr(), True, bound, None, packed, bias, (None, None, None), y, _dev(y, 'y'), batch, c_in,
-                         frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y), stats_part)
+                         frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y), stats_part, frame_tile)
 
 
 def input_range(x, frames, out):
@@ -427,7 +427,7 @@ def input_range(x, frames, out):
 
 
 def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, c_out, kernel, bias, y, stride, image=None, row_tile=128,
-                              stats_part=None):
+                              stats_part=None, frame_tile=256):
     """The model's first dense conv with per-utterance routing on the device: ordinary utterances on the 2-way fp16 split,
     extreme ones (non-finite samples, > 2^12 dynamic range between frames) on the 3-way bf16 split; same output tensor.
     ``image``: uint8 workspace of ``nbasr_split_image_bytes`` -- the fp16 leg then runs on the image path (one split pass over
@@ -444,7 +444,7 @@ def dense_conv1d_first_ranged(x, frames_in, x_range, packed_f16, packed_bf16x3, 
                'nbasr_split_image_ranged')
     if image is not None:
         _dense_packed('f16x2', image.data_ptr(), True, None, x_range, packed_f16, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in, ld_in,
-                      c_out, kernel, stride, row_tile, None, stream, stats_part)
+                      c_out, kernel, stride, row_tile, None, stream, stats_part, frame_tile)
     else:
         _dense_packed('f16x2', _dev(x, 'x'), False, None, x_range, packed_f16, bias, none3, y, _dev(y, 'y'), b, c_in, frames_in, ld_in,
                       c_out, kernel, stride, 128, None, stream, stats_part)
@@ -497,14 +497,14 @@ def pack_dense_weights(weight, stride, scheme='bf16x3', row_tile=128):
 
 
 def _dense_packed(scheme, x_ptr, image, x_absmax, x_range, packed, bias, s, y, y_ptr, b, c_in, frames_in, ld_in, c_out, kernel, stride,
-                  row_tile, ln, stream, stats_part=None):
+                  row_tile, ln, stream, stats_part=None, frame_tile=256):
     """The one C entry point of the packed k = 8 convolution (nbasr.h: nbasr_dense_conv1d_packed)."""
     if stats_part is not None and stats_part.numel() < dense_stats_part_floats(b, c_out, y.shape[2]):
         raise HipError('stats_part too small: ceil(c_out / 16) * batch * 2 * ld_out floats (dense_stats_part_floats)')
     _check(load_library().nbasr_dense_conv1d_packed(
         _scheme_code(scheme), x_ptr, int(image), _opt(x_absmax, 'x_absmax'), _opt(x_range, 'x_range'), packed.data_ptr(),
         _dev(bias, 'bias'), _opt(s[0], 'skip0'), _opt(s[1], 'skip1'), _opt(s[2], 'skip2'), y_ptr, b, c_in, frames_in, ld_in, c_out,
-        y.shape[2], kernel, stride, row_tile, _ln(ln), _opt(stats_part, 'stats_part'), stream), 'nbasr_dense_conv1d_packed')
+        y.shape[2], kernel, stride, row_tile, int(frame_tile), _ln(ln), _opt(stats_part, 'stats_part'), stream), 'nbasr_dense_conv1d_packed')
     return y
 
 
@@ -526,9 +526,10 @@ def _check_packed(packed, scheme, c_out, c_in, kernel, row_tile=128):
 
 
 def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, y, stride, ln=None, scheme='bf16x3',
-                              x_absmax=None):
+                              x_absmax=None, stats_part=None):
     """Dense k=8 conv on packed weights; ``scheme`` must be the one the weights were packed with.  'f16x2' needs
-    ``x_absmax``: a (B,) float32 device tensor of upper bounds of max|x[b]| (see nbasr.h) and takes no deferred LayerNorm."""
+    ``x_absmax``: a (B,) float32 device tensor of upper bounds of max|x[b]| (see nbasr.h) and takes no deferred LayerNorm.
+    ``stats_part`` (no skips): also emit the partial LayerNorm statistics of y (dense_stats_part_floats)."""
     b, c_in, ld_in = x.shape
     s = list(skips) + [None] * (3 - len(skips))
     _check_packed(packed, scheme, c_out, c_in, kernel)
@@ -540,7 +541,7 @@ def dense_conv1d_fused_packed(x, frames_in, packed, c_out, kernel, bias, skips, 
     elif ln is not None and any(t is not None for t in s):
         raise HipError('the packed path takes a deferred LayerNorm only without skip inputs')
     return _dense_packed(scheme, _dev(x, 'x'), False, x_absmax if scheme == 'f16x2' else None, None, packed, bias, s, y, _dev(y, 'y'),
-                         b, c_in, frames_in, ld_in, c_out, kernel, stride, 128, ln, _stream(x))
+                         b, c_in, frames_in, ld_in, c_out, kernel, stride, 128, ln, _stream(x), stats_part)
 
 
 def lstm_forward(x, frames, w_ih, w_hh, b_ih, b_hh, gates_ws, cell_ws, h_out, ln=None):

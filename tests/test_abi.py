@@ -57,16 +57,16 @@ def test_argument_errors_are_reported_without_a_gpu():
     rc = lib.nbasr_linear_head(16, 16, 16, 16, 10, 500, 65, None)
     assert rc == -1
     # the packed / split entry points and the front-end validate the same way
-    # nbasr_dense_conv1d_packed(scheme, x, x_is_image, x_absmax, x_range, packed_w, bias, skip0..2, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, ln, stats_part, stream)
-    rc = lib.nbasr_dense_conv1d_packed(0, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 10, 10, 800, 12, 8, 1, 128, None, None, None)   # ld_in % 4
+    # nbasr_dense_conv1d_packed(scheme, x, x_is_image, x_absmax, x_range, packed_w, bias, skip0..2, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, frame_tile, ln, stats_part, stream)
+    rc = lib.nbasr_dense_conv1d_packed(0, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 10, 10, 800, 12, 8, 1, 128, 256, None, None, None)   # ld_in % 4
     assert rc == -2 and b'multiple of 4' in lib.nbasr_last_error()
-    rc = lib.nbasr_dense_conv1d_packed(1, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, 128, None, None, None)
+    rc = lib.nbasr_dense_conv1d_packed(1, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, 128, 256, None, None, None)
     assert rc == -3 and b'x_absmax' in lib.nbasr_last_error()
     rc = lib.nbasr_pack_dense_weights(1, 16, 16, 128, 16, 5, 1, 128, None)
     assert rc == -1 and b'unsupported' in lib.nbasr_last_error()
-    rc = lib.nbasr_dense_conv1d_packed(7, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, 128, None, None, None)
+    rc = lib.nbasr_dense_conv1d_packed(7, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, 128, 256, None, None, None)
     assert rc == -1 and b'unknown scheme' in lib.nbasr_last_error()
-    rc = lib.nbasr_dense_conv1d_packed(2, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, 128, None, None, None)
+    rc = lib.nbasr_dense_conv1d_packed(2, 16, 0, None, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 800, 16, 8, 1, 128, 256, None, None, None)
     assert rc == -1 and b'operand image' in lib.nbasr_last_error()            # the bf16 scheme reads images only
     rc = lib.nbasr_linear_fused_packed(16, None, 16, 16, None, None, None, 16, 1, 600, 16, 16, 600, None, 0, 0, None)
     assert rc == -3 and b'workspace' in lib.nbasr_last_error()

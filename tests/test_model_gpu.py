@@ -259,12 +259,19 @@ def test_dense_scheme_selection():
         y0 = model(x)
     plan = next(iter(model._plans.values()))
     assert plan.dense_schemes == {0: 'f16x2-image', 1: 'f16x2-image', 2: 'f16x2-image', 3: 'f16x2-image'}
-    assert set(plan.dense_row_tiles) == {0, 1, 2, 3} and set(plan.dense_row_tiles.values()) <= {64, 128, 160}
+    assert set(plan.dense_row_tiles) == {0, 1, 2, 3} and set(plan.dense_row_tiles.values()) <= {64, 96, 128, 160}
+    assert set(plan.dense_frame_tiles) == {0, 1, 2, 3} and set(plan.dense_frame_tiles.values()) <= {128, 256}
     assert plan._row_tile(800, 1000) == 64 and plan._row_tile(1200, 250) == 64            # 2 utterances: under one round, so the smallest tiles
     plan.batch = 64
     assert plan._row_tile(800, 1000) == 160 and plan._row_tile(1000, 500) == 128 and plan._row_tile(1200, 250) == 160 and plan._row_tile(600, 1000) == 128
     plan.batch = 8
     assert plan._row_tile(1000, 500) == 64 and plan._row_tile(1200, 250) == 64 and plan._row_tile(800, 1000) == 128
+    # round 5: the measured table (dense_tile_table.json) overrules the whole-rounds model where it knows the shape: 128-frame tiles for the
+    # stride-2 convs of a small batch, 64-row tiles (two workgroups per CU) for conv 0; shapes it does not know keep the model's choice
+    c0, c2, c3 = model.model[0], [l for l in model.model if getattr(l, 'strides', 0) == 2][0], [l for l in model.model if getattr(l, 'strides', 0) == 2][1]
+    assert plan._dense_tile(c3, 250) == (64, 128) and plan._dense_tile(c2, 500) == (128, 128) and plan._dense_tile(c3, 77) == (plan._row_tile(1200, 77), 256)
+    plan.batch = 64
+    assert plan._dense_tile(c0, 1000) == (64, 256) and plan._dense_tile(c2, 500) == (128, 256) and plan._dense_tile(c3, 250) == (160, 256)
     plan.batch = 2
     os.environ['NBASR_DENSE_MODE'] = 'bf16x3'
     try:

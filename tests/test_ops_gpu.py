@@ -802,6 +802,13 @@ def test_layernorm_split_image_feeds_the_convolution(c, cout, t, stride, b):
     hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed96, cout, 8, bias, got96, stride, row_tile=96)
     assert torch.equal(got96, got)
     assert torch.equal(got64, got)
+    # 128-frame tiles (round 5: twice the workgroups of a small batch): the same again, at every row tile
+    for rows_, packed_ in ((128, packed), (160, packed160), (64, packed64), (96, packed96)):
+        got128 = torch.full_like(want, float('nan'))
+        hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed_, cout, 8, bias, got128, stride, row_tile=rows_, frame_tile=128)
+        assert torch.equal(got128, got), rows_
+    with pytest.raises(hip.HipError, match='frame_tile=64'):
+        hip.dense_conv1d_fused_packed_f16_img(image, bound, b, c, t, ld, packed, cout, 8, bias, got64, stride, frame_tile=64)
 
 
 @pytest.mark.parametrize('c,cout,t,stride,b,rows', [(600, 800, 1000, 1, 2, 160), (96, 600, 301, 1, 3, 128), (112, 1000, 517, 2, 2, 128),
