@@ -28,6 +28,7 @@
 namespace nbasr {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4v __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128;
 constexpr int FLUSH = 4;     // K-steps per blocked-summation flush (power of two)
@@ -56,7 +57,19 @@ struct Geo {
     static constexpr int LDS_FLOATS = BK * LDA + KC * LDX;
 };
 
-template <int KW, int STRIDE, bool SWAP, bool RELU>
+// a wave-uniform buffer resource over `bytes` bytes at `p` (both forced into scalar registers: left to itself hipcc treats a resource built
+// inside the K loop as divergent and wraps every load in a waterfall loop)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* p, unsigned bytes)
+{
+    const uintptr_t u = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u)), hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(u >> 32));
+    float* q = reinterpret_cast<float*>((static_cast<uintptr_t>(hi) << 32) | lo);
+    return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+// LNX: the input carries a pending LayerNorm applied while staging (a template flag: its per-item statistics addresses cost the plain
+// instances ~36 registers when it was a run-time branch)
+template <int KW, int STRIDE, bool SWAP, bool RELU, bool LNX>
 __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
 {
     using G = Geo<KW, STRIDE>;
@@ -84,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
 
     const float* __restrict__ xb = a.x + static_cast<size_t>(b) * a.c_in * a.ld_in;
     const int tin0 = n0 * STRIDE - a.lpad;
-    const float* __restrict__ xstats = a.ln_x.stats ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
+    const float* __restrict__ xstats = LNX ? a.ln_x.stats + static_cast<size_t>(b) * 2 * a.ld_in : nullptr;
 
     // wave-uniform validity of the 32x32 blocks (skip MFMAs on fully out-of-range blocks)
     bool mval[2], nval[2];
@@ -109,29 +122,55 @@ __global__ __launch_bounds__(256, 2) void gemm_conv_kernel(const GemmConvArgs a)
     float xreg[G::XREGS];
     const int a_row = tid & 127, a_kh = tid >> 7;   // lane -> weight row; 16-byte k-chunks kh, kh+2, ...
 
+    // Operand fetches are bounds-checked BUFFER loads with one 32-bit offset per item (round 5): the K-step moves the resource's base
+    // (scalar arithmetic), the per-item offset is loop-invariant, and what lies outside the tensor -- weight rows beyond c_out, input
+    // channels beyond c_in, the zero padding left and right of the utterance -- is an offset beyond num_records, which reads as 0.  Rounds
+    // 1-4 kept a 64-bit address and a predicate per item: hoisted out of the K loop they spilled (156-180 bytes of scratch per lane in
+    // three of the six instances).
+    constexpr unsigned OOB = 0x7ffffff0u;
+    const unsigned w_bytes = static_cast<unsigned>(min(static_cast<long long>(a.c_out) * a.ktot * 4, 0x7fffffffll));
+    const unsigned x_bytes = static_cast<unsigned>(min(static_cast<long long>(a.c_in) * a.ld_in * 4, 0x7fffffffll));
+    const unsigned a_off = (m0 + a_row) < a.c_out ? static_cast<unsigned>(((m0 + a_row) * a.ktot + a_kh * 4) * 4) : OOB;
+    unsigned x_off[G::XREGS];
+#pragma unroll
+    for (int i = 0; i < G::XREGS; ++i) {
+        const int e = tid + 256 * i;
+        const int ci = e / G::XW;
+        const int p = e - ci * G::XW;
+        const int t = tin0 + p;
+        x_off[i] = (e < G::XELEMS && t >= 0 && t < a.frames_in) ? static_cast<unsigned>((ci * a.ld_in + t) * 4) : OOB;
+    }
     auto prefetch = [&](int ks) {
         const int k0 = ks * BK;
+        // (k0 floats into the weight rows; the rows' tail beyond ktot -- the last, partial K-step -- must read as zero, not as the next row)
+        const __amdgpu_buffer_rsrc_t wr = uniform_rsrc(a.w + k0, w_bytes > static_cast<unsigned>(k0) * 4u ? w_bytes - k0 * 4 : 0);
 #pragma unroll
         for (int i = 0; i < G::AREGS; ++i) {
-            const int row = m0 + a_row;
-            const int k = k0 + (a_kh + 2 * i) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < a.c_out && k < a.ktot)
-                v = *reinterpret_cast<const float4*>(a.w + static_cast<size_t>(row) * a.ktot + k);
-            areg[i] = v;
+            const bool in_k = k0 + (a_kh + 2 * i) * 4 < a.ktot;
+            const floatx4v v = __builtin_bit_cast(floatx4v, __builtin_amdgcn_raw_buffer_load_b128(wr, in_k ? a_off + i * 32 : OOB, 0, 0));
+            areg[i] = make_float4(v[0], v[1], v[2], v[3]);
         }
         const int ci0 = ks * G::KC;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t sr = uniform_rsrc(xstats, LNX ? static_cast<unsigned>(2 * a.ld_in * 4) : 0u);
+        const unsigned ch_left = LNX && ci0 < a.c_in ? static_cast<unsigned>((a.c_in - ci0) * 4) : 0u;
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t gr = uniform_rsrc(LNX ? a.ln_x.gamma + ci0 : nullptr, ch_left);
+        [[maybe_unused]] const __amdgpu_buffer_rsrc_t br = uniform_rsrc(LNX ? a.ln_x.beta + ci0 : nullptr, ch_left);
+        const unsigned row0_bytes = static_cast<unsigned>(ci0) * a.ld_in * 4;
+        const __amdgpu_buffer_rsrc_t xr = uniform_rsrc(xb + static_cast<size_t>(ci0) * a.ld_in, x_bytes > row0_bytes ? x_bytes - row0_bytes : 0);
 #pragma unroll
         for (int i = 0; i < G::XREGS; ++i) {
-            const int e = tid + 256 * i;
-            const int ci = e / G::XW;
-            const int p = e - ci * G::XW;
-            const int t = tin0 + p;
-            float v = 0.f;
-            if (e < G::XELEMS && (ci0 + ci) < a.c_in && t >= 0 && t < a.frames_in) {
-                v = xb[static_cast<size_t>(ci0 + ci) * a.ld_in + t];
-                if (a.ln_x.stats)
-                    v = ln_apply(v, xstats[t], xstats[a.ld_in + t], a.ln_x.gamma[ci0 + ci], a.ln_x.beta[ci0 + ci]);
+            float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, x_off[i], 0, 0));
+            if constexpr (LNX) {
+                const int e = tid + 256 * i;
+                const int ci = ci0 + e / G::XW, t = tin0 + e % G::XW;
+                if (x_off[i] != OOB && ci < a.c_in) {
+                    // (statistics through a resource + 32-bit offsets too: two 64-bit addresses per item were the LayerNorm instances' spills)
+                    const float mean = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, t * 4, 0, 0));
+                    const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(sr, (a.ld_in + t) * 4, 0, 0));
+                    const float gam = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gr, (e / G::XW) * 4, 0, 0));
+                    const float bet = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(br, (e / G::XW) * 4, 0, 0));
+                    v = ln_apply(v, mean, rstd, gam, bet);
+                }
             }
             xreg[i] = v;
         }
@@ -263,7 +302,8 @@ static int launch_gemm_conv(GemmConvArgs a, hipStream_t stream, const char* what
     const long long nwg = static_cast<long long>(a.n_mt) * a.n_nt * a.batch;
     if (nwg == 0) return NBASR_OK;
     NBASR_REQUIRE(nwg < (1ll << 31), NBASR_EINVAL, "%s: too many tiles (%lld)", what, nwg);
-    hipLaunchKernelGGL((gemm_conv_kernel<KW, STRIDE, SWAP, RELU>), dim3(static_cast<unsigned>(nwg)), dim3(256), 0, stream, a);
+    if (a.ln_x.stats) hipLaunchKernelGGL((gemm_conv_kernel<KW, STRIDE, SWAP, RELU, true>), dim3(static_cast<unsigned>(nwg)), dim3(256), 0, stream, a);
+    else              hipLaunchKernelGGL((gemm_conv_kernel<KW, STRIDE, SWAP, RELU, false>), dim3(static_cast<unsigned>(nwg)), dim3(256), 0, stream, a);
     return launch_status(what);
 }
 
