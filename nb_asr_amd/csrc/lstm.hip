@@ -17,6 +17,7 @@
 
 #include <cstdlib>
 #include <mutex>
+#include <vector>
 
 namespace nbasr {
 
@@ -460,9 +461,61 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     NBASR_REQUIRE(aligned16(packed_whh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence_packed: packed_whh, h_out must be 16-byte aligned");
     const dim3 grid(lstm_slices(hidden), (batch + 15) / 16);
     const int prio = batch <= 32;          // issue priority for the chain's waves where the chain is the critical path (see the kernel)
-    for (int t = 0; t < frames; ++t)
-        hipLaunchKernelGGL(lstm_step_packed_kernel, grid, dim3(64 * LSTM_WAVES), 0, as_stream(stream), gates_ws,
-                           static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, lstm_kchunks_p(hidden), t, prio);
+    hipStream_t s = as_stream(stream);
+    auto launch_chain = [&]() {
+        for (int t = 0; t < frames; ++t)
+            hipLaunchKernelGGL(lstm_step_packed_kernel, grid, dim3(64 * LSTM_WAVES), 0, s, gates_ws,
+                               static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, lstm_kchunks_p(hidden), t, prio);
+    };
+    // Round 5: the chain of `frames` dependent launches is replayed as ONE instantiated graph per (buffers, shape, device).  Issuing 250
+    // launches costs the host 0.6-0.7 ms per forward -- at 8 utterances per GPU that is half of the step, on the thread that also has to
+    // feed the encoder's stream; a graph launch costs ~15 us.  Same kernels, same order, same arguments: bit-identical h.  A stream that is
+    // being captured by the caller (forward_graph) takes the plain launches.
+    // (same-box A/B, alternating, bench.py --batch 8 / 16 / 64: 4 856 / 4 781 -> 5 036 / 4 873, 7 172 / 7 048 -> 7 258 / 7 248, 9 821 / 9 839 -> 9 852 / 9 896)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        launch_chain();
+        return launch_status("nbasr_lstm_recurrence_packed");
+    }
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); launch_chain(); return launch_status("nbasr_lstm_recurrence_packed"); }
+    struct Chain { const void* g; const void* w; void* c; void* h; int batch, frames, hidden, device; hipGraphExec_t exec; unsigned long long used; };
+    static std::mutex m;
+    static std::vector<Chain> cache;
+    static unsigned long long tick = 0;
+    hipGraphExec_t exec = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(m);
+        for (Chain& e : cache)
+            if (e.g == gates_ws && e.w == packed_whh && e.c == cell_ws && e.h == h_out && e.batch == batch && e.frames == frames && e.hidden == hidden &&
+                e.device == device) { e.used = ++tick; exec = e.exec; break; }
+    }
+    if (exec == nullptr) {
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            launch_chain();
+            e = hipStreamEndCapture(s, &graph);
+        }
+        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (e != hipSuccess || exec == nullptr) {                 // no graph on this runtime / stream: the plain chain
+            (void)hipGetLastError();
+            launch_chain();
+            return launch_status("nbasr_lstm_recurrence_packed");
+        }
+        std::lock_guard<std::mutex> lock(m);
+        if (cache.size() >= 16) {                                  // (two pipelined slots x a few shapes per plan; the least recently used one goes)
+            size_t lru = 0;
+            for (size_t i = 1; i < cache.size(); ++i) if (cache[i].used < cache[lru].used) lru = i;
+            (void)hipGraphExecDestroy(cache[lru].exec);
+            cache.erase(cache.begin() + lru);
+        }
+        cache.push_back(Chain{gates_ws, packed_whh, cell_ws, h_out, batch, frames, hidden, device, exec, ++tick});
+    }
+    const hipError_t e = hipGraphLaunch(exec, s);
+    if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_packed: hipGraphLaunch: %s", hipGetErrorString(e)); return static_cast<int>(e); }
     return launch_status("nbasr_lstm_recurrence_packed");
 }
 

@@ -275,6 +275,39 @@ def test_lstm_recurrence_packed_is_bit_identical(b, t, h):
     assert torch.isfinite(out1).all() and torch.equal(out0, out1)
 
 
+def test_per_frame_recurrence_replays_its_chain_as_a_graph():
+    """Round 5: nbasr_lstm_recurrence_packed replays its chain of per-frame launches as ONE cached graph per (buffers, shape, device).  The
+    graph bakes in pointers, not data: new gate values through the same buffers must give the new result (against the one-launch kernel,
+    which shares no launch path); more distinct buffer sets than the cache holds (16) evict without harm; a call on a stream that is being
+    captured by the caller takes the plain launches inside that capture."""
+    torch.manual_seed(3)
+    b, t, h = 5, 9, 500
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.2
+    packed = hip.lstm_pack_whh(w_hh)
+    ws = hip.lstm_seq_workspace(b, h, DEV)
+    sets = [(torch.empty(t, b, 4 * h, device=DEV), torch.empty(b, h, device=DEV), torch.empty(b, t, h, device=DEV)) for _ in range(20)]
+    for rnd in range(3):
+        for gates, cell, out in sets:
+            gates.copy_(torch.randn(t, b, 4 * h, device=DEV))
+            out.fill_(float('nan'))
+            hip.lstm_recurrence_packed(gates, packed, cell, out)
+            want, cell1 = torch.full_like(out, float('nan')), torch.empty_like(cell)
+            hip.lstm_recurrence_seq(gates, packed, cell1, want, ws)
+            assert torch.equal(out, want) and torch.equal(cell, cell1), rnd
+    gates, cell, out = sets[0]
+    want = out.clone()
+    out.fill_(float('nan'))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            hip.lstm_recurrence_packed(gates, packed, cell, out)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+
+
 @pytest.mark.parametrize('b,t,h', [(3, 7, 500), (17, 5, 36), (64, 3, 500), (2, 4, 12), (8, 250, 500), (33, 61, 500), (1, 1, 500), (16, 2, 512)])
 def test_lstm_recurrence_in_one_launch_is_bit_identical(b, t, h):
     """All frames in one launch (w_hh resident, flag-synchronised steps) against one launch per frame: same h, bit for bit; the status
