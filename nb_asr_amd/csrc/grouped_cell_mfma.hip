@@ -31,6 +31,13 @@
 
 #include <type_traits>
 
+#ifndef NBASR_CELLM_STAMPS
+#define NBASR_CELLM_STAMPS 0
+#endif
+#if NBASR_CELLM_STAMPS
+#include <cstdlib>
+#endif
+
 namespace nbasr {
 
 typedef __bf16 cm_bf8 __attribute__((ext_vector_type(8)));
@@ -49,6 +56,9 @@ struct CellMDims {
     int k[3], d[3], lpad[3], nstep[3];          // taps, dilation, left padding, MFMAs per column block of each node
     int skips;                                  // bit0 s00 | bit1 s10 | bit2 s11 | bit3 s20 | bit4 s21 | bit5 s22
     int nt;                                     // 256-frame wave tiles per row
+#if NBASR_CELLM_STAMPS
+    unsigned long long* stamps;                 // diagnostics build (tools/gpu/cellm_stamps.py): 16 clock stamps per wave
+#endif
 };
 
 __device__ __forceinline__ cm_f4 cm_unpack4(u2v p) { return cm_f4{bf16_lo(p.x), bf16_hi(p.x), bf16_lo(p.y), bf16_hi(p.y)}; }
@@ -72,6 +82,19 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     unsigned char* const tile_b = tile_a + tile_bytes;               // x1, then x3
     const int g = blockIdx.x * GPW + gi, b = blockIdx.y;             // (GPW divides the group count: host check)
     const int fb = ti * CM_WAVE_FRAMES;
+    // -DNBASR_CELLM_STAMPS=1 (NBASR_EXTRA_CXXFLAGS; tools/gpu/cellm_stamps.py): every wave records the 100 MHz clock at its phase boundaries
+#if NBASR_CELLM_STAMPS
+    unsigned long long* const stamp_row = a.stamps ? a.stamps + ((static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 16 : nullptr;
+    int stamp_i = 1;
+    auto stamp = [&]() {
+        if (stamp_row && lane == 0) stamp_row[stamp_i] = wall_clock64();
+        ++stamp_i;
+    };
+    if (stamp_row && lane == 0) stamp_row[0] = __builtin_amdgcn_s_getreg(4 | (31 << 11)) | (static_cast<unsigned long long>(__builtin_amdgcn_s_getreg(20 | (31 << 11))) << 32);
+#else
+    auto stamp = []() {};
+#endif
+    stamp();
 
     // ---- zero pads of every tile ---------------------------------------------------------------------------------------------------
     {
@@ -129,7 +152,9 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
             for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(dst + j * CP * 2) = pack_bf16x2(v0[j], v1[j]);
         }
     }
+    stamp();
     __syncthreads();
+    stamp();
 
     // ---- the three nodes -------------------------------------------------------------------------------------------------------------
     const int n16 = lane & 15, kb = lane >> 4;                       // MFMA fragment coordinates: column / row-in-tile, 8-deep k block
@@ -164,10 +189,10 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 #pragma unroll
         for (int r = 0; r < 4; ++r) bv[r] = (q4 + r < a.cg) ? bias[g * a.cg + q4 + r] : 0.f;
         cm_u4 nxt[NSMAX];
-        auto fetch = [&](int nb) {
+        auto fetch = [&](int nb, auto nsc) {
+            constexpr int NS = decltype(nsc)::value;
 #pragma unroll
-            for (int s = 0; s < NSMAX; ++s)
-                if (s < 3 || four) nxt[s] = *reinterpret_cast<const cm_u4*>(src + off[s] + nb * NB_STRIDE);
+            for (int s = 0; s < NS; ++s) nxt[s] = *reinterpret_cast<const cm_u4*>(src + off[s] + nb * NB_STRIDE);
         };
         // The node's skip inputs as all-ones / all-zeros MASKS on the packed bf16 pairs (wave-uniform): the column-block loop below has NO
         // branch on them, so the sixteen blocks are one straight line and the scheduler overlaps one block's epilogue with the next
@@ -179,19 +204,21 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
         const unsigned m_b = (NODE == 1 ? (sk & 4) : NODE == 2 ? (sk & 16) : 0) ? 0xffffffffu : 0u;               // x1 from tile B
         const unsigned m_k = (NODE == 2 && (sk & 8)) ? 0xffffffffu : 0u;                                          // x0n carried in registers
         const bool any = NODE == 0 ? (sk & 1) != 0 : NODE == 1 ? (sk & (2 | 4 | 8)) != 0 : (sk & (8 | 16 | 32)) != 0;
-        auto blocks = [&](auto with_skips) {
+        // (K steps as a compile-time count: a wave-uniform branch per block on `four` splits the unrolled blocks into basic blocks
+        // and pins every block's reads, MFMAs and epilogue in program order)
+        auto blocks = [&](auto with_skips, auto nsc) {
             constexpr bool SK = decltype(with_skips)::value;
-            fetch(0);
+            constexpr int NS = decltype(nsc)::value;
+            fetch(0, nsc);
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 cm_u4 cur[NSMAX];
 #pragma unroll
-                for (int s = 0; s < NSMAX; ++s) cur[s] = nxt[s];
-                if (nb + 1 < NBW) fetch(nb + 1);                     // the next block's operands are in flight behind this block's MFMAs
+                for (int s = 0; s < NS; ++s) cur[s] = nxt[s];
+                if (nb + 1 < NBW) fetch(nb + 1, nsc);                // the next block's operands are in flight behind this block's MFMAs
                 cm_f4 acc = bv;
 #pragma unroll
-                for (int s = 0; s < NSMAX; ++s)
-                    if (s < 3 || four) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[s], __builtin_bit_cast(cm_bf8, cur[s]), acc, 0, 0, 0);
+                for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[s], __builtin_bit_cast(cm_bf8, cur[s]), acc, 0, 0, 0);
                 float o[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[r]);
@@ -214,12 +241,24 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
                         add(m_a, ta);
                     }
                 }
-                if (tail && fb + fblk + nb * 16 + n16 >= a.frames) { o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f; }
                 *reinterpret_cast<u2v*>(dst + pos) = u2v{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             }
         };
-        if (any) blocks(std::true_type{}); else blocks(std::false_type{});
+        using N3 = std::integral_constant<int, 3>; using N4 = std::integral_constant<int, 4>;
+        if (any) { if (four) blocks(std::true_type{}, N4{}); else blocks(std::true_type{}, N3{}); }
+        else     { if (four) blocks(std::false_type{}, N4{}); else blocks(std::false_type{}, N3{}); }
+        if (tail) {
+            // frames beyond the row stay exactly 0: the wave tile that holds the row's end (and any tile beyond it) re-zeroes its rows of
+            // the output tile from `frames` on -- behind its own stores (one wave's LDS operations execute in order), before the barrier.
+            // (Round 5: was a compare + 4 selects on every column block of every wave.)
+            const int f_lo = a.frames > fb ? a.frames : fb;
+            const int units = (fb + CM_WAVE_FRAMES - f_lo) * CP * 2 / 16;
+            unsigned char* z = dst + (f_lo + CM_PADL) * CP * 2;
+            for (int i = lane; i < units; i += 64) *reinterpret_cast<cm_u4*>(z + i * 16) = cm_u4{0u, 0u, 0u, 0u};
+        }
+        stamp();
         __syncthreads();
+        stamp();
     };
     node(std::integral_constant<int, 0>{}, wp0, b0, tile_a, tile_b);
     node(std::integral_constant<int, 1>{}, wp1, b1, tile_b, tile_a);
@@ -247,6 +286,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
             __builtin_amdgcn_raw_buffer_store_b128(r1, yr, ok ? off + a.ld * 2 : off, 0, 2);
         }
     }
+    stamp();
 }
 
 static size_t cellm_lds_bytes(int cp, int nt, int gpw, int nbt)
@@ -372,6 +412,9 @@ extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const fl
     a.skips = skip_mask;
     const int nbt = cellm_nbt(ld, cellm_cp(channels / groups));
     a.nt = (ld + 16 * nbt - 1) / (16 * nbt);
+#if NBASR_CELLM_STAMPS
+    { const char* e = getenv("NBASR_CELLM_STAMPS"); a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
+#endif
     const void* const wp[3] = {wp0, wp1, wp2};
     const float* const bias[3] = {b0, b1, b2};
     const LnRef l = ln_ref(ln, true);
