@@ -8,22 +8,27 @@
 // exact bf16 x bf16 products, fp32 accumulation -- the reference's arithmetic up to the order of the sums.
 //
 // Mapping (per group of CG = 6..12 channels; groups never mix):
-//   * the group's tensor lives in LDS FRAME-major, tile[frame][CP channels] bf16 with CP = 8 or 16 (pad channels are zero), 16 zero
-//     frames either side: a frame's channels are 16 (or 2 x 16) contiguous, 16-byte aligned bytes;
+//   * the group's tensor lives in LDS as channel-quad PLANES, tile[quad][frame][4 channels] bf16 (CP = 8 or 16 channel slots = 2 or 4
+//     planes; pad channels are zero), 16 zero frames either side of every plane: a plane row is the 8 bytes one lane of the accumulator
+//     fragment holds (round 5; rounds 3-4 kept frame-major rows of CP channels: every store 4-way, every skip read 2-way bank-conflicted);
 //   * one MFMA = 16 fragment rows (M) x 16 frames (N) x 32 (tap, channel) pairs (K), always 2 taps per K step.  CP = 16: the rows are
 //     the group's 16 (padded) channels, K = 2 taps x 16 channels.  CP = 8: only 8 rows exist, so ONE MFMA serves TWO column blocks 128
 //     frames apart -- rows 0-7 x K slots 0-15 (2 taps x 8 channels of block nb), rows 8-15 x K slots 16-31 (the same taps of block
 //     nb + 8), weights packed block-diagonally -- and every lane of the accumulator fragment holds real outputs.  The B operand of lane
-//     (n, kb) is ONE aligned ds_read_b128 -- the 8 channels of frame f0 + n + tap * dilation - left_pad -- so dilation and padding are
-//     address arithmetic; the A operand is the weights, pre-packed per (node, group, K step, lane) and held in registers for the node
+//     (n, kb) is two ds_read_b64 one plane apart -- the 8 channels of frame f0 + n + tap * dilation - left_pad -- so dilation and padding
+//     are address arithmetic; the A operand is the weights, pre-packed per (node, group, K step, lane) and held in registers for the node
 //     (<= 16 registers);
-//   * a wave owns 256 frames = 16 column blocks (128 = 8 for rows of <= 1024 frames: twice the waves); per block (CP = 8: per pair of blocks) 3-4 MFMAs (taps padded to 6 / 8 with zero weights; a padded tap reads
-//     the lane's tap-0 window, so a NaN there surfaces at this frame as it does through the real tap 0), then the node's epilogue on the accumulator fragment -- lane =
-//     (frame, 4 channels): bias is the accumulator's initial value, relu + clamp, the skips in python's sum order, tail mask, ONE
-//     rounding to bf16 -- written as 8 bytes into the OTHER tile (ping-pong: x0n in A, x1 in B, x2 in A, x3 in B), so a node needs one
-//     barrier, not two.  Skip inputs are read at the lane's own position (x0n for the last node is carried in registers);
-//   * x0 comes in and x3 goes out channel-major (the tensors' layout in HBM) through a lane = (channel pair, 8-frame chunk) map:
-//     16-byte global accesses, 4-byte LDS accesses.
+//   * a wave owns 256 frames = 16 column blocks (128 = 8 for rows of <= 1024 frames: twice the waves); per block (CP = 8: per pair of
+//     blocks) 3-4 MFMAs (taps padded to 6 / 8 with zero weights; a padded tap reads the lane's tap-0 window, so a NaN there surfaces at
+//     this frame as it does through the real tap 0), then the node's epilogue on the accumulator fragment -- lane = (frame, 4 channels):
+//     bias is the accumulator's initial value, relu + clamp, the skips in python's sum order, ONE rounding to bf16 -- written as 8 bytes
+//     into the OTHER tile (ping-pong: x0n in A, x1 in B, x2 in A, x3 in B), so a node needs one barrier, not two; the wave tile that
+//     holds the row's end re-zeroes the frames beyond it once per node.  Skip inputs are read at the lane's own position (x0n for the
+//     last node is carried in registers);
+//   * x0 comes in and x3 goes out channel-major (the tensors' layout in HBM): 16-byte global accesses by lane = (channel, 8-frame chunk),
+//     a wave-private channel-major scratch image in the tile that is idle at that moment, and ds_read_b64_tr_b16 -- the hardware
+//     transposing read -- between that image and the planes; the pending LayerNorm is applied on the transposed side (lane = one frame,
+//     4 channels: one (mean, rstd) per lane and gather, packed arithmetic).
 // No statistics by-product (the bf16 executor's cell LayerNorm is consumed by the next convolution's image writer, which computes
 // them on the way); a cell whose consumer wants them runs on grouped_cell.hip.
 #include "common.h"
@@ -63,6 +68,27 @@ struct CellMDims {
 
 __device__ __forceinline__ cm_f4 cm_unpack4(u2v p) { return cm_f4{bf16_lo(p.x), bf16_hi(p.x), bf16_lo(p.y), bf16_hi(p.y)}; }
 
+// ---- LDS image of a group's tensor (round 5): channel-quad PLANES, tile[quad][frame][4 channels] ---------------------------------
+// A plane row is 8 bytes: the 4 channels of one frame -- exactly what one lane of the accumulator fragment holds (frame n, rows
+// 4 kb .. 4 kb + 3), so a node's output is ONE ds_write_b64 whose 16-lane groups cover 128 contiguous bytes (the frame-major rows of
+// rounds 3-4 put those lanes 32 bytes apart: 4-way bank conflicts on every store, 2-way on every skip read).  The B operand of lane
+// (n, kb) -- 8 channels of frame n + shift -- is two ds_read_b64 one plane apart.  Plane q starts at q * PB + {0, 128, 128, 256}[q]
+// with PB a multiple of 256: modulo the 256 bytes the 64 banks span, the planes sit at 0 / 128 / 128 / 0, so the two planes a
+// 32-lane half touches in one access (operand reads: quads {0, 2} or {1, 3}; own-position reads and stores: {0, 1} or {2, 3}) never
+// share banks.
+__host__ __device__ inline int cm_plane_bytes(int rows) { return (rows * 8 + 255) & ~255; }
+__host__ __device__ inline int cm_plane_off(int q, int pb) { return q * pb + (q == 0 ? 0 : q == 3 ? 256 : 128); }
+__host__ __device__ inline int cm_tile_bytes(int cp, int rows) { return (cp / 4) * cm_plane_bytes(rows) + 256; }
+
+typedef short cm_s4 __attribute__((ext_vector_type(4)));
+// ds_read_b64_tr_b16 (gfx950): per 16-lane group a block of 4 rows x 16 columns of 16-bit elements; lane 4q + p supplies the address of
+// row q, columns 4p .. 4p + 3; lane i receives column i of the 4 rows (row q in element q).  EXEC must be all ones.
+__device__ __forceinline__ u2v cm_tr_read(const unsigned char* p)
+{
+    const cm_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((cm_s4 __attribute__((address_space(3)))*)(p));
+    return __builtin_bit_cast(u2v, v);
+}
+
 template <int CP, int GPW, int NBT>
 __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     const bf16_t* __restrict__ x0, bf16_t* __restrict__ y,
@@ -71,10 +97,11 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     const float* __restrict__ ln_stats, const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, const CellMDims a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char cm_lds[];
-    constexpr int CM_NB = NBT, CM_WAVE_FRAMES = 16 * NBT;
+    constexpr int CM_NB = NBT, CM_WAVE_FRAMES = 16 * NBT, Q = CP / 4;
     const int nt = a.nt;
     const int rows = nt * CM_WAVE_FRAMES + CM_PADL + CM_PADR;        // frames of a tile, pads included
-    const int tile_bytes = rows * CP * 2;
+    const int pb = cm_plane_bytes(rows);
+    const int tile_bytes = Q * pb + 256;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gi = wave / nt, ti = wave - gi * nt;
@@ -96,65 +123,122 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 #endif
     stamp();
 
-    // ---- zero pads of every tile ---------------------------------------------------------------------------------------------------
-    {
-        const int units = (CM_PADL + CM_PADR) * CP * 2 / 16;         // 16-byte units per tile
-        for (int i = threadIdx.x; i < GPW * 2 * units; i += blockDim.x) {
-            const int t = i / units, u = i - t * units;
-            const int byte = u * 16 < CM_PADL * CP * 2 ? u * 16 : (rows - CM_PADR) * CP * 2 + (u * 16 - CM_PADL * CP * 2);
-            *reinterpret_cast<cm_u4*>(cm_lds + t * tile_bytes + byte) = cm_u4{0u, 0u, 0u, 0u};
+    // the 16 zero frames either side of every plane of one tile of every group of the workgroup (16-byte units: 8 per pad)
+    auto zero_pads = [&](int which) {
+        for (int i = threadIdx.x; i < GPW * Q * 16; i += blockDim.x) {
+            const int t = i / (Q * 16), r = i - t * (Q * 16), q = r >> 4, u = r & 15;
+            const int byte = cm_plane_off(q, pb) + (u < 8 ? u * 16 : (rows - CM_PADR) * 8 + (u - 8) * 16);
+            *reinterpret_cast<cm_u4*>(cm_lds + (t * 2 + which) * tile_bytes + byte) = cm_u4{0u, 0u, 0u, 0u};
         }
-    }
+    };
+    // frames beyond the row stay exactly 0: the wave tile that holds the row's end (and any tile beyond it) re-zeroes its rows of a
+    // tile from `frames` on -- behind its own stores (one wave's LDS operations execute in order), before the barrier
+    const bool tail = fb + CM_WAVE_FRAMES > a.frames;                // (wave-uniform)
+    auto zero_tail = [&](unsigned char* tile) {
+        const int f_lo = a.frames > fb ? a.frames : fb;
+        const int n = fb + CM_WAVE_FRAMES - f_lo;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            unsigned char* z = tile + cm_plane_off(q, pb) + (f_lo + CM_PADL) * 8;
+            for (int r = lane; r < n; r += 64) *reinterpret_cast<u2v*>(z + r * 8) = u2v{0u, 0u};
+        }
+    };
+    zero_pads(0);
 
-    // ---- x0 -> tile A, normalised (pending LayerNorm) and rounded: lane = (channel pair, 8-frame chunk) ------------------------------
-    constexpr int PAIRS = CP / 2, CPI = 64 / PAIRS;                  // channel pairs of a tile row; chunks per wave instruction
-    const int cp = lane % PAIRS, chl = lane / PAIRS;
+    // ---- x0 -> tile A, normalised (pending LayerNorm) and rounded ----------------------------------------------------------------------
+    // x0 arrives channel-major (the tensors' layout in HBM): lane = (channel, 8-frame chunk), 16-byte global loads, stored as they are
+    // into a wave-private channel-major scratch image (the wave's share of tile B, free until node 0 writes x1), then read back
+    // TRANSPOSED: ds_read_b64_tr_b16 hands lane i of a 16-lane group the 4 channels of a quad at frame i -- a plane row.  The image is
+    // [channel][16-frame unit ^ (channel & 7)][16 frames]: the 4 (8) channel rows a group (32-lane half) gathers from lie 512 (256) bytes
+    // apart, the swizzle spreads them over different banks.  (Rounds 3-4 wrote 4-byte channel pairs straight into frame-major rows: the
+    // chunks of a wave's lanes sat 128 bytes apart, 8-way bank conflicts on every store; and normalised 16 elements per lane with
+    // per-element statistics.)
+    constexpr int CH_CHUNKS = CM_WAVE_FRAMES / 8;                    // 8-frame chunks of a channel row within a wave tile
+    constexpr int NI = CP * CH_CHUNKS / 64;                          // global-access instructions per wave (pad channels included)
+    constexpr int NTR = Q * NBT / 4;                                 // transposed reads per wave: 4 (quad, 16-frame unit) blocks each
+    constexpr int ROWB = CM_WAVE_FRAMES * 2;                         // bytes of a scratch channel row
     const size_t group_row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * a.cg) * a.ld;
-    const bool pair_ok = 2 * cp < a.cg;
+    const int i16 = lane & 15, gq = lane >> 4;
+    const int tquad = Q == 2 ? (gq & 1) : gq;                        // the quad this lane's group transposes
+    const int tun = Q == 2 ? (gq >> 1) : 0;                          // and its unit within an instruction's pair (Q == 2: two units per instruction)
+    constexpr int UPI = Q == 2 ? 2 : 1;                              // units per transposed-read instruction
     {
+        unsigned char* const scr = tile_b + ti * (CP * ROWB);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x0 + group_row0), 0, a.cg * a.ld * 2, 0x00020000);
-        const bool has_ln = ln_stats != nullptr;
-        const int c0 = min(2 * cp, a.cg - 2);
-        float gam0 = 1.f, bet0 = 0.f, gam1 = 1.f, bet1 = 0.f;
+        cm_u4 raw[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 64 + lane, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS, f0 = fb + chunk * 8;
+            const int off = (ch < a.cg && f0 < a.ld) ? (ch * a.ld + f0) * 2 : 0x7ffffff0;   // out of range (pad channels, beyond the row): zeros
+            raw[it] = __builtin_bit_cast(cm_u4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
+        }
+        const bool has_ln = ln_stats != nullptr;                     // (workgroup-uniform)
+        typedef float cm_f2 __attribute__((ext_vector_type(2)));
+        float nmean[NTR], rstd[NTR];
+        cm_f2 gam01{0.f, 0.f}, gam23 = gam01, bet01 = gam01, bet23 = gam01;
         if (has_ln) {
-            gam0 = ln_gamma[g * a.cg + c0]; bet0 = ln_beta[g * a.cg + c0];
-            gam1 = ln_gamma[g * a.cg + c0 + 1]; bet1 = ln_beta[g * a.cg + c0 + 1];
-        }
-        const float* mrow = ln_stats + static_cast<size_t>(b) * 2 * a.ld;
+            // (mean, rstd) of the wave's frames: two 16-byte loads per lane at most, parked in the wave's own rows of tile A's first plane
+            // (which x0n overwrites below) and picked up per (unit, frame) from there -- 2 NTR four-byte global loads per lane otherwise,
+            // and the texture path, not the data, is what 16 waves staging at once wait for
+            const float* mrow = ln_stats + static_cast<size_t>(b) * 2 * a.ld;
+            float* const sarea = reinterpret_cast<float*>(tile_a + (CM_PADL + fb) * 8);          // 2 x CM_WAVE_FRAMES floats
+            constexpr int QR = CM_WAVE_FRAMES / 4;                   // 16-byte pieces per statistics row
 #pragma unroll
-        for (int it = 0; it < (2 * NBT) / CPI; ++it) {
-            const int chunk = ti * (2 * NBT) + it * CPI + chl, f0 = chunk * 8;
-            const bool ok = pair_ok && f0 < a.ld;
-            const int off = ok ? (2 * cp * a.ld + f0) * 2 : 0x7ffffff0;              // out of range: the buffer load returns zeros
-            const cm_u4 r0 = __builtin_bit_cast(cm_u4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
-            const cm_u4 r1 = __builtin_bit_cast(cm_u4, __builtin_amdgcn_raw_buffer_load_b128(xr, ok ? off + a.ld * 2 : off, 0, 0));
-            float v0[8], v1[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { v0[2 * j] = bf16_lo(r0[j]); v0[2 * j + 1] = bf16_hi(r0[j]); v1[2 * j] = bf16_lo(r1[j]); v1[2 * j + 1] = bf16_hi(r1[j]); }
-            if (has_ln) {                                            // (workgroup-uniform)
-                float mean[8], rstd[8];
-                const int fs = f0 < a.ld ? f0 : 0;                   // (beyond the row: any valid address; the values are zeros anyway)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float4 m4 = *reinterpret_cast<const float4*>(mrow + fs + 4 * h);
-                    const float4 r4 = *reinterpret_cast<const float4*>(mrow + a.ld + fs + 4 * h);
-                    mean[4 * h] = m4.x; mean[4 * h + 1] = m4.y; mean[4 * h + 2] = m4.z; mean[4 * h + 3] = m4.w;
-                    rstd[4 * h] = r4.x; rstd[4 * h + 1] = r4.y; rstd[4 * h + 2] = r4.z; rstd[4 * h + 3] = r4.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    v0[j] = ok ? ln_apply(v0[j], mean[j], rstd[j], gam0, bet0) : 0.f;
-                    v1[j] = ok ? ln_apply(v1[j], mean[j], rstd[j], gam1, bet1) : 0.f;
-                }
+            for (int i0 = 0; i0 < 2 * QR; i0 += 64) {
+                const int i = i0 + lane, row = i / QR, c = i - row * QR, f = fb + 4 * c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < 2 * QR && f < a.ld) v = *reinterpret_cast<const float4*>(mrow + row * a.ld + f);
+                if (i < 2 * QR) *reinterpret_cast<float4*>(sarea + row * CM_WAVE_FRAMES + 4 * c) = v;
             }
-            unsigned char* dst = tile_a + ((f0 + CM_PADL) * CP + 2 * cp) * 2;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) *reinterpret_cast<unsigned*>(dst + j * CP * 2) = pack_bf16x2(v0[j], v1[j]);
+            for (int k = 0; k < NTR; ++k) {
+                const int fl = 16 * (UPI * k + tun) + i16;
+                nmean[k] = -sarea[fl]; rstd[k] = sarea[CM_WAVE_FRAMES + fl];
+            }
+            // pad channels of the last quad: gamma = beta = 0, so that their (zero) inputs stay zero
+            const int c = 4 * tquad;
+            float gm[4], bt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool real = c + j < a.cg;
+                const int idx = g * a.cg + (real ? c + j : 0);
+                gm[j] = real ? ln_gamma[idx] : 0.f; bt[j] = real ? ln_beta[idx] : 0.f;
+            }
+            gam01 = cm_f2{gm[0], gm[1]}; gam23 = cm_f2{gm[2], gm[3]}; bet01 = cm_f2{bt[0], bt[1]}; bet23 = cm_f2{bt[2], bt[3]};
         }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 64 + lane, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS;
+            *reinterpret_cast<cm_u4*>(scr + ch * ROWB + (((chunk >> 1) ^ (ch & 7)) * 32) + (chunk & 1) * 16) = raw[it];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int tch = 4 * tquad + ((lane >> 2) & 3);              // the channel row this lane addresses for the gather
+        const unsigned char* const trow = scr + tch * ROWB + (lane & 3) * 8;
+        unsigned char* const drow = tile_a + cm_plane_off(tquad, pb) + (CM_PADL + fb + 16 * tun + i16) * 8;
+        // (all gathers first: a store to the plane between two of them would pin the next gather behind it -- the compiler cannot tell
+        // the plane from the scratch image -- and the eight LDS round trips would run one after the other)
+        u2v tv[NTR];
+#pragma unroll
+        for (int k = 0; k < NTR; ++k) tv[k] = cm_tr_read(trow + (((UPI * k + tun) ^ (tch & 7)) * 32));
+#pragma unroll
+        for (int k = 0; k < NTR; ++k) {
+            u2v v = tv[k];
+            if (has_ln) {
+                const cm_f2 nm{nmean[k], nmean[k]}, rs{rstd[k], rstd[k]};
+                const cm_f2 lo = __builtin_elementwise_fma((cm_f2{bf16_lo(v.x), bf16_hi(v.x)} + nm) * rs, gam01, bet01);
+                const cm_f2 hi = __builtin_elementwise_fma((cm_f2{bf16_lo(v.y), bf16_hi(v.y)} + nm) * rs, gam23, bet23);
+                v = u2v{pack_bf16x2(lo.x, lo.y), pack_bf16x2(hi.x, hi.y)};
+            }
+            *reinterpret_cast<u2v*>(drow + k * (UPI * 128)) = v;
+        }
+        if (tail) zero_tail(tile_a);                                 // (normalising a zero beyond `frames` gives beta, not 0)
     }
     stamp();
     __syncthreads();
     stamp();
+    zero_pads(1);                                                    // (tile B's pads lay under the scratch image; node 0 writes only frames of the row)
 
     // ---- the three nodes -------------------------------------------------------------------------------------------------------------
     const int n16 = lane & 15, kb = lane >> 4;                       // MFMA fragment coordinates: column / row-in-tile, 8-deep k block
@@ -165,10 +249,11 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     constexpr int NBW = CP == 8 ? CM_NB / 2 : CM_NB;                 // column-block iterations per wave
     const int fblk = CP == 8 ? (kb >> 1) * (CM_WAVE_FRAMES / 2) : 0; // this lane's frame offset within the wave tile (second block of the pair)
     const int q4 = CP == 8 ? (kb & 1) * 4 : kb * 4;                  // first of this lane's 4 output channels in the accumulator fragment
-    const int own = ((fb + fblk + n16 + CM_PADL) * CP + q4) * 2;     // this lane's (frame, 4 channels) of column block 0, bytes
-    constexpr int NB_STRIDE = 16 * CP * 2;                           // bytes between column blocks
+    const int own = cm_plane_off(q4 >> 2, pb) + (fb + fblk + n16 + CM_PADL) * 8;   // this lane's (frame, channel quad) of column block 0, bytes
+    constexpr int NB_STRIDE = 16 * 8;                                // bytes between column blocks (within a plane)
+    const int opq = CP == 8 ? 0 : 2 * (kb & 1);                      // first of the two quads this lane's B operand takes
+    const int op_plane = cm_plane_off(opq, pb), op_next = pb + 128;  // (plane opq + 1 starts pb + 128 bytes after plane opq, for opq 0 and 2)
     u2v keep0[NBW];                                                  // x0n at the lane's positions, for the last node's skip
-    const bool tail = fb + CM_WAVE_FRAMES > a.frames;                // (wave-uniform) only the wave tile that holds the row's end masks frames
 
     constexpr int NSMAX = 4;                                         // K steps per column block: 2 taps each, 6 or 8 taps (3 or 4 steps)
     auto node = [&](auto idx, const cm_u4* __restrict__ wp, const float* __restrict__ bias, const unsigned char* src, unsigned char* dst) {
@@ -180,9 +265,8 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 #pragma unroll
         for (int s = 0; s < NSMAX; ++s) {
             const int tap = CP == 8 ? s * 2 + (kb & 1) : s * 2 + (kb >> 1);
-            const int chb = CP == 8 ? 0 : (kb & 1);
             // a padded tap (tap >= K) has zero weights; its B operand is the lane's tap-0 window (finite wherever the data are)
-            off[s] = ((fb + fblk + n16 + (tap < K ? tap * D - LP : -LP) + CM_PADL) * CP + chb * 8) * 2;
+            off[s] = op_plane + (fb + fblk + n16 + (tap < K ? tap * D - LP : -LP) + CM_PADL) * 8;
             aw[s] = __builtin_bit_cast(cm_bf8, wp[(static_cast<size_t>(g) * ns + (s < ns ? s : 0)) * 64 + lane]);
         }
         cm_f4 bv;
@@ -192,7 +276,11 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
         auto fetch = [&](int nb, auto nsc) {
             constexpr int NS = decltype(nsc)::value;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) nxt[s] = *reinterpret_cast<const cm_u4*>(src + off[s] + nb * NB_STRIDE);
+            for (int s = 0; s < NS; ++s) {
+                const u2v lo = *reinterpret_cast<const u2v*>(src + off[s] + nb * NB_STRIDE);
+                const u2v hi = *reinterpret_cast<const u2v*>(src + off[s] + op_next + nb * NB_STRIDE);
+                nxt[s] = cm_u4{lo.x, lo.y, hi.x, hi.y};
+            }
         };
         // The node's skip inputs as all-ones / all-zeros MASKS on the packed bf16 pairs (wave-uniform): the column-block loop below has NO
         // branch on them, so the sixteen blocks are one straight line and the scheduler overlaps one block's epilogue with the next
@@ -247,15 +335,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
         using N3 = std::integral_constant<int, 3>; using N4 = std::integral_constant<int, 4>;
         if (any) { if (four) blocks(std::true_type{}, N4{}); else blocks(std::true_type{}, N3{}); }
         else     { if (four) blocks(std::false_type{}, N4{}); else blocks(std::false_type{}, N3{}); }
-        if (tail) {
-            // frames beyond the row stay exactly 0: the wave tile that holds the row's end (and any tile beyond it) re-zeroes its rows of
-            // the output tile from `frames` on -- behind its own stores (one wave's LDS operations execute in order), before the barrier.
-            // (Round 5: was a compare + 4 selects on every column block of every wave.)
-            const int f_lo = a.frames > fb ? a.frames : fb;
-            const int units = (fb + CM_WAVE_FRAMES - f_lo) * CP * 2 / 16;
-            unsigned char* z = dst + (f_lo + CM_PADL) * CP * 2;
-            for (int i = lane; i < units; i += 64) *reinterpret_cast<cm_u4*>(z + i * 16) = cm_u4{0u, 0u, 0u, 0u};
-        }
+        if (tail) zero_tail(dst);                                    // (round 5: was a compare + 4 selects on every column block of every wave)
         stamp();
         __syncthreads();
         stamp();
@@ -264,26 +344,37 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     node(std::integral_constant<int, 1>{}, wp1, b1, tile_b, tile_a);
     node(std::integral_constant<int, 2>{}, wp2, b2, tile_a, tile_b);
 
-    // ---- x3 (tile B) -> y, channel-major: lane = (channel pair, 8-frame chunk) -------------------------------------------------------
+    // ---- x3 (tile B) -> y, channel-major: the way in, backwards ---------------------------------------------------------------------------
+    // Transposed gather from the planes (rows = 4 frames, 4 channels each; lane i receives channel i & 3 at frames 4 (i >> 2) .. + 3), an
+    // 8-byte store into the wave-private channel-major scratch image (its share of tile A: nobody reads x2 after the barrier above), then
+    // lane = (channel, 8-frame chunk): 16-byte LDS reads, 16-byte global stores.
     {
+        int ln2 = lane;                                              // (a fresh value: keeps the offsets of the way in from being carried -- spilled -- across the nodes)
+        asm volatile("" : "+v"(ln2));
+        unsigned char* const scr = tile_a + ti * (CP * ROWB);
+        const unsigned char* const prow = tile_b + cm_plane_off(tquad, pb) + (CM_PADL + fb + 16 * tun + 4 * (ln2 & 3) + ((ln2 >> 2) & 3)) * 8;
+        const int och = 4 * tquad + (ln2 & 3);
+        unsigned char* const srow = scr + och * ROWB + ((ln2 >> 2) & 3) * 8;
+        u2v tv[NTR];
+#pragma unroll
+        for (int k = 0; k < NTR; ++k) tv[k] = cm_tr_read(prow + k * (UPI * 128));
+#pragma unroll
+        for (int k = 0; k < NTR; ++k) *reinterpret_cast<u2v*>(srow + (((UPI * k + tun) ^ (och & 7)) * 32)) = tv[k];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(y + group_row0, 0, a.cg * a.ld * 2, 0x00020000);
+        cm_u4 rr[NI];
 #pragma unroll
-        for (int it = 0; it < (2 * NBT) / CPI; ++it) {
-            const int chunk = ti * (2 * NBT) + it * CPI + chl, f0 = chunk * 8;
-            const unsigned char* srcp = tile_b + ((f0 + CM_PADL) * CP + 2 * cp) * 2;
-            unsigned dd[8];
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 64 + ln2, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS;
+            rr[it] = *reinterpret_cast<const cm_u4*>(scr + ch * ROWB + (((chunk >> 1) ^ (ch & 7)) * 32) + (chunk & 1) * 16);
+        }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) dd[j] = *reinterpret_cast<const unsigned*>(srcp + j * CP * 2);
-            cm_u4 r0, r1;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r0[j] = __builtin_amdgcn_perm(dd[2 * j + 1], dd[2 * j], 0x05040100u);       // channel 2 cp:     frames 2j, 2j + 1
-                r1[j] = __builtin_amdgcn_perm(dd[2 * j + 1], dd[2 * j], 0x07060302u);       // channel 2 cp + 1
-            }
-            const bool ok = pair_ok && f0 < a.ld;
-            const int off = ok ? (2 * cp * a.ld + f0) * 2 : 0x7ffffff0;                      // out of range: the store is dropped
-            __builtin_amdgcn_raw_buffer_store_b128(r0, yr, off, 0, 2);
-            __builtin_amdgcn_raw_buffer_store_b128(r1, yr, ok ? off + a.ld * 2 : off, 0, 2);
+        for (int it = 0; it < NI; ++it) {
+            const int item = it * 64 + ln2, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS, f0 = fb + chunk * 8;
+            const int off = (ch < a.cg && f0 < a.ld) ? (ch * a.ld + f0) * 2 : 0x7ffffff0;   // out of range: the store is dropped
+            __builtin_amdgcn_raw_buffer_store_b128(rr[it], yr, off, 0, 2);
         }
     }
     stamp();
@@ -291,7 +382,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 
 static size_t cellm_lds_bytes(int cp, int nt, int gpw, int nbt)
 {
-    return static_cast<size_t>(gpw) * 2 * (nt * 16 * nbt + CM_PADL + CM_PADR) * cp * 2;
+    return static_cast<size_t>(gpw) * 2 * cm_tile_bytes(cp, nt * 16 * nbt + CM_PADL + CM_PADR);
 }
 static int cellm_cp(int cg) { return cg <= 8 ? 8 : 16; }
 // groups per workgroup: as many as fit 160 KiB of LDS and 16 waves, from {4, 2, 1}; 0 = the row does not fit at all
