@@ -285,7 +285,8 @@ int nbasr_grouped_cell_fused(const void* x0, const float* w0, const float* b0, i
  * other tensor (the reference's LayerNorm output is one).  Weights: the fp32 values of the bf16 parameters, re-laid-out once per
  * weight version as MFMA fragments (nbasr_grouped_cell_mfma_weights_bytes / nbasr_grouped_cell_mfma_pack, one image per node).
  * No statistics by-product.  nbasr_grouped_cell_mfma_fits: 0 = the row does not fit a workgroup (two bf16 tiles per group within
- * 160 KiB of LDS), else the groups per workgroup. */
+ * 160 KiB of LDS), else the groups per workgroup of the tiling a launch of 32 utterances takes (a launch picks its tiling -- frames
+ * per wave, groups per workgroup -- from the sizes it is given, the batch included). */
 size_t nbasr_grouped_cell_mfma_weights_bytes(int channels, int groups, int kernel);
 int nbasr_grouped_cell_mfma_pack(const float* w, void* packed, int channels, int groups, int kernel, nbasr_stream_t stream);
 int nbasr_grouped_cell_mfma_fits(int channels, int frames_ld, int groups);

@@ -39,9 +39,8 @@
 #ifndef NBASR_CELLM_STAMPS
 #define NBASR_CELLM_STAMPS 0
 #endif
-#if NBASR_CELLM_STAMPS
+#include <cstdio>
 #include <cstdlib>
-#endif
 
 namespace nbasr {
 
@@ -50,12 +49,7 @@ typedef float cm_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned cm_u4 __attribute__((ext_vector_type(4)));
 
 constexpr int CM_PADL = 16, CM_PADR = 16;       // zero frames either side of a tile (taps reach <= 12 frames back, <= 14 ahead)
-// NBT = 16-frame column blocks per wave (template): 16 (256 frames per wave), or 8 (128) for the 16-channel-slot groups at rows of <= 1024
-// frames, where 256-frame tiles leave a CU with 8 waves (two workgroups of 400 / 800-frame rows) -- too few to hide a block's dependent
-// latency (106 / 62 -> 88 / 49 us per cell at 32 x 800 / 400).  8-slot groups at 1000 frames already have 16 waves per CU and lose 10 % to the
-// extra per-wave overhead.
-static inline int cellm_nbt(int ld, int cp) { return (cp == 16 && ld <= 1024) ? 8 : 16; }
-
+// NBT = 16-frame column blocks per wave (template): 8, 10, 14 or 16 (128 .. 256 frames per wave); which one a launch takes: cellm_plan.
 struct CellMDims {
     int channels, frames, ld, groups, batch, cg;
     int k[3], d[3], lpad[3], nstep[3];          // taps, dilation, left padding, MFMAs per column block of each node
@@ -78,7 +72,15 @@ __device__ __forceinline__ cm_f4 cm_unpack4(u2v p) { return cm_f4{bf16_lo(p.x), 
 // share banks.
 __host__ __device__ inline int cm_plane_bytes(int rows) { return (rows * 8 + 255) & ~255; }
 __host__ __device__ inline int cm_plane_off(int q, int pb) { return q * pb + (q == 0 ? 0 : q == 3 ? 256 : 128); }
-__host__ __device__ inline int cm_tile_bytes(int cp, int rows) { return (cp / 4) * cm_plane_bytes(rows) + 256; }
+// a tile also hosts the wave-private channel-major scratch images of the way in / out: nt x SR rows (SR = 8, or 12 for the 16-slot
+// groups: 10 or 12 real channels, the fourth quad is all padding and never stored) of (NBT + 1) x 32 bytes (one
+// 16-frame unit of padding per row: the 8 channel rows a 32-lane half gathers from then start on 8 different 32-byte bank groups)
+__host__ __device__ inline int cm_scratch_row(int nbt) { return (nbt + 1) * 32; }
+__host__ __device__ inline int cm_tile_bytes(int cp, int nt, int nbt)
+{
+    const int planes = (cp / 4) * cm_plane_bytes(nt * 16 * nbt + 32) + 256, scratch = nt * (cp == 16 ? 12 : 8) * cm_scratch_row(nbt);
+    return ((planes > scratch ? planes : scratch) + 255) & ~255;
+}
 
 typedef short cm_s4 __attribute__((ext_vector_type(4)));
 // ds_read_b64_tr_b16 (gfx950): per 16-lane group a block of 4 rows x 16 columns of 16-bit elements; lane 4q + p supplies the address of
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     const int nt = a.nt;
     const int rows = nt * CM_WAVE_FRAMES + CM_PADL + CM_PADR;        // frames of a tile, pads included
     const int pb = cm_plane_bytes(rows);
-    const int tile_bytes = Q * pb + 256;
+    const int tile_bytes = cm_tile_bytes(CP, nt, NBT);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gi = wave / nt, ti = wave - gi * nt;
@@ -149,21 +151,22 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     // x0 arrives channel-major (the tensors' layout in HBM): lane = (channel, 8-frame chunk), 16-byte global loads, stored as they are
     // into a wave-private channel-major scratch image (the wave's share of tile B, free until node 0 writes x1), then read back
     // TRANSPOSED: ds_read_b64_tr_b16 hands lane i of a 16-lane group the 4 channels of a quad at frame i -- a plane row.  The image is
-    // [channel][16-frame unit ^ (channel & 7)][16 frames]: the 4 (8) channel rows a group (32-lane half) gathers from lie 512 (256) bytes
-    // apart, the swizzle spreads them over different banks.  (Rounds 3-4 wrote 4-byte channel pairs straight into frame-major rows: the
+    // [channel][NBT + 1 units of 16 frames]: the pad unit puts the 8 channel rows a 32-lane half gathers from on 8 different 32-byte bank
+    // groups.  (Rounds 3-4 wrote 4-byte channel pairs straight into frame-major rows: the
     // chunks of a wave's lanes sat 128 bytes apart, 8-way bank conflicts on every store; and normalised 16 elements per lane with
     // per-element statistics.)
     constexpr int CH_CHUNKS = CM_WAVE_FRAMES / 8;                    // 8-frame chunks of a channel row within a wave tile
-    constexpr int NI = CP * CH_CHUNKS / 64;                          // global-access instructions per wave (pad channels included)
+    constexpr int SR = CP == 16 ? 12 : 8;                            // channel rows of a scratch image (the 16-slot groups' fourth quad is all padding)
+    constexpr int NI = (SR * CH_CHUNKS + 63) / 64;                   // global-access instructions per wave (pad channels of a real quad included)
     constexpr int NTR = Q * NBT / 4;                                 // transposed reads per wave: 4 (quad, 16-frame unit) blocks each
-    constexpr int ROWB = CM_WAVE_FRAMES * 2;                         // bytes of a scratch channel row
+    constexpr int ROWB = (NBT + 1) * 32;                             // bytes of a scratch channel row (cm_scratch_row)
     const size_t group_row0 = (static_cast<size_t>(b) * a.channels + static_cast<size_t>(g) * a.cg) * a.ld;
     const int i16 = lane & 15, gq = lane >> 4;
     const int tquad = Q == 2 ? (gq & 1) : gq;                        // the quad this lane's group transposes
     const int tun = Q == 2 ? (gq >> 1) : 0;                          // and its unit within an instruction's pair (Q == 2: two units per instruction)
     constexpr int UPI = Q == 2 ? 2 : 1;                              // units per transposed-read instruction
     {
-        unsigned char* const scr = tile_b + ti * (CP * ROWB);
+        unsigned char* const scr = tile_b + ti * (SR * ROWB);
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x0 + group_row0), 0, a.cg * a.ld * 2, 0x00020000);
         cm_u4 raw[NI];
 #pragma unroll
@@ -209,22 +212,24 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int item = it * 64 + lane, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS;
-            *reinterpret_cast<cm_u4*>(scr + ch * ROWB + (((chunk >> 1) ^ (ch & 7)) * 32) + (chunk & 1) * 16) = raw[it];
+            if (NI * 64 == SR * CH_CHUNKS || item < SR * CH_CHUNKS) *reinterpret_cast<cm_u4*>(scr + ch * ROWB + chunk * 16) = raw[it];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int tch = 4 * tquad + ((lane >> 2) & 3);              // the channel row this lane addresses for the gather
-        const unsigned char* const trow = scr + tch * ROWB + (lane & 3) * 8;
+        const bool pad_quad = 4 * tquad >= SR;                       // (16-slot groups: the group of lanes that would gather the all-padding quad)
+        const int tch = 4 * (pad_quad ? 0 : tquad) + ((lane >> 2) & 3);   // the channel row this lane addresses for the gather (any valid one for a padding quad)
+        const unsigned char* const trow = scr + tch * ROWB + tun * 32 + (lane & 3) * 8;
         unsigned char* const drow = tile_a + cm_plane_off(tquad, pb) + (CM_PADL + fb + 16 * tun + i16) * 8;
         // (all gathers first: a store to the plane between two of them would pin the next gather behind it -- the compiler cannot tell
         // the plane from the scratch image -- and the eight LDS round trips would run one after the other)
         u2v tv[NTR];
 #pragma unroll
-        for (int k = 0; k < NTR; ++k) tv[k] = cm_tr_read(trow + (((UPI * k + tun) ^ (tch & 7)) * 32));
+        for (int k = 0; k < NTR; ++k) tv[k] = cm_tr_read(trow + k * (UPI * 32));
 #pragma unroll
         for (int k = 0; k < NTR; ++k) {
             u2v v = tv[k];
+            if (CP == 16 && pad_quad) v = u2v{0u, 0u};
             if (has_ln) {
                 const cm_f2 nm{nmean[k], nmean[k]}, rs{rstd[k], rstd[k]};
                 const cm_f2 lo = __builtin_elementwise_fma((cm_f2{bf16_lo(v.x), bf16_hi(v.x)} + nm) * rs, gam01, bet01);
@@ -298,12 +303,26 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
             constexpr bool SK = decltype(with_skips)::value;
             constexpr int NS = decltype(nsc)::value;
             fetch(0, nsc);
+            // the skip inputs of the NEXT block are read before this block's store: the compiler cannot tell the positions apart (tile A is
+            // read at a position and then overwritten there by nodes 1's output), so reads placed after the store wait behind it -- an
+            // exposed LDS round trip per block
+            u2v sa_n{0u, 0u}, sb_n{0u, 0u};
+            auto fetch_skips = [&](int nb) {
+                const int pos = own + nb * NB_STRIDE;
+                sa_n = *reinterpret_cast<const u2v*>(tile_a + pos);
+                if constexpr (NODE != 0) sb_n = *reinterpret_cast<const u2v*>(tile_b + pos);
+            };
+            if constexpr (SK) fetch_skips(0);
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 cm_u4 cur[NSMAX];
 #pragma unroll
                 for (int s = 0; s < NS; ++s) cur[s] = nxt[s];
-                if (nb + 1 < NBW) fetch(nb + 1, nsc);                // the next block's operands are in flight behind this block's MFMAs
+                const u2v ta = sa_n, tb = sb_n;
+                if (nb + 1 < NBW) {
+                    fetch(nb + 1, nsc);                              // the next block's operands are in flight behind this block's MFMAs
+                    if constexpr (SK) fetch_skips(nb + 1);
+                }
                 cm_f4 acc = bv;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aw[s], __builtin_bit_cast(cm_bf8, cur[s]), acc, 0, 0, 0);
@@ -316,16 +335,15 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
                         const cm_f4 v = cm_unpack4(u2v{p.x & m, p.y & m});
                         o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
                     };
-                    const u2v ta = *reinterpret_cast<const u2v*>(tile_a + pos);
                     if constexpr (NODE == 0) {
                         add(m_a, ta);
                     } else if constexpr (NODE == 1) {
                         keep0[nb] = ta;
                         add(m_a, ta);
-                        add(m_b, *reinterpret_cast<const u2v*>(tile_b + pos));
+                        add(m_b, tb);
                     } else {
                         add(m_k, keep0[nb]);
-                        add(m_b, *reinterpret_cast<const u2v*>(tile_b + pos));
+                        add(m_b, tb);
                         add(m_a, ta);
                     }
                 }
@@ -351,15 +369,16 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
     {
         int ln2 = lane;                                              // (a fresh value: keeps the offsets of the way in from being carried -- spilled -- across the nodes)
         asm volatile("" : "+v"(ln2));
-        unsigned char* const scr = tile_a + ti * (CP * ROWB);
+        unsigned char* const scr = tile_a + ti * (SR * ROWB);
         const unsigned char* const prow = tile_b + cm_plane_off(tquad, pb) + (CM_PADL + fb + 16 * tun + 4 * (ln2 & 3) + ((ln2 >> 2) & 3)) * 8;
         const int och = 4 * tquad + (ln2 & 3);
-        unsigned char* const srow = scr + och * ROWB + ((ln2 >> 2) & 3) * 8;
+        unsigned char* const srow = scr + och * ROWB + tun * 32 + ((ln2 >> 2) & 3) * 8;
         u2v tv[NTR];
 #pragma unroll
         for (int k = 0; k < NTR; ++k) tv[k] = cm_tr_read(prow + k * (UPI * 128));
 #pragma unroll
-        for (int k = 0; k < NTR; ++k) *reinterpret_cast<u2v*>(srow + (((UPI * k + tun) ^ (och & 7)) * 32)) = tv[k];
+        for (int k = 0; k < NTR; ++k)
+            if (CP != 16 || 4 * tquad < SR) *reinterpret_cast<u2v*>(srow + k * (UPI * 32)) = tv[k];    // (the all-padding quad has no scratch rows)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -368,12 +387,12 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int item = it * 64 + ln2, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS;
-            rr[it] = *reinterpret_cast<const cm_u4*>(scr + ch * ROWB + (((chunk >> 1) ^ (ch & 7)) * 32) + (chunk & 1) * 16);
+            rr[it] = *reinterpret_cast<const cm_u4*>(scr + (item < SR * CH_CHUNKS ? ch * ROWB + chunk * 16 : 0));
         }
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int item = it * 64 + ln2, ch = item / CH_CHUNKS, chunk = item - ch * CH_CHUNKS, f0 = fb + chunk * 8;
-            const int off = (ch < a.cg && f0 < a.ld) ? (ch * a.ld + f0) * 2 : 0x7ffffff0;   // out of range: the store is dropped
+            const int off = (item < SR * CH_CHUNKS && ch < a.cg && f0 < a.ld) ? (ch * a.ld + f0) * 2 : 0x7ffffff0;   // out of range: the store is dropped
             __builtin_amdgcn_raw_buffer_store_b128(rr[it], yr, off, 0, 2);
         }
     }
@@ -382,18 +401,44 @@ __global__ __launch_bounds__(1024) void grouped_cell_mfma_kernel(
 
 static size_t cellm_lds_bytes(int cp, int nt, int gpw, int nbt)
 {
-    return static_cast<size_t>(gpw) * 2 * cm_tile_bytes(cp, nt * 16 * nbt + CM_PADL + CM_PADR);
+    return static_cast<size_t>(gpw) * 2 * cm_tile_bytes(cp, nt, nbt);
 }
 static int cellm_cp(int cg) { return cg <= 8 ? 8 : 16; }
-// groups per workgroup: as many as fit 160 KiB of LDS and 16 waves, from {4, 2, 1}; 0 = the row does not fit at all
-static int cellm_gpw(int cg, int nt, int groups, int nbt)
+// The tiling of a launch: NBT (column blocks per wave; nt = waves per row follows) and groups per workgroup, picked by a small cost model
+// of what the per-wave phase stamps show (tools/gpu/cellm_stamps.py, profiles/NOTES_r05.md): a wave lives a fixed ~7 us (loads, the way
+// in and out, four barriers) plus ~0.3 us per column-block step and node, whatever else runs beside it -- the kernel is bound by
+// per-wave latency, so a launch takes (rounds of workgroups over the CU slots) x (life of a wave).  What varies with the tiling: the
+// frames a row's last wave computes for nothing (1600 frames = 100 blocks: 7 x 16 wastes 12, 8 x 14 as well but runs 16 waves per CU
+// instead of 14, 5 x 10 at 800 frames wastes none and fits three workgroups per CU), and the round count.  Rounds 3-4 fixed NBT = 16
+// (8 for 16-slot groups at <= 1024 frames) and took the most groups per workgroup that left two workgroups per CU.
+struct CellMPlan { int nbt, gpw, nt; };
+static CellMPlan cellm_plan(int cg, int ld, int groups, int batch)
 {
-    // two workgroups per CU where a group's tiles allow it (<= 80 KiB per workgroup): their barriers and load phases then interleave;
-    // within that, as many groups per workgroup as fit (waves per barrier domain)
-    for (int budget = 80; budget <= 160; budget += 80)
-        for (int gpw = 4; gpw >= 1; gpw >>= 1)
-            if (groups % gpw == 0 && gpw * nt <= 16 && cellm_lds_bytes(cellm_cp(cg), nt, gpw, nbt) <= static_cast<size_t>(budget) * 1024) return gpw;
-    return 0;
+    static const int kNbt[4] = {16, 14, 10, 8};
+    const int cp = cellm_cp(cg), nblk = (ld + 15) / 16;
+    CellMPlan best{0, 0, 0};
+    double best_cost = 0.0;
+    for (int nbt : kNbt) {
+        // (16-slot groups: the 10- and 14-block instances need more than 128 registers -- x0n carried for the last node's skip is 2 per
+        // block -- and measured slower spilling than 8 blocks do with a workgroup less per CU: 93 vs 90 us at 32 x 1000 x 800)
+        if (cp == 16 && (nbt == 10 || nbt == 14)) continue;
+        const int nt = (nblk + nbt - 1) / nbt;
+        for (int gpw = 1; gpw <= 4; gpw <<= 1) {                    // (ties go to the smaller barrier domain)
+            if (groups % gpw || gpw * nt > 16) continue;
+            const size_t lds = cellm_lds_bytes(cp, nt, gpw, nbt);
+            if (lds > 160 * 1024) continue;
+            const int by_lds = static_cast<int>(160 * 1024 / lds), by_waves = 16 / (gpw * nt);       // (128 registers: 4 waves per SIMD)
+            const int per_cu = by_lds < by_waves ? by_lds : by_waves;
+            const long wgs = static_cast<long>(groups / gpw) * (batch > 0 ? batch : 32);
+            const long rounds = (wgs + 256L * per_cu - 1) / (256L * per_cu);
+            // fixed part: ~4.8 us of loads and the way in / out + four barriers whose skew grows with the waves behind them
+            double life = 4.8 + 0.3 * (gpw * nt) + 3 * 0.3 * (cp == 8 ? nbt / 2 : nbt);
+            if (per_cu == 1) life *= 1.1;                            // (nothing to run beside a workgroup that waits)
+            const double cost = rounds * life;
+            if (best.nbt == 0 || cost < best_cost - 1e-9) { best = CellMPlan{nbt, gpw, nt}; best_cost = cost; }
+        }
+    }
+    return best;
 }
 static int cellm_nstep(int /*cp*/, int kernel) { return (kernel + 1) / 2; }      // 2 taps per K step either way
 
@@ -467,8 +512,7 @@ extern "C" int nbasr_grouped_cell_mfma_fits(int channels, int frames_ld, int gro
     if (channels <= 0 || groups <= 0 || channels % groups || frames_ld <= 0 || frames_ld % 8) return 0;
     const int cg = channels / groups;
     if (cg != 6 && cg != 8 && cg != 10 && cg != 12) return 0;
-    const int nbt = cellm_nbt(frames_ld, cellm_cp(cg)), nt = (frames_ld + 16 * nbt - 1) / (16 * nbt);
-    return cellm_gpw(cg, nt, groups, nbt);
+    return cellm_plan(cg, frames_ld, groups, 0).gpw;
 }
 
 extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const float* b0, int k0, int d0,
@@ -487,8 +531,7 @@ extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const fl
     NBASR_REQUIRE(batch <= 65535 && skip_mask >= 0 && skip_mask < 64, NBASR_EINVAL, "nbasr_grouped_cell_mfma: bad batch / skip mask");
     NBASR_REQUIRE(!ln || (ln->stats && ln->gamma && ln->beta && aligned16(ln->stats)), NBASR_ENULL,
                   "nbasr_grouped_cell_mfma: deferred LayerNorm needs stats (16-byte aligned), gamma and beta");
-    const int gpw = nbasr_grouped_cell_mfma_fits(channels, ld, groups);
-    NBASR_REQUIRE(gpw != 0, NBASR_EINVAL,
+    NBASR_REQUIRE(nbasr_grouped_cell_mfma_fits(channels, ld, groups) != 0, NBASR_EINVAL,
                   "nbasr_grouped_cell_mfma: a row of %d frames x %d channels per group does not fit one workgroup (channels/groups in {6, 8, 10, 12}, "
                   "two bf16 tiles per group within 160 KiB of LDS); use nbasr_grouped_cell_fused or the per-node launches", ld, channels / groups);
     const int ks[3] = {k0, k1, k2}, ds[3] = {d0, d1, d2};
@@ -501,8 +544,18 @@ extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const fl
         a.k[i] = ks[i]; a.d[i] = ds[i]; a.lpad[i] = pad_left(ks[i], ds[i], 1); a.nstep[i] = cellm_nstep(cp, ks[i]);
     }
     a.skips = skip_mask;
-    const int nbt = cellm_nbt(ld, cellm_cp(channels / groups));
-    a.nt = (ld + 16 * nbt - 1) / (16 * nbt);
+    CellMPlan plan = cellm_plan(a.cg, ld, groups, batch);
+    if (const char* e = getenv("NBASR_CELLM_TILING")) {              // diagnostics (tools/ubench/bench_cell_mfma.py --sweep): "nbt,gpw"
+        int nbt_e = 0, gpw_e = 0;
+        if (sscanf(e, "%d,%d", &nbt_e, &gpw_e) == 2 && (nbt_e == 8 || nbt_e == 16 || (cp == 8 && (nbt_e == 10 || nbt_e == 14))) && (gpw_e == 1 || gpw_e == 2 || gpw_e == 4)) {
+            const int nt_e = ((ld + 15) / 16 + nbt_e - 1) / nbt_e;
+            NBASR_REQUIRE(groups % gpw_e == 0 && gpw_e * nt_e <= 16 && cellm_lds_bytes(cp, nt_e, gpw_e, nbt_e) <= 160 * 1024, NBASR_EINVAL,
+                          "nbasr_grouped_cell_mfma: NBASR_CELLM_TILING=%s does not fit this row", e);
+            plan = CellMPlan{nbt_e, gpw_e, nt_e};
+        }
+    }
+    const int nbt = plan.nbt, gpw = plan.gpw;
+    a.nt = plan.nt;
 #if NBASR_CELLM_STAMPS
     { const char* e = getenv("NBASR_CELLM_STAMPS"); a.stamps = e ? reinterpret_cast<unsigned long long*>(strtoull(e, nullptr, 0)) : nullptr; }
 #endif
@@ -520,6 +573,8 @@ extern "C" int nbasr_grouped_cell_mfma(const void* x0, const void* wp0, const fl
     } while (0)
     if (cp == 8) {
         if (nbt == 8) NBASR_CELLM_LAUNCH(8, 8);
+        if (nbt == 10) NBASR_CELLM_LAUNCH(8, 10);
+        if (nbt == 14) NBASR_CELLM_LAUNCH(8, 14);
         NBASR_CELLM_LAUNCH(8, 16);
     }
     if (nbt == 8) NBASR_CELLM_LAUNCH(16, 8);

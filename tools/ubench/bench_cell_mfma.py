@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--mask', type=int, default=63)
     ap.add_argument('--iters', type=int, default=30)
     ap.add_argument('--kds', default='7,1;7,2;5,2')
+    ap.add_argument('--sweep', action='store_true', help='time every tiling (NBASR_CELLM_TILING) per block shape')
     ap.add_argument('--lib', default=None, help='another build of libnbasr_hip.so to time (A/B)')
     a = ap.parse_args()
     if a.lib:
@@ -46,6 +47,24 @@ def main():
 
         def step(i):
             hip.grouped_cell_mfma(bufs[i % nbuf], nodes, a.mask, bufs[(i + 1) % nbuf], tt, 100, ln)
+        if a.sweep:
+            import os
+            for nbt in (8, 10, 14, 16):
+                for g in (1, 2, 4):
+                    os.environ['NBASR_CELLM_TILING'] = f'{nbt},{g}'
+                    try:
+                        for i in range(3):
+                            step(i)
+                    except hip.HipError:
+                        continue
+                    torch.cuda.synchronize()
+                    ts = []
+                    for i in range(a.iters):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(); step(i); e1.record(); e1.synchronize()
+                        ts.append(e0.elapsed_time(e1) * 1e3)
+                    print(f'   block {blk} nbt={nbt} gpw={g}: {statistics.median(ts):7.1f} us', flush=True)
+            del os.environ['NBASR_CELLM_TILING']
         for i in range(5):
             step(i)
         torch.cuda.synchronize()
