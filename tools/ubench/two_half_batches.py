@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--ways', type=int, default=2)
+ap.add_argument('--full', action='store_true', help='every way runs the WHOLE batch (two batches in flight on two streams) instead of a slice of it')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 model = nb.get_model([[1, 0], [1, 0, 0], [1, 0, 0, 0]], use_rnn=True, dropout_rate=0.0)
@@ -33,7 +34,7 @@ def whole():
         return [h.result() for h in hs][-1]
 
 
-parts = [x[i * a.batch // a.ways:(i + 1) * a.batch // a.ways].contiguous() for i in range(a.ways)]
+parts = [x.clone() if a.full else x[i * a.batch // a.ways:(i + 1) * a.batch // a.ways].contiguous() for i in range(a.ways)]
 streams = [torch.cuda.Stream(device=dev) for _ in range(a.ways)]
 outs = [None] * a.ways
 
@@ -51,7 +52,7 @@ def split():
         t.start()
     for t in ts:
         t.join()
-    return torch.cat(outs, 0)
+    return outs[0] if a.full else torch.cat(outs, 0)
 
 
 for fn in (whole, split, whole, split):
@@ -63,5 +64,6 @@ for name, fn in (('whole', whole), ('split', split), ('whole', whole), ('split',
     y = fn()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f'{name}: {a.batch * a.steps / dt:8.0f} utterances/s  ({1e3 * dt / a.steps:.3f} ms per {a.batch})', flush=True)
+    n = a.batch * a.steps * (a.ways if (a.full and name == 'split') else 1)
+    print(f'{name}: {n / dt:8.0f} utterances/s  ({1e3 * dt / a.steps:.3f} ms per {a.batch})', flush=True)
 print('bit-equal', torch.equal(whole(), split()))
