@@ -349,6 +349,39 @@ def test_bf16_cell_on_the_matrix_cores(c, groups, t, kds, mask, with_ln):
     assert float((v - g).abs().max()) <= 0.05 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize('c,groups,t,b', [(600, 100, 1600, 3), (800, 100, 1000, 2), (1000, 100, 800, 3), (1200, 100, 392, 5)])
+def test_bf16_cell_tilings_are_bit_identical(c, groups, t, b, monkeypatch):
+    """A launch of the matrix-core cell picks its tiling -- 16-frame blocks per wave (8, 10, 14 or 16; 8 or 16 for the 16-slot groups),
+    groups per workgroup -- from a cost model of the sizes it is given, the batch included (what bench.py's 32 x 1600 takes is not what
+    a 2-utterance test takes).  The tiling decides which wave computes an output, never the order of its sums: every tiling that fits
+    must give the same bits, tail frames and pitch columns included.  NBASR_CELLM_TILING (diagnostics) forces one."""
+    torch.manual_seed(c + t)
+    x = (torch.randn(b, c, t) * 1.5 + 0.3).to(BF).float()
+    xp = pitched(x, BF)
+    ld = xp.shape[2]
+    stats = torch.empty(b, 2, ld, device=DEV)
+    hip.channel_stats(xp, stats, t, 1e-3)
+    ln = (stats, (torch.rand(c) + 0.5).to(DEV), (torch.randn(c) * 0.2).to(DEV))
+    ws = [((torch.randn(c, c // groups, k) * 0.3).to(BF).float(), (torch.randn(c) * 0.2).to(BF).float(), k, d) for k, d in ((7, 1), (5, 2), (7, 2))]
+    nodes = [(hip.grouped_cell_mfma_pack(w.to(DEV), groups), bias.to(DEV), k, d) for w, bias, k, d in ws]
+    monkeypatch.delenv('NBASR_CELLM_TILING', raising=False)
+    want = torch.full_like(xp, 7.0)
+    hip.grouped_cell_mfma(xp, nodes, 63, want, t, groups, ln)
+    assert torch.all(want[:, :, t:] == 0) and torch.isfinite(want.float()).all()
+    ran = 0
+    for nbt in (8, 10, 14, 16):
+        for gpw in (1, 2, 4):
+            monkeypatch.setenv('NBASR_CELLM_TILING', f'{nbt},{gpw}')
+            got = torch.full_like(xp, 7.0)
+            try:
+                hip.grouped_cell_mfma(xp, nodes, 63, got, t, groups, ln)
+            except hip.HipError:
+                continue                                   # (this tiling does not fit the row: too many waves or too much LDS)
+            ran += 1
+            assert torch.equal(got, want), (nbt, gpw)
+    assert ran >= 3, ran
+
+
 @pytest.mark.parametrize('c,groups,t', [(600, 100, 1600), (1200, 100, 1600), (800, 100, 1000)])
 def test_bf16_cell_on_the_matrix_cores_contains_a_non_finite_input(c, groups, t):
     """Accepted divergence, pinned: the matrix-core cell multiplies zero WEIGHTS with real window data -- taps padded
