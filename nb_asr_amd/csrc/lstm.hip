@@ -472,6 +472,10 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     // feed the encoder's stream; a graph launch costs ~15 us.  Same kernels, same order, same arguments: bit-identical h.  A stream that is
     // being captured by the caller (forward_graph) takes the plain launches.
     // (same-box A/B, alternating, bench.py --batch 8 / 16 / 64: 4 856 / 4 781 -> 5 036 / 4 873, 7 172 / 7 048 -> 7 258 / 7 248, 9 821 / 9 839 -> 9 852 / 9 896)
+    // Round 6: a graph is only built for a key that has been SEEN three times (a serving loop with a new frame count per
+    // batch, or the autograd caller with fresh buffers per step, would otherwise pay capture + instantiate + destroy on every call
+    // and never replay); the caches are per device; an entry is launched under the lock, and an evicted one is destroyed only after
+    // the event behind its last launch has completed.
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
         (void)hipGetLastError();
@@ -479,20 +483,46 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
         return launch_status("nbasr_lstm_recurrence_packed");
     }
     int device = -1;
-    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); launch_chain(); return launch_status("nbasr_lstm_recurrence_packed"); }
-    struct Chain { const void* g; const void* w; void* c; void* h; int batch, frames, hidden, device; hipGraphExec_t exec; unsigned long long used; };
-    static std::mutex m;
-    static std::vector<Chain> cache;
-    static unsigned long long tick = 0;
-    hipGraphExec_t exec = nullptr;
-    {
-        std::lock_guard<std::mutex> lock(m);
-        for (Chain& e : cache)
-            if (e.g == gates_ws && e.w == packed_whh && e.c == cell_ws && e.h == h_out && e.batch == batch && e.frames == frames && e.hidden == hidden &&
-                e.device == device) { e.used = ++tick; exec = e.exec; break; }
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= NBASR_MAX_DEVICES) {
+        (void)hipGetLastError();
+        launch_chain();
+        return launch_status("nbasr_lstm_recurrence_packed");
     }
-    if (exec == nullptr) {
+    struct Key {
+        const void* g; const void* w; void* c; void* h; int batch, frames, hidden;
+        bool operator==(const Key& o) const { return g == o.g && w == o.w && c == o.c && h == o.h && batch == o.batch && frames == o.frames && hidden == o.hidden; }
+    };
+    struct Chain { Key key; hipGraphExec_t exec; hipEvent_t last; unsigned long long used; };
+    struct Seen { Key key; int count; unsigned long long used; };
+    struct PerDevice { std::mutex m; std::vector<Chain> cache; std::vector<Seen> seen; unsigned long long tick = 0; };
+    static PerDevice per_device[NBASR_MAX_DEVICES];
+    constexpr size_t CHAIN_CACHE = 16, SEEN_TABLE = 64;        // per device: 2 pipelined slots x a few (batch, frames) shapes
+    constexpr int SEEN_BEFORE_CAPTURE = 3;
+    PerDevice& pd = per_device[device];
+    const Key key{gates_ws, packed_whh, cell_ws, h_out, batch, frames, hidden};
+    std::lock_guard<std::mutex> lock(pd.m);                    // (held across the launch: an entry cannot be destroyed under a launcher)
+    Chain* hit = nullptr;
+    for (Chain& e : pd.cache) if (e.key == key) { hit = &e; break; }
+    if (hit == nullptr) {
+        Seen* sn = nullptr;
+        for (Seen& e : pd.seen) if (e.key == key) { sn = &e; break; }
+        if (sn == nullptr) {
+            if (pd.seen.size() >= SEEN_TABLE) {
+                size_t lru = 0;
+                for (size_t i = 1; i < pd.seen.size(); ++i) if (pd.seen[i].used < pd.seen[lru].used) lru = i;
+                pd.seen.erase(pd.seen.begin() + lru);
+            }
+            pd.seen.push_back(Seen{key, 0, 0});
+            sn = &pd.seen.back();
+        }
+        sn->used = ++pd.tick;
+        if (++sn->count < SEEN_BEFORE_CAPTURE) {                // not (yet) a recurring call: the plain chain
+            launch_chain();
+            return launch_status("nbasr_lstm_recurrence_packed");
+        }
         hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipEvent_t last = nullptr;
         hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
         if (e == hipSuccess) {
             launch_chain();
@@ -500,21 +530,28 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
         }
         if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (graph) (void)hipGraphDestroy(graph);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&last, hipEventDisableTiming);
         if (e != hipSuccess || exec == nullptr) {                 // no graph on this runtime / stream: the plain chain
             (void)hipGetLastError();
+            if (exec) (void)hipGraphExecDestroy(exec);
+            sn->count = 0;
             launch_chain();
             return launch_status("nbasr_lstm_recurrence_packed");
         }
-        std::lock_guard<std::mutex> lock(m);
-        if (cache.size() >= 16) {                                  // (two pipelined slots x a few shapes per plan; the least recently used one goes)
+        if (pd.cache.size() >= CHAIN_CACHE) {                      // the least recently used one goes -- once its last launch has completed
             size_t lru = 0;
-            for (size_t i = 1; i < cache.size(); ++i) if (cache[i].used < cache[lru].used) lru = i;
-            (void)hipGraphExecDestroy(cache[lru].exec);
-            cache.erase(cache.begin() + lru);
+            for (size_t i = 1; i < pd.cache.size(); ++i) if (pd.cache[i].used < pd.cache[lru].used) lru = i;
+            (void)hipEventSynchronize(pd.cache[lru].last);
+            (void)hipGraphExecDestroy(pd.cache[lru].exec);
+            (void)hipEventDestroy(pd.cache[lru].last);
+            pd.cache.erase(pd.cache.begin() + lru);
         }
-        cache.push_back(Chain{gates_ws, packed_whh, cell_ws, h_out, batch, frames, hidden, device, exec, ++tick});
+        pd.cache.push_back(Chain{key, exec, last, 0});
+        hit = &pd.cache.back();
     }
-    const hipError_t e = hipGraphLaunch(exec, s);
+    hit->used = ++pd.tick;
+    hipError_t e = hipGraphLaunch(hit->exec, s);
+    if (e == hipSuccess) e = hipEventRecord(hit->last, s);
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_packed: hipGraphLaunch: %s", hipGetErrorString(e)); return static_cast<int>(e); }
     return launch_status("nbasr_lstm_recurrence_packed");
 }

@@ -253,6 +253,8 @@ class ForwardPlan:
             raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', '0' or '1'")
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
+        self._seq_outcome = {}       # ring slot -> whether that launch failed, once its word has been read (check_seq_slot)
+        self._seq_lock = threading.Lock()    # PendingLogits.result() may run on another thread than the one enqueueing through the plan
         self._seq_last = None        # (event, slot) of the status copy the forward being enqueued has just added
         # statistics of a downsample convolution's output from its own epilogue (round 5); NBASR_CONV_STATS=0: a pass over the output
         self.conv_stats = os.environ.get('NBASR_CONV_STATS', '1') != '0'
@@ -327,19 +329,29 @@ class ForwardPlan:
         if self._seq_host is None:
             self._seq_host = torch.zeros(self._SEQ_RING, dtype=torch.int32).pin_memory()
             self._seq_pending = collections.deque()
-        if len(self._seq_pending) >= self._SEQ_RING:          # the slot about to be re-used still holds an unread word: read it first
-            ev, slot = self._seq_pending.popleft()
-            ev.synchronize()
-            self._seq_failed |= int(self._seq_host[slot]) != 0
-        slot = self._seq_slot
-        self._seq_slot = (slot + 1) % self._SEQ_RING
-        self._seq_host[slot: slot + 1].copy_(ws.view(torch.int32)[:1], non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
-        self._seq_pending.append((ev, slot))
-        self._seq_last = (ev, slot)
+        with self._seq_lock:
+            if len(self._seq_pending) >= self._SEQ_RING:      # the slot about to be re-used still holds an unread word: read it first
+                ev, slot = self._seq_pending.popleft()
+                ev.synchronize()
+                self._seq_note(slot)
+            slot = self._seq_slot
+            self._seq_outcome.pop(slot, None)                 # (a new launch takes the slot: its old verdict is history)
+            self._seq_slot = (slot + 1) % self._SEQ_RING
+            self._seq_host[slot: slot + 1].copy_(ws.view(torch.int32)[:1], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            self._seq_pending.append((ev, slot))
+            self._seq_last = (ev, slot)
 
     _SEQ_RING = 256
+
+    def _seq_note(self, slot):
+        """The verdict of the launch behind ring slot ``slot`` (its status copy has landed): latched for the next forward
+        (``_seq_failed``) AND remembered per slot, so that the handle of exactly that forward still raises from its ``result()`` when
+        ``check_seq`` got to the word first (it used to return NaN logits silently then)."""
+        failed = int(self._seq_host[slot]) != 0
+        self._seq_outcome[slot] = failed
+        self._seq_failed |= failed
 
     def check_seq(self, wait=False):
         """Raise if a one-launch recurrence enqueued through this plan timed out (that forward's logits hold NaN rows); the
@@ -347,16 +359,17 @@ class ForwardPlan:
         that launch has finished (tests, `ASRModel.check`); otherwise only a finished launch is looked at -- called at the start of
         every forward, so a failure surfaces at the next call at the latest."""
         pending = self._seq_pending
-        while pending:
-            ev, slot = pending[0]
-            if wait:
-                ev.synchronize()
-            elif not ev.query():
-                break
-            pending.popleft()
-            self._seq_failed |= int(self._seq_host[slot]) != 0
-        if self._seq_failed:
-            self._seq_failed = False
+        with self._seq_lock:
+            while pending:
+                ev, slot = pending[0]
+                if wait:
+                    ev.synchronize()
+                elif not ev.query():
+                    break
+                pending.popleft()
+                self._seq_note(slot)
+            failed, self._seq_failed = self._seq_failed, False
+        if failed:
             self.lstm_seq_mode = '0'
             self._tapes.clear()
             raise hip.HipError('the one-launch LSTM recurrence of an EARLIER forward timed out waiting for its peer workgroups (the grid was '
@@ -367,11 +380,16 @@ class ForwardPlan:
         """Wait for ONE one-launch recurrence (the status copy behind it) and raise if it timed out: what ``PendingLogits.result()``
         does for the forward it belongs to."""
         ev.synchronize()
-        try:
-            self._seq_pending.remove((ev, slot))              # reported here, not again at the next forward
-        except ValueError:
-            return                                             # check_seq has looked at it already (and raised if it had to)
-        if int(self._seq_host[slot]) != 0:
+        with self._seq_lock:
+            try:
+                self._seq_pending.remove((ev, slot))          # reported here, not again at the next forward
+                failed = int(self._seq_host[slot]) != 0
+            except ValueError:
+                # check_seq (the next forward's poll) or the ring wrap has consumed the word already: its verdict was recorded per slot
+                failed = bool(self._seq_outcome.pop(slot, False))
+                if failed:
+                    self._seq_failed = False                  # reported here, by the forward it belongs to
+        if failed:
             self.lstm_seq_mode = '0'
             self._tapes.clear()
             raise hip.HipError('the one-launch LSTM recurrence of THIS forward timed out waiting for its peer workgroups (the grid was not '
@@ -868,7 +886,9 @@ class ForwardPlan:
                 # the convolution's own epilogue (round 5) instead of a pass over the output
                 nxt1 = model.model[idx + 1] if idx + 1 < n_layers else None
                 nxt2 = model.model[idx + 2] if idx + 2 < n_layers else None
-                want_stats = self.conv_stats and isinstance(nxt1, nn.LayerNorm) and self._cheap_consumer(nxt2) and layer.kernel_size == 8
+                # (the finalize kernel merges <= 128 partial rows: wider than 128 x 16 channels falls back to the statistics pass)
+                want_stats = (self.conv_stats and isinstance(nxt1, nn.LayerNorm) and self._cheap_consumer(nxt2) and layer.kernel_size == 8
+                              and -(-layer.conv.out_channels // hip.DENSE_STATS_UNIT) <= 128)
                 self._conv_part = None
                 if input_range is not None and layer.kernel_size == 8 and ln is None and img is None:
                     rng, input_range = input_range, None

@@ -11,7 +11,8 @@ The torch modules nested inside (``nn.Conv1d``, ``nn.Linear``) are parameter con
 their ``forward`` is never called.  Calling an op on its own takes a ``(B, C, T)`` float32 tensor
 on a HIP device; inside ``ASRModel`` the executor drives the same C entry points on pitched
 workspace buffers instead (see ``executor.py``).  Dropout is the identity in eval mode or with
-``p == 0``; training-mode dropout with ``p > 0`` is outside this package's scope and raises.
+``p == 0``; in training mode with ``p > 0`` every op applies ATen's dropout to its output, as the
+reference does (ops.py:22,29,40,48) -- with or without gradients enabled.
 """
 import functools
 
@@ -39,16 +40,20 @@ def _pitched(x):
 
 
 def _train_dropout(module, y):
-    """The op's trailing nn.Dropout (reference ops.py:22,29 / 38,47) on the differentiable path: ATen's dropout on the op's output."""
+    """The op's trailing nn.Dropout (reference ops.py:22,29 / 40,48): ATen's dropout on the op's output -- on the differentiable path
+    and, round 6, on the plain one too (a training-mode module under ``torch.no_grad()``: the reference applies its masks there)."""
     if module.training and module.dropout_rate > 0:
         return torch.nn.functional.dropout(y, module.dropout_rate, True)
     return y
 
 
 def _check_dropout(module):
+    """The FUSED executor (fused cells, deferred LayerNorms, launch tapes, pipelined tails, captured graphs) has no dropout masks:
+    a training-mode model with p > 0 runs one op at a time instead (``ASRModel.forward``); the executor-only entry points
+    (``forward_async``, ``forward_graph``, ``forward_with_taps``) refuse."""
     if module.training and module.dropout_rate > 0:
-        raise NotImplementedError('training-mode dropout (p > 0) is outside the HIP forward path; '
-                                  'call .eval() or build the model with dropout_rate=0.0')
+        raise NotImplementedError('training-mode dropout (p > 0) is outside the fused HIP executor (forward_async / forward_graph / '
+                                  'forward_with_taps); model(x) applies it op by op -- or call .eval() / build the model with dropout_rate=0.0')
 
 
 class PadConvRelu(nn.Module):
@@ -81,7 +86,6 @@ class PadConvRelu(nn.Module):
         if differentiable and self.groups > 1 and self.strides == 1:
             from .autograd import grouped_pad_conv_relu              # the node op is trainable on its own (first block)
             return _train_dropout(self, grouped_pad_conv_relu(x, self.conv.weight, self.conv.bias, self.groups, self.kernel_size, self.dilation))
-        _check_dropout(self)
         xp, frames = _pitched(x)
         t_out = self.out_frames(frames)
         y = torch.empty(xp.shape[0], self.conv.out_channels, hip.round_up4(t_out), device=xp.device, dtype=xp.dtype)
@@ -92,7 +96,7 @@ class PadConvRelu(nn.Module):
                 raise NotImplementedError('grouped PadConvRelu only exists with stride 1 in the search space')
             hip.grouped_conv1d_fused(xp, self.conv.weight.detach(), self.conv.bias.detach(), (), y, frames,
                                      self.groups, self.kernel_size, self.dilation)
-        return y[:, :, :t_out]
+        return _train_dropout(self, y[:, :, :t_out])
 
 
 class Linear(nn.Module):
@@ -108,11 +112,10 @@ class Linear(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or self.linear.weight.requires_grad) and x.dtype == torch.float32:
             from .autograd import dense_pad_conv_relu               # trainable on its own
             return _train_dropout(self, dense_pad_conv_relu(x, self.linear.weight, self.linear.bias, 1))
-        _check_dropout(self)
         xp, frames = _pitched(x)
         y = torch.empty(xp.shape[0], self.linear.out_features, xp.shape[2], device=xp.device, dtype=xp.dtype)
         hip.dense_conv1d_fused(xp, frames, self.linear.weight.detach().unsqueeze(-1), self.linear.bias.detach(), (), y, 1)
-        return y[:, :, :frames]
+        return _train_dropout(self, y[:, :, :frames])
 
 
 class Identity(nn.Module):

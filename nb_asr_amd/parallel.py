@@ -30,7 +30,8 @@ class ShardedForward:
         self.rank = int(os.environ.get('RANK', '0')) if rank is None else rank
         self.device = device
         self._own_group = False
-        # ``force_collective``: take the collective path with a single rank too (tests; bench.py --force-collective)
+        # ``force_collective``: take the collective path with a single rank too (tests/test_rccl_gpu.py: a 1-rank nccl group on the
+        # GPU box; bench.py --force-collective: every step then ends with the all-gather, `allgather_us` in the line)
         self.collective = self.world_size > 1 or bool(force_collective)
         if self.collective and not dist.is_initialized():
             if backend is None:
@@ -56,7 +57,7 @@ class ShardedForward:
 
     def gather_ragged(self, local, n_items):
         """All-gather shards of a global batch of ``n_items`` split by ``shard_bounds`` (sizes may differ by one)."""
-        if self.world_size == 1:
+        if not self.collective:
             return local
         sizes = [e - b for b, e in (shard_bounds(n_items, self.world_size, r) for r in range(self.world_size))]
         pad = max(sizes)

@@ -119,7 +119,7 @@ def worst_ratio(got, want, rtol, atol):
 #     the same noise, and 1.25 x would reject the exact-fp32 kernel.  The worst element of ~10^4 heavy-tailed errors is only
 #     reproducible to a few tens of per cent, hence the looser factor on it.
 QUIET = 0.4
-FACTORS = {'default': (1.5, 2.0), 'strict': (1.5, 2.0)}
+FACTORS = (1.5, 2.0)      # (RMS, worst element) -- ONE rule for every path: the default and the exact-fp32 leg are held to the same factors
 
 
 def _rms(v):
@@ -127,9 +127,9 @@ def _rms(v):
     return float(v.pow(2).mean().sqrt()) if v.numel() else 0.0
 
 
-def assert_parity(got, want, truth, what='', rtol=1e-4, atol=1e-5, mode='default'):
+def assert_parity(got, want, truth, what='', rtol=1e-4, atol=1e-5):
     """`want` = the reference's (or the fp32 oracle's) output, `truth` = the fp64 evaluation of the same weights."""
-    f_rms, f_max = FACTORS[mode]
+    f_rms, f_max = FACTORS
     got, want, truth = (torch.as_tensor(t).double().cpu() for t in (got, want, truth))
     noise = worst_ratio(want, truth, rtol, atol)
     ratio = worst_ratio(got, want, rtol, atol)
@@ -143,7 +143,7 @@ def assert_parity(got, want, truth, what='', rtol=1e-4, atol=1e-5, mode='default
     return ratio, noise
 
 
-def assert_layer_parity(got, ref, f64, scale, what='', tol=1e-4, mode='default'):
+def assert_layer_parity(got, ref, f64, scale, what='', tol=1e-4):
     """Sampled values of one layer: within `tol` of the layer's scale of the reference where the reference itself is that
     close to fp64; otherwise no further from fp64 than the reference (same two legs as assert_parity)."""
     got, ref, f64 = (torch.as_tensor(t).double().cpu() for t in (got, ref, f64))
@@ -152,6 +152,6 @@ def assert_layer_parity(got, ref, f64, scale, what='', tol=1e-4, mode='default')
         d = float((got - ref).abs().max())
         assert d <= tol * scale, f'{what}: sample err {d:.3e} vs scale {scale:.3e}'
     else:
-        f_rms, f_max = FACTORS[mode]
+        f_rms, f_max = FACTORS
         assert _rms(e_got) <= f_rms * _rms(e_ref) and float(e_got.max()) <= f_max * float(e_ref.max()), \
             f'{what}: err vs fp64 rms {_rms(e_got):.3e} max {float(e_got.max()):.3e}; reference rms {_rms(e_ref):.3e} max {float(e_ref.max()):.3e}'
