@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NBASR_ABI_VERSION 5
+#define NBASR_ABI_VERSION 6
 
 #define NBASR_OK 0
 #define NBASR_EINVAL (-1)   /* bad size / unsupported shape */
@@ -204,6 +204,27 @@ size_t nbasr_lstm_seq_workspace_bytes(int batch, int hidden);
 int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* packed_whh, float* cell_ws, float* h_out, void* seq_ws,
                               int batch, int frames, int hidden, int flags, nbasr_stream_t stream);
 int nbasr_lstm_seq_status(const void* seq_ws, nbasr_stream_t stream);
+/* ABI 6 -- the recurrence as ONE resident launch whose per-frame exchange stays inside an XCD, on the 16-bit matrix cores (reference
+ * model.py:100,118-121; csrc/lstm_xcd.hip).  A tile of 16 utterances is owned by the ceil(hidden / 16) workgroups of ONE XCD (16 hidden
+ * units x 4 gates each, w_hh resident in registers as two fp16 terms per weight, row-independent power-of-two scale): h_t is published
+ * with plain stores and polled with L1-bypassing loads, both served by that XCD's L2 -- one L2 round trip per frame instead of two
+ * fabric trips.  A workgroup reads its XCD from the hardware id and takes its slice from a per-XCD arrival ticket; the first arrival of
+ * an XCD that has collected all its slices claims whole tiles from a global ticket; XCDs that never complete claim nothing, surplus
+ * workgroups leave at once: correctness does not depend on how the dispatcher places workgroups.  The product w_hh . h_(t-1) is
+ * fp32-accurate (3 v_mfma_f32_16x16x32_f16 per 32 k: hi*hi + hi*lo + lo*hi, fp32 accumulation; operand error 2^-23 relative, as in
+ * nbasr_dense_conv1d_packed's NBASR_DENSE_F16X2): h_out agrees with nbasr_lstm_recurrence_packed to fp32 round-off, not bit for bit.
+ * packed_whh16: nbasr_lstm_packed_whh16_bytes / nbasr_lstm_pack_whh16 (once per weight version; hidden <= 512, else 0 bytes / EINVAL).
+ * xcd_ws: nbasr_lstm_xcd_workspace_bytes (0 where the form does not apply: hidden > 512 or batch > 4096), zeroed by the call.
+ * Every wait is bounded (1 s); the status word -- the first 32-bit word of xcd_ws, as for nbasr_lstm_recurrence_seq, read by
+ * nbasr_lstm_seq_status -- is 1 after a timeout (that slice's remaining h rows are NaN) and 2 when a tile was never computed.
+ * Launches from different streams of one process are chained by an event (more than two such grids at once could split an XCD's
+ * units among them so that none collects its slices); a launch on a stream under capture becomes plain graph nodes outside that chain.
+ * flags: 0, or NBASR_LSTM_SEQ_INJECT_FAULT (tests: one slice of every XCD never starts). */
+size_t nbasr_lstm_packed_whh16_bytes(int hidden);
+int nbasr_lstm_pack_whh16(const float* w_hh, void* packed, int hidden, nbasr_stream_t stream);
+size_t nbasr_lstm_xcd_workspace_bytes(int batch, int hidden);
+int nbasr_lstm_recurrence_xcd(const float* gates_ws, const void* packed_whh16, float* cell_ws, float* h_out, void* xcd_ws,
+                              int batch, int frames, int hidden, int flags, nbasr_stream_t stream);
 
 /* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
  * logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias. */

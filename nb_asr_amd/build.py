@@ -20,7 +20,7 @@ LIB_PATH = PKG_DIR / 'lib' / 'libnbasr_hip.so'
 INCLUDE_DIR = REPO_DIR / 'include'
 ARCH = 'gfx950'
 
-SOURCES = ['api.cpp', 'grouped_conv.hip', 'grouped_conv_alt.hip', 'grouped_conv_osplit.hip', 'grouped_conv_ring.hip', 'grouped_conv_bf16.hip', 'grouped_cell.hip', 'grouped_cell_mfma.hip', 'layernorm.hip', 'gemm_conv.hip', 'gemm_conv_split.hip', 'gemm_pointwise_split.hip', 'gemm_pointwise_bf16.hip', 'lstm.hip', 'backward.hip', 'ctc.hip', 'ctc_decode.hip', 'frontend.hip']
+SOURCES = ['api.cpp', 'grouped_conv.hip', 'grouped_conv_alt.hip', 'grouped_conv_osplit.hip', 'grouped_conv_ring.hip', 'grouped_conv_bf16.hip', 'grouped_cell.hip', 'grouped_cell_mfma.hip', 'layernorm.hip', 'gemm_conv.hip', 'gemm_conv_split.hip', 'gemm_pointwise_split.hip', 'gemm_pointwise_bf16.hip', 'lstm.hip', 'lstm_xcd.hip', 'backward.hip', 'ctc.hip', 'ctc_decode.hip', 'frontend.hip']
 CXXFLAGS = ['-O3', '-std=c++17', '-fPIC', f'--offload-arch={ARCH}', '-Wall', '-Wno-unused-function']
 CXXFLAGS += os.environ.get('NBASR_EXTRA_CXXFLAGS', '').split()      # diagnostics (A/B builds); part of the build id
 

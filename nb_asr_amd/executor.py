@@ -244,13 +244,13 @@ class ForwardPlan:
             raise ValueError(f"NBASR_CELL_FUSION={_cf!r}: expected '1', '0' or 'valu'")
         self.cell_fusion = _cf != '0'
         self.cell_mfma = _cf == '1'          # bf16 storage: the matrix-core cell kernel ('valu': the vector-ALU one, as for fp32)
-        # the LSTM recurrence in ONE launch (w_hh resident in registers; nbasr.h: nbasr_lstm_recurrence_seq): 'auto' = in the plain forward
-        # (latency: 4.2 instead of 5.6 us per frame), not in a pipelined tail, whose resident grid would hold CUs the next batch's
-        # encoder needs (measured: -3...-8 % utterances/s at 8-64 utterances); '0' = one launch per frame everywhere; '1' = wherever
-        # the form applies
+        # the LSTM recurrence: 'auto' / 'xcd' = ONE resident launch, a tile of 16 utterances per XCD, fp16-pair matrix cores (round 6;
+        # nbasr.h: nbasr_lstm_recurrence_xcd) in the plain forward AND in the pipelined tail; '0' = one launch per frame everywhere
+        # (fp32 MFMA; what a failed status word demotes a plan to); '1' = the round-4 chip-wide resident grid (nbasr_lstm_recurrence_seq,
+        # fp32 MFMA, bit-identical to '0') wherever it applies
         self.lstm_seq_mode = os.environ.get('NBASR_LSTM_SEQ', 'auto')
-        if self.lstm_seq_mode not in ('auto', '0', '1'):
-            raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', '0' or '1'")
+        if self.lstm_seq_mode not in ('auto', 'xcd', '0', '1'):
+            raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', 'xcd', '0' or '1'")
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
         self._seq_outcome = {}       # ring slot -> whether that launch failed, once its word has been read (check_seq_slot)
@@ -296,21 +296,33 @@ class ForwardPlan:
             self.grow_count += 1
         return t
 
-    def _recurrence(self, gates, packed_hh, hidden, pipe, capturing=False):
-        """The LSTM recurrence into ``self.h_out``: all frames in one launch where that form applies and pays, else one launch per frame."""
+    def _recurrence(self, gates, w_hh, hidden, pipe, capturing=False):
+        """The LSTM recurrence into ``self.h_out``.  Round 6: ONE resident launch with a tile of 16 utterances per XCD on the fp16 matrix
+        cores (nbasr_lstm_recurrence_xcd) wherever it applies -- plain forward, pipelined tail and captured graph alike (every route the same
+        arithmetic); a layer wider than 512 or a plan demoted by a failed status word takes one launch per frame (replayed as a graph)."""
         # (launches of the resident grid are chained across the process's streams by an event, which a graph capture cannot hold)
         if not capturing and torch.cuda.is_current_stream_capturing():       # a caller's own torch.cuda.graph(...) around model(x)
             capturing = True
-        use = self.lstm_seq_mode != '0' and not capturing and (self.lstm_seq_mode == '1' or not pipe)
-        nbytes = hip.lstm_seq_workspace_bytes(self.batch, hidden, self.device) if use else 0
+        mode = self.lstm_seq_mode
+        if mode in ('auto', 'xcd'):
+            nbytes = hip.lstm_xcd_workspace_bytes(self.batch, hidden)
+            if nbytes:
+                ws = self._buf('lstm_xcd', nbytes, torch.uint8)
+                out = hip.lstm_recurrence_xcd(gates, self._packed_whh16(w_hh), self.cell_ws, self.h_out, ws, self._seq_flags)
+                if not capturing:              # (a captured graph holds the launch, not the host-side read-back of its status word)
+                    self._host(lambda: self._seq_status_readback(ws))
+                return out
+        packed_hh = self._packed_whh(w_hh)
+        nbytes = hip.lstm_seq_workspace_bytes(self.batch, hidden, self.device) if (mode == '1' and not capturing) else 0
         if nbytes:
             ws = self._buf('lstm_seq', nbytes, torch.uint8)
             try:
                 out = hip.lstm_recurrence_seq(gates, packed_hh, self.cell_ws, self.h_out, ws, self._seq_flags)
             except hip.HipError as e:
                 # ONLY the device refusing the cooperative grid (a partition / CU mask smaller than the occupancy query said) demotes the
-                # plan to per-frame launches; an argument, alignment or capture error is the caller's to see (ADVICE r4)
-                if 'cooperative launch' not in str(e):
+                # plan to per-frame launches; an argument, alignment or capture error is the caller's to see (ADVICE r4).  The refusal is
+                # recognised by its CODE (hipErrorCooperativeLaunchTooLarge, passed through by the entry point), not by its wording (ADVICE r5)
+                if e.code != hip.HIP_ERROR_COOPERATIVE_LAUNCH_TOO_LARGE:
                     raise
                 self.lstm_seq_mode = '0'
                 self._tapes.clear()
@@ -527,9 +539,13 @@ class ForwardPlan:
         w = op.conv.weight
         return self._cached(w, 'gc_wperm', lambda: hip.pack_grouped_weights(self._f32(w).contiguous(), op.groups))
 
+    def _packed_whh16(self, w):
+        """w_hh as the resident operand image of the XCD-local recurrence (two fp16 terms per weight), rebuilt when the parameter changes."""
+        return self._cached(w, 'whh16', lambda: hip.lstm_pack_whh16(self._f32(w).contiguous()))
+
     def _packed_whh(self, w):
         """Fragment-ordered copy of the LSTM's recurrent weight, rebuilt whenever the parameter changes."""
-        return self._cached(w, 'whh', lambda: hip.lstm_pack_whh(w.detach()))
+        return self._cached(w, 'whh', lambda: hip.lstm_pack_whh(self._f32(w).contiguous()))
 
     def _pointwise_ws(self, c_in, ld):
         need = hip.load_library().nbasr_pointwise_workspace_bytes(self.batch, c_in, ld)
@@ -1009,9 +1025,8 @@ class ForwardPlan:
                     self._to_side_stream()
                     tail_ctx = torch.cuda.stream(self.side_stream)
                     tail_ctx.__enter__()
-                packed_hh = self._packed_whh(layer.weight_hh_l0)
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: self._recurrence(gates, packed_hh, layer.hidden_size, pipe, _capturing))
+                            lambda: self._recurrence(gates, layer.weight_hh_l0, layer.hidden_size, pipe, _capturing))
                 act, pending = self.h_out, None            # (batch, frames, hidden)
                 if taps is not None:
                     taps[idx] = self._tap(act, act_frames)
@@ -1287,9 +1302,8 @@ class ForwardPlan:
                     self._to_side_stream()
                     tail_ctx = torch.cuda.stream(self.side_stream)
                     tail_ctx.__enter__()
-                packed_hh = self._cached(layer.weight_hh_l0, 'whh', lambda: hip.lstm_pack_whh(w_hh32))
                 self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
-                            lambda: self._recurrence(gates, packed_hh, layer.hidden_size, pipe, capturing))
+                            lambda: self._recurrence(gates, layer.weight_hh_l0, layer.hidden_size, pipe, capturing))
                 act = self.h_out
                 if taps is not None:
                     taps[idx] = act.permute(0, 2, 1).clone()

@@ -15,7 +15,7 @@ import pathlib
 import torch
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / 'lib' / 'libnbasr_hip.so'
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_float_p = ctypes.c_void_p      # device pointers travel as opaque addresses
 _c_int = ctypes.c_int
@@ -84,6 +84,10 @@ SIGNATURES = {
     'nbasr_lstm_seq_workspace_bytes': (ctypes.c_size_t, [_c_int] * 2),
     'nbasr_lstm_recurrence_seq': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
     'nbasr_lstm_seq_status': (_c_int, [_c_float_p, _c_stream]),
+    'nbasr_lstm_packed_whh16_bytes': (ctypes.c_size_t, [_c_int]),
+    'nbasr_lstm_pack_whh16': (_c_int, [_c_float_p] * 2 + [_c_int, _c_stream]),
+    'nbasr_lstm_xcd_workspace_bytes': (ctypes.c_size_t, [_c_int] * 2),
+    'nbasr_lstm_recurrence_xcd': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     # post-logits step
@@ -583,6 +587,7 @@ def lstm_seq_workspace(batch, hidden, device):
     return torch.empty(nbytes, dtype=torch.uint8, device=device) if nbytes else None
 
 
+HIP_ERROR_COOPERATIVE_LAUNCH_TOO_LARGE = 720       # hipErrorCooperativeLaunchTooLarge: nbasr_lstm_recurrence_seq passes a refused grid's code through
 LSTM_SEQ_INJECT_FAULT = 1       # NBASR_LSTM_SEQ_INJECT_FAULT of nbasr_lstm_recurrence_seq (tests)
 
 
@@ -612,6 +617,45 @@ def lstm_seq_workspace_bytes(batch, hidden, device):
 def lstm_seq_status(seq_ws):
     """Synchronises the current stream and raises HipError if a step of the last one-launch recurrence timed out."""
     _check(load_library().nbasr_lstm_seq_status(seq_ws.data_ptr(), _stream(seq_ws)), 'nbasr_lstm_seq_status')
+
+
+def lstm_pack_whh16(w_hh):
+    """w_hh (4*hidden, hidden) fp32 -> the resident operand image of lstm_recurrence_xcd (two fp16 terms per weight; hidden <= 512)."""
+    hidden = w_hh.shape[1]
+    lib = load_library()
+    nbytes = lib.nbasr_lstm_packed_whh16_bytes(hidden)
+    if w_hh.shape[0] != 4 * hidden or nbytes == 0:
+        raise HipError(f'lstm_pack_whh16: w_hh must be (4*hidden, hidden) with hidden <= 512, got {tuple(w_hh.shape)}')
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w_hh.device)
+    _check(lib.nbasr_lstm_pack_whh16(_dev(w_hh, 'w_hh'), packed.data_ptr(), hidden, _stream(w_hh)), 'nbasr_lstm_pack_whh16')
+    return packed
+
+
+def lstm_xcd_workspace_bytes(batch, hidden):
+    return load_library().nbasr_lstm_xcd_workspace_bytes(int(batch), int(hidden))
+
+
+def lstm_xcd_workspace(batch, hidden, device):
+    nbytes = lstm_xcd_workspace_bytes(batch, hidden)
+    if nbytes == 0:
+        raise HipError(f'lstm_recurrence_xcd does not apply to batch={batch}, hidden={hidden} (hidden <= 512, batch <= 4096)')
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def lstm_recurrence_xcd(gates_ws, packed_whh16, cell_ws, h_out, xcd_ws, flags=0):
+    """The recurrence as ONE resident launch, a tile of 16 utterances per XCD, on the fp16 matrix cores (nbasr.h, ABI 6): h_out agrees
+    with lstm_recurrence_packed to fp32 round-off.  The status word of ``xcd_ws`` is read by ``lstm_seq_status``."""
+    b, frames, hidden = h_out.shape
+    lib = load_library()
+    if not packed_whh16.is_cuda or packed_whh16.dtype != torch.uint8 or packed_whh16.numel() != lib.nbasr_lstm_packed_whh16_bytes(hidden):
+        raise HipError('packed_whh16 must be the uint8 device tensor returned by lstm_pack_whh16 for this hidden size')
+    need = lstm_xcd_workspace_bytes(b, hidden)
+    if need == 0 or not xcd_ws.is_cuda or xcd_ws.dtype != torch.uint8 or xcd_ws.numel() < need:
+        raise HipError(f'lstm_recurrence_xcd: batch={b} hidden={hidden} needs a uint8 device workspace of {need} bytes from lstm_xcd_workspace '
+                       f'(0 = the form does not apply)')
+    _check(lib.nbasr_lstm_recurrence_xcd(_dev(gates_ws, 'gates_ws'), packed_whh16.data_ptr(), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
+                                         xcd_ws.data_ptr(), b, frames, hidden, int(flags), _stream(h_out)), 'nbasr_lstm_recurrence_xcd')
+    return h_out
 
 
 def lstm_recurrence(gates_ws, w_hh, cell_ws, h_out):

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(built_library):
     lib = ctypes.CDLL(str(built_library))
     for name in declared_symbols():
         assert hasattr(lib, name), name
-    assert hip.load_library().nbasr_version() == hip.ABI_VERSION == 5
+    assert hip.load_library().nbasr_version() == hip.ABI_VERSION == 6
 
 
 def test_loaded_library_was_built_from_these_sources(built_library):

@@ -1,0 +1,144 @@
+"""nbasr_lstm_recurrence_xcd (ABI 6): the LSTM recurrence as one resident launch, a tile of 16 utterances per XCD, on the fp16 matrix
+cores with fp32-accurate two-term operands (reference model.py:100,118-121: nn.LSTM(1200, 500), zero initial state).
+
+It shares no arithmetic order with the fp32 recurrence kernels, so the checks are against a float64 evaluation of the same recurrence:
+no further from it than the exact-fp32 kernel (nbasr_lstm_recurrence_packed) is, up to a small factor -- the parity rule of
+tests/cases.py for a kernel that is another fp32-accurate summation order, not a narrower one."""
+import pytest
+import torch
+
+from nb_asr_amd import hip
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def ref64(gates, w_hh):
+    """float64 recurrence on the CPU: gates (T, B, 4H) = the input projection incl. both biases; returns h (B, T, H), c_T (B, H)."""
+    gates, w = gates.double().cpu(), w_hh.double().cpu()
+    t_n, b, h4 = gates.shape
+    hid = h4 // 4
+    h = torch.zeros(b, hid, dtype=torch.float64)
+    c = torch.zeros(b, hid, dtype=torch.float64)
+    out = torch.empty(b, t_n, hid, dtype=torch.float64)
+    for t in range(t_n):
+        pre = gates[t] + h @ w.t()
+        i, f, g, o = pre.split(hid, dim=1)
+        c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(g)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        out[:, t] = h
+    return out, c
+
+
+def run_xcd(gates, w_hh, flags=0):
+    t_n, b, h4 = gates.shape
+    hid = h4 // 4
+    packed = hip.lstm_pack_whh16(w_hh)
+    ws = hip.lstm_xcd_workspace(b, hid, DEV)
+    cell = torch.full((b, hid), float('nan'), device=DEV)
+    out = torch.full((b, t_n, hid), float('nan'), device=DEV)
+    hip.lstm_recurrence_xcd(gates, packed, cell, out, ws, flags)
+    return out, cell, ws
+
+
+def run_f32(gates, w_hh):
+    t_n, b, h4 = gates.shape
+    hid = h4 // 4
+    cell = torch.empty(b, hid, device=DEV)
+    out = torch.empty(b, t_n, hid, device=DEV)
+    hip.lstm_recurrence_packed(gates, hip.lstm_pack_whh(w_hh), cell, out)
+    return out, cell
+
+
+@pytest.mark.parametrize('b,t,h,wscale', [(3, 7, 500, 0.2), (17, 5, 36, 0.2), (64, 3, 500, 0.2), (2, 4, 12, 0.2), (8, 250, 500, 0.045),
+                                          (33, 61, 500, 0.045), (1, 1, 500, 0.2), (16, 2, 512, 0.2), (130, 9, 500, 0.1), (64, 250, 500, 0.045),
+                                          (5, 40, 8, 0.3), (20, 33, 20, 0.3)])
+def test_xcd_recurrence_matches_float64_like_the_fp32_kernel(b, t, h, wscale):
+    torch.manual_seed(h * 1000 + b)
+    gates = torch.randn(t, b, 4 * h, device=DEV)
+    w_hh = torch.randn(4 * h, h, device=DEV) * wscale
+    want, c_want = ref64(gates, w_hh)
+    got, cell, ws = run_xcd(gates, w_hh)
+    f32, cell32 = run_f32(gates, w_hh)
+    hip.lstm_seq_status(ws)                                   # raises if a wait timed out or a tile was never computed
+    assert torch.isfinite(got).all() and torch.isfinite(cell).all()
+    e_x = (got.double().cpu() - want).abs()
+    e_f = (f32.double().cpu() - want).abs()
+    ec_x = (cell.double().cpu() - c_want).abs()
+    ec_f = (cell32.double().cpu() - c_want).abs()
+    rms = lambda e: float(e.pow(2).mean().sqrt())            # noqa: E731
+    print(f'b={b} t={t} h={h}: rms err vs fp64 xcd {rms(e_x):.3e} fp32 kernel {rms(e_f):.3e}; worst {float(e_x.max()):.3e} / {float(e_f.max()):.3e}')
+    assert rms(e_x) <= 1.5 * rms(e_f) + 2e-8 and float(e_x.max()) <= 2.0 * float(e_f.max()) + 2e-7
+    assert rms(ec_x) <= 1.5 * rms(ec_f) + 4e-8 and float(ec_x.max()) <= 2.0 * float(ec_f.max()) + 4e-7
+
+
+def test_xcd_recurrence_is_deterministic_and_batch_invariant():
+    """Same inputs, same bits -- whichever XCD takes which tile; an utterance's h does not depend on the batch it sits in (tiles of 16
+    are independent columns of the same MFMA sequence)."""
+    torch.manual_seed(7)
+    t, h = 50, 500
+    gates = torch.randn(t, 64, 4 * h, device=DEV)
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.05
+    a, ca, _ = run_xcd(gates, w_hh)
+    for _ in range(3):
+        b, cb, _ = run_xcd(gates, w_hh)
+        assert torch.equal(a, b) and torch.equal(ca, cb)
+    for lo, hi in ((0, 8), (8, 24), (40, 41), (16, 64)):
+        sub, csub, _ = run_xcd(gates[:, lo:hi].contiguous(), w_hh)
+        assert torch.equal(sub, a[lo:hi]) and torch.equal(csub, ca[lo:hi])
+
+
+def test_xcd_recurrence_scales_extreme_weights_and_keeps_nan_visible():
+    """w_hh is scaled by one power of two into fp16's range: tiny and large matrices keep fp32 accuracy; a NaN gate poisons exactly its
+    utterance from that frame on."""
+    torch.manual_seed(11)
+    t, b, h = 12, 6, 64
+    gates = torch.randn(t, b, 4 * h, device=DEV)
+    for scale in (1e-6, 1e-3, 40.0, 3e3):
+        w_hh = torch.randn(4 * h, h, device=DEV) * scale
+        want, _ = ref64(gates, w_hh)
+        got, _, ws = run_xcd(gates, w_hh)
+        f32, _ = run_f32(gates, w_hh)
+        hip.lstm_seq_status(ws)
+        e_x, e_f = (got.double().cpu() - want).abs(), (f32.double().cpu() - want).abs()
+        rms = lambda e: float(e.pow(2).mean().sqrt())        # noqa: E731
+        # (at 3e3 the pre-activations are ~1e4-1e5 and every gate sits on a saturation edge: fp32 itself is then 1e-4 off in places, and
+        # the worst element is a coin toss between two such evaluations -- hence the RMS there)
+        assert rms(e_x) <= 1.5 * rms(e_f) + 2e-8, (scale, rms(e_x), rms(e_f))
+        if scale < 1e3:
+            assert float(e_x.max()) <= 2.0 * float(e_f.max()) + 3e-7, (scale, float(e_x.max()), float(e_f.max()))
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.1
+    clean, _, _ = run_xcd(gates, w_hh)
+    bad = gates.clone()
+    bad[4, 2, 17] = float('nan')
+    got, _, ws = run_xcd(bad, w_hh)
+    hip.lstm_seq_status(ws)
+    others = [i for i in range(b) if i != 2]
+    assert torch.equal(got[others], clean[others]) and torch.equal(got[2, :4], clean[2, :4])
+    assert torch.isnan(got[2, 4, 17 % h]) and torch.isnan(got[2, 5:]).all()
+
+
+def test_xcd_recurrence_that_loses_a_slice_raises_the_status_word():
+    torch.manual_seed(5)
+    t, b, h = 6, 4, 500
+    gates = torch.randn(t, b, 4 * h, device=DEV)
+    w_hh = torch.randn(4 * h, h, device=DEV) * 0.1
+    got, _, ws = run_xcd(gates, w_hh, hip.LSTM_SEQ_INJECT_FAULT)
+    with pytest.raises(hip.HipError, match='status'):
+        hip.lstm_seq_status(ws)
+    assert not torch.isfinite(got).all()                      # the failure is visible in the output too
+    good, _, ws = run_xcd(gates, w_hh)                        # and the next launch is healthy
+    hip.lstm_seq_status(ws)
+    assert torch.isfinite(good).all()
+
+
+def test_xcd_entry_point_argument_errors():
+    lib = hip.load_library()
+    assert lib.nbasr_lstm_packed_whh16_bytes(516) == 0 and lib.nbasr_lstm_xcd_workspace_bytes(8, 516) == 0
+    assert lib.nbasr_lstm_xcd_workspace_bytes(8, 500) > 0 and lib.nbasr_lstm_xcd_workspace_bytes(5000, 500) == 0
+    with pytest.raises(hip.HipError):
+        hip.lstm_pack_whh16(torch.zeros(4 * 516, 516, device=DEV))
+    g = torch.zeros(2, 3, 4 * 8, device=DEV)
+    w = hip.lstm_pack_whh16(torch.zeros(32, 8, device=DEV))
+    with pytest.raises(hip.HipError):
+        hip.lstm_recurrence_xcd(g, w, torch.zeros(3, 8, device=DEV), torch.zeros(3, 2, 8, device=DEV), torch.zeros(16, dtype=torch.uint8, device=DEV))
