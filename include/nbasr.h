@@ -225,6 +225,12 @@ int nbasr_lstm_pack_whh16(const float* w_hh, void* packed, int hidden, nbasr_str
 size_t nbasr_lstm_xcd_workspace_bytes(int batch, int hidden);
 int nbasr_lstm_recurrence_xcd(const float* gates_ws, const void* packed_whh16, float* cell_ws, float* h_out, void* xcd_ws,
                               int batch, int frames, int hidden, int flags, nbasr_stream_t stream);
+/* The same arithmetic as ONE LAUNCH PER FRAME (bit-identical h_out to nbasr_lstm_recurrence_xcd): what a caller runs where a resident
+ * grid is unwelcome -- beside other work that needs every XCD (a pipelined tail next to the following batch's encoder) -- and what a
+ * plan falls back to after a failed status word.  Same packed weights, same workspace (only its images are used; no status word to
+ * read); the chain of `frames` launches is replayed as one cached graph where the call recurs, like nbasr_lstm_recurrence_packed. */
+int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void* packed_whh16, float* cell_ws, float* h_out, void* xcd_ws,
+                                   int batch, int frames, int hidden, nbasr_stream_t stream);
 
 /* CTC head nn.Linear(features -> classes) (reference model.py:101 / 122-124):
  * logits(rows, classes) = h(rows, features) . w(classes, features)^T + bias. */

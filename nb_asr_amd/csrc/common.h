@@ -59,6 +59,21 @@ __device__ __forceinline__ float relu_clamp(float v) {
 // the scaled fp16 GEMM would otherwise flush every finite sample of that utterance to zero
 __device__ __forceinline__ float finite_abs(float v) { const float a = fabsf(v); return a <= 3.4028234664e38f ? a : 0.f; }
 
+// A chain of dependent launches replayed as ONE instantiated graph per key (api.cpp).  `launch_chain` enqueues the chain on `stream`;
+// `key` names everything the launches depend on (buffers, shapes, a tag for the entry point).  A graph is only built for a key that has
+// been SEEN three times (a caller with fresh buffers or a new frame count per call would otherwise pay capture + instantiate + destroy
+// every time and never replay); caches are per device; an entry is launched under the lock and destroyed only after the event behind
+// its last launch has completed; a stream that is being captured by the caller takes the plain launches.
+struct ChainKey {
+    const void* ptr[5];
+    int val[5];
+    bool operator==(const ChainKey& o) const {
+        for (int i = 0; i < 5; ++i) if (ptr[i] != o.ptr[i] || val[i] != o.val[i]) return false;
+        return true;
+    }
+};
+int replay_chain(hipStream_t stream, const ChainKey& key, const char* what, void (*launch_chain)(void*), void* ctx);
+
 #define NBASR_REQUIRE(cond, code, ...)          \
     do {                                        \
         if (!(cond)) {                          \

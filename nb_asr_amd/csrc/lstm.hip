@@ -461,99 +461,16 @@ extern "C" int nbasr_lstm_recurrence_packed(const float* gates_ws, const void* p
     NBASR_REQUIRE(aligned16(packed_whh) && aligned16(h_out), NBASR_EALIGN, "nbasr_lstm_recurrence_packed: packed_whh, h_out must be 16-byte aligned");
     const dim3 grid(lstm_slices(hidden), (batch + 15) / 16);
     const int prio = batch <= 32;          // issue priority for the chain's waves where the chain is the critical path (see the kernel)
-    hipStream_t s = as_stream(stream);
-    auto launch_chain = [&]() {
-        for (int t = 0; t < frames; ++t)
-            hipLaunchKernelGGL(lstm_step_packed_kernel, grid, dim3(64 * LSTM_WAVES), 0, s, gates_ws,
-                               static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, lstm_kchunks_p(hidden), t, prio);
-    };
-    // Round 5: the chain of `frames` dependent launches is replayed as ONE instantiated graph per (buffers, shape, device).  Issuing 250
-    // launches costs the host 0.6-0.7 ms per forward -- at 8 utterances per GPU that is half of the step, on the thread that also has to
-    // feed the encoder's stream; a graph launch costs ~15 us.  Same kernels, same order, same arguments: bit-identical h.  A stream that is
-    // being captured by the caller (forward_graph) takes the plain launches.
-    // (same-box A/B, alternating, bench.py --batch 8 / 16 / 64: 4 856 / 4 781 -> 5 036 / 4 873, 7 172 / 7 048 -> 7 258 / 7 248, 9 821 / 9 839 -> 9 852 / 9 896)
-    // Round 6: a graph is only built for a key that has been SEEN three times (a serving loop with a new frame count per
-    // batch, or the autograd caller with fresh buffers per step, would otherwise pay capture + instantiate + destroy on every call
-    // and never replay); the caches are per device; an entry is launched under the lock, and an evicted one is destroyed only after
-    // the event behind its last launch has completed.
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        launch_chain();
-        return launch_status("nbasr_lstm_recurrence_packed");
-    }
-    int device = -1;
-    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= NBASR_MAX_DEVICES) {
-        (void)hipGetLastError();
-        launch_chain();
-        return launch_status("nbasr_lstm_recurrence_packed");
-    }
-    struct Key {
-        const void* g; const void* w; void* c; void* h; int batch, frames, hidden;
-        bool operator==(const Key& o) const { return g == o.g && w == o.w && c == o.c && h == o.h && batch == o.batch && frames == o.frames && hidden == o.hidden; }
-    };
-    struct Chain { Key key; hipGraphExec_t exec; hipEvent_t last; unsigned long long used; };
-    struct Seen { Key key; int count; unsigned long long used; };
-    struct PerDevice { std::mutex m; std::vector<Chain> cache; std::vector<Seen> seen; unsigned long long tick = 0; };
-    static PerDevice per_device[NBASR_MAX_DEVICES];
-    constexpr size_t CHAIN_CACHE = 16, SEEN_TABLE = 64;        // per device: 2 pipelined slots x a few (batch, frames) shapes
-    constexpr int SEEN_BEFORE_CAPTURE = 3;
-    PerDevice& pd = per_device[device];
-    const Key key{gates_ws, packed_whh, cell_ws, h_out, batch, frames, hidden};
-    std::lock_guard<std::mutex> lock(pd.m);                    // (held across the launch: an entry cannot be destroyed under a launcher)
-    Chain* hit = nullptr;
-    for (Chain& e : pd.cache) if (e.key == key) { hit = &e; break; }
-    if (hit == nullptr) {
-        Seen* sn = nullptr;
-        for (Seen& e : pd.seen) if (e.key == key) { sn = &e; break; }
-        if (sn == nullptr) {
-            if (pd.seen.size() >= SEEN_TABLE) {
-                size_t lru = 0;
-                for (size_t i = 1; i < pd.seen.size(); ++i) if (pd.seen[i].used < pd.seen[lru].used) lru = i;
-                pd.seen.erase(pd.seen.begin() + lru);
-            }
-            pd.seen.push_back(Seen{key, 0, 0});
-            sn = &pd.seen.back();
-        }
-        sn->used = ++pd.tick;
-        if (++sn->count < SEEN_BEFORE_CAPTURE) {                // not (yet) a recurring call: the plain chain
-            launch_chain();
-            return launch_status("nbasr_lstm_recurrence_packed");
-        }
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        hipEvent_t last = nullptr;
-        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            launch_chain();
-            e = hipStreamEndCapture(s, &graph);
-        }
-        if (e == hipSuccess) e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        if (graph) (void)hipGraphDestroy(graph);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&last, hipEventDisableTiming);
-        if (e != hipSuccess || exec == nullptr) {                 // no graph on this runtime / stream: the plain chain
-            (void)hipGetLastError();
-            if (exec) (void)hipGraphExecDestroy(exec);
-            sn->count = 0;
-            launch_chain();
-            return launch_status("nbasr_lstm_recurrence_packed");
-        }
-        if (pd.cache.size() >= CHAIN_CACHE) {                      // the least recently used one goes -- once its last launch has completed
-            size_t lru = 0;
-            for (size_t i = 1; i < pd.cache.size(); ++i) if (pd.cache[i].used < pd.cache[lru].used) lru = i;
-            (void)hipEventSynchronize(pd.cache[lru].last);
-            (void)hipGraphExecDestroy(pd.cache[lru].exec);
-            (void)hipEventDestroy(pd.cache[lru].last);
-            pd.cache.erase(pd.cache.begin() + lru);
-        }
-        pd.cache.push_back(Chain{key, exec, last, 0});
-        hit = &pd.cache.back();
-    }
-    hit->used = ++pd.tick;
-    hipError_t e = hipGraphLaunch(hit->exec, s);
-    if (e == hipSuccess) e = hipEventRecord(hit->last, s);
-    if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_packed: hipGraphLaunch: %s", hipGetErrorString(e)); return static_cast<int>(e); }
-    return launch_status("nbasr_lstm_recurrence_packed");
+    struct Ctx { dim3 grid; hipStream_t s; const float* gates; const float4* w; float* cell; float* h; int batch, frames, hidden, prio; };
+    Ctx ctx{grid, as_stream(stream), gates_ws, static_cast<const float4*>(packed_whh), cell_ws, h_out, batch, frames, hidden, prio};
+    // the chain of `frames` dependent launches, replayed as ONE cached graph per (buffers, shape, device) where the call recurs (common.h)
+    const ChainKey key{{gates_ws, packed_whh, cell_ws, h_out, nullptr}, {batch, frames, hidden, 32, 0}};
+    return replay_chain(ctx.s, key, "nbasr_lstm_recurrence_packed", [](void* p) {
+        const Ctx& c = *static_cast<const Ctx*>(p);
+        for (int t = 0; t < c.frames; ++t)
+            hipLaunchKernelGGL(lstm_step_packed_kernel, c.grid, dim3(64 * LSTM_WAVES), 0, c.s, c.gates, c.w, c.cell, c.h, c.batch, c.frames, c.hidden,
+                               lstm_kchunks_p(c.hidden), t, c.prio);
+    }, &ctx);
 }
 
 // Workgroups of lstm_seq_kernel the CURRENT device holds at once (not a constant -- a partitioned (CPX) or CU-masked

@@ -3,14 +3,17 @@
 //
 // Why.  The recurrence is `frames` dependent steps of a tiny GEMM (gates(2000) x utterances(16) x hidden(500)).  Rounds 2-5 ran it
 // as one launch per frame (4.4-6.5 us per frame) or as a resident grid of 252 workgroups over the whole chip that exchange h_t in
-// tagged write-through granules (3.85 us per frame: ~0.85 of fp32 MFMA, the rest the fabric round trip of an `sc1` store that drops
-// its line from L2 + an `sc1` load that has to fetch it from the memory side).  At 8 utterances per GPU -- one rank's share of the
-// north star's 8-GPU run -- the chain (0.8-1.0 ms) was as long as the whole encoder, and at 64 its 250 launches took 0.64 ms from the
-// encoder they were supposed to hide behind.  Here:
-//   * a tile of 16 utterances is owned by the (<= 32) workgroups of ONE XCD: workgroup = 16 hidden units x 4 gates (4 MFMA row
-//     tiles), all of K = hidden <= 512.  Producers and consumers of a tile share one L2, so h_t is published with PLAIN stores (the
-//     line stays in that L2) and polled with `sc1` loads (they bypass the CU's L1 and are served by L2): one L2 round trip per frame
-//     instead of two fabric trips (/opt/skills/guides/MI355X_MICROARCH.md, "stores of each flavour", handoff rows);
+// tagged write-through granules (3.1-3.8 us per frame: ~0.85 of fp32 MFMA, the rest the fabric round trip of an `sc1` store that
+// drops its line from L2 + an `sc1` load that has to fetch it from the memory side, and an 8-way reduction through LDS).  Here:
+//   * a tile of 16 utterances is owned by the (<= 32) workgroups of ONE XCD: workgroup = 16 hidden units x 4 gates = 4 MFMA row
+//     tiles, one per wave, each wave holding ITS rows of w_hh for all of K = hidden <= 512 in registers (128 per lane).  A wave's
+//     accumulators are complete sums: no reduction across waves, the gate arithmetic follows in the same registers;
+//   * producers and consumers of a tile share one L2, so h_t is published with PLAIN stores (the line stays in that L2) behind
+//     which each storing wave drains (`s_waitcnt vmcnt(0)`: L2 has the bytes) and sets its flag word; a consumer wave polls the
+//     tile's 128 flag words (512 bytes) with `sc1` loads -- they bypass the CU's L1 and are served by L2 -- and then brings its
+//     quarter of the 32 KiB image into LDS by LDS-DMA (`global_load_lds_dwordx4 sc1`: no registers, no LDS-store issue), one
+//     workgroup barrier, and every wave reads all of h as ready-made B fragments.  One L2 round trip for the flag, one for the data,
+//     per frame; nothing crosses the fabric (/opt/skills/guides/MI355X_MICROARCH.md, "stores of each flavour", hand-off rows);
 //   * placement is not assumed, it is READ: a workgroup takes its XCD from HW_REG_XCC_ID and its slice from a per-XCD arrival ticket;
 //     the first arrival of an XCD claims whole tiles from a global ticket once its XCD has all its slices, publishes the claim, and
 //     its peers follow.  Whatever the dispatcher does, the workgroups that exchange a tile's h ARE on one XCD; an XCD that never
@@ -18,19 +21,22 @@
 //     (observed, not promised) only decides how many XCDs take part.  The last workgroup to leave checks that every tile was
 //     computed and raises the status word otherwise;
 //   * the recurrent product runs on v_mfma_f32_16x16x32_f16 with fp32-accurate operands: w_hh (scaled by one power of two) and h
-//     (|h| <= 1) are two fp16 terms each, value = hi + lo * 2^-11, and a product is hi*hi (first accumulator) + (hi*lo' + lo'*hi)
+//     (|h| <= 1) are two fp16 terms each, value = hi + lo' * 2^-11, and a product is hi*hi (first accumulator) + (hi*lo' + lo'*hi)
 //     (second accumulator, folded in with its 2^-11 at the end): 3 MFMAs per 32 k, 1/5 of the fp32 MFMA time.  The dropped lo*lo
 //     term is <= 2^-24 of the product; the representation error of an operand is 2^-23 relative (as in the dense convs and the
-//     input projection, gemm_conv_split.hip) -- an fp32 evaluation in another summation order, not a narrower one;
-//   * h_t travels as it is consumed: dword = (fp16 hi << 16) | fp16 lo', four units per 16-byte granule, bit 30 of every dword
-//     (= bit 14 of hi: free, |hi| <= 1) carries the tag of the step as in lstm_seq_kernel: no flag, no drain, no second location.
-//     A non-finite h travels as lo' = NaN, which every product it meets turns into NaN: a diverged utterance stays visible;
+//     input projection, gemm_conv_split.hip) -- an fp32 evaluation in another summation order, not a narrower one (measured
+//     against float64: tests/test_lstm_xcd_gpu.py);
+//   * h_t is stored as it is consumed: the image IS the B operand of the MFMA, [k-step][hi | lo'][lane] x 8 halves; a wave
+//     writes the 4 units of its row tile as one 8-byte piece per utterance and term.  A non-finite h travels as lo' = NaN, which
+//     every product it meets turns into NaN: a diverged utterance stays visible;
+//   * the gates use the hardware exp2 / rcp (1 ulp each) -- sigmoid(x) = rcp(1 + exp2(-x log2 e)); tanh(x) = (1 - e) rcp(1 + e),
+//     e = exp2(-2 |x| log2 e), and an odd polynomial below |x| = 0.35 where that form would cancel: ~55 vector instructions per
+//     frame instead of the ~200 of the library calls, at <= 2 ulp;
 //   * every wait is bounded (1 s of the 100 MHz clock); a timeout raises the status word (nbasr_lstm_seq_status, or the
 //     executor's asynchronous read-back) and fills the rest of that slice's h rows with NaN.
-// Per frame and workgroup: poll 4 granule loads per lane (2 k-steps x 2) -> 16 v_perm + 24 MFMAs per wave -> partial tiles through
-// LDS, one barrier -> waves 0-3: gates, cell, h for 4 units x 16 utterances each -> granule store.
 #include "common.h"
 
+#include <cstdlib>
 #include <mutex>
 
 namespace nbasr {
@@ -38,12 +44,15 @@ namespace nbasr {
 typedef float xfloat4 __attribute__((ext_vector_type(4)));
 typedef _Float16 xhalf8 __attribute__((ext_vector_type(8)));
 typedef unsigned xuint4 __attribute__((ext_vector_type(4)));
+typedef unsigned xuint2 __attribute__((ext_vector_type(2)));
 
-constexpr int LX_WAVES = 8;                      // K = 512 split eight ways: a wave owns 2 k-steps of 32
-constexpr int LX_UNITS = 16;                     // hidden units per workgroup = 4 row tiles of (4 units x 4 gates)
-constexpr int LX_MT = LX_UNITS / 4;
+constexpr int LX_WAVES = 4;                      // a wave = one MFMA row tile (4 hidden units x 4 gates) x all of K
+constexpr int LX_UNITS = 16;                     // hidden units per workgroup
 constexpr int LX_KSTEPS = 16;                    // hidden <= 512
-constexpr int LX_IMAGE_BYTES = LX_KSTEPS * 2 * 64 * 16;    // one exchange image of one tile: [k-step][granule][lane] x 16 B = 32 KiB
+constexpr int LX_MAX_SLICES = LX_KSTEPS * 32 / LX_UNITS;   // 32
+constexpr int LX_IMAGE_BYTES = LX_KSTEPS * 2 * 64 * 16;    // one exchange image of one tile: [k-step][hi | lo'][lane] x 16 B = 32 KiB
+constexpr int LX_FLAGS = LX_MAX_SLICES * LX_WAVES;         // flag words of one tile (one per publishing wave): 128
+constexpr int LX_TILE_BYTES = 2 * LX_IMAGE_BYTES + LX_FLAGS * 4;      // two images (step parity) + the flags
 constexpr int LX_MAX_XCD = 16;
 constexpr int LX_MAX_TILES = 256;                // batch <= 4096
 // header of the workspace (32-bit words); [0] is the status word nbasr_lstm_seq_status reads
@@ -54,10 +63,10 @@ constexpr int LX_CLAIM_STRIDE = LX_MAX_TILES + 16;
 constexpr int LX_HEADER_WORDS = LX_W_CLAIMS + LX_MAX_XCD * LX_CLAIM_STRIDE;
 constexpr unsigned LX_DONE = 0xffffffffu;
 constexpr unsigned long long LX_TIMEOUT_TICKS = 100000000ull;         // 1 s of the constant 100 MHz clock
-constexpr int LX_PACK_HEADER_BYTES = 256;        // packed w_hh: [0] 2^-e, [1] 2^-(e+11) (floats), [2] max |w| bits (pack-time scratch)
+constexpr int LX_PACK_HEADER_BYTES = 256;        // packed w_hh: [0] 2^-e (float), [2] max |w| bits (pack-time scratch)
 
 // Diagnostic build (-DNBASR_LX_STAMPS=1, tools/ubench/lstm_xcd_stamps.py): wave 0 of every slice of tile 0 stamps the shader clock at its
-// phase boundaries of every frame into a region behind the exchange images.  Never in the shipped library.
+// phase boundaries of every frame into a region behind the tiles' images.  Never in the shipped library.
 #ifndef NBASR_LX_STAMPS
 #define NBASR_LX_STAMPS 0
 #endif
@@ -69,8 +78,24 @@ constexpr size_t LX_STAMP_BYTES = NBASR_LX_STAMPS ? static_cast<size_t>(32) * LX
 #define LX_STAMP(i) do { } while (0)
 #endif
 
-__device__ __forceinline__ float lx_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
-__device__ __forceinline__ unsigned lx_tag(int t) { return (static_cast<unsigned>((t >> 1) + 1) & 1u) << 30; }
+// sigmoid and tanh on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: 1 ulp each).  Saturation is exact: exp2 -> 0 or +inf, rcp(inf) = 0.
+__device__ __forceinline__ float lx_sigmoid(float v)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+}
+__device__ __forceinline__ float lx_tanh(float v)
+{
+    const float a = fabsf(v);
+    const float e = __builtin_amdgcn_exp2f(a * -2.8853900817779268f);           // exp(-2 |v|) in (0, 1]
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);               // absolute error ~3e-8: fine from 0.35 up
+    const float x2 = v * v;                                                       // below: the odd series through x^11 (next term 1.2e-8 relative at 0.35)
+    float p = __builtin_fmaf(x2, -0.0088632355299021966f, 0.021869488536155203f);
+    p = __builtin_fmaf(x2, p, -0.053968253968253971f);
+    p = __builtin_fmaf(x2, p, 0.13333333333333333f);
+    p = __builtin_fmaf(x2, p, -0.33333333333333331f);
+    const float small = __builtin_fmaf(v * x2, p, v);
+    return a < 0.35f ? small : __builtin_copysignf(big, v);                       // (NaN: a < 0.35 is false, big is NaN)
+}
 
 __device__ __forceinline__ unsigned lx_load_sc1(const unsigned* p)
 {
@@ -93,8 +118,8 @@ __global__ __launch_bounds__(256) void lx_absmax_kernel(const float* __restrict_
     if ((threadIdx.x & 63) == 0) atomicMax(header + 2, __float_as_uint(m));          // non-negative floats order like their bits
 }
 
-// packed[256 B header][slice][wave][kk (2)][mt (4)][part (hi, lo')][lane] x 16 B: the A fragment of v_mfma_f32_16x16x32_f16 for row tile mt of
-// the slice (row i = lane & 15: unit slice*16 + mt*4 + (i >> 2), gate i & 3) and k-step 2*wave + kk (k = kstep*32 + (lane >> 4)*8 + j)
+// packed[256 B header][slice][wave (= row tile)][k-step][part (hi, lo')][lane] x 16 B: the A fragment of v_mfma_f32_16x16x32_f16 for the
+// row tile (row i = lane & 15: unit slice*16 + wave*4 + (i >> 2), gate i & 3) and k-step (k = kstep*32 + (lane >> 4)*8 + j)
 __global__ __launch_bounds__(256) void lx_pack_kernel(const float* __restrict__ w_hh, unsigned char* __restrict__ packed, int hidden, int slices)
 {
     float* const hdr = reinterpret_cast<float*>(packed);
@@ -102,20 +127,19 @@ __global__ __launch_bounds__(256) void lx_pack_kernel(const float* __restrict__ 
     int e = 0;
     if (amax > 0.f) { int ex; (void)frexpf(amax, &ex); e = 14 - ex; }                // amax * 2^e in [2^13, 2^14)
     const float scale = ldexpf(1.0f, e);
-    if (blockIdx.x == 0 && threadIdx.x == 0) { hdr[0] = ldexpf(1.0f, -e); hdr[1] = ldexpf(1.0f, -e - 11); }
+    if (blockIdx.x == 0 && threadIdx.x == 0) hdr[0] = ldexpf(1.0f, -e);
     xuint4* const out = reinterpret_cast<xuint4*>(packed + LX_PACK_HEADER_BYTES);
-    const size_t total = static_cast<size_t>(slices) * LX_WAVES * 2 * LX_MT * 2 * 64;
+    const size_t total = static_cast<size_t>(slices) * LX_WAVES * LX_KSTEPS * 2 * 64;
     for (size_t idx = static_cast<size_t>(blockIdx.x) * blockDim.x + threadIdx.x; idx < total; idx += static_cast<size_t>(gridDim.x) * blockDim.x) {
         size_t r = idx;
         const int lane = r % 64; r /= 64;
         const int part = r % 2; r /= 2;
-        const int mt = r % LX_MT; r /= LX_MT;
-        const int kk = r % 2; r /= 2;
+        const int ks = r % LX_KSTEPS; r /= LX_KSTEPS;
         const int wave = r % LX_WAVES; r /= LX_WAVES;
         const int slice = static_cast<int>(r);
         const int i = lane & 15, kq = lane >> 4;
-        const int unit = slice * LX_UNITS + mt * 4 + (i >> 2), gate = i & 3;
-        const int k0 = (2 * wave + kk) * 32 + kq * 8;
+        const int unit = slice * LX_UNITS + wave * 4 + (i >> 2), gate = i & 3;
+        const int k0 = ks * 32 + kq * 8;
         unsigned short h[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -130,26 +154,153 @@ __global__ __launch_bounds__(256) void lx_pack_kernel(const float* __restrict__ 
     }
 }
 
-// ---- the recurrence ------------------------------------------------------------------------------------------------------------
+// ---- one row tile (4 hidden units x 4 gates) x all of K: the chain both recurrence kernels run, in this order ---------------------------
+// acc0 += hi * hi ; acc1 += hi * lo' + lo' * hi, k-step after k-step.  (Measured on the way, 250 frames x 64 utterances: the fragment
+// reads issued step by step, two registers deep -- what the scheduler makes of the plain loop -- 2 100 cycles per frame for this phase, a
+// wave alone on its SIMD has nobody to hide an LDS round trip behind; all 32 reads first 1 630; this order 1 450.  The chain split into the
+// wave's own quarter before the barrier and the rest behind it: slower, 580 + 1 420.)
+__device__ __forceinline__ void lx_row_tile_product(const xuint4 (&h)[LX_KSTEPS][2][64], const xuint4 (&w)[LX_KSTEPS][2], int lane, xfloat4& acc0, xfloat4& acc1)
+{
+    xuint4 bfrag[LX_KSTEPS][2];
+#pragma unroll
+    for (int ks = 0; ks < LX_KSTEPS; ++ks) { bfrag[ks][0] = h[ks][0][lane]; bfrag[ks][1] = h[ks][1][lane]; }
+#pragma unroll
+    for (int ks = 0; ks < LX_KSTEPS; ++ks) {
+        const xhalf8 hh = __builtin_bit_cast(xhalf8, bfrag[ks][0]), hl = __builtin_bit_cast(xhalf8, bfrag[ks][1]);
+        const xhalf8 wh = __builtin_bit_cast(xhalf8, w[ks][0]), wl = __builtin_bit_cast(xhalf8, w[ks][1]);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, acc1, 0, 0, 0);
+    }
+    // the order the scheduler is to keep: the reads of 6 k-steps ahead, then per k-step its 3 MFMAs and the reads of the step six ahead
+    // (lgkmcnt counts to 15: twelve reads in flight are still told apart) -- the first MFMA starts one LDS round trip after the barrier,
+    // the rest of the reads travel beside the matrix work
+    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+    for (int ks = 0; ks < LX_KSTEPS; ++ks) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        if (ks + 6 < LX_KSTEPS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+}
+
+// gates i, f, g, o of one (hidden unit, utterance): s = w_hh . h_(t-1) (the four accumulator registers), pre = the input projection
+__device__ __forceinline__ float lx_cell_update(const xfloat4& s, const float (&pre)[4], float& c_state)
+{
+    const float p0 = s[0] + pre[0], p1 = s[1] + pre[1], p2 = s[2] + pre[2], p3 = s[3] + pre[3];
+    const float c_new = lx_sigmoid(p1) * c_state + lx_sigmoid(p0) * lx_tanh(p2);
+    c_state = c_new;
+    return lx_sigmoid(p3) * lx_tanh(c_new);
+}
+
+// h as it is consumed: (fp16 hi << 16) | fp16 lo', lo' = (h - hi) * 2^11; a value that cannot be an LSTM output travels as lo' = NaN
+__device__ __forceinline__ unsigned lx_split_h(float h_new)
+{
+    const _Float16 hi = static_cast<_Float16>(h_new);
+    const _Float16 lo = static_cast<_Float16>((h_new - static_cast<float>(hi)) * 2048.0f);
+    const unsigned dw = (static_cast<unsigned>(__builtin_bit_cast(unsigned short, hi)) << 16) | __builtin_bit_cast(unsigned short, lo);
+    return fabsf(h_new) <= 1.0f ? dw : 0x00007e00u;
+}
+
+// the 4 units of a row tile x one utterance as two 8-byte pieces of the image (4 hi halves, 4 lo' halves): lanes 0..15 store
+__device__ __forceinline__ void lx_publish(unsigned dw, int n16, bool q_ok, unsigned char* dst)
+{
+    const unsigned d0 = static_cast<unsigned>(__shfl(static_cast<int>(dw), n16)), d1 = static_cast<unsigned>(__shfl(static_cast<int>(dw), n16 + 16));
+    const unsigned d2 = static_cast<unsigned>(__shfl(static_cast<int>(dw), n16 + 32)), d3 = static_cast<unsigned>(__shfl(static_cast<int>(dw), n16 + 48));
+    if (q_ok) {
+        const xuint2 hq = {__builtin_amdgcn_perm(d1, d0, 0x07060302u), __builtin_amdgcn_perm(d3, d2, 0x07060302u)};
+        const xuint2 lq = {__builtin_amdgcn_perm(d1, d0, 0x05040100u), __builtin_amdgcn_perm(d3, d2, 0x05040100u)};
+        *reinterpret_cast<xuint2*>(dst) = hq;                         // PLAIN stores: the lines stay in this XCD's L2
+        *reinterpret_cast<xuint2*>(dst + 1024) = lq;
+    }
+}
+
+// where wave `wave` of slice `slice` writes its pieces for utterance n16: k-step slice/2, k-octet 2*(slice&1) + (wave>>1), halves 4*(wave&1) .. +3
+__device__ __forceinline__ int lx_publish_offset(int slice, int wave, int n16)
+{
+    return (((slice >> 1) * 2 * 64) + (2 * (slice & 1) + (wave >> 1)) * 16 + n16) * 16 + (wave & 1) * 8;
+}
+
+// ---- one launch per frame, the SAME arithmetic -------------------------------------------------------------------------------------------
+// What a pipelined tail runs beside the next batch's encoder (a resident grid there would fill whole XCDs for the length of the
+// recurrence, and every encoder kernel has workgroups dealt to those XCDs), and what a plan demoted by a failed status word falls back
+// to: frame t as its own launch, workgroup = (slice of 16 hidden units, tile of 16 utterances) as in lstm_xcd_kernel, the weights
+// fetched from L2 per launch, h_(t-1) read from the image the previous launch wrote.  Same product chain, same gate arithmetic, same
+// image: bit-identical h to the resident form.  Against the fp32 per-frame kernel (lstm.hip): a fifth of the matrix time and half the
+// workgroups per frame (128 instead of 252 at 64 utterances).
+// WPB = row tiles (waves) per workgroup, 1, 2 or 4: the decomposition does not touch the arithmetic (a row tile is one wave's chain
+// whatever the workgroup) -- small batches take one-wave workgroups (125 per tile: each fetches 32 KiB of weights + the 32 KiB image, the
+// shortest frame), large ones four-wave workgroups (32 per tile: the image is fetched once per four row tiles, the least work beside
+// the encoder).
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void lstm_step16_kernel(
+    const float* __restrict__ gates_in, const unsigned char* __restrict__ wp, float* __restrict__ cell, float* __restrict__ h_out,
+    unsigned char* tiles, int batch, int frames, int hidden, int t, int prio)
+{
+    __shared__ xuint4 htile[LX_KSTEPS][2][64];
+    if (prio) __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n16 = lane & 15, kq = lane >> 4;
+    const int row_tile = blockIdx.x * WPB + wib;           // of the layer: 4 hidden units x 4 gates
+    const int slice = row_tile >> 2, wave = row_tile & 3;  // as lstm_xcd_kernel names them (weights, image)
+    const int tile = blockIdx.y, b0 = tile * 16;
+    unsigned char* const tile_ws = tiles + static_cast<size_t>(tile) * LX_TILE_BYTES;
+    const int eu = row_tile * 4 + kq, eb = b0 + n16;
+    const bool e_ok = eu < hidden && eb < batch;
+    const size_t gate_off = static_cast<size_t>(min(eb, batch - 1)) * (4 * hidden) + min(eu, hidden - 1);
+    float pre[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) pre[g] = gates_in[static_cast<size_t>(t) * batch * (4 * hidden) + gate_off + g * hidden];
+    float c_state = (t > 0 && e_ok) ? cell[static_cast<size_t>(eb) * hidden + eu] : 0.f;
+    xfloat4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const float inv = reinterpret_cast<const float*>(wp)[0];
+    if (t > 0) {
+        const unsigned char* img = tile_ws + ((t - 1) & 1) * LX_IMAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 32 / WPB; ++j) {
+            const int chunk = wib * (32 / WPB) + j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + chunk * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(&htile[0][0][0]) + chunk * 1024), 16, 0, 0);
+        }
+        xuint4 wfrag[LX_KSTEPS][2];
+        // (a row tile beyond the layer -- the grid is rounded up to whole workgroups -- reads the zero rows the packer wrote up to the slice's end,
+        // or, past the last slice, the last slice's: its sums are never stored)
+        const int wslice = min(slice, (hidden + LX_UNITS - 1) / LX_UNITS - 1);
+        const xuint4* src = reinterpret_cast<const xuint4*>(wp + LX_PACK_HEADER_BYTES) + (static_cast<size_t>(wslice) * LX_WAVES + wave) * (LX_KSTEPS * 2 * 64) + lane;
+#pragma unroll
+        for (int ks = 0; ks < LX_KSTEPS; ++ks) { wfrag[ks][0] = src[(ks * 2) * 64]; wfrag[ks][1] = src[(ks * 2 + 1) * 64]; }
+        __syncthreads();                                   // (drains this wave's transfers, then the whole image is in LDS)
+        lx_row_tile_product(htile, wfrag, lane, acc0, acc1);
+    }
+    const xfloat4 s = (acc0 + acc1 * 0.00048828125f) * inv;
+    const float h_new = lx_cell_update(s, pre, c_state);
+    const bool q_ok = kq == 0 && row_tile * 4 < hidden && eb < batch;
+    lx_publish(lx_split_h(h_new), n16, q_ok, tile_ws + (t & 1) * LX_IMAGE_BYTES + lx_publish_offset(slice, wave, n16));
+    if (e_ok) {
+        h_out[(static_cast<size_t>(eb) * frames + t) * hidden + eu] = h_new;
+        cell[static_cast<size_t>(eb) * hidden + eu] = c_state;
+    }
+}
+
+// ---- the recurrence in ONE launch ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64 * LX_WAVES) void lstm_xcd_kernel(
     const float* __restrict__ gates_in,     // (frames, batch, 4*hidden)
     const unsigned char* __restrict__ wp,   // packed w_hh (lx_pack_kernel)
     float* __restrict__ cell, float* __restrict__ h_out, unsigned* ws,
     int batch, int frames, int hidden, int slices, int n_tiles, int total_wgs, int flags)
 {
-    __shared__ xfloat4 red[2][LX_WAVES][LX_MT][64];       // [step parity][wave][row tile][lane]: a lane's 4 accumulator registers (= gates)
+    __shared__ xuint4 htile[2][LX_KSTEPS][2][64];          // [step parity][k-step][hi | lo'][lane]: h_(t-1) of the tile as B fragments (2 x 32 KiB)
     __shared__ unsigned s_role[4];                         // [0] xcd, [1] rank, [2] claim of the current round, [3] stop
 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
-    unsigned char* const images = reinterpret_cast<unsigned char*>(ws + LX_HEADER_WORDS);
+    unsigned char* const tiles = reinterpret_cast<unsigned char*>(ws + LX_HEADER_WORDS);
 
     // ---- who am I: XCD from the hardware register, slice from the XCD's arrival ticket ----
     if (threadIdx.x == 0) {
         const unsigned xcd = __builtin_amdgcn_s_getreg(20 | (31 << 11)) & 0xfu;        // HW_REG_XCC_ID
         unsigned rank = atomicAdd(ws + LX_W_ARRIVALS + xcd * 16, 1u);
-        // NBASR_LSTM_SEQ_INJECT_FAULT (tests): the second arrival of every XCD takes its ticket and leaves -- what compute units taken
-        // away by another process look like to its peers: the XCD never completes, claims nothing, and the last leaver finds tiles missing
+        // NBASR_LSTM_SEQ_INJECT_FAULT (tests): the second arrival of every XCD takes its ticket and leaves -- what a compute unit taken
+        // away by another process looks like to its peers: they wait for its flags, time out, raise the status word
         if ((flags & NBASR_LSTM_SEQ_INJECT_FAULT) && rank == 1) rank = 0x7fffffffu;
         s_role[0] = xcd; s_role[1] = rank; s_role[3] = 0;
     }
@@ -159,7 +310,7 @@ __global__ __launch_bounds__(64 * LX_WAVES) void lstm_xcd_kernel(
     const bool member = rank < static_cast<unsigned>(slices);
     const int slice = static_cast<int>(rank);
 
-    xuint4 wfrag[2][LX_MT][2];                             // [kk][row tile][hi, lo']: 64 registers, loaded with the first claimed tile
+    xuint4 wfrag[LX_KSTEPS][2];                            // [k-step][hi, lo']: 128 registers, loaded with the first claimed tile
     bool have_w = false;
     float inv = 1.f;
 
@@ -191,7 +342,7 @@ __global__ __launch_bounds__(64 * LX_WAVES) void lstm_xcd_kernel(
             }
             s_role[2] = claim;
         }
-        __syncthreads();                                   // (also: the partials of the previous tile's last step have been read)
+        __syncthreads();                                   // (also: every wave has left the previous tile's last step)
         const unsigned claim = s_role[2];
         if (claim == LX_DONE) break;
         const int tile = static_cast<int>(claim) - 1;
@@ -199,47 +350,42 @@ __global__ __launch_bounds__(64 * LX_WAVES) void lstm_xcd_kernel(
 
         if (!have_w) {
             have_w = true;
-            const float* hdr = reinterpret_cast<const float*>(wp);
-            inv = hdr[0];
-            const xuint4* src = reinterpret_cast<const xuint4*>(wp + LX_PACK_HEADER_BYTES) + (static_cast<size_t>(slice) * LX_WAVES + wave) * (2 * LX_MT * 2 * 64) + lane;
+            inv = reinterpret_cast<const float*>(wp)[0];
+            const xuint4* src = reinterpret_cast<const xuint4*>(wp + LX_PACK_HEADER_BYTES) + (static_cast<size_t>(slice) * LX_WAVES + wave) * (LX_KSTEPS * 2 * 64) + lane;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int ks = 0; ks < LX_KSTEPS; ++ks) { wfrag[ks][0] = src[(ks * 2) * 64]; wfrag[ks][1] = src[(ks * 2 + 1) * 64]; }
+            // RESIDENT, in the accumulator half of the register file (an MFMA takes its A operand from there as well): without this the
+            // compiler, short of architectural VGPRs (256) for 128 weight + 128 fragment registers, re-loads the `const __restrict__`
+            // weights from memory in EVERY frame (32 KiB per wave and frame through L2: seen in the ISA, 2 100 cycles per frame)
 #pragma unroll
-                for (int mt = 0; mt < LX_MT; ++mt)
-#pragma unroll
-                    for (int p = 0; p < 2; ++p) wfrag[kk][mt][p] = src[((kk * LX_MT + mt) * 2 + p) * 64];
+            for (int ks = 0; ks < LX_KSTEPS; ++ks) { asm volatile("" : "+a"(wfrag[ks][0])); asm volatile("" : "+a"(wfrag[ks][1])); }
         }
 
-        unsigned char* const image = images + static_cast<size_t>(tile) * 2 * LX_IMAGE_BYTES;
-        // the granules this lane consumes: utterance n16 of the tile, k-steps 2*wave + kk, units kstep*32 + kq*8 + 4*g .. +3
-        bool live[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int g = 0; g < 2; ++g) live[kk][g] = (b0 + n16) < batch && ((2 * wave + kk) * 32 + kq * 8 + 4 * g) < hidden;
+        unsigned char* const tile_ws = tiles + static_cast<size_t>(tile) * LX_TILE_BYTES;
+        unsigned* const tflags = reinterpret_cast<unsigned*>(tile_ws + 2 * LX_IMAGE_BYTES);
+        // the flags this lane watches: words lane and lane + 64 of the tile's 128 (word = slice * 4 + wave); only those of slices that exist
+        const bool watch0 = (lane >> 2) < slices, watch1 = ((lane + 64) >> 2) < slices;
 
-        // epilogue role of waves 0..3: wave = row tile, lane = (unit kq of the tile, utterance n16); 4 accumulator registers = 4 gates
-        const int eu = slice * LX_UNITS + (wave & 3) * 4 + kq, eb = b0 + n16;
-        const bool e_ok = wave < LX_MT && eu < hidden && eb < batch;
+        // this lane's (unit, utterance): row tile = wave, unit kq of the tile, utterance n16; its 4 accumulator registers = the 4 gates
+        const int eu = slice * LX_UNITS + wave * 4 + kq, eb = b0 + n16;
+        const bool e_ok = eu < hidden && eb < batch;
         const size_t gate_off = static_cast<size_t>(min(eb, batch - 1)) * (4 * hidden) + min(eu, hidden - 1);
-        const bool q_ok = wave < LX_MT && kq == 0 && (slice * LX_UNITS + wave * 4) < hidden && eb < batch;     // lanes 0..15 publish the tile's 4 units
-        // where this wave's granule goes: k-step slice/2, k-octet 2*(slice&1) + (wave>>1), granule wave&1
-        const int pub_off = ((((slice >> 1) * 2 + (wave & 1)) * 4 + 2 * (slice & 1) + ((wave & 3) >> 1)) * 16 + n16) * 16;
+        const bool q_ok = kq == 0 && (slice * LX_UNITS + wave * 4) < hidden && eb < batch;     // lanes 0..15 publish the tile's 4 units of one utterance
+        // where this wave's 8-byte pieces go: k-step slice/2, k-octet 2*(slice&1) + (wave>>1), halves 4*(wave&1) .. +3 of the fragment
+        const int pub_off = lx_publish_offset(slice, wave, n16);
         float c_state = 0.f;
 
         // gate pre-activations two frames ahead (HBM / last-level cache latency is longer than a step)
-        float pre_a[4] = {0.f, 0.f, 0.f, 0.f}, pre_b[4] = {0.f, 0.f, 0.f, 0.f};
-        if (wave < LX_MT) {
+        float pre_a[4], pre_b[4];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                pre_a[g] = gates_in[gate_off + g * hidden];
-                if (frames > 1) pre_b[g] = gates_in[static_cast<size_t>(batch) * (4 * hidden) + gate_off + g * hidden];
-            }
+        for (int g = 0; g < 4; ++g) {
+            pre_a[g] = gates_in[gate_off + g * hidden];
+            pre_b[g] = frames > 1 ? gates_in[static_cast<size_t>(batch) * (4 * hidden) + gate_off + g * hidden] : 0.f;
         }
 
 #if NBASR_LX_STAMPS
         const bool stamping = tile == 0 && wave == 0 && lane == 0;
-        unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(images + static_cast<size_t>(n_tiles) * 2 * LX_IMAGE_BYTES) +
+        unsigned long long* const stamp_base = reinterpret_cast<unsigned long long*>(tiles + static_cast<size_t>(n_tiles) * LX_TILE_BYTES) +
                                                static_cast<size_t>(slice) * LX_STAMP_FRAMES * LX_STAMP_POINTS;
         unsigned long long st[LX_STAMP_POINTS] = {};
 #endif
@@ -247,115 +393,71 @@ __global__ __launch_bounds__(64 * LX_WAVES) void lstm_xcd_kernel(
         bool failed = false;
         for (; t < frames; ++t) {
             LX_STAMP(0);
-            float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
-            if (wave < LX_MT && t + 2 < frames) {
-                const float* gin = gates_in + static_cast<size_t>(t + 2) * batch * (4 * hidden) + gate_off;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) pre_c[g] = gin[g * hidden];
-            }
-            xfloat4 acc0[LX_MT], acc1[LX_MT];
-#pragma unroll
-            for (int mt = 0; mt < LX_MT; ++mt) { acc0[mt] = xfloat4{0.f, 0.f, 0.f, 0.f}; acc1[mt] = xfloat4{0.f, 0.f, 0.f, 0.f}; }
+            xfloat4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            const int par = (t - 1) & 1;
             if (t > 0) {
-                const unsigned char* img = image + ((t - 1) & 1) * LX_IMAGE_BYTES;
-                const unsigned want = lx_tag(t - 1);
-                xuint4 raw[2][2];
+                // 1. every publishing wave of the tile has set its flag to t (= it has stored h_(t-1) and L2 has the bytes)
                 const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
                 bool ok = false;
                 for (;;) {
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const unsigned char* gp = img + ((((2 * wave + kk) * 2 + g) * 64) + lane) * 16;
-                            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(raw[kk][g]) : "v"(gp) : "memory");   // sc1: past this CU's L1, served by the XCD's L2
-                        }
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]) :: "memory");
-                    bool mine = true;
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            unsigned tags = 0x40000000u;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) tags &= raw[kk][g][e] ^ ~want;          // bit 30 stays set while every dword's tag == want
-                            mine = mine && (!live[kk][g] || (tags & 0x40000000u) != 0);
-                        }
-                    ok = __all(mine);
+                    unsigned f0, f1;
+                    asm volatile("global_load_dword %0, %2, off sc1\n\tglobal_load_dword %1, %2, off offset:256 sc1\n\ts_waitcnt vmcnt(0)"
+                                 : "=&v"(f0), "=&v"(f1) : "v"(tflags + lane) : "memory");
+                    ok = __all((!watch0 || f0 >= static_cast<unsigned>(t)) && (!watch1 || f1 >= static_cast<unsigned>(t)));
                     if (ok || __builtin_amdgcn_s_memrealtime() - t_start > LX_TIMEOUT_TICKS) break;
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (!ok && lane == 0) { s_role[3] = 1; __hip_atomic_store(ws + LX_W_STATUS, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
                 LX_STAMP(1);
+                // 2. this wave's quarter of the image (k-steps 4*wave .. +3, both terms: 8 KiB) straight into LDS; sc1 = past this CU's L1
+                const unsigned char* img = tile_ws + par * LX_IMAGE_BYTES;
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    // 8 dwords (hi << 16 | lo') of 8 units -> the two B fragments: 8 hi halves, 8 lo' halves (element j = unit j of the octet)
-                    unsigned d[8];
-#pragma unroll
-                    for (int g = 0; g < 2; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) d[g * 4 + e] = live[kk][g] ? raw[kk][g][e] : 0u;
-                    xuint4 bh, bl;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        bh[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x07060302u) & 0xbfffbfffu;      // (tag bits off)
-                        bl[j] = __builtin_amdgcn_perm(d[2 * j + 1], d[2 * j], 0x05040100u);
-                    }
-                    const xhalf8 hh = __builtin_bit_cast(xhalf8, bh), hl = __builtin_bit_cast(xhalf8, bl);
-#pragma unroll
-                    for (int mt = 0; mt < LX_MT; ++mt) {
-                        const xhalf8 wh = __builtin_bit_cast(xhalf8, wfrag[kk][mt][0]), wl = __builtin_bit_cast(xhalf8, wfrag[kk][mt][1]);
-                        acc0[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hh, acc0[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, hl, acc1[mt], 0, 0, 0);
-                        acc1[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, hh, acc1[mt], 0, 0, 0);
-                    }
+                for (int j = 0; j < 8; ++j) {
+                    const int chunk = wave * 8 + j;        // 1 KiB = one (k-step, term) plane of 64 lanes x 16 B
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + chunk * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(&htile[par][0][0][0]) + chunk * 1024),
+                                                     16, 0, 16);
                 }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                LX_STAMP(2);
+                __syncthreads();                           // ONE barrier per step: all four quarters are in LDS
+                LX_STAMP(3);
+                if (s_role[3]) { failed = true; break; }   // (workgroup-uniform: read behind the barrier)
             }
-            const int par = t & 1;
-            LX_STAMP(2);
+            // the gate pre-activations of frame t + 2, requested HERE: every wait above is `vmcnt(0)` (the counter is in issue order, so
+            // a younger flag load or DMA cannot be waited for without them), and the matrix work below covers their trip
+            float pre_c[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t + 2 < frames) {
+                const float* gin = gates_in + static_cast<size_t>(t + 2) * batch * (4 * hidden) + gate_off;
 #pragma unroll
-            for (int mt = 0; mt < LX_MT; ++mt) red[par][wave][mt][lane] = acc0[mt] + acc1[mt] * 0.00048828125f;     // hi*hi + 2^-11 (hi*lo' + lo'*hi)
-            LX_STAMP(3);
-            // ONE barrier per step; the partials are double-buffered by step parity (a wave can only write those of step t + 2 after the
-            // barrier of step t + 1, which the epilogue waves reach after they have read those of step t)
-            __syncthreads();
+                for (int g = 0; g < 4; ++g) pre_c[g] = gin[g * hidden];
+            }
+            if (t > 0) lx_row_tile_product(htile[par], wfrag, lane, acc0, acc1);       // 3. this wave's row tile x all of K
+            // 4. gates, cell, h -- in the registers the sums arrived in
+            const xfloat4 s = (acc0 + acc1 * 0.00048828125f) * inv;                  // hi*hi + 2^-11 (hi*lo' + lo'*hi), then the weights' 2^-e
+#if NBASR_LX_STAMPS
+            { xfloat4 ss = s; asm volatile("" : "+v"(ss)); }
+#endif
             LX_STAMP(4);
-            if (s_role[3]) { failed = true; break; }       // (workgroup-uniform: read behind the barrier)
-            if (wave < LX_MT) {
-                xfloat4 s = red[par][0][wave][lane];
+            const float h_new = lx_cell_update(s, pre_a, c_state);
+#if NBASR_LX_STAMPS
+            { float hh = h_new; asm volatile("" : "+v"(hh)); }
+#endif
+            LX_STAMP(5);
+            // 5. h as it is consumed, 4 units x one utterance per 8-byte piece
+            lx_publish(lx_split_h(h_new), n16, q_ok, tile_ws + (t & 1) * LX_IMAGE_BYTES + pub_off);
+            // the flag follows the bytes: drain this wave's stores (L2 has them), then one lane sets the wave's word
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) asm volatile("global_store_dword %0, %1, off" :: "v"(tflags + slice * LX_WAVES + wave), "v"(static_cast<unsigned>(t + 1)) : "memory");
+            LX_STAMP(6);
+            if (e_ok) h_out[(static_cast<size_t>(eb) * frames + t) * hidden + eu] = h_new;
 #pragma unroll
-                for (int w = 1; w < LX_WAVES; ++w) s += red[par][w][wave][lane];
+            for (int g = 0; g < 4; ++g) { pre_a[g] = pre_b[g]; pre_b[g] = pre_c[g]; }
+            LX_STAMP(7);
 #if NBASR_LX_STAMPS
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s) :: "memory");
+            if (stamping && t < LX_STAMP_FRAMES)
+                for (int i = 0; i < LX_STAMP_POINTS; ++i) stamp_base[t * LX_STAMP_POINTS + i] = st[i];
 #endif
-                LX_STAMP(5);
-                const float p0 = __builtin_fmaf(s[0], inv, pre_a[0]), p1 = __builtin_fmaf(s[1], inv, pre_a[1]);
-                const float p2 = __builtin_fmaf(s[2], inv, pre_a[2]), p3 = __builtin_fmaf(s[3], inv, pre_a[3]);
-                const float c_new = lx_sigmoid(p1) * c_state + lx_sigmoid(p0) * tanhf(p2);
-                const float h_new = lx_sigmoid(p3) * tanhf(c_new);
-                c_state = c_new;
-#if NBASR_LX_STAMPS
-                { float hh = h_new; asm volatile("" : "+v"(hh)); }
-#endif
-                LX_STAMP(6);
-                // h as it is consumed: fp16 hi, fp16 lo' = (h - hi) * 2^11; a value that cannot be an LSTM output travels as lo' = NaN
-                const _Float16 hi = static_cast<_Float16>(h_new);
-                const _Float16 lo = static_cast<_Float16>((h_new - static_cast<float>(hi)) * 2048.0f);
-                unsigned dw = (static_cast<unsigned>(__builtin_bit_cast(unsigned short, hi)) << 16) | __builtin_bit_cast(unsigned short, lo);
-                if (!(fabsf(h_new) <= 1.0f)) dw = 0x00007e00u;
-                dw |= lx_tag(t);
-                const xuint4 gran = {static_cast<unsigned>(__shfl(static_cast<int>(dw), n16)), static_cast<unsigned>(__shfl(static_cast<int>(dw), n16 + 16)),
-                                     static_cast<unsigned>(__shfl(static_cast<int>(dw), n16 + 32)), static_cast<unsigned>(__shfl(static_cast<int>(dw), n16 + 48))};
-                if (q_ok) *reinterpret_cast<xuint4*>(image + (t & 1) * LX_IMAGE_BYTES + pub_off) = gran;      // PLAIN store: the line stays in this XCD's L2
-                if (e_ok) h_out[(static_cast<size_t>(eb) * frames + t) * hidden + eu] = h_new;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) { pre_a[g] = pre_b[g]; pre_b[g] = pre_c[g]; }
-                LX_STAMP(7);
-#if NBASR_LX_STAMPS
-                if (stamping && t < LX_STAMP_FRAMES)
-                    for (int i = 0; i < LX_STAMP_POINTS; ++i) stamp_base[t * LX_STAMP_POINTS + i] = st[i];
-#endif
-            }
         }
         if (failed) {                                      // timed out: make the failure visible in the output too
             if (e_ok) {
@@ -388,7 +490,7 @@ static inline int lx_slices(int hidden) { return (hidden + LX_UNITS - 1) / LX_UN
 extern "C" size_t nbasr_lstm_packed_whh16_bytes(int hidden)
 {
     if (hidden <= 0 || hidden > LX_KSTEPS * 32) return 0;
-    return LX_PACK_HEADER_BYTES + static_cast<size_t>(lx_slices(hidden)) * LX_WAVES * 2 * LX_MT * 2 * 64 * 16;
+    return LX_PACK_HEADER_BYTES + static_cast<size_t>(lx_slices(hidden)) * LX_WAVES * LX_KSTEPS * 2 * 64 * 16;
 }
 
 extern "C" int nbasr_lstm_pack_whh16(const float* w_hh, void* packed, int hidden, nbasr_stream_t stream)
@@ -423,12 +525,44 @@ static int lx_grid(int hidden)
     return cached[device] >= lx_slices(hidden) ? cached[device] : 0;
 }
 
+extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void* packed_whh16, float* cell_ws, float* h_out, void* xcd_ws,
+                                              int batch, int frames, int hidden, nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch >= 0 && frames >= 0 && hidden > 0, NBASR_EINVAL, "nbasr_lstm_recurrence_frames16: bad sizes");
+    NBASR_REQUIRE(hidden % 4 == 0, NBASR_EALIGN, "nbasr_lstm_recurrence_frames16: hidden=%d must be a multiple of 4", hidden);
+    if (batch == 0 || frames == 0) return NBASR_OK;
+    NBASR_REQUIRE(gates_ws && packed_whh16 && cell_ws && h_out && xcd_ws, NBASR_ENULL, "nbasr_lstm_recurrence_frames16: NULL pointer");
+    NBASR_REQUIRE(aligned16(packed_whh16) && aligned16(xcd_ws), NBASR_EALIGN, "nbasr_lstm_recurrence_frames16: packed_whh16, xcd_ws must be 16-byte aligned");
+    NBASR_REQUIRE(nbasr_lstm_xcd_workspace_bytes(batch, hidden) != 0, NBASR_EINVAL, "nbasr_lstm_recurrence_frames16: batch=%d hidden=%d does not fit the form "
+                  "(hidden <= %d, batch <= %d); use nbasr_lstm_recurrence_packed", batch, hidden, LX_KSTEPS * 32, LX_MAX_TILES * 16);
+    // the images are zeroed by every call (a node of the cached graph): the rows of k beyond `hidden` and the columns beyond `batch` are
+    // never written, and a NaN pattern left there by an earlier owner of the memory would turn 0 x NaN into NaN sums
+    const size_t tiles_n = (batch + 15) / 16;
+    struct Ctx { hipStream_t s; const float* gates; const unsigned char* w; float* cell; float* h; unsigned char* tiles; size_t tiles_bytes; int batch, frames, hidden, prio, wpb; };
+    Ctx ctx{as_stream(stream), gates_ws, static_cast<const unsigned char*>(packed_whh16), cell_ws, h_out,
+            static_cast<unsigned char*>(xcd_ws) + LX_HEADER_WORDS * sizeof(unsigned), tiles_n * LX_TILE_BYTES, batch, frames, hidden, batch <= 32,
+            batch <= 32 ? 1 : 4};
+    if (const char* force = getenv("NBASR_LX_WPB")) ctx.wpb = (force[0] == '1') ? 1 : 4;          // (A/B hook; both forms give the same bits)
+    const ChainKey key{{gates_ws, packed_whh16, cell_ws, h_out, xcd_ws}, {batch, frames, hidden, 16, ctx.wpb}};
+    return replay_chain(ctx.s, key, "nbasr_lstm_recurrence_frames16", [](void* p) {
+        const Ctx& c = *static_cast<const Ctx*>(p);
+        (void)hipMemsetAsync(c.tiles, 0, c.tiles_bytes, c.s);
+        const int row_tiles = (c.hidden + 3) / 4;
+        const dim3 grid((row_tiles + c.wpb - 1) / c.wpb, (c.batch + 15) / 16);
+        for (int t = 0; t < c.frames; ++t) {
+            if (c.wpb == 1) hipLaunchKernelGGL(lstm_step16_kernel<1>, grid, dim3(64), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
+            else hipLaunchKernelGGL(lstm_step16_kernel<4>, grid, dim3(256), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
+        }
+    }, &ctx);
+}
+
 extern "C" size_t nbasr_lstm_xcd_workspace_bytes(int batch, int hidden)
 {
     if (batch <= 0 || hidden <= 0 || hidden % 4 || hidden > LX_KSTEPS * 32) return 0;
     const size_t tiles = (batch + 15) / 16;
     if (tiles > LX_MAX_TILES) return 0;
-    return LX_HEADER_WORDS * sizeof(unsigned) + tiles * 2 * LX_IMAGE_BYTES + LX_STAMP_BYTES;
+    return LX_HEADER_WORDS * sizeof(unsigned) + tiles * LX_TILE_BYTES + LX_STAMP_BYTES;
 }
 
 extern "C" int nbasr_lstm_recurrence_xcd(const float* gates_ws, const void* packed_whh16, float* cell_ws, float* h_out, void* xcd_ws,

@@ -244,13 +244,17 @@ class ForwardPlan:
             raise ValueError(f"NBASR_CELL_FUSION={_cf!r}: expected '1', '0' or 'valu'")
         self.cell_fusion = _cf != '0'
         self.cell_mfma = _cf == '1'          # bf16 storage: the matrix-core cell kernel ('valu': the vector-ALU one, as for fp32)
-        # the LSTM recurrence: 'auto' / 'xcd' = ONE resident launch, a tile of 16 utterances per XCD, fp16-pair matrix cores (round 6;
-        # nbasr.h: nbasr_lstm_recurrence_xcd) in the plain forward AND in the pipelined tail; '0' = one launch per frame everywhere
-        # (fp32 MFMA; what a failed status word demotes a plan to); '1' = the round-4 chip-wide resident grid (nbasr_lstm_recurrence_seq,
-        # fp32 MFMA, bit-identical to '0') wherever it applies
+        # the LSTM recurrence (round 6: fp16-pair matrix cores, a tile of 16 utterances per workgroup row): 'auto' = ONE resident launch whose
+        # exchange stays inside an XCD (nbasr_lstm_recurrence_xcd) in the plain forward and in a captured graph, the same arithmetic as one
+        # launch per frame (nbasr_lstm_recurrence_frames16) in a pipelined tail on the side stream; 'xcd' / 'frames' = that form everywhere
+        # ('frames' is also what a failed status word demotes a plan to); the fp32-MFMA kernels of rounds 1-5, another summation order:
+        # '0' = one launch per frame, '1' = the chip-wide resident grid (bit-identical to '0') wherever it applies
         self.lstm_seq_mode = os.environ.get('NBASR_LSTM_SEQ', 'auto')
-        if self.lstm_seq_mode not in ('auto', 'xcd', '0', '1'):
-            raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', 'xcd', '0' or '1'")
+        if self.lstm_seq_mode not in ('auto', 'xcd', 'frames', '0', '1'):
+            raise ValueError(f"NBASR_LSTM_SEQ={self.lstm_seq_mode!r}: expected 'auto', 'xcd', 'frames', '0' or '1'")
+        self.tail_mode = os.environ.get('NBASR_TAIL', 'auto')
+        if self.tail_mode not in ('auto', 'side', 'main'):
+            raise ValueError(f"NBASR_TAIL={self.tail_mode!r}: expected 'auto', 'side' or 'main'")
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
         self._seq_outcome = {}       # ring slot -> whether that launch failed, once its word has been read (check_seq_slot)
@@ -304,14 +308,21 @@ class ForwardPlan:
         if not capturing and torch.cuda.is_current_stream_capturing():       # a caller's own torch.cuda.graph(...) around model(x)
             capturing = True
         mode = self.lstm_seq_mode
-        if mode in ('auto', 'xcd'):
+        # 'auto': the resident launch everywhere except in a tail on the SIDE stream -- a resident grid there fills whole XCDs (32 compute
+        # units each, for the length of the recurrence) while the hardware deals every workgroup of the next batch's encoder kernels to a
+        # fixed XCD: the encoder stalls on the occupied ones (measured, round 6: 9 620 against 9 995 utterances/s at 64, 4 136 against
+        # 5 398 at 8).  There, and in a plan demoted by a failed status word ('frames'), the SAME arithmetic runs as one launch per frame
+        # (nbasr_lstm_recurrence_frames16): every route of the default configuration gives the same bits
+        if mode in ('auto', 'xcd', 'frames'):
             nbytes = hip.lstm_xcd_workspace_bytes(self.batch, hidden)
             if nbytes:
                 ws = self._buf('lstm_xcd', nbytes, torch.uint8)
-                out = hip.lstm_recurrence_xcd(gates, self._packed_whh16(w_hh), self.cell_ws, self.h_out, ws, self._seq_flags)
-                if not capturing:              # (a captured graph holds the launch, not the host-side read-back of its status word)
-                    self._host(lambda: self._seq_status_readback(ws))
-                return out
+                if mode == 'xcd' or (mode == 'auto' and not pipe):
+                    out = hip.lstm_recurrence_xcd(gates, self._packed_whh16(w_hh), self.cell_ws, self.h_out, ws, self._seq_flags)
+                    if not capturing:          # (a captured graph holds the launch, not the host-side read-back of its status word)
+                        self._host(lambda: self._seq_status_readback(ws))
+                    return out
+                return hip.lstm_recurrence_frames16(gates, self._packed_whh16(w_hh), self.cell_ws, self.h_out, ws)
         packed_hh = self._packed_whh(w_hh)
         nbytes = hip.lstm_seq_workspace_bytes(self.batch, hidden, self.device) if (mode == '1' and not capturing) else 0
         if nbytes:
@@ -365,6 +376,11 @@ class ForwardPlan:
         self._seq_outcome[slot] = failed
         self._seq_failed |= failed
 
+    def _demote(self):
+        """After a resident recurrence reported a timeout: one launch per frame from now on, in the SAME arithmetic as the form that failed."""
+        self.lstm_seq_mode = '0' if self.lstm_seq_mode == '1' else 'frames'
+        self._tapes.clear()
+
     def check_seq(self, wait=False):
         """Raise if a one-launch recurrence enqueued through this plan timed out (that forward's logits hold NaN rows); the
         one-launch form is switched off for this plan then, so the caller's retry runs the per-frame launches.  ``wait``: block until
@@ -382,11 +398,10 @@ class ForwardPlan:
                 self._seq_note(slot)
             failed, self._seq_failed = self._seq_failed, False
         if failed:
-            self.lstm_seq_mode = '0'
-            self._tapes.clear()
+            self._demote()
             raise hip.HipError('the one-launch LSTM recurrence of an EARLIER forward timed out waiting for its peer workgroups (the grid was '
                                'not co-resident: compute units taken by another process or stream); that forward\'s logits are invalid. '
-                               'The plan now uses one launch per frame (as NBASR_LSTM_SEQ=0): run the forward again')
+                               'The plan now uses one launch per frame (same arithmetic): run the forward again')
 
     def check_seq_slot(self, ev, slot):
         """Wait for ONE one-launch recurrence (the status copy behind it) and raise if it timed out: what ``PendingLogits.result()``
@@ -402,8 +417,7 @@ class ForwardPlan:
                 if failed:
                     self._seq_failed = False                  # reported here, by the forward it belongs to
         if failed:
-            self.lstm_seq_mode = '0'
-            self._tapes.clear()
+            self._demote()
             raise hip.HipError('the one-launch LSTM recurrence of THIS forward timed out waiting for its peer workgroups (the grid was not '
                                'co-resident: compute units taken by another process or stream); its logits are invalid. The plan now '
                                'uses one launch per frame (as NBASR_LSTM_SEQ=0): run the forward again')
@@ -538,6 +552,17 @@ class ForwardPlan:
         """[group][ci][tap][co] copy of a grouped conv's weights (what the fused cell's scalar loads read), rebuilt whenever the parameter changes."""
         w = op.conv.weight
         return self._cached(w, 'gc_wperm', lambda: hip.pack_grouped_weights(self._f32(w).contiguous(), op.groups))
+
+    def _tail_on_side_stream(self, batch):
+        """Where a pipelined forward (``forward_async``) runs its LSTM + head.  'side': on the plan's second stream, one launch per frame,
+        beside the next batch's encoder (rounds 2-5).  'main': behind the encoder on the same stream, the recurrence as the resident
+        XCD-local launch -- no overlap, but a recurrence of ~0.45 ms instead of 250 launches that take ~0.6 ms from the encoder they hide
+        behind.  NBASR_TAIL=auto picks by batch size (measured table in DESIGN 6)."""
+        if self.tail_mode == 'auto':
+            return batch < self._TAIL_MAIN_FROM or self.lstm_seq_mode in ('0', '1')
+        return self.tail_mode == 'side'
+
+    _TAIL_MAIN_FROM = 1 << 30            # utterances per forward from which 'auto' keeps the tail on the main stream (set from measurements)
 
     def _packed_whh16(self, w):
         """w_hh as the resident operand image of the XCD-local recurrence (two fp16 terms per weight), rebuilt when the parameter changes."""
@@ -782,7 +807,7 @@ class ForwardPlan:
             found = [(m._parameters, n) for m in model.modules() for n, p in m._parameters.items() if p is not None]
             slots = self._param_slots = (weakref.ref(model), found, epoch)
         params = tuple([(d[n].data_ptr(), d[n]._version) for d, n in slots[1]])
-        pipe = bool(pipelined) and model.use_rnn
+        pipe = bool(pipelined) and model.use_rnn and self._tail_on_side_stream(x.shape[0])
         return (x.dtype, tuple(x.shape), x.data_ptr() % 16 == 0, bool(pipelined), (self._turn ^ 1) if pipe else -1,
                 torch.cuda.current_stream(self.device).cuda_stream, tuple(os.environ.get(k) for k in self._TAPE_ENV),
                 epoch, tuple(map(id, model.model)), params, self._structure_fingerprint(model))
@@ -858,7 +883,8 @@ class ForwardPlan:
         if self._mutations == before:
             if len(self._tapes) >= 16:
                 self._tapes.clear()
-            self._tapes[key] = LaunchTape(entries, x.data_ptr(), bool(pipelined), bool(pipelined) and model.use_rnn)
+            self._tapes[key] = LaunchTape(entries, x.data_ptr(), bool(pipelined),
+                                          bool(pipelined) and model.use_rnn and self._tail_on_side_stream(x.shape[0]))
         self._tape_logits = None
         return out
 
@@ -866,7 +892,7 @@ class ForwardPlan:
         from .model import SearchCell
         from .ops import PadConvRelu
         import torch.nn as nn
-        pipe = bool(pipelined) and model.use_rnn and taps is None
+        pipe = bool(pipelined) and model.use_rnn and taps is None and self._tail_on_side_stream(x.shape[0])
         if not pipe and not _capturing:
             # the plain path shares the gate / cell / h buffers with pipelined tails that may still be running
             self.wait_tails()
@@ -1072,7 +1098,7 @@ class ForwardPlan:
         from .ops import PadConvRelu, Linear, Zero, Identity
         import torch.nn as nn
         bf16 = torch.bfloat16
-        pipe = bool(pipelined) and model.use_rnn and taps is None
+        pipe = bool(pipelined) and model.use_rnn and taps is None and self._tail_on_side_stream(x.shape[0])
         if not pipe and not capturing:
             self.wait_tails()
         self._set_shape(x.shape[0], x.shape[2], model.use_rnn)

@@ -88,6 +88,7 @@ SIGNATURES = {
     'nbasr_lstm_pack_whh16': (_c_int, [_c_float_p] * 2 + [_c_int, _c_stream]),
     'nbasr_lstm_xcd_workspace_bytes': (ctypes.c_size_t, [_c_int] * 2),
     'nbasr_lstm_recurrence_xcd': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [_c_stream]),
+    'nbasr_lstm_recurrence_frames16': (_c_int, [_c_float_p] * 5 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head': (_c_int, [_c_float_p] * 4 + [_c_int] * 3 + [_c_stream]),
     'nbasr_linear_head_bct': (_c_int, [_c_float_p] * 4 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     # post-logits step
@@ -655,6 +656,20 @@ def lstm_recurrence_xcd(gates_ws, packed_whh16, cell_ws, h_out, xcd_ws, flags=0)
                        f'(0 = the form does not apply)')
     _check(lib.nbasr_lstm_recurrence_xcd(_dev(gates_ws, 'gates_ws'), packed_whh16.data_ptr(), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
                                          xcd_ws.data_ptr(), b, frames, hidden, int(flags), _stream(h_out)), 'nbasr_lstm_recurrence_xcd')
+    return h_out
+
+
+def lstm_recurrence_frames16(gates_ws, packed_whh16, cell_ws, h_out, xcd_ws):
+    """lstm_recurrence_xcd's arithmetic as one launch per frame (bit-identical h_out): the form of a pipelined tail and of a demoted plan."""
+    b, frames, hidden = h_out.shape
+    lib = load_library()
+    if not packed_whh16.is_cuda or packed_whh16.dtype != torch.uint8 or packed_whh16.numel() != lib.nbasr_lstm_packed_whh16_bytes(hidden):
+        raise HipError('packed_whh16 must be the uint8 device tensor returned by lstm_pack_whh16 for this hidden size')
+    need = lstm_xcd_workspace_bytes(b, hidden)
+    if need == 0 or not xcd_ws.is_cuda or xcd_ws.dtype != torch.uint8 or xcd_ws.numel() < need:
+        raise HipError(f'lstm_recurrence_frames16: batch={b} hidden={hidden} needs a uint8 device workspace of {need} bytes from lstm_xcd_workspace')
+    _check(lib.nbasr_lstm_recurrence_frames16(_dev(gates_ws, 'gates_ws'), packed_whh16.data_ptr(), _dev(cell_ws, 'cell_ws'), _dev(h_out, 'h_out'),
+                                              xcd_ws.data_ptr(), b, frames, hidden, _stream(h_out)), 'nbasr_lstm_recurrence_frames16')
     return h_out
 
 

@@ -826,20 +826,21 @@ def test_node_kernel_variants_are_chosen_and_change_nothing(monkeypatch):
 
 
 def test_recurrence_forms_same_logits_on_every_route(monkeypatch):
-    """NBASR_LSTM_SEQ: 'auto' (default, = 'xcd') runs the LSTM recurrence as ONE resident launch with a tile of 16 utterances per XCD on the
-    fp16 matrix cores (round 6) on EVERY route -- plain, tape replay, pipelined tail, captured graph; '0' = one fp32 launch per frame
-    everywhere, '1' = the round-4 chip-wide resident fp32 grid everywhere.  '0' and '1' are the same arithmetic in the same order
-    (bit-identical logits); the default is another fp32-accurate summation order: bit-identical across ITS routes, and within a small
-    fraction of the tolerance of the fp32 forms.  The choice is really made (spied on the library wrappers)."""
+    """NBASR_LSTM_SEQ: 'auto' (default) runs the LSTM recurrence on the fp16 matrix cores (round 6) -- ONE resident launch with a tile of 16
+    utterances per XCD in the plain forward, its tape replay and a captured graph; the same arithmetic as one launch per frame in a
+    pipelined tail ('xcd' / 'frames' = that form everywhere); '0' = one fp32 launch per frame everywhere, '1' = the round-4 chip-wide
+    resident fp32 grid everywhere.  '0' and '1' are the same arithmetic in the same order (bit-identical logits); so are 'auto', 'xcd'
+    and 'frames' -- another fp32-accurate summation order, within a small fraction of the tolerance of the fp32 forms.  The choice
+    is really made (spied on the library wrappers)."""
     from nb_asr_amd import hip
     m = build(cases.ARCH_D, True, 'lively')
     x = keyed_input(5, 333, seed=12).to(DEV)
     calls = []
-    for name in ('lstm_recurrence_seq', 'lstm_recurrence_packed', 'lstm_recurrence_xcd'):
+    for name in ('lstm_recurrence_seq', 'lstm_recurrence_packed', 'lstm_recurrence_xcd', 'lstm_recurrence_frames16'):
         original = getattr(hip, name)
         monkeypatch.setattr(hip, name, (lambda orig, tag: lambda *a, **k: (calls.append(tag), orig(*a, **k))[1])(original, name))
     outs = {}
-    for mode in ('0', 'auto', '1', 'xcd'):
+    for mode in ('0', 'auto', '1', 'xcd', 'frames'):
         monkeypatch.setenv('NBASR_LSTM_SEQ', mode)
         monkeypatch.setenv('NBASR_TAPE', '0')                  # (a tape replays recorded C calls: the python wrappers would not be seen)
         m._plans.clear()
@@ -851,8 +852,9 @@ def test_recurrence_forms_same_logits_on_every_route(monkeypatch):
             piped = m.forward_async(x).result().clone()
             piped_route = set(calls)
             m.check()
-        want_route = {'0': 'lstm_recurrence_packed', '1': 'lstm_recurrence_seq'}.get(mode, 'lstm_recurrence_xcd')
-        assert plain_route == {want_route} and piped_route == {want_route}, (mode, plain_route, piped_route)
+        plain_want = {'0': 'lstm_recurrence_packed', '1': 'lstm_recurrence_seq', 'frames': 'lstm_recurrence_frames16'}.get(mode, 'lstm_recurrence_xcd')
+        piped_want = 'lstm_recurrence_frames16' if mode == 'auto' else plain_want      # (a resident grid in the side-stream tail would fill whole XCDs)
+        assert plain_route == {plain_want} and piped_route == {piped_want}, (mode, plain_route, piped_route)
         monkeypatch.setenv('NBASR_TAPE', '1')
         m._plans.clear()
         with torch.no_grad():
@@ -861,7 +863,7 @@ def test_recurrence_forms_same_logits_on_every_route(monkeypatch):
         assert all(torch.equal(r, plain) for r in replays) and torch.equal(piped, plain), mode
         assert torch.equal(graphed, plain), mode                 # ('1': a captured graph takes the per-frame launches -- the same bits)
         outs[mode] = plain
-    assert torch.equal(outs['0'], outs['1']) and torch.equal(outs['auto'], outs['xcd'])
+    assert torch.equal(outs['0'], outs['1']) and torch.equal(outs['auto'], outs['xcd']) and torch.equal(outs['auto'], outs['frames'])
     assert cases.worst_ratio(outs['auto'], outs['0'], 1e-4, 1e-5) <= 0.25
     monkeypatch.setenv('NBASR_LSTM_SEQ', 'sometimes')
     m._plans.clear()
@@ -877,7 +879,7 @@ def test_one_launch_recurrence_that_loses_its_peers_raises_and_falls_back(monkey
     from nb_asr_amd import hip
     m = build(cases.ARCH_D, True, 'lively')
     x = keyed_input(3, 160, seed=5).to(DEV)
-    monkeypatch.setenv('NBASR_LSTM_SEQ', '0')
+    monkeypatch.setenv('NBASR_LSTM_SEQ', 'frames')
     m._plans.clear()
     with torch.no_grad():
         want = m(x).clone()
@@ -891,7 +893,7 @@ def test_one_launch_recurrence_that_loses_its_peers_raises_and_falls_back(monkey
         assert not bool(torch.isfinite(bad).all())                # (the failure is in the output too: NaN rows, never quiet garbage)
         m.check()                                                  # reported once
         plan = m._plans.values()[-1]
-        assert plan.lstm_seq_mode == '0'
+        assert plan.lstm_seq_mode == 'frames'
         again = m(x)
         m.check()
         assert torch.equal(again, want)
@@ -915,20 +917,32 @@ def test_one_launch_recurrence_that_loses_its_peers_raises_and_falls_back(monkey
         assert (fine is None or torch.equal(fine, want)) and torch.equal(m(x), want)
         # a HANDLE checks its own launch -- `result()` of the failing pipelined forward itself raises (a plain model(x)
         # returns a tensor and can only report at the next call / through check(), as above)
-        monkeypatch.setenv('NBASR_LSTM_SEQ', '1')                   # the one-launch form in pipelined mode too
+        monkeypatch.setenv('NBASR_LSTM_SEQ', 'xcd')                 # the one-launch form in pipelined mode too
         m._plans.clear()
         handle = m.forward_async(x)                                 # fails on the device; nothing has looked yet
         with pytest.raises(hip.HipError, match='THIS forward timed out|of THIS forward'):
             handle.result()
         plan = m._plans.values()[-1]
-        assert plan.lstm_seq_mode == '0'
+        assert plan.lstm_seq_mode == 'frames'
         m.check()                                                   # reported once, by the handle
         assert torch.equal(m.forward_async(x).result(), want)       # the retry runs one launch per frame
         # a healthy one-launch forward: result() waits for its status word and returns the logits
         monkeypatch.delenv('NBASR_LSTM_SEQ_FAULT')
         m._plans.clear()
         assert torch.equal(m.forward_async(x).result(), want)
-        assert m._plans.values()[-1].lstm_seq_mode == '1'
+        assert m._plans.values()[-1].lstm_seq_mode == 'xcd'
+        # the round-4 chip-wide fp32 grid ('1') fails the same way and falls back to ITS per-frame form ('0': the same fp32 bits)
+        monkeypatch.setenv('NBASR_LSTM_SEQ', '0')
+        m._plans.clear()
+        want32 = m(x).clone()
+        monkeypatch.setenv('NBASR_LSTM_SEQ', '1')
+        monkeypatch.setenv('NBASR_LSTM_SEQ_FAULT', '1')
+        m._plans.clear()
+        handle = m.forward_async(x)
+        with pytest.raises(hip.HipError, match='THIS forward timed out|of THIS forward'):
+            handle.result()
+        assert m._plans.values()[-1].lstm_seq_mode == '0'
+        assert torch.equal(m.forward_async(x).result(), want32)
 
 
 def test_one_launch_recurrence_beside_a_stream_that_hogs_the_chip():

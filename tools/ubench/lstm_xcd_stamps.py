@@ -1,6 +1,6 @@
 """Per-frame phase times of lstm_xcd_kernel from in-kernel shader-clock stamps (diagnostic library built with -DNBASR_LX_STAMPS=1:
-tools/ubench/build_lx_stamps.sh).  Wave 0 of every slice of utterance tile 0 stamps: 0 loop top, 1 poll matched, 2 MFMAs issued,
-3 partials written, 4 barrier passed, 5 partials summed, 6 gates done, 7 granule + h stores issued."""
+tools/ubench/build_lx_stamps.sh).  Wave 0 of every slice of utterance tile 0 stamps: 0 loop top, 1 flags all set, 2 quarter in LDS,
+3 barrier passed, 4 sums in registers, 5 gates done, 6 pieces stored, drained, flag set, 7 h_out stored."""
 import pathlib
 import sys
 
@@ -29,7 +29,7 @@ points, nfr = 8, 256
 n_tiles = (b + 15) // 16
 tail = ws[ws.numel() - 32 * nfr * points * 8:].view(torch.int64).view(32, nfr, points).cpu().double()
 st = tail[:, 20:240]                                       # steady state
-names = ['poll (top -> matched)', 'perm + MFMA issue', 'partials to LDS', 'barrier', 'partial sums read', 'gate math', 'granule + h stores']
+names = ["own flags polled (top -> set)", "DMA of the quarter landed", "gate loads + own 12 MFMAs + barrier", "36 MFMAs + sums", "gate math", "h split, gather, stores drained, flag", "h_out store + shift"]
 d = st[:, :, 1:] - st[:, :, :-1]
 period = (st[:, 1:, 0] - st[:, :-1, 0]).mean()
 print(f'batch {b}: frame period {period:.0f} cycles (shader clock)')
