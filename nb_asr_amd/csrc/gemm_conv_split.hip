@@ -136,8 +136,14 @@ struct GeoP {
     static constexpr int A_STEP_BYTES = P::NS * TP * PBM * PB_CI * 2;
     static constexpr int XR = (PBN - 1) * S + PB_TAPS;           // input frames needed per channel
     static constexpr int XRH = (XR + 1) / 2;                     // rows per parity plane (stride 2)
-    static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per split plane
-    static constexpr int X_BYTES = P::NS * ROWS * PB_CI * 2;
+    static constexpr int ROWS = (S == 1) ? XR : 2 * XRH;         // rows per (split, channel half) plane that hold data
+    // Round 6: the planes are PITCHED to whole 16-row units.  A B fragment read (ds_read_b128) is served in groups of 16 lanes that mix two
+    // k quarters -- lanes {0-3, 12-15} of channel half 0 with lanes {20-27} of half 1, one plane further -- and the group is conflict-free
+    // only if a plane's pitch is a multiple of 256 bytes: its 16 rows x 16 bytes then tile all 64 banks.  At 263 (stride 1) / 518
+    // (stride 2) rows the second half landed 28 / 24 banks off and every fragment read of the input tile took two LDS cycles per group
+    // (profiles/r05_pmc_lds_cfg3_bf16.csv: 0.31-0.34 of the LDS-active cycles were bank conflicts).
+    static constexpr int RP = (ROWS + 15) / 16 * 16;             // plane pitch in rows
+    static constexpr int X_BYTES = P::NS * RP * PB_CI * 2;
     // the tile is fetched as ALIGNED 4-frame quads (one global_load_dwordx4 per channel): NQUADS covers XR rows at any
     // misalignment of the tile's first frame; an item = (quad, channel pair), 8 consecutive quads x 8 pairs per wave
     static constexpr int NQUADS = ((XR + 3 + 3) / 4 + 7) / 8 * 8;
@@ -340,9 +346,9 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         for (int i = wave * QS + q; i < NP; i += 8 * QS) {
             const int o = i * 1024 + lane * 16;
             if (o < G::X_BYTES) {
-                const int plane = o / (G::ROWS * 16), rr = (o - plane * (G::ROWS * 16)) >> 4;
+                const int plane = o / (G::RP * 16), rr = (o - plane * (G::RP * 16)) >> 4;
                 const int frame = tin0 + (S == 1 ? rr : 2 * (rr % G::XRH) + rr / G::XRH);
-                const int row = (frame >= 0 && frame < a.ld_in) ? frame + 1 : 0;
+                const int row = (rr < G::ROWS && frame >= 0 && frame < a.ld_in) ? frame + 1 : 0;     // (pitch rows: the zero row)
                 __builtin_amdgcn_global_load_lds(
                     (const __attribute__((address_space(1))) void*)(img + (static_cast<size_t>(plane) * (a.ld_in + 1) + row) * 16),
                     (__attribute__((address_space(3))) void*)(Xbase + xbuf * G::X_BYTES + i * 1024), 16, 0, 0);
@@ -395,7 +401,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
             const int row0 = 4 * ((e >> 6) * 8 + (e & 7)) - xoff;
             if (e >= G::XITEMS) continue;
             // image [split][half][row][8 ci]: channel pair p sits in half p >> 2, dword p & 3 of the 16-byte row
-            unsigned* const col = X + (p >> 2) * G::ROWS * 4 + (p & 3);
+            unsigned* const col = X + (p >> 2) * G::RP * 4 + (p & 3);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = row0 + j;
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                 P::split(xreg[i][1][j], s1);
                 unsigned* dst = col + G::rowmap(row) * 4;
 #pragma unroll
-                for (int k = 0; k < P::NS; ++k) dst[k * 2 * G::ROWS * 4] = pack2(s0[k], s1[k]);
+                for (int k = 0; k < P::NS; ++k) dst[k * 2 * G::RP * 4] = pack2(s0[k], s1[k]);
             }
         }
     };
@@ -416,21 +422,23 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     // of a quarter read 256 contiguous bytes (all 64 banks) and a fragment is one ds_read_b128.
     const int l15 = lane & 15, kq = lane >> 4;
     const int a_lane = (((kq >> 1) * 2 + (kq & 1)) * PB_M + wm * WROWS + l15) * 16;
-    const int x_lane = (kq & 1) * G::ROWS * 16;
+    const int x_lane = (kq & 1) * G::RP * 16;
 
     // PIPE (where the registers allow): the fragment reads are software-pipelined IN PLACE over the fully unrolled step --
     // the A triple of row block i+1 is read while block i multiplies (one extra register set), and each B triple of the
     // next tap pair is read into its own registers right after its last use in the current pair.  Only the first reads of a
     // step wait on LDS latency, so a wave keeps the matrix pipe busy on its own while its SIMD partner is staging.  The
     // MFMAs of every accumulator are issued in the same order either way: results are bit-identical.
-    constexpr bool PIPE = P::NS == 2;
+    // (round 6: the one-term bf16 flavour too -- its plain loop read a fragment, waited, multiplied four times: matrix pipe 0.39-0.41 busy,
+    // profiles/r05_pmc_mfma_utilisation_cfg3_bf16.csv)
+    constexpr bool PIPE = P::NS <= 2;
     auto mma_step = [&](int q, int abuf, int xbuf) {
         const unsigned char* A = Abuf + abuf * ASTEP + a_lane;
         const unsigned char* X = Xbase + xbuf * G::X_BYTES + x_lane;
         auto read_b = [&](int pp, int j, vec8 (&f)[P::NS]) {
             const int row = G::rowmap((wn * WCOLS + j * 16 + l15) * S + q * TP + 2 * pp + (kq >> 1));
 #pragma unroll
-            for (int k = 0; k < P::NS; ++k) f[k] = *reinterpret_cast<const vec8*>(X + (k * 2 * G::ROWS + row) * 16);
+            for (int k = 0; k < P::NS; ++k) f[k] = *reinterpret_cast<const vec8*>(X + (k * 2 * G::RP + row) * 16);
         };
         auto read_a = [&](int pp, int i, vec8 (&f)[P::NS]) {
 #pragma unroll

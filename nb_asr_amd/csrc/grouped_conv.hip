@@ -37,56 +37,70 @@ __global__ __launch_bounds__(256) void pack_grouped_weights_kernel(const float* 
 // then one thread per frame merges the 8 lane results from LDS.  The first version walked all 25-50 partials of a frame in ONE
 // thread, five at a time: 5-10 dependent round trips = 10-12 us per launch whatever the batch, 15 launches per forward
 // (0.18 ms: 10 % of a step at 8 utterances per GPU).  Chan's merge throughout; the order is fixed, so results are reproducible.
-constexpr int SF_FRAMES = 32, SF_LANES = 8, SF_MAX_PER_LANE = 16;      // <= 128 partials per frame (per-group partials of a fused cell: 100)
-__global__ __launch_bounds__(SF_FRAMES * SF_LANES) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                                                int batch, int frames, int ld, int groups, int cg, int gpp, float eps)
+// Round 5: a thread takes FOUR consecutive frames (16-byte loads: a wave reads 512 contiguous bytes per partial row instead of 128) and
+// only the partials that exist (the clamped duplicates of the first version were 19 % of the loads at 100 partials, 75 % at 25); per
+// frame the merges and their order are the first version's, so the statistics are the same bit for bit.  51 MB of per-group partials:
+// 20 -> see profiles/NOTES_r05.md.
+constexpr int SF_QUADS = 32, SF_FRAMES = 4 * SF_QUADS, SF_LANES = 8, SF_MAX_PER_LANE = 16;      // <= 128 partials per frame (per-group partials of a fused cell: 100)
+__global__ __launch_bounds__(SF_QUADS * SF_LANES) void stats_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                                               int batch, int frames, int ld, int groups, int cg, int gpp, float eps)
 {
     __shared__ float s_cnt[SF_LANES][SF_FRAMES], s_mean[SF_LANES][SF_FRAMES], s_m2[SF_LANES][SF_FRAMES];
-    const int tf = threadIdx.x & (SF_FRAMES - 1), pl = threadIdx.x / SF_FRAMES;      // frames fastest: a wave reads 128 contiguous bytes per partial row
-    const int t = blockIdx.x * SF_FRAMES + tf;
+    const int tq = threadIdx.x & (SF_QUADS - 1), pl = threadIdx.x / SF_QUADS;        // frame quads fastest
+    const int t0 = blockIdx.x * SF_FRAMES + 4 * tq;
     const int b = blockIdx.y;
-    const int nparts = (groups + gpp - 1) / gpp;          // partials per frame: one per `gpp` groups (4: node kernels; 2: some fused cells)
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;
-    if (t < frames) {
-        float pm[SF_MAX_PER_LANE], pq[SF_MAX_PER_LANE];
+    const int nparts = (groups + gpp - 1) / gpp;          // partials per frame: one per `gpp` groups (4: node kernels; 2 / 1: fused cells; 16 channels: dense convs)
+    float cnt[4] = {0.f, 0.f, 0.f, 0.f}, mean[4] = {0.f, 0.f, 0.f, 0.f}, m2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t0 < frames) {                                    // (ld % 4 == 0: the quad lies inside the row; its frames beyond `frames` are discarded below)
+        float4 pm[SF_MAX_PER_LANE], pq[SF_MAX_PER_LANE];
 #pragma unroll
         for (int u = 0; u < SF_MAX_PER_LANE; ++u) {
-            const int k = min(pl + u * SF_LANES, nparts - 1);
-            const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld;
-            pm[u] = prow[t];
-            pq[u] = prow[ld + t];
+            const int k = pl + u * SF_LANES;
+            pm[u] = make_float4(0.f, 0.f, 0.f, 0.f); pq[u] = pm[u];
+            if (k < nparts) {
+                const float* prow = part + (static_cast<size_t>(k) * batch + b) * 2 * ld + t0;
+                pm[u] = *reinterpret_cast<const float4*>(prow);
+                pq[u] = *reinterpret_cast<const float4*>(prow + ld);
+            }
         }
 #pragma unroll
         for (int u = 0; u < SF_MAX_PER_LANE; ++u) {
             const int k = pl + u * SF_LANES;
             if (k < nparts) {
                 const float nb = static_cast<float>(cg * min(gpp, groups - gpp * k));
-                const float tot = cnt + nb;
-                const float delta = pm[u] - mean;
-                mean += delta * (nb / tot);
-                m2 += pq[u] + delta * delta * (cnt * nb / tot);
-                cnt = tot;
+                const float pmv[4] = {pm[u].x, pm[u].y, pm[u].z, pm[u].w}, pqv[4] = {pq[u].x, pq[u].y, pq[u].z, pq[u].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float tot = cnt[r] + nb;
+                    const float delta = pmv[r] - mean[r];
+                    mean[r] += delta * (nb / tot);
+                    m2[r] += pqv[r] + delta * delta * (cnt[r] * nb / tot);
+                    cnt[r] = tot;
+                }
             }
         }
     }
-    s_cnt[pl][tf] = cnt; s_mean[pl][tf] = mean; s_m2[pl][tf] = m2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s_cnt[pl][4 * tq + r] = cnt[r]; s_mean[pl][4 * tq + r] = mean[r]; s_m2[pl][4 * tq + r] = m2[r]; }
     __syncthreads();
-    if (pl != 0 || t >= ld) return;
+    const int tf = threadIdx.x, t = blockIdx.x * SF_FRAMES + tf;                     // one thread per frame merges the 8 lane results, lane 0's first
+    if (tf >= SF_FRAMES || t >= ld) return;
     float* srow = stats + static_cast<size_t>(b) * 2 * ld;
     if (t >= frames) { srow[t] = 0.f; srow[ld + t] = 0.f; return; }
+    float c = s_cnt[0][tf], mu = s_mean[0][tf], q = s_m2[0][tf];
 #pragma unroll
     for (int p = 1; p < SF_LANES; ++p) {
         const float nb = s_cnt[p][tf];
         if (nb > 0.f) {
-            const float tot = cnt + nb;
-            const float delta = s_mean[p][tf] - mean;
-            mean += delta * (nb / tot);
-            m2 += s_m2[p][tf] + delta * delta * (cnt * nb / tot);
-            cnt = tot;
+            const float tot = c + nb;
+            const float delta = s_mean[p][tf] - mu;
+            mu += delta * (nb / tot);
+            q += s_m2[p][tf] + delta * delta * (c * nb / tot);
+            c = tot;
         }
     }
-    srow[t] = mean;
-    srow[ld + t] = 1.0f / sqrtf(m2 / cnt + eps);
+    srow[t] = mu;
+    srow[ld + t] = 1.0f / sqrtf(q / c + eps);
 }
 
 // y = 0 + skip0 + skip1 + skip2 for a node whose main op is `zero` (reference ops.py:67-68); skip0 may carry a pending
@@ -449,9 +463,10 @@ extern "C" int nbasr_grouped_stats_finalize(const float* stats_ws, float* stats_
     NBASR_REQUIRE(groups_per_part >= 1, NBASR_EINVAL, "nbasr_grouped_stats_finalize: groups_per_part=%d (4, 2 or 1 for grouped convolutions, the row tile for a dense one)", groups_per_part);
     if (batch == 0 || ld == 0) return NBASR_OK;
     NBASR_REQUIRE(stats_ws && stats_out, NBASR_ENULL, "nbasr_grouped_stats_finalize: NULL pointer");
+    NBASR_REQUIRE(ld % 4 == 0 && aligned16(stats_ws), NBASR_EALIGN, "nbasr_grouped_stats_finalize: ld=%d must be a multiple of 4 and stats_ws 16-byte aligned", ld);
     NBASR_REQUIRE((groups + groups_per_part - 1) / groups_per_part <= SF_LANES * SF_MAX_PER_LANE, NBASR_EINVAL,
                   "nbasr_grouped_stats_finalize: %d groups in parts of %d are more than %d partials per frame", groups, groups_per_part, SF_LANES * SF_MAX_PER_LANE);
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + SF_FRAMES - 1) / SF_FRAMES, batch), dim3(SF_FRAMES * SF_LANES), 0, as_stream(stream), stats_ws, stats_out,
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((ld + SF_FRAMES - 1) / SF_FRAMES, batch), dim3(SF_QUADS * SF_LANES), 0, as_stream(stream), stats_ws, stats_out,
                        batch, frames, ld, groups, channels / groups, groups_per_part, eps);
     return launch_status("nbasr_grouped_stats_finalize");
 }

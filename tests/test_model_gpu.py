@@ -379,7 +379,8 @@ def test_training_mode_dropout():
     # the same op without gradients: the statistics of its masks (the RNG streams of two frameworks cannot be matched, the law can):
     # what the op keeps is its eval output scaled by 1 / (1 - p), it keeps 1 - p of the non-zero outputs, and a zero stays a zero
     xin = torch.randn(4, 600, 500, device=DEV)
-    for node_op, p_drop in ((m.model[2].nodes[0].op, 0.2), (m.model[0], 0.2)):
+    # (the downsample convolutions carry no dropout: the reference builds them with the default rate 0, model.py:82-89)
+    for node_op, p_drop in ((m.model[2].nodes[0].op, 0.2), (m.model[3].nodes[2].op, 0.2), (m.model[0], 0.0)):
         xi = xin if node_op is not m.model[0] else torch.randn(4, 80, 500, device=DEV)
         with torch.no_grad():
             y_train = node_op.train()(xi)
@@ -390,6 +391,7 @@ def test_training_mode_dropout():
         rate = float(kept.sum()) / float(live.sum())
         assert abs(rate - (1 - p_drop)) < 0.01, rate
         assert torch.allclose(y_train[kept], y_eval[kept] / (1 - p_drop), rtol=1e-6, atol=0)
+        assert node_op.dropout_rate == p_drop
     # p == 0: training mode under no_grad is the fused executor, bit for bit the eval result
     m0 = keyed_fill_(nb.get_model(cases.ARCH_D, use_rnn=True, dropout_rate=0.0), 5, 'lively').to(DEV)
     with torch.no_grad():
