@@ -263,9 +263,8 @@ __device__ __forceinline__ int lx_publish_offset(int slice, int wave, int n16)
 // image: bit-identical h to the resident form.  Against the fp32 per-frame kernel (lstm.hip): a fifth of the matrix time and half the
 // workgroups per frame (128 instead of 252 at 64 utterances).
 // WPB = row tiles (waves) per workgroup, 1, 2 or 4: the decomposition does not touch the arithmetic (a row tile is one wave's chain
-// whatever the workgroup) -- small batches take one-wave workgroups (125 per tile: each fetches 32 KiB of weights + the 32 KiB image, the
-// shortest frame), large ones four-wave workgroups (32 per tile: the image is fetched once per four row tiles, the least work beside
-// the encoder).
+// whatever the workgroup) -- small batches take two-wave workgroups (63 per tile: the shortest frames), large ones four-wave workgroups
+// (32 per tile: the image is fetched once per four row tiles, the least work beside the encoder).
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void lstm_step16_kernel(
     const float* __restrict__ gates_in, const unsigned char* __restrict__ wp, float* __restrict__ cell, float* __restrict__ h_out,
@@ -292,11 +291,15 @@ __global__ __launch_bounds__(64 * WPB) void lstm_step16_kernel(
     const float inv = reinterpret_cast<const float*>(wp)[0] * hs_inv;
     if (t > 0) {
         const unsigned char* img = tile_ws + ((t - 1) & 1) * LX_IMAGE_BYTES;
+        // (columns of utterances beyond the batch are not fetched: nothing reads their sums, and a part-filled tile -- 8 utterances, one
+        // rank's share of the benchmark batch on 8 GPUs -- moves half the image)
+        if (eb < batch) {
 #pragma unroll
-        for (int j = 0; j < 32 / WPB; ++j) {
-            const int chunk = wib * (32 / WPB) + j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + chunk * 1024 + lane * 16),
-                                             (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(&htile[0][0][0]) + chunk * 1024), 16, 0, 0);
+            for (int j = 0; j < 32 / WPB; ++j) {
+                const int chunk = wib * (32 / WPB) + j;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + chunk * 1024 + lane * 16),
+                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(&htile[0][0][0]) + chunk * 1024), 16, 0, 0);
+            }
         }
         xuint4 wfrag[LX_KSTEPS][2];
         // (a row tile beyond the layer -- the grid is rounded up to whole workgroups -- reads the zero rows the packer wrote up to the slice's end,
@@ -581,9 +584,12 @@ extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void*
     const size_t tiles_n = (batch + 15) / 16;
     struct Ctx { hipStream_t s; const float* gates; const unsigned char* w; float* cell; float* h; unsigned char* tiles; size_t tiles_bytes; int batch, frames, hidden, prio, wpb; };
     Ctx ctx{as_stream(stream), gates_ws, static_cast<const unsigned char*>(packed_whh16), cell_ws, h_out,
-            static_cast<unsigned char*>(xcd_ws) + LX_HEADER_WORDS * sizeof(unsigned), tiles_n * LX_TILE_BYTES, batch, frames, hidden, batch <= 32,
-            batch <= 32 ? 1 : 4};
-    if (const char* force = getenv("NBASR_LX_WPB")) ctx.wpb = (force[0] == '1') ? 1 : 4;          // (A/B hook; both forms give the same bits)
+            static_cast<unsigned char*>(xcd_ws) + LX_HEADER_WORDS * sizeof(unsigned), tiles_n * LX_TILE_BYTES, batch, frames, hidden, 1,
+            batch <= 32 ? 2 : 4};
+    // (same-box A/B of the shapes, pipelined utterances/s: 8 utterances 5 349 / 5 381 / - with 1 / 2 / 4 waves per workgroup, 16: 7 613 / 7 685 / 6 968,
+    // 64: 9 871 / 10 299 / 10 413; issue priority for the chain's waves 10 413 -> 10 554 at 64, within noise below)
+    if (const char* force = getenv("NBASR_LX_WPB")) ctx.wpb = (force[0] == '1') ? 1 : (force[0] == '2') ? 2 : 4;      // (A/B hook; every form gives the same bits)
+    if (const char* force = getenv("NBASR_LX_PRIO")) ctx.prio = force[0] == '1';
     const ChainKey key{{gates_ws, packed_whh16, cell_ws, h_out, xcd_ws}, {batch, frames, hidden, 16, ctx.wpb}};
     return replay_chain(ctx.s, key, "nbasr_lstm_recurrence_frames16", [](void* p) {
         const Ctx& c = *static_cast<const Ctx*>(p);
@@ -594,6 +600,7 @@ extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void*
         const dim3 grid((row_tiles + c.wpb - 1) / c.wpb, (c.batch + 15) / 16);
         for (int t = 0; t < c.frames; ++t) {
             if (c.wpb == 1) hipLaunchKernelGGL(lstm_step16_kernel<1>, grid, dim3(64), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
+            else if (c.wpb == 2) hipLaunchKernelGGL(lstm_step16_kernel<2>, grid, dim3(128), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
             else hipLaunchKernelGGL(lstm_step16_kernel<4>, grid, dim3(256), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
         }
     }, &ctx);
