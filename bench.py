@@ -361,20 +361,21 @@ def kernel_source_hash():
     import hashlib
     here = os.path.dirname(os.path.abspath(__file__))
     h = hashlib.sha256()
-    for name in ('csrc/grouped_conv.hip', 'csrc/grouped_conv_osplit.hip', 'csrc/grouped_conv_ring.hip', 'csrc/grouped_cell.hip', 'csrc/common.h', 'gc_variant_table.json'):
+    for name in ('csrc/grouped_conv.hip', 'csrc/grouped_conv_osplit.hip', 'csrc/grouped_conv_ring.hip', 'csrc/grouped_cell.hip', 'csrc/grouped_cell_mfma.hip',
+                 'csrc/common.h', 'gc_variant_table.json'):
         with open(os.path.join(here, 'nb_asr_amd', name), 'rb') as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
-def pmc_traffic_per_launch(kernel_prefix):
+def pmc_traffic_per_launch(kernel_prefix, suffix=''):
     """HBM bytes per launch of a kernel family from the newest committed PMC summary (profiles/rNN_pmc_hbm_traffic.csv:
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 correction applied by tools/summarize_pmc.py).
     Launch-weighted mean over the family's template instances; None when no summary is committed."""
     import csv
     import glob
     here = os.path.dirname(os.path.abspath(__file__))
-    files = sorted(glob.glob(os.path.join(here, 'profiles', 'r*_pmc_hbm_traffic.csv')))
+    files = sorted(glob.glob(os.path.join(here, 'profiles', f'r*_pmc_hbm_traffic{suffix}.csv')))      # ('' = the default workload; '_cfg3_bf16')
     if not files:
         return None, None
     # the counters describe ONE build of the kernel: the summary's first line records the hash of the kernel's sources
@@ -446,9 +447,12 @@ def roofline_leg(model, x, args):
     if launches:
         prefix = ('nbasr::grouped_cell_mfma_kernel' if 'grouped_cell_mfma' in kinds else
                   'nbasr::grouped_cell_kernel' if 'grouped_cell' in kinds else 'nbasr::grouped_conv_f32')
-        traffic, traffic_src = pmc_traffic_per_launch(prefix)
-        if args.batch != BATCH or args.frames != FRAMES or args.arch != 'conv5' or args.dtype != 'f32' or any(k.startswith('NBASR_') for k in os.environ):
-            traffic, traffic_src = None, None          # the committed counters are for the default workload and modes only
+        # the committed counters describe two workloads in the default modes: the benchmark's own and BASELINE configs[3] per GPU in bf16
+        default_wl = (args.batch, args.frames, args.arch, args.dtype) == (BATCH, FRAMES, 'conv5', 'f32')
+        cfg3_wl = (args.batch, args.frames, args.arch, args.dtype) == (32, 1600, 'dense-skip', 'bf16')
+        traffic, traffic_src = pmc_traffic_per_launch(prefix, '' if default_wl else '_cfg3_bf16')
+        if not (default_wl or cfg3_wl) or any(k.startswith('NBASR_') for k in os.environ):
+            traffic, traffic_src = None, None
         secs = tot_ms * 1e-3
 
         def block_entry(v):

@@ -150,7 +150,13 @@ struct GeoP {
     static constexpr int XITEMS = NQUADS * (PB_CI / 2);
     static constexpr int NCHUNK = QSTEPS > 1 ? QSTEPS - 1 : 1;   // the next group's tile is staged in QSTEPS-1 chunks (register staging path)
     static constexpr int XI = (XITEMS + PB_THREADS * NCHUNK - 1) / (PB_THREADS * NCHUNK);   // items per thread per chunk
-    static constexpr int OPERAND_BYTES = 2 * A_STEP_BYTES + 2 * X_BYTES;   // weights and input tile both double-buffered
+    // operand slots: two (the transfers of step s + 1 are issued in step s).  Round 6 also built THREE for the one-term bf16 flavour
+    // (step s issues the operands of step s + 2, a bare s_barrier per step; its tests passed): 0.983 against 0.988 ms of dense convs per
+    // forward at 32 x 1600 -- nothing, as round 5 found for the fp16 x 2 flavour.  What bounds that flavour is LDS READ bandwidth: a wave's
+    // 80 x 64 register tile re-uses an A fragment 4 times and a B fragment 5 times, 0.45 KiB of ds_read_b128 per 16-cycle MFMA and wave =
+    // 230 of the CU's 256 bytes per clock at the full matrix rate (the split flavours issue 2-3 MFMAs per fragment pair).
+    static constexpr int RING = 2;
+    static constexpr int OPERAND_BYTES = RING * (A_STEP_BYTES + X_BYTES);
     static constexpr int STAGING_BYTES = 8 * 32 * 68 * 4;            // the fp32 epilogue's output staging (8 waves x 32 rows x 68 floats)
     static constexpr int LDS_BYTES = OPERAND_BYTES > STAGING_BYTES ? OPERAND_BYTES : STAGING_BYTES;
     __device__ static constexpr int rowmap(int row) { return (S == 1) ? row : (row & 1) * XRH + (row >> 1); }
@@ -256,7 +262,8 @@ __global__ __launch_bounds__(256) void pack_dense_weights_kernel(const float* __
 template <class P, int S, bool LNX, bool XIMG = false, int MI = 4, int NJ = 4>
 __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const PackedConvArgs a)
 {
-    static_assert(NJ == 4 || (NJ == 2 && XIMG && P::NS == 2), "128-frame tiles exist for the fp16 image path only");
+    static_assert(NJ == 4 || (NJ == 2 && XIMG && P::NS == 2) || (NJ == 8 && XIMG && P::NS == 1),
+                  "128-frame tiles exist for the fp16 image path only, 512-frame tiles for the one-term bf16 flavour only");
     static_assert(!(XIMG && LNX) && !(XIMG && !has_image_path<P>()), "the image path: scaled fp16 scheme or plain bf16, no LayerNorm on load");
     static_assert(XIMG || P::NS > 1, "plain bf16 operands exist as an image only");
     static_assert(MI == 4 || ((MI == 5 || MI == 3 || MI == 2) && XIMG), "160-, 96- and 64-row tiles exist for the image path only");
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
     using vec8 = typename P::vec8;
     constexpr int TP = G::TP, QS = G::QSTEPS, ASTEP = G::A_STEP_BYTES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* const Abuf = smem;                       // [2][ASTEP]    weights of the current / next K-step
-    unsigned char* const Xbase = smem + 2 * ASTEP;          // [2][X_BYTES]  input tile of the current / next channel group
+    unsigned char* const Abuf = smem;                       // [RING][ASTEP]    weights of the current / next (/ next but one) K-step
+    unsigned char* const Xbase = smem + G::RING * ASTEP;    // [RING][X_BYTES]  input tile of the current / next (/ next but one) channel group
 
     // XCD-aware tile order (the bijective remap of gemm_conv.hip), frame-tile major
     const int nwg = gridDim.x, id = blockIdx.x;
@@ -560,36 +567,48 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
         // ---- bf16 output: bias + ReLU + min(20), ONE rounding, then out through LDS so that a store instruction writes whole
         // 128-byte row segments (64 frames) instead of 32-byte ones.  Each wave owns WROWS x 64 bf16 = WROWS x 128 bytes of
         // the staging buffers, which nobody reads any more (the last K-step ended with a barrier).
-        unsigned short* const T = reinterpret_cast<unsigned short*>(smem) + wave * (WROWS * 64);
-        static_assert(8 * WROWS * 128 <= G::LDS_BYTES, "output staging must fit the operand buffers");
+        // Passes of two 16-row MFMA tiles per wave: 32 rows x WCOLS bf16 (row stride + 16 bytes: the four row groups of a fragment land on
+        // different banks), out as 16-byte pieces -- 8 (64 frames) or 16 (128 frames) lanes per row.
+        constexpr int TSH = WCOLS + 8;                      // staged row stride in bf16 elements
+        constexpr int LPR = WCOLS / 8, RPI = 64 / LPR;      // lanes per staged row; rows per copy-out instruction
+        unsigned short* const T = reinterpret_cast<unsigned short*>(smem) + wave * (32 * TSH);
+        static_assert(8 * 32 * TSH * 2 <= G::LDS_BYTES, "output staging must fit the operand buffers");
         if (wave_active) {
+            bf16_t* const yb = reinterpret_cast<bf16_t*>(a.y);
+            const int n = n0 + wn * WCOLS + (lane % LPR) * 8;
 #pragma unroll
-            for (int i = 0; i < MI; ++i)
+            for (int i0 = 0; i0 < MI; i0 += 2) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool live = n0 + wn * 64 + j * 16 + l15 < a.frames_out;
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = i0 + ii;
+                    if (i >= MI) break;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int ml = i * 16 + kq * 4 + r, m = m0 + wm * WROWS + ml;
-                        const float v = (live && m < a.c_out) ? relu_clamp(acc[i][j][r] + a.bias[m]) : 0.f;
-                        T[ml * 64 + j * 16 + l15] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+                    for (int j = 0; j < NJ; ++j) {
+                        const bool live = n0 + wn * WCOLS + j * 16 + l15 < a.frames_out;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = m0 + wm * WROWS + i * 16 + kq * 4 + r;
+                            const float v = (live && m < a.c_out) ? relu_clamp(acc[i][j][r] + a.bias[m]) : 0.f;
+                            T[(ii * 16 + kq * 4 + r) * TSH + j * 16 + l15] = __builtin_bit_cast(unsigned short, static_cast<__bf16>(v));
+                        }
                     }
                 }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done (wave-private tile); also keeps
-                                                                 // the compiler from moving the differently-typed reads above them
-            bf16_t* const yb = reinterpret_cast<bf16_t*>(a.y);
-            const int n = n0 + wn * 64 + (lane & 7) * 8;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS writes are done (wave-private tile); also keeps
+                                                                     // the compiler from moving the differently-typed reads above them
+                const int rows_pass = (MI - i0 >= 2) ? 32 : 16;
 #pragma unroll
-            for (int it = 0; it < WROWS / 8; ++it) {
-                const int ml = it * 8 + (lane >> 3), m = m0 + wm * WROWS + ml;
-                if (m < a.c_out && n < a.ld_out) {
-                    const u4v t = *reinterpret_cast<const u4v*>(T + ml * 64 + (lane & 7) * 8);
-                    *reinterpret_cast<u4v*>(yb + (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n) = t;
+                for (int it = 0; it < 32 / RPI; ++it) {
+                    const int ml = it * RPI + lane / LPR, m = m0 + wm * WROWS + i0 * 16 + ml;
+                    if (ml < rows_pass && m < a.c_out && n < a.ld_out) {
+                        const u4v t = *reinterpret_cast<const u4v*>(T + ml * TSH + (lane % LPR) * 8);
+                        *reinterpret_cast<u4v*>(yb + (static_cast<size_t>(b) * a.c_out + m) * a.ld_out + n) = t;
+                    }
                 }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next pass overwrites the tile
             }
         }
         return;
-    }
+    } else {
     // ---- epilogue without skips (every downsample conv of the model): bias + ReLU + min(20), then out through LDS so that a store
     // instruction writes four 256-byte row segments (16 lanes x 16 B) instead of four 64-byte ones.  Two 16-row MFMA tiles at a time
     // per wave: 32 rows x 64 frames fp32 (row stride 68 floats: the four row groups of a fragment land 2-way instead of 4-way on the
@@ -696,6 +715,7 @@ __global__ __launch_bounds__(PB_THREADS, 2) void gemm_conv_split_kernel(const Pa
                 a.y[off] = live ? v : 0.f;
             }
         }
+    }
     }
 }
 
@@ -891,7 +911,7 @@ extern "C" int nbasr_pack_dense_weights(int scheme, const float* w, void* packed
 }
 
 static int dense_bf16_image_impl(const void* x_image, const void* packed_w, const float* bias, void* y, int batch, int c_in,
-                                 int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile,
+                                 int frames_in, int ld_in, int c_out, int ld_out, int kernel, int stride, int row_tile, int frame_tile,
                                  nbasr_stream_t stream)
 {
     using P = PlainBf16;
@@ -916,6 +936,12 @@ static int dense_bf16_image_impl(const void* x_image, const void* packed_w, cons
     a.ln_x = LnRef{nullptr, nullptr, nullptr};
     a.x_is_image = 1;
     hipStream_t s = as_stream(stream);
+    if (frame_tile == 512) {
+        // 512-frame tiles (round 6): a wave's register tile is 16 MI rows x 128 frames -- a B fragment is re-used MI times as before, an A
+        // fragment 8 times instead of 4: 0.33 instead of 0.45 KiB of LDS reads per MFMA, where the LDS read rate bounds this flavour
+        if (mi == 5) return stride == 1 ? launch_image<P, 1, 5, 8>(a, s) : launch_image<P, 2, 5, 8>(a, s);
+        return stride == 1 ? launch_image<P, 1, 4, 8>(a, s) : launch_image<P, 2, 4, 8>(a, s);
+    }
     if (mi == 5) return stride == 1 ? launch_image<P, 1, 5>(a, s) : launch_image<P, 2, 5>(a, s);
     return stride == 1 ? launch_image<P, 1, 4>(a, s) : launch_image<P, 2, 4>(a, s);
 }
@@ -944,10 +970,10 @@ extern "C" int nbasr_dense_conv1d_packed(int scheme, const void* x, int x_is_ima
             return dense_packed_impl<SplitF16x2>(xf, packed_w, bias, skip0, skip1, skip2, yf, batch, c_in, frames_in, ld_in, c_out, ld_out,
                                                  kernel, stride, nullptr, x_absmax, stream, image, row_tile, x_range, 0, stats_part, frame_tile);
         case NBASR_DENSE_BF16:
-            NBASR_REQUIRE(frame_tile == 256, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the bf16 scheme has 256-frame tiles only");
+            NBASR_REQUIRE(frame_tile == 256 || frame_tile == 512, NBASR_EINVAL, "nbasr_dense_conv1d_packed: the bf16 scheme has 256- and 512-frame tiles");
             NBASR_REQUIRE(image && !x_absmax && !x_range && !ln && !skip0 && !skip1 && !skip2 && !stats_part, NBASR_EINVAL,
                           "nbasr_dense_conv1d_packed: the bf16 scheme reads nbasr_bf16_image's operand image only (no bound, range, LayerNorm, skips or statistics)");
-            return dense_bf16_image_impl(x, packed_w, bias, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, stream);
+            return dense_bf16_image_impl(x, packed_w, bias, y, batch, c_in, frames_in, ld_in, c_out, ld_out, kernel, stride, row_tile, frame_tile, stream);
         default: break;
     }
     NBASR_REQUIRE(false, NBASR_EINVAL, "nbasr_dense_conv1d_packed: unknown scheme %d", scheme);

@@ -520,6 +520,24 @@ class ForwardPlan:
                     rows, score = r, margin * cost(r)
         return rows
 
+    def _bf16_tile(self, c_out, frames_out, pipe=False):
+        """(rows, frames) per workgroup of the one-term bf16 GEMM: rows 128 / 160, frames 256 / 512 (results are bit-identical, the choice
+        is speed only).  That flavour is bound by LDS reads; a 512-frame tile re-uses a weight fragment 8 times instead of 4 and runs
+        its K-steps ~10 % faster per unit of work (measured at 32 x 1600: conv 2 312 -> 283 us, conv 3 237 -> 213) -- where the frames
+        and the workgroup count still fill whole tiles and rounds (conv 1, 1600 frames = 3.1 tiles of 512: 357 -> 362).  Cost = rounds
+        of 256 workgroups x tile area x that factor.  In a PIPELINED forward the 256-frame tiles stay: the wide tiles' workgroups (237-245
+        registers, twice as long-lived) leave the per-frame launches of the previous batch's LSTM tail waiting for a compute unit --
+        dense convs 0.983 -> 0.924 ms per forward but 9 620 -> 9 190 utterances/s (three alternating same-box runs each)."""
+        forced = os.environ.get('NBASR_BF16_FTILE')
+        best = None
+        for rows in (128, 160):
+            for ftile in ((int(forced),) if forced else (256,) if pipe else (256, 512)):
+                wgs = -(-c_out // rows) * -(-hip.row_pitch(frames_out, torch.bfloat16) // ftile) * self.batch
+                cost = -(-wgs // 256) * rows * ftile * (0.9 if ftile == 512 else 1.0)
+                if best is None or cost < best[0]:
+                    best = (cost, rows, ftile)
+        return best[1], best[2]
+
     def _dense_tile(self, layer, frames_out):
         """(row tile, frame tile) of the image-path fp16 GEMM for this launch.  Every tiling computes the same sums in the same order
         (results are bit-identical), so the choice is speed only: `_row_tile`'s whole-rounds model, overruled by the measured table
@@ -1145,7 +1163,8 @@ class ForwardPlan:
                 dst = 0 if cur != 0 else 1
                 t_out = self.block_frames[blk]
                 out = self._view16(dst, layer.conv.out_channels, t_out)
-                rows = self.dense_row_tiles[blk] = self._row_tile(layer.conv.out_channels, t_out, allow_64=False)      # (the one-term bf16 GEMM has 128 / 160)
+                rows, ftile = self._bf16_tile(layer.conv.out_channels, t_out, pipe)
+                self.dense_row_tiles[blk], self.dense_frame_tiles[blk] = rows, ftile
                 w = layer.conv.weight
                 packed = self._cached(w, ('bf16', rows, layer.strides),
                                       lambda: hip.pack_dense_weights_bf16(self._f32(w), layer.strides, rows))
@@ -1153,7 +1172,7 @@ class ForwardPlan:
                 self.dense_schemes[blk] = 'bf16'
                 self._timed('dense_conv', (blk, layer.conv.in_channels, layer.conv.out_channels, layer.kernel_size, t_out, 0),
                             lambda: hip.dense_conv1d_bf16_img(img_now, B, src_shape[1], frames_now, src_shape[2], packed,
-                                                              layer.conv.out_channels, layer.kernel_size, bias, out, layer.strides, rows))
+                                                              layer.conv.out_channels, layer.kernel_size, bias, out, layer.strides, rows, ftile))
                 act, act_frames, cur, image = out, t_out, dst, None
                 if taps is not None:
                     taps[idx] = act[:, :, :act_frames].clone()

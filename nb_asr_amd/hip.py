@@ -991,12 +991,12 @@ def pack_dense_weights_bf16(weight, stride, row_tile=128):
     return pack_dense_weights(weight, stride, 'bf16', row_tile)
 
 
-def dense_conv1d_bf16_img(image, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride, row_tile=128):
+def dense_conv1d_bf16_img(image, batch, c_in, frames_in, ld_in, packed, c_out, kernel, bias, y, stride, row_tile=128, frame_tile=256):
     _check_packed(packed, 'bf16', c_out, c_in, kernel, row_tile)
     if image.numel() < load_library().nbasr_bf16_image_bytes(batch, c_in, ld_in):
         raise HipError('image buffer too small for (batch, c_in, ld_in)')
     return _dense_packed('bf16', image.data_ptr(), True, None, None, packed, bias, (None, None, None), y, _act(y, 'y', torch.bfloat16), batch,
-                         c_in, frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y))
+                         c_in, frames_in, ld_in, c_out, kernel, stride, row_tile, None, _stream(y), None, frame_tile)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -148,6 +148,28 @@ class TestFullSize:
         truth = oracle.asr_forward(params, cases.ARCH_A, x[sel], use_rnn=True, dtype=torch.float64)
         cases.assert_parity(y[sel], want, truth, 'sampled utterances')
 
+    def test_pipelined_and_tape_replayed_routes_match_oracle(self, run):
+        """the routes bench.py times -- K back-to-back `forward_async` calls (the LSTM tail on the side stream, its
+        recurrence one launch per frame) and the launch-tape replay of the plain forward -- on the FULL-size workload, each against the
+        oracle on 8 of the 64 utterances, and bit-equal to the plain route (one arithmetic on every route)."""
+        m, x, y, _ = run
+        xd = x.to(DEV)
+        with torch.no_grad():
+            handles = [m.forward_async(xd) for _ in range(4)]           # the third and fourth are tape replays of the pipelined sequence
+            piped = [h.result().clone() for h in handles]
+            plain = [m(xd).clone() for _ in range(3)]                   # ... and these of the plain one
+        torch.cuda.synchronize()
+        m.check()
+        plan = m._plans.values()[-1]
+        assert plan.tape_replays >= 2
+        params = {k: v.cpu() for k, v in m.state_dict().items()}
+        sel = list(range(0, 64, 9))
+        want = oracle.asr_forward(params, cases.ARCH_A, x[sel], use_rnn=True)
+        truth = oracle.asr_forward(params, cases.ARCH_A, x[sel], use_rnn=True, dtype=torch.float64)
+        for name, out in (('pipelined', piped[-1]), ('tape replay', plain[-1])):
+            cases.assert_parity(out[sel], want, truth, f'sampled utterances, {name} route')
+        assert all(torch.equal(p, y) for p in piped) and all(torch.equal(p, y) for p in plain)
+
     def test_bounded_look_ahead(self, run):
         """Every conv looks at most `context` = 4 of ITS frames ahead (ops.py:8; 2 for the stride-2 downsample
         convs), LayerNorm is per frame and the LSTM is causal.  In input frames the encoder's total look-ahead
