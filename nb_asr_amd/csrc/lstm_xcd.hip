@@ -264,60 +264,81 @@ __device__ __forceinline__ int lx_publish_offset(int slice, int wave, int n16)
 // workgroups per frame (128 instead of 252 at 64 utterances).
 // WPB = row tiles (waves) per workgroup, 1, 2 or 4: the decomposition does not touch the arithmetic (a row tile is one wave's chain
 // whatever the workgroup) -- small batches take two-wave workgroups (63 per tile: the shortest frames), large ones four-wave workgroups
-// (32 per tile: the image is fetched once per four row tiles, the least work beside the encoder).
+// (32 per tile: the image is fetched once per four row tiles, the least work beside the encoder).  A workgroup CAN walk several utterance
+// tiles with one fetch of its weights (tiles_per_block); measured slower, see the launcher.
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void lstm_step16_kernel(
     const float* __restrict__ gates_in, const unsigned char* __restrict__ wp, float* __restrict__ cell, float* __restrict__ h_out,
-    unsigned char* tiles, int batch, int frames, int hidden, int t, int prio)
+    unsigned char* tiles, int batch, int frames, int hidden, int t, int prio, int tiles_per_block)
 {
+    constexpr int MAX_TPB = 4;                             // utterance tiles a workgroup walks with ONE fetch of its weights
     __shared__ xuint4 htile[LX_KSTEPS][2][64];
     if (prio) __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
     const int row_tile = blockIdx.x * WPB + wib;           // of the layer: 4 hidden units x 4 gates
     const int slice = row_tile >> 2, wave = row_tile & 3;  // as lstm_xcd_kernel names them (weights, image)
-    const int tile = blockIdx.y, b0 = tile * 16;
-    unsigned char* const tile_ws = tiles + static_cast<size_t>(tile) * LX_TILE_BYTES;
-    const int eu = row_tile * 4 + kq, eb = b0 + n16;
-    const bool e_ok = eu < hidden && eb < batch;
-    const size_t gate_off = static_cast<size_t>(min(eb, batch - 1)) * (4 * hidden) + min(eu, hidden - 1);
-    float pre[4];
+    const int n_tiles = (batch + 15) >> 4, tile0 = blockIdx.y * tiles_per_block;
+    const int eu = row_tile * 4 + kq;
+    const unsigned* const range = reinterpret_cast<const unsigned*>(tiles) - (LX_HEADER_WORDS - LX_W_RANGE);
+
+    // everything that comes from far away is requested first, for all of the workgroup's tiles: the gate pre-activations and the cell
+    // states (HBM / last-level cache), then the weights; the images follow tile by tile
+    float pre[MAX_TPB][4], c_prev[MAX_TPB];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) pre[g] = gates_in[static_cast<size_t>(t) * batch * (4 * hidden) + gate_off + g * hidden];
-    float c_state = (t > 0 && e_ok) ? cell[static_cast<size_t>(eb) * hidden + eu] : 0.f;
-    xfloat4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    float hs, hs_inv;
-    lx_h_scale((reinterpret_cast<const unsigned*>(tiles) - (LX_HEADER_WORDS - LX_W_RANGE))[min(eb, batch - 1)], hs, hs_inv);
-    const float inv = reinterpret_cast<const float*>(wp)[0] * hs_inv;
+    for (int k = 0; k < MAX_TPB; ++k) {
+        const int eb = (tile0 + k) * 16 + n16;
+        const bool live = k < tiles_per_block && tile0 + k < n_tiles;
+        const size_t gate_off = static_cast<size_t>(min(eb, batch - 1)) * (4 * hidden) + min(eu, hidden - 1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[k][g] = live ? gates_in[static_cast<size_t>(t) * batch * (4 * hidden) + gate_off + g * hidden] : 0.f;
+        c_prev[k] = (live && t > 0 && eu < hidden && eb < batch) ? cell[static_cast<size_t>(eb) * hidden + eu] : 0.f;
+    }
+    xuint4 wfrag[LX_KSTEPS][2];
     if (t > 0) {
-        const unsigned char* img = tile_ws + ((t - 1) & 1) * LX_IMAGE_BYTES;
-        // (columns of utterances beyond the batch are not fetched: nothing reads their sums, and a part-filled tile -- 8 utterances, one
-        // rank's share of the benchmark batch on 8 GPUs -- moves half the image)
-        if (eb < batch) {
-#pragma unroll
-            for (int j = 0; j < 32 / WPB; ++j) {
-                const int chunk = wib * (32 / WPB) + j;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + chunk * 1024 + lane * 16),
-                                                 (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(&htile[0][0][0]) + chunk * 1024), 16, 0, 0);
-            }
-        }
-        xuint4 wfrag[LX_KSTEPS][2];
         // (a row tile beyond the layer -- the grid is rounded up to whole workgroups -- reads the zero rows the packer wrote up to the slice's end,
         // or, past the last slice, the last slice's: its sums are never stored)
         const int wslice = min(slice, (hidden + LX_UNITS - 1) / LX_UNITS - 1);
         const xuint4* src = reinterpret_cast<const xuint4*>(wp + LX_PACK_HEADER_BYTES) + (static_cast<size_t>(wslice) * LX_WAVES + wave) * (LX_KSTEPS * 2 * 64) + lane;
 #pragma unroll
         for (int ks = 0; ks < LX_KSTEPS; ++ks) { wfrag[ks][0] = src[(ks * 2) * 64]; wfrag[ks][1] = src[(ks * 2 + 1) * 64]; }
-        __syncthreads();                                   // (drains this wave's transfers, then the whole image is in LDS)
-        lx_row_tile_product(htile, wfrag, lane, acc0, acc1);
     }
-    const xfloat4 s = (acc0 + acc1 * 0.00048828125f) * inv;
-    const float h_new = lx_cell_update(s, pre, c_state);
-    const bool q_ok = kq == 0 && row_tile * 4 < hidden && eb < batch;
-    lx_publish(lx_split_h(h_new, hs), n16, q_ok, tile_ws + (t & 1) * LX_IMAGE_BYTES + lx_publish_offset(slice, wave, n16));
-    if (e_ok) {
-        h_out[(static_cast<size_t>(eb) * frames + t) * hidden + eu] = h_new;
-        cell[static_cast<size_t>(eb) * hidden + eu] = c_state;
+    const float winv = reinterpret_cast<const float*>(wp)[0];
+#pragma unroll
+    for (int k = 0; k < MAX_TPB; ++k) {
+        const int tile = tile0 + k;
+        if (k >= tiles_per_block || tile >= n_tiles) break;                           // (workgroup-uniform)
+        unsigned char* const tile_ws = tiles + static_cast<size_t>(tile) * LX_TILE_BYTES;
+        const int eb = tile * 16 + n16;
+        const bool e_ok = eu < hidden && eb < batch;
+        float hs, hs_inv;
+        lx_h_scale(range[min(eb, batch - 1)], hs, hs_inv);
+        xfloat4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {
+            const unsigned char* img = tile_ws + ((t - 1) & 1) * LX_IMAGE_BYTES;
+            if (k > 0) __syncthreads();                    // every wave has read the previous tile's image
+            // (columns of utterances beyond the batch are not fetched: nothing reads their sums, and a part-filled tile -- 8 utterances, one
+            // rank's share of the benchmark batch on 8 GPUs -- moves half the image)
+            if (eb < batch) {
+#pragma unroll
+                for (int j = 0; j < 32 / WPB; ++j) {
+                    const int chunk = wib * (32 / WPB) + j;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(img + chunk * 1024 + lane * 16),
+                                                     (__attribute__((address_space(3))) void*)(reinterpret_cast<unsigned char*>(&htile[0][0][0]) + chunk * 1024), 16, 0, 0);
+                }
+            }
+            __syncthreads();                               // (drains this wave's transfers, then the whole image is in LDS)
+            lx_row_tile_product(htile, wfrag, lane, acc0, acc1);
+        }
+        const xfloat4 s = (acc0 + acc1 * 0.00048828125f) * (winv * hs_inv);
+        float c_state = c_prev[k];
+        const float h_new = lx_cell_update(s, pre[k], c_state);
+        const bool q_ok = kq == 0 && row_tile * 4 < hidden && eb < batch;
+        lx_publish(lx_split_h(h_new, hs), n16, q_ok, tile_ws + (t & 1) * LX_IMAGE_BYTES + lx_publish_offset(slice, wave, n16));
+        if (e_ok) {
+            h_out[(static_cast<size_t>(eb) * frames + t) * hidden + eu] = h_new;
+            cell[static_cast<size_t>(eb) * hidden + eu] = c_state;
+        }
     }
 }
 
@@ -582,26 +603,30 @@ extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void*
     // the images are zeroed by every call (a node of the cached graph): the rows of k beyond `hidden` and the columns beyond `batch` are
     // never written, and a NaN pattern left there by an earlier owner of the memory would turn 0 x NaN into NaN sums
     const size_t tiles_n = (batch + 15) / 16;
-    struct Ctx { hipStream_t s; const float* gates; const unsigned char* w; float* cell; float* h; unsigned char* tiles; size_t tiles_bytes; int batch, frames, hidden, prio, wpb; };
+    struct Ctx { hipStream_t s; const float* gates; const unsigned char* w; float* cell; float* h; unsigned char* tiles; size_t tiles_bytes; int batch, frames, hidden, prio, wpb, tpb; };
     Ctx ctx{as_stream(stream), gates_ws, static_cast<const unsigned char*>(packed_whh16), cell_ws, h_out,
             static_cast<unsigned char*>(xcd_ws) + LX_HEADER_WORDS * sizeof(unsigned), tiles_n * LX_TILE_BYTES, batch, frames, hidden, 1,
-            batch <= 32 ? 2 : 4};
+            batch <= 32 ? 2 : 4, 1};
+    // (tiles per workgroup, NBASR_LX_TPB: walking 2 / 4 utterance tiles with one fetch of the weights halves / quarters the bytes a frame
+    // moves, but a launch then lasts 2-4 x as long and the CHAIN becomes the critical path: 10 630 -> 10 150 -> 8 690 utterances/s at 64)
     // (same-box A/B of the shapes, pipelined utterances/s: 8 utterances 5 349 / 5 381 / - with 1 / 2 / 4 waves per workgroup, 16: 7 613 / 7 685 / 6 968,
     // 64: 9 871 / 10 299 / 10 413; issue priority for the chain's waves 10 413 -> 10 554 at 64, within noise below)
     if (const char* force = getenv("NBASR_LX_WPB")) ctx.wpb = (force[0] == '1') ? 1 : (force[0] == '2') ? 2 : 4;      // (A/B hook; every form gives the same bits)
     if (const char* force = getenv("NBASR_LX_PRIO")) ctx.prio = force[0] == '1';
-    const ChainKey key{{gates_ws, packed_whh16, cell_ws, h_out, xcd_ws}, {batch, frames, hidden, 16, ctx.wpb}};
+    if (const char* force = getenv("NBASR_LX_TPB")) ctx.tpb = std::min(std::max(atoi(force), 1), 4);
+    const ChainKey key{{gates_ws, packed_whh16, cell_ws, h_out, xcd_ws}, {batch, frames, hidden, 16, ctx.wpb * 8 + ctx.tpb}};
     return replay_chain(ctx.s, key, "nbasr_lstm_recurrence_frames16", [](void* p) {
         const Ctx& c = *static_cast<const Ctx*>(p);
         unsigned* const range = reinterpret_cast<unsigned*>(c.tiles) - (LX_HEADER_WORDS - LX_W_RANGE);
         (void)hipMemsetAsync(range, 0, (LX_HEADER_WORDS - LX_W_RANGE) * sizeof(unsigned) + c.tiles_bytes, c.s);      // the range words + the images
         hipLaunchKernelGGL(lx_gate_range_kernel, dim3(std::min(c.frames, 64), c.batch), dim3(256), 0, c.s, c.gates, range, c.batch, c.frames, 4 * c.hidden);
         const int row_tiles = (c.hidden + 3) / 4;
-        const dim3 grid((row_tiles + c.wpb - 1) / c.wpb, (c.batch + 15) / 16);
+        const int n_tiles = (c.batch + 15) / 16;
+        const dim3 grid((row_tiles + c.wpb - 1) / c.wpb, (n_tiles + c.tpb - 1) / c.tpb);
         for (int t = 0; t < c.frames; ++t) {
-            if (c.wpb == 1) hipLaunchKernelGGL(lstm_step16_kernel<1>, grid, dim3(64), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
-            else if (c.wpb == 2) hipLaunchKernelGGL(lstm_step16_kernel<2>, grid, dim3(128), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
-            else hipLaunchKernelGGL(lstm_step16_kernel<4>, grid, dim3(256), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio);
+            if (c.wpb == 1) hipLaunchKernelGGL(lstm_step16_kernel<1>, grid, dim3(64), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio, c.tpb);
+            else if (c.wpb == 2) hipLaunchKernelGGL(lstm_step16_kernel<2>, grid, dim3(128), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio, c.tpb);
+            else hipLaunchKernelGGL(lstm_step16_kernel<4>, grid, dim3(256), 0, c.s, c.gates, c.w, c.cell, c.h, c.tiles, c.batch, c.frames, c.hidden, t, c.prio, c.tpb);
         }
     }, &ctx);
 }
