@@ -167,18 +167,29 @@ __global__ __launch_bounds__(256) void lx_pack_kernel(const float* __restrict__ 
 // utterance of ordinary size (gmax >= 2^-8: every trained or He-initialised model) gets k = 0 and bits as without the scaling.
 __global__ __launch_bounds__(256) void lx_gate_range_kernel(const float* __restrict__ gates, unsigned* __restrict__ range, int batch, int frames, int row)
 {
-    const int b = blockIdx.y;
+    // a workgroup = one utterance x 8 frames; a thread's loads of the 8 frames are independent (all in flight together): the pass is one
+    // read of the gate tensor at memory speed (first version, a loop over frames with two loads in flight per thread: 1.6 TB/s)
+    const int b = blockIdx.y, t0 = blockIdx.x * 8, nq = row >> 2;
     float m = 0.f;
-    for (int t = blockIdx.x; t < frames; t += gridDim.x) {
-        const float4* p = reinterpret_cast<const float4*>(gates + (static_cast<size_t>(t) * batch + b) * row);
-        for (int i = threadIdx.x; i < row / 4; i += blockDim.x) {
-            const float4 v = p[i];
-            m = fmaxf(fmaxf(m, fmaxf(finite_abs(v.x), finite_abs(v.y))), fmaxf(finite_abs(v.z), finite_abs(v.w)));
+    for (int i = threadIdx.x; i < nq; i += blockDim.x) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int t = min(t0 + j, frames - 1);
+            v[j] = reinterpret_cast<const float4*>(gates + (static_cast<size_t>(t) * batch + b) * row)[i];
         }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = fmaxf(fmaxf(m, fmaxf(finite_abs(v[j].x), finite_abs(v[j].y))), fmaxf(finite_abs(v[j].z), finite_abs(v[j].w)));
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(range + b, __float_as_uint(m));
+    __shared__ float s_m[4];
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+        if (m > 0.f) atomicMax(range + b, __float_as_uint(m));
+    }
 }
 // (2^k, 2^-k) from the range word
 __device__ __forceinline__ void lx_h_scale(unsigned range_bits, float& hs, float& hs_inv)
@@ -619,7 +630,7 @@ extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void*
         const Ctx& c = *static_cast<const Ctx*>(p);
         unsigned* const range = reinterpret_cast<unsigned*>(c.tiles) - (LX_HEADER_WORDS - LX_W_RANGE);
         (void)hipMemsetAsync(range, 0, (LX_HEADER_WORDS - LX_W_RANGE) * sizeof(unsigned) + c.tiles_bytes, c.s);      // the range words + the images
-        hipLaunchKernelGGL(lx_gate_range_kernel, dim3(std::min(c.frames, 64), c.batch), dim3(256), 0, c.s, c.gates, range, c.batch, c.frames, 4 * c.hidden);
+        hipLaunchKernelGGL(lx_gate_range_kernel, dim3((c.frames + 7) / 8, c.batch), dim3(256), 0, c.s, c.gates, range, c.batch, c.frames, 4 * c.hidden);
         const int row_tiles = (c.hidden + 3) / 4;
         const int n_tiles = (c.batch + 15) / 16;
         const dim3 grid((row_tiles + c.wpb - 1) / c.wpb, (n_tiles + c.tpb - 1) / c.tpb);
@@ -679,7 +690,7 @@ extern "C" int nbasr_lstm_recurrence_xcd(const float* gates_ws, const void* pack
     if (e == hipSuccess) e = hipMemsetAsync(xcd_ws, 0, ws_bytes, as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_xcd: %s", hipGetErrorString(e)); return static_cast<int>(e); }
     const int n_tiles = (batch + 15) / 16;
-    hipLaunchKernelGGL(lx_gate_range_kernel, dim3(std::min(frames, 64), batch), dim3(256), 0, as_stream(stream), gates_ws,
+    hipLaunchKernelGGL(lx_gate_range_kernel, dim3((frames + 7) / 8, batch), dim3(256), 0, as_stream(stream), gates_ws,
                        static_cast<unsigned*>(xcd_ws) + LX_W_RANGE, batch, frames, 4 * hidden);
     hipLaunchKernelGGL(lstm_xcd_kernel, dim3(grid), dim3(64 * LX_WAVES), 0, as_stream(stream), gates_ws, static_cast<const unsigned char*>(packed_whh16),
                        cell_ws, h_out, static_cast<unsigned*>(xcd_ws), batch, frames, hidden, lx_slices(hidden), n_tiles, grid, flags);

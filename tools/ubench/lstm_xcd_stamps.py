@@ -29,7 +29,7 @@ points, nfr = 8, 256
 n_tiles = (b + 15) // 16
 tail = ws[ws.numel() - 32 * nfr * points * 8:].view(torch.int64).view(32, nfr, points).cpu().double()
 st = tail[:, 20:240]                                       # steady state
-names = ["own flags polled (top -> set)", "DMA of the quarter landed", "gate loads + own 12 MFMAs + barrier", "36 MFMAs + sums", "gate math", "h split, gather, stores drained, flag", "h_out store + shift"]
+names = ["flags polled (top -> all set)", "DMA of the quarter landed", "barrier", "gate loads issued + 48 MFMAs + sums", "gate math", "h split, gather, stores drained, flag", "h_out store + shift"]
 d = st[:, :, 1:] - st[:, :, :-1]
 period = (st[:, 1:, 0] - st[:, :-1, 0]).mean()
 print(f'batch {b}: frame period {period:.0f} cycles (shader clock)')
