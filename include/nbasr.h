@@ -124,7 +124,9 @@ int nbasr_dense_conv1d_fused(const float* x, const float* w, const float* bias,
  *     workgroup.  Results are bit-identical between tiles: the K order of every output is the same.
  * NBASR_DENSE_BF16    the bf16 storage path (BASELINE config 4): ONE v_mfma_f32_16x16x32_bf16 per 32 products, fp32 accumulation,
  *     bias + relu + min(20) in fp32, one rounding to the bf16 output y (ld_out % 8 == 0).  x: nbasr_bf16_image's operand image
- *     (x_is_image = 1); weights: the fp32 values of the bf16 parameter; row_tile 128 or 160; no bound, range, LayerNorm or skips.
+ *     (x_is_image = 1); weights: the fp32 values of the bf16 parameter; row_tile 128 or 160; frame_tile 256 or (ABI 6) 512 -- this
+ *     flavour is bound by LDS fragment reads and a 512-frame tile re-uses a weight fragment 8 times instead of 4; bit-identical
+ *     results; no bound, range, LayerNorm or skips.
  *
  * Per-utterance routing of caller data (x_range != NULL in place of x_absmax; the model input, whose range this library does not
  * control): nbasr_input_range writes, per utterance, range[4 b] = { max finite |x|, the quietest non-silent frame's max |x| over
