@@ -501,7 +501,8 @@ int nbasr_conv_fold(const float* cols, float* dx, int batch, int c_in, int frame
  *                              overwritten by the gate activations, cells (H, T, ldb) <- c_t
  *   nbasr_lstm_backward_step   frame t of the reverse recurrence: dh_out (H, T, ldb) = dL/d(output), w_hh_t (H, 4H) the transposed recurrent
  *                              weight (the term w_hh^T . dpre[:, t+1, :] is formed in the kernel), dc (H, ldb) the carried dL/dc_t ->
- *                              dpre[:, t, :] and the new carry; call for t = T-1 .. 0
+ *                              dpre[:, t, :] and the new carry; call for t = T-1 .. 0, or ONCE with t = -1: all frames T-1 .. 0 as one
+ *                              chain of launches (ABI 6), replayed as a cached graph where the call recurs with the same buffers
  * The GEMMs in between (nbasr_pointwise_linear) and the orchestration are in nb_asr_amd/autograd.py. */
 int nbasr_lstm_gate_scan(float* pre, float* cells, int hidden, int frames, int batch, int ldb, nbasr_stream_t stream);
 int nbasr_lstm_backward_step(const float* dh_out, const float* w_hh_t, float* dc, const float* acts, const float* cells, float* dpre,

@@ -685,9 +685,22 @@ extern "C" int nbasr_lstm_backward_step(const float* dh_out, const float* w_hh_t
                                         int hidden, int frames, int batch, int ldb, int t, nbasr_stream_t stream)
 {
     clear_error();
-    NBASR_REQUIRE(hidden > 0 && frames > 0 && batch > 0 && ldb >= batch && t >= 0 && t < frames, NBASR_EINVAL, "nbasr_lstm_backward_step: bad sizes");
+    NBASR_REQUIRE(hidden > 0 && frames > 0 && batch > 0 && ldb >= batch && t >= -1 && t < frames, NBASR_EINVAL, "nbasr_lstm_backward_step: bad sizes");
     NBASR_REQUIRE(dh_out && w_hh_t && dc && acts && cells && dpre, NBASR_ENULL, "nbasr_lstm_backward_step: NULL pointer");
     NBASR_REQUIRE(hidden % LSTM_BW_UNITS == 0 && hidden / LSTM_BW_UNITS <= 65535, NBASR_EINVAL, "nbasr_lstm_backward_step: hidden %d (a multiple of 4, at most 262140)", hidden);
+    if (t == -1) {
+        // the whole reverse recurrence, frames T-1 .. 0, as one chain of launches (round 6: the trainer's step issued them from a python
+        // loop); replayed as one cached graph where the same buffers recur (common.h)
+        struct Ctx { hipStream_t s; const float* dh; const float* w; float* dc; const float* acts; const float* cells; float* dpre; int hidden, frames, batch, ldb; };
+        Ctx ctx{as_stream(stream), dh_out, w_hh_t, dc, acts, cells, dpre, hidden, frames, batch, ldb};
+        const ChainKey key{{dh_out, w_hh_t, dc, acts, dpre}, {hidden, frames, batch, ldb, -32}};
+        return replay_chain(ctx.s, key, "nbasr_lstm_backward_step", [](void* p) {
+            const Ctx& c = *static_cast<const Ctx*>(p);
+            for (int u = c.frames - 1; u >= 0; --u)
+                hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((c.ldb + 63) / 64, c.hidden / LSTM_BW_UNITS), dim3(64 * LSTM_BW_SLICES), 0, c.s, c.dh, c.w, c.dc, c.acts,
+                                   c.cells, c.dpre, c.hidden, c.frames, c.batch, c.ldb, u);
+        }, &ctx);
+    }
     hipLaunchKernelGGL(lstm_backward_step_kernel, dim3((ldb + 63) / 64, hidden / LSTM_BW_UNITS), dim3(64 * LSTM_BW_SLICES), 0, as_stream(stream), dh_out, w_hh_t, dc, acts, cells, dpre,
                        hidden, frames, batch, ldb, t);
     return launch_status("nbasr_lstm_backward_step");

@@ -1179,9 +1179,9 @@ def lstm_backward(xp, frames, gates, h_out, w_ih, w_hh, dh_out):
     dpre = torch.empty(g4, t_n, ldb, device=dev, dtype=f32)
     dc = torch.zeros(hidden, ldb, device=dev, dtype=f32)
     w_hh_t = w_hh.detach().t().contiguous()                    # (H, 4H)
-    for t in range(t_n - 1, -1, -1):
-        _check(lib.nbasr_lstm_backward_step(_dev(dho, 'dho'), _dev(w_hh_t, 'w_hh_t'), _dev(dc, 'dc'), _dev(acts, 'acts'), _dev(cells, 'cells'),
-                                            _dev(dpre, 'dpre'), hidden, t_n, b, ldb, t, stream), 'nbasr_lstm_backward_step')
+    # (t = -1: the whole reverse recurrence, frames T-1 .. 0, in one call -- round 6; rounds 2-5 issued the frames from a python loop)
+    _check(lib.nbasr_lstm_backward_step(_dev(dho, 'dho'), _dev(w_hh_t, 'w_hh_t'), _dev(dc, 'dc'), _dev(acts, 'acts'), _dev(cells, 'cells'),
+                                        _dev(dpre, 'dpre'), hidden, t_n, b, ldb, -1, stream), 'nbasr_lstm_backward_step')
     d2 = dpre.view(g4, n)
     ldc = round_up4(c + 1)
     if split:
