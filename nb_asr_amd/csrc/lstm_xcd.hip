@@ -284,7 +284,10 @@ __global__ __launch_bounds__(64 * WPB) void lstm_step16_kernel(
 {
     constexpr int MAX_TPB = 4;                             // utterance tiles a workgroup walks with ONE fetch of its weights
     __shared__ xuint4 htile[LX_KSTEPS][2][64];
-    if (prio) __builtin_amdgcn_s_setprio(3);
+    if (prio & 1) __builtin_amdgcn_s_setprio(3);
+#ifdef NBASR_LX_TAIL_EXPERIMENT        // (tools/ubench/tail_cost.py --what: timing only, wrong results)
+    if (prio & 4) return;                                  // the launches alone
+#endif
     const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n16 = lane & 15, kq = lane >> 4;
     const int row_tile = blockIdx.x * WPB + wib;           // of the layer: 4 hidden units x 4 gates
@@ -306,6 +309,12 @@ __global__ __launch_bounds__(64 * WPB) void lstm_step16_kernel(
         c_prev[k] = (live && t > 0 && eu < hidden && eb < batch) ? cell[static_cast<size_t>(eb) * hidden + eu] : 0.f;
     }
     xuint4 wfrag[LX_KSTEPS][2];
+#ifdef NBASR_LX_TAIL_EXPERIMENT
+    if (prio & 2) {                                        // no weight fetch
+#pragma unroll
+        for (int ks = 0; ks < LX_KSTEPS; ++ks) { wfrag[ks][0] = xuint4{0, 0, 0, 0}; wfrag[ks][1] = xuint4{0, 0, 0, 0}; }
+    } else
+#endif
     if (t > 0) {
         // (a row tile beyond the layer -- the grid is rounded up to whole workgroups -- reads the zero rows the packer wrote up to the slice's end,
         // or, past the last slice, the last slice's: its sums are never stored)
@@ -621,9 +630,10 @@ extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void*
     // (tiles per workgroup, NBASR_LX_TPB: walking 2 / 4 utterance tiles with one fetch of the weights halves / quarters the bytes a frame
     // moves, but a launch then lasts 2-4 x as long and the CHAIN becomes the critical path: 10 630 -> 10 150 -> 8 690 utterances/s at 64)
     // (same-box A/B of the shapes, pipelined utterances/s: 8 utterances 5 349 / 5 381 / - with 1 / 2 / 4 waves per workgroup, 16: 7 613 / 7 685 / 6 968,
-    // 64: 9 871 / 10 299 / 10 413; issue priority for the chain's waves 10 413 -> 10 554 at 64, within noise below)
+    // 64: 9 871 / 10 299 / 10 413 (8 waves: 8 800 -- a 512-thread workgroup finds no room beside the encoder's); issue priority for the
+    // chain's waves 10 413 -> 10 554 at 64, within noise below)
     if (const char* force = getenv("NBASR_LX_WPB")) ctx.wpb = (force[0] == '1') ? 1 : (force[0] == '2') ? 2 : 4;      // (A/B hook; every form gives the same bits)
-    if (const char* force = getenv("NBASR_LX_PRIO")) ctx.prio = force[0] == '1';
+    if (const char* force = getenv("NBASR_LX_PRIO")) ctx.prio = atoi(force);
     if (const char* force = getenv("NBASR_LX_TPB")) ctx.tpb = std::min(std::max(atoi(force), 1), 4);
     const ChainKey key{{gates_ws, packed_whh16, cell_ws, h_out, xcd_ws}, {batch, frames, hidden, 16, ctx.wpb * 8 + ctx.tpb}};
     return replay_chain(ctx.s, key, "nbasr_lstm_recurrence_frames16", [](void* p) {

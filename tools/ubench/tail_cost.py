@@ -20,7 +20,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument('--skip', action='store_true')
 ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=30)
+ap.add_argument('--lib', default=None, help='another build of the library (the -DNBASR_LX_TAIL_EXPERIMENT=1 twin: NBASR_LX_PRIO=3 no weight fetch, 5 empty launches)')
 a = ap.parse_args()
+if a.lib:
+    from nb_asr_amd import hip as _hip
+    _hip.LIB_PATH = pathlib.Path(a.lib).resolve()
 if a.skip:
     executor.ForwardPlan._recurrence = lambda self, *args, **kw: None
 dev = torch.device('cuda', 0)
