@@ -223,15 +223,79 @@ __device__ __forceinline__ void conv_taps(cell_f2 (&acc)[CG / 2][4], cell_cptr w
     }
 }
 
+// Round 6 -- a wave that computes only CH of the group's CG output channels (the output-channel split of small batches, see the
+// kernel): of every (input channel, tap) it needs CH consecutive weights out of CG, i.e. K pieces at a pitch of CG floats.  All K
+// taps of an input channel are requested by one statement and waited for once, like WeightBatch (K * CH <= 42 scalars).
+template <int K, int CH, int CG>
+struct StridedBatch {
+    static_assert((CH == 6 && CG == 12) || (CH == 4 && CG == 8), "output-channel halves: 6 of 12 or 4 of 8");
+    static_assert(K == 5 || K == 7, "5 or 7 taps");
+    cell_f4 a[K]; cell_f2 b[K];                              // tap j: channels 0-3 in a[j], 4-5 (CH == 6) in b[j]
+    __device__ __forceinline__ cell_f2 pair(int i) const     // output channels (2 pp, 2 pp + 1) of tap jj; i = jj * (CH / 2) + pp
+    {
+        const int jj = i / (CH / 2), pp = i % (CH / 2);
+        return pp < 2 ? cell_f2{a[jj][2 * pp], a[jj][2 * pp + 1]} : b[jj];
+    }
+    __device__ __forceinline__ void load(cell_cptr p)
+    {
+#define A_(j) [a##j] "=&s"(a[j])
+#define B_(j) [b##j] "=&s"(b[j])
+        if constexpr (CH == 6 && K == 5)
+            asm volatile("s_load_dwordx4 %[a0], %[p], 0x0\n\ts_load_dwordx2 %[b0], %[p], 0x10\n\ts_load_dwordx4 %[a1], %[p], 0x30\n\ts_load_dwordx2 %[b1], %[p], 0x40\n\t"
+                         "s_load_dwordx4 %[a2], %[p], 0x60\n\ts_load_dwordx2 %[b2], %[p], 0x70\n\ts_load_dwordx4 %[a3], %[p], 0x90\n\ts_load_dwordx2 %[b3], %[p], 0xa0\n\t"
+                         "s_load_dwordx4 %[a4], %[p], 0xc0\n\ts_load_dwordx2 %[b4], %[p], 0xd0\n\ts_waitcnt lgkmcnt(0)"
+                         : A_(0), B_(0), A_(1), B_(1), A_(2), B_(2), A_(3), B_(3), A_(4), B_(4) : [p] "s"(p));
+        if constexpr (CH == 6 && K == 7)
+            asm volatile("s_load_dwordx4 %[a0], %[p], 0x0\n\ts_load_dwordx2 %[b0], %[p], 0x10\n\ts_load_dwordx4 %[a1], %[p], 0x30\n\ts_load_dwordx2 %[b1], %[p], 0x40\n\t"
+                         "s_load_dwordx4 %[a2], %[p], 0x60\n\ts_load_dwordx2 %[b2], %[p], 0x70\n\ts_load_dwordx4 %[a3], %[p], 0x90\n\ts_load_dwordx2 %[b3], %[p], 0xa0\n\t"
+                         "s_load_dwordx4 %[a4], %[p], 0xc0\n\ts_load_dwordx2 %[b4], %[p], 0xd0\n\ts_load_dwordx4 %[a5], %[p], 0xf0\n\ts_load_dwordx2 %[b5], %[p], 0x100\n\t"
+                         "s_load_dwordx4 %[a6], %[p], 0x120\n\ts_load_dwordx2 %[b6], %[p], 0x130\n\ts_waitcnt lgkmcnt(0)"
+                         : A_(0), B_(0), A_(1), B_(1), A_(2), B_(2), A_(3), B_(3), A_(4), B_(4), A_(5), B_(5), A_(6), B_(6) : [p] "s"(p));
+        if constexpr (CH == 4 && K == 5)
+            asm volatile("s_load_dwordx4 %[a0], %[p], 0x0\n\ts_load_dwordx4 %[a1], %[p], 0x20\n\ts_load_dwordx4 %[a2], %[p], 0x40\n\ts_load_dwordx4 %[a3], %[p], 0x60\n\t"
+                         "s_load_dwordx4 %[a4], %[p], 0x80\n\ts_waitcnt lgkmcnt(0)"
+                         : A_(0), A_(1), A_(2), A_(3), A_(4) : [p] "s"(p));
+        if constexpr (CH == 4 && K == 7)
+            asm volatile("s_load_dwordx4 %[a0], %[p], 0x0\n\ts_load_dwordx4 %[a1], %[p], 0x20\n\ts_load_dwordx4 %[a2], %[p], 0x40\n\ts_load_dwordx4 %[a3], %[p], 0x60\n\t"
+                         "s_load_dwordx4 %[a4], %[p], 0x80\n\ts_load_dwordx4 %[a5], %[p], 0xa0\n\ts_load_dwordx4 %[a6], %[p], 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                         : A_(0), A_(1), A_(2), A_(3), A_(4), A_(5), A_(6) : [p] "s"(p));
+#undef A_
+#undef B_
+    }
+};
+
+// all K taps of one input channel for a wave's CH output channels (wt: [tap][CG], already at the wave's first channel)
+template <int CG, int CH, int K, int D>
+__device__ __forceinline__ void conv_taps_strided(cell_f2 (&acc)[CH / 2][4], cell_cptr wt, const cell_f4 (&xq)[Win<K, D>::NCH])
+{
+    using W = Win<K, D>;
+    StridedBatch<K, CH, CG> wb;
+    wb.load(wt);
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+#pragma unroll
+        for (int p = 0; p < CH / 2; ++p) {
+            const cell_f2 wv = wb.pair(j * (CH / 2) + p);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int e = W::BASE + r + j * D;
+                const cell_f2 xp = {xq[e / 4][(e & 3) & ~1], xq[e / 4][(e & 3) | 1]};
+                if (e & 1) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc[p][r]) : "s"(wv), "v"(xp));
+                else       asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc[p][r]) : "s"(wv), "v"(xp));
+            }
+        }
+    }
+}
+
 // acc = bias + conv over one group's CG input channels, the input read from this group's LDS tile (row pitch rl floats; a lane's own
-// chunk of channel ci at row[ci * rl + 4 * col]).  acc[p][r] = output channels (2p, 2p + 1) at the lane's frame r;
-// wg = this group's weights as [ci][tap][co]
-template <int CG, int K, int D>
-__device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CG / 2][4], cell_cptr wg, cell_cptr bg, const float* tile, int rl, int col)
+// chunk of channel ci at row[ci * rl + 4 * col]).  acc[p][r] = output channels (2p, 2p + 1) of the wave's CH at the lane's frame r;
+// wg = this group's weights as [ci][tap][co], bg its bias, both already at the wave's first output channel (CH == CG: the whole group)
+template <int CG, int CH, int K, int D>
+__device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CH / 2][4], cell_cptr wg, cell_cptr bg, const float* tile, int rl, int col)
 {
     using W = Win<K, D>;
 #pragma unroll
-    for (int p = 0; p < CG / 2; ++p) {
+    for (int p = 0; p < CH / 2; ++p) {
         const cell_f2 bv = {bg[2 * p], bg[2 * p + 1]};
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[p][r] = bv;
@@ -247,6 +311,8 @@ __device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CG / 2][4], cell_c
 #pragma unroll
         for (int c = 0; c < W::NCH; ++c) xq[c] = *reinterpret_cast<const cell_f4*>(win + ci * rl + 4 * c);
         const cell_cptr wc = wg + ci * (K * CG);
+        if constexpr (CH != CG) conv_taps_strided<CG, CH, K, D>(acc, wc, xq);
+        else {
         conv_taps<CG, K, D, 0, (TB < K ? TB : K)>(acc, wc, xq);
         if constexpr (NB >= 2) {
             __builtin_amdgcn_sched_barrier(0);      // (this batch's loads stay behind the previous batch's FMAs)
@@ -255,6 +321,7 @@ __device__ __forceinline__ void conv_from_tile(cell_f2 (&acc)[CG / 2][4], cell_c
         if constexpr (NB >= 3) {
             __builtin_amdgcn_sched_barrier(0);
             conv_taps<CG, K, D, 2 * TB, K - 2 * TB>(acc, wc + 2 * TB * CG, xq);
+        }
         }
     }
 }
@@ -292,16 +359,26 @@ __device__ __forceinline__ uintptr_t cell_arg()
     return (static_cast<uint64_t>(hi) << 32) | lo;
 }
 
-template <typename T, int CG, bool KEEP1, int NTB, int GPW>
-__global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const CellArgs<T> A)
+// OS (round 6): waves per (group, row tile) -- 2 = the output channels of a group split over two waves (CG 12 -> 6 + 6, 8 -> 4 + 4).
+// At 8-16 utterances a one-wave row in block 3 leaves the chip with less than one wave per SIMD, and a wave's life is one dependent
+// chain of LDS windows and FMAs; two waves per row halve the FMAs of each (both still read every input channel's window).  Every
+// output channel's sum is formed by one wave in the same order as before and the statistics are taken over all CG channels in channel
+// order by the first wave of the pair (the second hands its x3 over through the tile): bit-identical to OS = 1.
+template <typename T, int CG, bool KEEP1, int NTB, int GPW, int OS = 1>
+__global__ __launch_bounds__(64 * GPW * NTB * OS) void grouped_cell_kernel(const CellArgs<T> A)
 {
+    constexpr int CH = CG / OS;                              // output channels of this wave
+    static_assert(CG % OS == 0 && CH % 2 == 0, "a wave's output channels come in pairs");
     extern __shared__ __attribute__((aligned(16))) float cell_tiles[];
     const CellDims& a = A.a;
     const int nt = a.nt;
     const int nq = a.ld >> 2;                                // chunks of a row
     const int rl = (a.rowq + a.padl + a.padr) * 4;           // tile row length in floats
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_raw = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int oh = OS > 1 ? wave_raw % OS : 0;               // which part of the output channels (neighbouring waves: different SIMDs)
+    const int c_base = oh * CH;                              // this wave's first channel within the group
+    const int wave = wave_raw / OS;
     const int gi = wave / nt, ti = wave - gi * nt;           // group within the quad, tile within the row
     float* const tile = cell_tiles + gi * (CG * rl);         // this group's tile: [CG][rl]
 
@@ -385,25 +462,26 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     // between the phases of a node: the nt waves of a group row read each other's halo chunks, so they meet at a workgroup barrier;
     // a one-wave row (NTB == 1) is wave-private -- LDS operations of one wave execute in order -- and its waves run free
     auto phase_sync = [&]() {
-        if constexpr (NTB > 1) __syncthreads();
+        if constexpr (NTB > 1 || OS > 1) __syncthreads();
         else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
-    cell_f2 acc[CG / 2][4];                         // the convolution's accumulators: output channels (2p, 2p + 1) at frame r
-    float out[CG][4];                               // a node's finished output (after the epilogue): channel co at frame r
-    float keep1[KEEP1 ? CG : 1][4];
+    cell_f2 acc[CH / 2][4];                         // the convolution's accumulators: this wave's output channels (2p, 2p + 1) at frame r
+    float out[CH][4];                               // a node's finished output (after the epilogue): channel c_base + c at frame r
+    float keep1[KEEP1 ? CH : 1][4];
 
     // ---- the cell input: own chunks of all CG channels (all loads in flight together), normalised once, into the tile ------------
     {
         const T* __restrict__ xg = A.x0 + row0;
 #pragma unroll
-        for (int ci = 0; ci < CG; ++ci) {
-            const float4 v = x0_raw(xg, ci);
-            out[ci][0] = v.x; out[ci][1] = v.y; out[ci][2] = v.z; out[ci][3] = v.w;
+        for (int c = 0; c < CH; ++c) {              // (OS > 1: each wave of the pair brings in its own channels)
+            const float4 v = x0_raw(xg, c_base + c);
+            out[c][0] = v.x; out[c][1] = v.y; out[c][2] = v.z; out[c][3] = v.w;
         }
 #pragma unroll
-        for (int ci = 0; ci < CG; ++ci) {
-            const float4 v = normalise(make_float4(out[ci][0], out[ci][1], out[ci][2], out[ci][3]), ci, A.ln_gamma, A.ln_beta);
+        for (int c = 0; c < CH; ++c) {
+            const int ci = c_base + c;
+            const float4 v = normalise(make_float4(out[c][0], out[c][1], out[c][2], out[c][3]), ci, A.ln_gamma, A.ln_beta);
             float o[4] = {v.x, v.y, v.z, v.w};
             if (has_ln) mask_tail(o);               // (beta, not 0, beyond the row otherwise)
             if (q < a.rowq) *reinterpret_cast<cell_f4*>(tile + ci * rl + 4 * col) = cell_f4{o[0], o[1], o[2], o[3]};   // (a tile row ends with the row's last chunk + pads)
@@ -417,7 +495,7 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     auto conv = [&](auto kc, auto dc, const float* w, const float* bias) {
         constexpr int K = decltype(kc)::value, D = decltype(dc)::value;
-        conv_from_tile<CG, K, D>(acc, cell_const(w) + static_cast<size_t>(g) * (CG * CG * K), cell_const(bias) + g * CG, tile, rl, col);
+        conv_from_tile<CG, CH, K, D>(acc, cell_const(w) + static_cast<size_t>(g) * (CG * CG * K) + c_base, cell_const(bias) + g * CG + c_base, tile, rl, col);
     };
 #define NBASR_KD_SWITCH(kd, W_, B_)                                                                    \
     switch (kd) {                                                                                      \
@@ -426,23 +504,23 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     }
     auto tile_write = [&]() {                       // the node output in `out` becomes the next node's input
 #pragma unroll
-        for (int co = 0; co < CG; ++co)
-            if (q < a.rowq) *reinterpret_cast<cell_f4*>(tile + co * rl + 4 * col) = cell_f4{out[co][0], out[co][1], out[co][2], out[co][3]};
+        for (int c = 0; c < CH; ++c)
+            if (q < a.rowq) *reinterpret_cast<cell_f4*>(tile + (c_base + c) * rl + 4 * col) = cell_f4{out[c][0], out[c][1], out[c][2], out[c][3]};
     };
 
     // ---- node 0: x1 = op0(x0n) + s00 x0n (x0n read back from the tile) -------------------------------------------------------------
     NBASR_KD_SWITCH(a.kd0, A.w0, A.b0)
     stamp();
 #pragma unroll
-    for (int co = 0; co < CG; ++co) {
+    for (int c = 0; c < CH; ++c) {
         float o[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co >> 1][r][co & 1]);
-        if (a.skips & 1) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
+        for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[c >> 1][r][c & 1]);
+        if (a.skips & 1) { const float4 v = tile_own(c_base + c); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
         mask_tail(o);
         cell_round<T>(o);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { out[co][r] = o[r]; if (KEEP1) keep1[KEEP1 ? co : 0][r] = o[r]; }
+        for (int r = 0; r < 4; ++r) { out[c][r] = o[r]; if (KEEP1) keep1[KEEP1 ? c : 0][r] = o[r]; }
     }
     phase_sync();                                   // every read of x0n is done
     tile_write();
@@ -462,25 +540,26 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
         const T* __restrict__ xg = nullptr; const float* __restrict__ gamma = nullptr; const float* __restrict__ beta = nullptr;
         if (s10) { xg = NBASR_CELL_ARG(T, x0) + row0; if (has_ln) { gamma = NBASR_CELL_ARG(T, ln_gamma); beta = NBASR_CELL_ARG(T, ln_beta); } }
 #pragma unroll
-        for (int c0 = 0; c0 < CG; c0 += 4) {
+        for (int c0 = 0; c0 < CH; c0 += 4) {
             float4 u[4];
             if (s10) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(xg, c0 + c);
+                for (int c = 0; c < 4; ++c) if (c0 + c < CH) u[c] = x0_raw(xg, c_base + c0 + c);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int co = c0 + c;
-                if (co >= CG) break;
+                const int cl = c0 + c;                  // channel within this wave's CH; co within the group
+                if (cl >= CH) break;
+                const int co = c_base + cl;
                 float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co >> 1][r][co & 1]);
+                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[cl >> 1][r][cl & 1]);
                 if (s10) { const float4 v = normalise(u[c], co, gamma, beta); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
                 if (a.skips & 4) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
                 mask_tail(o);
                 cell_round<T>(o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[co][r] = o[r];
+                for (int r = 0; r < 4; ++r) out[cl][r] = o[r];
             }
         }
     }
@@ -504,31 +583,32 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
         const T* __restrict__ xg = nullptr; const float* __restrict__ gamma = nullptr; const float* __restrict__ beta = nullptr;
         if (s20) { xg = NBASR_CELL_ARG(T, x0) + row0; if (has_ln) { gamma = NBASR_CELL_ARG(T, ln_gamma); beta = NBASR_CELL_ARG(T, ln_beta); } }
 #pragma unroll
-        for (int c0 = 0; c0 < CG; c0 += 4) {
+        for (int c0 = 0; c0 < CH; c0 += 4) {
             float4 u[4];
             if (s20) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) if (c0 + c < CG) u[c] = x0_raw(xg, c0 + c);
+                for (int c = 0; c < 4; ++c) if (c0 + c < CH) u[c] = x0_raw(xg, c_base + c0 + c);
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int co = c0 + c;
-                if (co >= CG) break;
+                const int cl = c0 + c;
+                if (cl >= CH) break;
+                const int co = c_base + cl;
                 float o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[co >> 1][r][co & 1]);
+                for (int r = 0; r < 4; ++r) o[r] = relu_clamp(acc[cl >> 1][r][cl & 1]);
                 if (s20) { const float4 v = normalise(u[c], co, gamma, beta); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
                 if (KEEP1) {
                     if (a.skips & 16) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? co : 0][r];
+                        for (int r = 0; r < 4; ++r) o[r] += keep1[KEEP1 ? cl : 0][r];
                     }
                 }
                 if (a.skips & 32) { const float4 v = tile_own(co); o[0] += v.x; o[1] += v.y; o[2] += v.z; o[3] += v.w; }
                 mask_tail(o);
                 cell_store_frames(yg + static_cast<size_t>(co) * a.ld, store_len, q, o);        // (no predicate: lanes beyond the row store nothing)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) out[co][r] = o[r];    // the final values, for the statistics
+                for (int r = 0; r < 4; ++r) out[cl][r] = o[r];    // the final values, for the statistics
             }
         }
     }
@@ -540,22 +620,35 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     // quad's first group merges the four groups (same arithmetic and order as the node kernel's statistics epilogue) -------------------
     // (frame pairs as packed arithmetic: per frame the same operations in the same order as the scalar form)
     float pm[4], p2[4];
+    float all_[OS > 1 ? CG : 1][4];                 // OS > 1: x3 of the whole group at this lane's frames (first wave of the pair)
+    if constexpr (OS > 1) {
+        // the other wave's channels come through the tile: every read of x2 done -> each wave writes its x3 -> the first wave reads all
+        __syncthreads();
+        tile_write();
+        __syncthreads();
+#pragma unroll
+        for (int co = 0; co < CG; ++co) {           // (both waves: the second one's copy is never stored)
+            const float4 v = tile_own(co);
+            all_[co][0] = v.x; all_[co][1] = v.y; all_[co][2] = v.z; all_[co][3] = v.w;
+        }
+    }
+    auto x3 = [&](int co, int r) -> float { if constexpr (OS > 1) return all_[co][r]; else return out[co][r]; };
     {
         cell_f2 s01{0.f, 0.f}, s23 = s01;
 #pragma unroll
-        for (int co = 0; co < CG; ++co) { s01 += cell_f2{out[co][0], out[co][1]}; s23 += cell_f2{out[co][2], out[co][3]}; }
+        for (int co = 0; co < CG; ++co) { s01 += cell_f2{x3(co, 0), x3(co, 1)}; s23 += cell_f2{x3(co, 2), x3(co, 3)}; }
         const cell_f2 m01 = s01 * (1.0f / CG), m23 = s23 * (1.0f / CG);
         cell_f2 q01{0.f, 0.f}, q23 = q01;
 #pragma unroll
         for (int co = 0; co < CG; ++co) {
-            const cell_f2 d01 = cell_f2{out[co][0], out[co][1]} - m01, d23 = cell_f2{out[co][2], out[co][3]} - m23;
+            const cell_f2 d01 = cell_f2{x3(co, 0), x3(co, 1)} - m01, d23 = cell_f2{x3(co, 2), x3(co, 3)} - m23;
             q01 = __builtin_elementwise_fma(d01, d01, q01); q23 = __builtin_elementwise_fma(d23, d23, q23);
         }
         pm[0] = m01.x; pm[1] = m01.y; pm[2] = m23.x; pm[3] = m23.y;
         p2[0] = q01.x; p2[1] = q01.y; p2[2] = q23.x; p2[3] = q23.y;
     }
     if constexpr (GPW == 1) {                       // one group per workgroup: the lane's own (mean, M2) IS the partial -- no exchange, no barrier
-        if (in_row) {
+        if (in_row && oh == 0) {
             float* prow = part + (static_cast<size_t>(blockIdx.x) * gridDim.y + b) * 2 * a.ld + t0;
             *reinterpret_cast<float4*>(prow) = make_float4(pm[0], pm[1], pm[2], pm[3]);
             *reinterpret_cast<float4*>(prow + a.ld) = make_float4(p2[0], p2[1], p2[2], p2[3]);
@@ -565,13 +658,15 @@ __global__ __launch_bounds__(64 * GPW * NTB) void grouped_cell_kernel(const Cell
     }
     __syncthreads();                                // every read of x2 is done: the tiles become the exchange buffer [GPW][nt][8][64]
     float* const sp = cell_tiles;
+    if (oh == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        sp[((gi * nt + ti) * 8 + r) * 64 + lane] = pm[r];
-        sp[((gi * nt + ti) * 8 + 4 + r) * 64 + lane] = p2[r];
+        for (int r = 0; r < 4; ++r) {
+            sp[((gi * nt + ti) * 8 + r) * 64 + lane] = pm[r];
+            sp[((gi * nt + ti) * 8 + 4 + r) * 64 + lane] = p2[r];
+        }
     }
     __syncthreads();
-    if (gi == 0 && in_row) {
+    if (gi == 0 && oh == 0 && in_row) {
         const int nw = min(GPW, a.groups - static_cast<int>(blockIdx.x) * GPW);  // groups (waves) that hold real data
         float om[4], o2[4];
 #pragma unroll
@@ -608,10 +703,10 @@ static int cell_gpw(int cg, int nt)
     return 2 * cell_lds_bytes(cg, nt * 64, 4) <= 160 * 1024 ? 4 : 2;
 }
 
-template <typename T, int CG, bool KEEP1, int NTB, int GPW>
+template <typename T, int CG, bool KEEP1, int NTB, int GPW, int OS = 1>
 static int launch_cell_kernel(const CellArgs<T>& p, hipStream_t stream)
 {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(grouped_cell_kernel<T, CG, KEEP1, NTB, GPW, OS>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr != hipSuccess) {
         set_error("nbasr_grouped_cell_fused: cannot raise the dynamic LDS limit: %s", hipGetErrorString(attr));
@@ -620,14 +715,37 @@ static int launch_cell_kernel(const CellArgs<T>& p, hipStream_t stream)
     const CellDims& a = p.a;
     // (the tiles double as the statistics exchange buffer [GPW][nt][8][64] floats of a multi-group workgroup)
     const size_t lds = std::max(cell_lds_bytes(CG, a.rowq, GPW, a.padl + a.padr), GPW > 1 ? static_cast<size_t>(GPW) * a.nt * 8 * 64 * 4 : 0);
-    hipLaunchKernelGGL((grouped_cell_kernel<T, CG, KEEP1, NTB, GPW>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * 64), lds, stream, p);
+    hipLaunchKernelGGL((grouped_cell_kernel<T, CG, KEEP1, NTB, GPW, OS>), dim3((a.groups + GPW - 1) / GPW, a.batch), dim3(GPW * a.nt * OS * 64), lds, stream, p);
     return launch_status("nbasr_grouped_cell_fused");
+}
+
+// Two waves per (group, row tile) -- the output-channel split -- while the launch would otherwise leave SIMDs without a wave (1024 on
+// the chip): block 3 (12 channels per group, one-wave rows) up to 10 utterances.  Measured (tools/ubench/cell_os.py, 1200 channels x
+// 250 frames): 43.6 -> 38.1 us per launch at 8 utterances, 40.5 -> 34.6 at 4, no difference from 16 on; phase stamps at 8 utterances
+// (tools/gpu/cell_stamps.py): a convolution loop 5.0 -> 3.8 us, the node boundaries 1.0-1.3 -> 1.6 us (a barrier of 8 waves).  A whole
+// forward at 8 utterances does not notice (5 409 vs 5 354 utterances/s, within the run-to-run spread): the six block-3 cells are
+// 0.2 of its 1.47 ms.  NBASR_CELL_OS = 0 / 1 forces the split off / on wherever an instantiation exists (fp32, 12 or 8 channels per
+// group), NBASR_CELL_OS_WAVES moves the threshold.
+// (read at every launch: the tests flip it between calls)
+static bool cell_os_split(const CellDims& a)
+{
+    const char* e = getenv("NBASR_CELL_OS");
+    if (e && *e) return atoi(e) != 0;
+    const char* w = getenv("NBASR_CELL_OS_WAVES");
+    return static_cast<long long>(a.batch) * a.groups * a.nt <= (w && *w ? atoi(w) : 1024);
 }
 
 template <typename T, int CG, bool KEEP1>
 static int launch_cell_nt(const CellArgs<T>& p, hipStream_t stream)
 {
     const CellDims& a = p.a;
+    if constexpr (std::is_same<T, float>::value && (CG == 12 || CG == 8)) {
+        if (cell_os_split(a)) {
+            if (cell_gpw(CG, a.nt) == 1 && a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 1, 2>(p, stream);
+            if (cell_gpw(CG, a.nt) == 1 && a.nt <= 4) return launch_cell_kernel<T, CG, KEEP1, 4, 1, 2>(p, stream);
+            if (cell_gpw(CG, a.nt) == 4 && a.nt == 1) return launch_cell_kernel<T, CG, KEEP1, 1, 4, 2>(p, stream);
+        }
+    }
     if (cell_gpw(CG, a.nt) == 1) {
         if (a.nt == 2) return launch_cell_kernel<T, CG, KEEP1, 2, 1>(p, stream);
         if (a.nt <= 4) return launch_cell_kernel<T, CG, KEEP1, 4, 1>(p, stream);

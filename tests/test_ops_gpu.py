@@ -688,6 +688,21 @@ def test_grouped_conv_epilogue_statistics(c, groups, t, k, d):
                                       (((7, 2), (5, 1), (7, 2)), 0b010101)])
 @pytest.mark.parametrize('with_ln', [False, True])
 def test_fused_cell_is_bit_identical_to_three_node_launches(c, groups, t, kds, mask, with_ln):
+    _fused_cell_vs_three_node_launches(c, groups, t, kds, mask, with_ln)
+
+
+@pytest.mark.parametrize('c,groups,t', [(1200, 100, 250), (24, 2, 500), (36, 3, 1000), (32, 4, 1000), (800, 100, 499), (24, 3, 77), (48, 4, 130), (40, 5, 7)])
+@pytest.mark.parametrize('kds,mask', [(((7, 1), (7, 2), (5, 2)), 63), (((5, 2), (7, 2), (7, 1)), 0b101010), (((5, 1), (5, 1), (7, 2)), 0)])
+@pytest.mark.parametrize('split', ['0', '1'])
+def test_fused_cell_output_channel_split_changes_no_bit(c, groups, t, kds, mask, split, monkeypatch):
+    """Round 6: two waves per (group, row tile), each with half of the group's output channels (12 -> 6 + 6, 8 -> 4 + 4; the form small
+    batches take by themselves): forced on and off (NBASR_CELL_OS is read at every launch), the output and the statistics are those
+    of the three node launches."""
+    monkeypatch.setenv('NBASR_CELL_OS', split)
+    _fused_cell_vs_three_node_launches(c, groups, t, kds, mask, True)
+
+
+def _fused_cell_vs_three_node_launches(c, groups, t, kds, mask, with_ln):
     torch.manual_seed(c + t + mask)
     b = 2
     x = torch.randn(b, c, t) * 1.5 + 0.3

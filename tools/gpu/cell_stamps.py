@@ -3,7 +3,7 @@
 
 Needs a library built with the stamps compiled in:
     NBASR_EXTRA_CXXFLAGS=-DNBASR_CELL_STAMPS=1 python -c "import nb_asr_amd.build as b; b.build_library(force=True)"
-    python tools/gpu/cell_stamps.py [batch=64] [block=0..3]
+    python tools/gpu/cell_stamps.py [batch=64] [block=0..3] [--lib nb_asr_amd/lib/libnbasr_hip_cstamps.so]
 Wave 0 of every workgroup records the 100 MHz clock at its phase boundaries into the buffer whose address the launcher reads from
 NBASR_CELL_STAMPS.  The round-4 record is profiles/r04_cell_phase_stamps.txt."""
 import os, sys, pathlib
@@ -11,6 +11,10 @@ import numpy as np
 import torch
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parents[2]))
 from nb_asr_amd import hip
+if '--lib' in sys.argv:            # tools/ubench/build_cell_stamps.sh: a stamped twin beside the shipped library
+    i = sys.argv.index('--lib')
+    hip.LIB_PATH = pathlib.Path(sys.argv[i + 1]).resolve()
+    del sys.argv[i:i + 2]
 DEV = 'cuda:0'
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 blk = int(sys.argv[2]) if len(sys.argv) > 2 else 0

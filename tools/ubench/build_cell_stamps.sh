@@ -1,0 +1,10 @@
+#!/bin/bash
+# Diagnostic twin of libnbasr_hip.so with the phase stamps of the fused cell compiled in (tools/gpu/cell_stamps.py --lib ...).
+set -e
+cd "$(dirname "$0")/../.."
+python -m nb_asr_amd.build > /dev/null
+B=nb_asr_amd/csrc/build
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -DNBASR_CELL_STAMPS=1 -Iinclude -Inb_asr_amd/csrc -x hip -c nb_asr_amd/csrc/grouped_cell.hip -o $B/grouped_cell_stamps.o
+OBJS=$(ls $B/*.o | grep -v "grouped_cell\.o\|grouped_cell_stamps\|lstm_xcd_stamps")
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o nb_asr_amd/lib/libnbasr_hip_cstamps.so $OBJS $B/grouped_cell_stamps.o
+echo built nb_asr_amd/lib/libnbasr_hip_cstamps.so
