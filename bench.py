@@ -44,6 +44,7 @@ import json
 import os
 import statistics
 import sys
+import threading
 import time
 
 import torch
@@ -92,6 +93,10 @@ def main():
     ap.add_argument('--no-strong', action='store_true', help='with N > 1: skip the strong-scaling leg (the headline `value` then stays weak)')
     ap.add_argument('--no-strong-proxy', action='store_true',
                     help='with N = 1: skip the strong-scaling proxy (the same steps at --batch / 8 utterances: one rank\'s share at 8 GPUs)')
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help='chains of pipelined steps in flight at once: W streams (one host thread each) take the K steps in turn, so '
+                         'that one step\'s kernels fill the compute units another step\'s leave idle (8 utterances occupy 200 of 256 '
+                         'CUs with one wave per SIMD).  Every step is still a complete forward of the whole batch; 1 = one chain')
     ap.add_argument('--force-collective', action='store_true',
                     help='take the RCCL path with one rank too: a 1-rank nccl group on this GPU, every step ends with the all-gather of '
                          'the logits (parallel.ShardedForward(force_collective=True)); reports allgather_us')
@@ -152,15 +157,48 @@ def main():
             out = step()
         return out
 
-    def pipelined():
+    way_streams = [torch.cuda.Stream(device=device) for _ in range(max(args.in_flight, 1))] if args.in_flight > 1 else []
+
+    def pipelined(ways=None):
         # back-to-back batches: the LSTM + head of step i run on a side stream while the main stream already runs the
         # encoder of step i+1 (model.forward_async); every step is a complete forward and all K finish before the
         # closing synchronize
-        with torch.no_grad():
-            handles = [model.forward_async(cur['x']) for _ in range(args.steps)]
-            out = None
-            for h in handles:
-                out = runner.gather_logits(h.result())
+        ways = args.in_flight if ways is None else ways
+        if ways <= 1:
+            with torch.no_grad():
+                handles = [model.forward_async(cur['x']) for _ in range(args.steps)]
+                out = None
+                for h in handles:
+                    out = runner.gather_logits(h.result())
+            return out
+        # W chains in flight (round 6): thread i enqueues its share of the K steps on its own stream (its own plan, tapes and cached
+        # recurrence graphs: executor.PlanPool keeps a plan with the stream it was released on) and waits for that stream.  The
+        # all-gathers are issued afterwards by THIS thread in one fixed order (a collective must be enqueued in the same order on every
+        # rank).  (An event behind every step's logits for the issuing thread to wait on, instead of the stream synchronisation in the
+        # worker, halved the rate: tools/ubench/two_half_batches.py --events.)
+        counts = [args.steps // ways + (1 if i < args.steps % ways else 0) for i in range(ways)]
+        done, errors = [None] * ways, []
+
+        def worker(i):
+            try:
+                with torch.no_grad(), torch.cuda.stream(way_streams[i]):
+                    handles = [model.forward_async(cur['x']) for _ in range(counts[i])]
+                    done[i] = [h.result() for h in handles]
+                    way_streams[i].synchronize()
+            except BaseException as e:                    # noqa: BLE001 -- re-raised by the issuing thread below
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(i,)) for i in range(ways)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        out = None
+        for outs in done:
+            for o in outs:
+                out = runner.gather_logits(o)
         return out
 
     for _ in range(args.warmup):
@@ -168,13 +206,22 @@ def main():
     with torch.no_grad():
         for _ in range(2):
             model.forward_async(x).result()
+    def warm_chains():
+        if args.in_flight > 1 and not args.no_pipeline:
+            pipelined()                                   # every chain's plan, launch tapes and recurrence graphs exist before a timed region
+
+    warm_chains()
     elapsed_seq, out = timed(sequential)
     assert out.shape == (args.batch * world, (((args.frames + 1) // 2) + 1) // 2, 49) and bool(torch.isfinite(out.float()).all())
     if args.no_pipeline:
-        elapsed = elapsed_seq
+        elapsed = elapsed_one = elapsed_seq
     else:
         elapsed, out2 = timed(pipelined)
         assert torch.equal(out2, out)
+        elapsed_one = elapsed
+        if args.in_flight > 1:
+            elapsed_one, out3 = timed(lambda: pipelined(1))          # the same K steps as ONE chain, beside the headline
+            assert torch.equal(out3, out)
 
     # p50 forward latency: each forward bracketed by HIP events on the launch stream
     lat = []
@@ -201,6 +248,7 @@ def main():
                 step()
             with torch.no_grad():
                 model.forward_async(x).result()
+            warm_chains()
             elapsed_strict, out_s = timed(sequential if args.no_pipeline else pipelined)
             worst = float(((out_s.double() - out.double()).abs() / (1e-5 + 1e-4 * out.double().abs())).max())
             strict = {'value': args.batch * world * args.steps / elapsed_strict, 'ms_per_step': 1e3 * elapsed_strict / args.steps,
@@ -231,9 +279,15 @@ def main():
             step()
         with torch.no_grad():
             model.forward_async(cur['x']).result()
+        warm_chains()
         elapsed_strong, out_g = timed(sequential if args.no_pipeline else pipelined)
         assert out_g.shape[0] == args.batch
+        elapsed_strong1 = elapsed_strong
+        if args.in_flight > 1 and not args.no_pipeline:
+            elapsed_strong1, out_g1 = timed(lambda: pipelined(1))
+            assert torch.equal(out_g1, out_g)
         strong = {'value': args.batch * args.steps / elapsed_strong, 'ms_per_step': 1e3 * elapsed_strong / args.steps,
+                  'value_one_in_flight': args.batch * args.steps / elapsed_strong1, 'ms_per_step_one_in_flight': 1e3 * elapsed_strong1 / args.steps,
                   'per_gpu_batch': hi - lo, 'global_batch': args.batch}
         cur['x'] = x
 
@@ -249,9 +303,15 @@ def main():
         with torch.no_grad():
             for _ in range(3):
                 model.forward_async(cur['x']).result()
+        warm_chains()
         elapsed_p, out_p = timed(sequential if args.no_pipeline else pipelined)
         assert out_p.shape[0] == b8 and bool(torch.isfinite(out_p.float()).all())
+        elapsed_p1 = elapsed_p
+        if args.in_flight > 1 and not args.no_pipeline:
+            elapsed_p1, out_p1 = timed(lambda: pipelined(1))
+            assert torch.equal(out_p1, out_p)
         proxy = {'per_gpu_batch': b8, 'value': b8 * args.steps / elapsed_p, 'ms_per_step': 1e3 * elapsed_p / args.steps,
+                 'value_one_in_flight': b8 * args.steps / elapsed_p1, 'ms_per_step_one_in_flight': 1e3 * elapsed_p1 / args.steps,
                  'projected_x8': 8.0 * (b8 * args.steps / elapsed_p) / (args.batch * args.steps / elapsed),
                  'note': f'one GPU, the first {b8} of the {args.batch} utterances per step: the per-rank share of an 8-GPU strong-scaled run; '
                          'projected_x8 = 8 x this rate / `value` (all-gather not included: allgather_us with --force-collective)'}
@@ -290,6 +350,9 @@ def main():
         'ms_per_step': strong['ms_per_step'] if headline_strong else weak_ms,
         'value_weak': weak_value if world > 1 and args.scaling == 'weak' else None,
         'ms_per_step_weak': weak_ms if world > 1 and args.scaling == 'weak' else None,
+        'in_flight': max(args.in_flight, 1) if not args.no_pipeline else 1,
+        'value_one_in_flight': args.batch * world * args.steps / elapsed_one,
+        'ms_per_step_one_in_flight': 1e3 * elapsed_one / args.steps,
         'strong_proxy': proxy,
         'allgather_us': allgather_us,
         'p50_forward_ms': p50,

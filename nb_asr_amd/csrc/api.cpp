@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -28,7 +29,8 @@ int replay_chain(hipStream_t s, const ChainKey& key, const char* what, void (*la
     constexpr int MAX_DEVICES = 64;
     hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
     int device = -1;
-    if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone ||
+    static const bool no_graph = [] { const char* e = getenv("NBASR_CHAIN_GRAPH"); return e && e[0] == '0'; }();   // A/B and diagnosis: always the plain chain
+    if (no_graph || hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone ||
         hipGetDevice(&device) != hipSuccess || device < 0 || device >= MAX_DEVICES) {
         (void)hipGetLastError();
         launch_chain(ctx);
@@ -95,6 +97,18 @@ int replay_chain(hipStream_t s, const ChainKey& key, const char* what, void (*la
     if (e == hipSuccess) e = hipEventRecord(hit->last, s);
     if (e != hipSuccess) { set_error("%s: hipGraphLaunch: %s", what, hipGetErrorString(e)); return static_cast<int>(e); }
     return launch_status(what);
+}
+
+__global__ __launch_bounds__(256) void zero_words_kernel(unsigned* __restrict__ p, size_t words)
+{
+    for (size_t i = blockIdx.x * static_cast<size_t>(blockDim.x) + threadIdx.x; i < words; i += static_cast<size_t>(gridDim.x) * blockDim.x) p[i] = 0u;
+}
+void zero_async(void* p, size_t bytes, hipStream_t stream)
+{
+    const size_t words = bytes / 4;
+    if (words == 0) return;
+    const size_t blocks = (words + 1023) / 1024;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(static_cast<unsigned>(blocks < 256 ? blocks : 256)), dim3(256), 0, stream, static_cast<unsigned*>(p), words);
 }
 
 }  // namespace nbasr

@@ -74,6 +74,12 @@ struct ChainKey {
 };
 int replay_chain(hipStream_t stream, const ChainKey& key, const char* what, void (*launch_chain)(void*), void* ctx);
 
+// Zero `bytes` (a multiple of 4) at `p`, stream-ordered, as a KERNEL.  Not hipMemsetAsync (round 6): captured into a graph -- the cached
+// per-frame recurrence chain, a whole-forward graph -- the fill becomes a memset node, and such nodes ran out of order under load: with
+// three chains of forwards in flight on three streams of the device, one of them the default stream, NaN logits in every second
+// forward (tools/ubench/in_flight_check.py --overlap-main; clean with the plain chain, NBASR_CHAIN_GRAPH=0, and with this kernel node).
+void zero_async(void* p, size_t bytes, hipStream_t stream);
+
 #define NBASR_REQUIRE(cond, code, ...)          \
     do {                                        \
         if (!(cond)) {                          \

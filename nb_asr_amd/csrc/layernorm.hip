@@ -221,8 +221,7 @@ static int layernorm_impl(const char* what, const void* x, const float* gamma, c
             hipLaunchKernelGGL((layernorm_channels_kernel<bf16_t, float, false>), grid, dim3(256), 0, as_stream(stream),
                                static_cast<const bf16_t*>(x), gamma, beta, static_cast<float*>(y), channels, frames, ld, eps, static_cast<unsigned*>(nullptr));
     } else if (absmax) {
-        const hipError_t e = hipMemsetAsync(absmax, 0, sizeof(float) * batch, as_stream(stream));
-        if (e != hipSuccess) { set_error("%s: hipMemsetAsync failed: %s", what, hipGetErrorString(e)); return static_cast<int>(e); }
+        zero_async(absmax, sizeof(float) * batch, as_stream(stream));
         hipLaunchKernelGGL((layernorm_channels_kernel<float, float, true>), grid, dim3(256), 0, as_stream(stream),
                            static_cast<const float*>(x), gamma, beta, static_cast<float*>(y), channels, frames, ld, eps, reinterpret_cast<unsigned*>(absmax));
     } else {
@@ -404,8 +403,7 @@ extern "C" int nbasr_layernorm_split_image(const float* x, const float* gamma, c
     NBASR_REQUIRE(x && gamma && beta && stats && bound && image, NBASR_ENULL, "nbasr_layernorm_split_image: NULL pointer");
     NBASR_REQUIRE(aligned16(x) && aligned16(stats) && aligned16(image), NBASR_EALIGN, "nbasr_layernorm_split_image: x, stats, image must be 16-byte aligned");
     NBASR_REQUIRE(batch <= 65535, NBASR_EINVAL, "nbasr_layernorm_split_image: batch %d > 65535", batch);
-    const hipError_t e = hipMemsetAsync(bound, 0, sizeof(float) * batch, as_stream(stream));
-    if (e != hipSuccess) { set_error("nbasr_layernorm_split_image: hipMemsetAsync failed: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    zero_async(bound, sizeof(float) * batch, as_stream(stream));
     const int nq = ld / 4;
     hipLaunchKernelGGL(channel_stats_bound_kernel, dim3((nq + LN_QS - 1) / LN_QS, batch), dim3(256), 0, as_stream(stream),
                        x, gamma, beta, stats, reinterpret_cast<unsigned*>(bound), channels, frames, ld, eps);

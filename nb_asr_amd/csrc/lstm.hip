@@ -543,8 +543,8 @@ extern "C" int nbasr_lstm_recurrence_seq(const float* gates_ws, const void* pack
     hipEvent_t& done = chain_done[device];
     if (done == nullptr) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
     else e = hipStreamWaitEvent(as_stream(stream), done, 0);
-    if (e == hipSuccess) e = hipMemsetAsync(seq_ws, 0, nbasr_lstm_seq_workspace_bytes(batch, hidden), as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_seq: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    zero_async(seq_ws, nbasr_lstm_seq_workspace_bytes(batch, hidden), as_stream(stream));
     // A COOPERATIVE launch where the device offers it: the runtime then refuses a grid it cannot hold at once (instead of starting part
     // of it) and dispatches it as a unit.  What neither form can promise is that ANOTHER process leaves the compute units alone -- that
     // is what the bounded waits and the status word are for, and the executor reads the word behind every such launch (executor.py).

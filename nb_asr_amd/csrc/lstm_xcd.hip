@@ -584,8 +584,7 @@ extern "C" int nbasr_lstm_pack_whh16(const float* w_hh, void* packed, int hidden
                   "nbasr_lstm_pack_whh16: hidden=%d must be a positive multiple of 4, at most %d", hidden, LX_KSTEPS * 32);
     NBASR_REQUIRE(w_hh && packed, NBASR_ENULL, "nbasr_lstm_pack_whh16: NULL pointer");
     NBASR_REQUIRE(aligned16(packed), NBASR_EALIGN, "nbasr_lstm_pack_whh16: packed must be 16-byte aligned");
-    hipError_t e = hipMemsetAsync(packed, 0, LX_PACK_HEADER_BYTES, as_stream(stream));
-    if (e != hipSuccess) { set_error("nbasr_lstm_pack_whh16: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    zero_async(packed, LX_PACK_HEADER_BYTES, as_stream(stream));
     hipLaunchKernelGGL(lx_absmax_kernel, dim3(256), dim3(256), 0, as_stream(stream), w_hh, static_cast<size_t>(4) * hidden * hidden,
                        static_cast<unsigned*>(packed));
     hipLaunchKernelGGL(lx_pack_kernel, dim3(512), dim3(256), 0, as_stream(stream), w_hh, static_cast<unsigned char*>(packed), hidden, lx_slices(hidden));
@@ -639,7 +638,7 @@ extern "C" int nbasr_lstm_recurrence_frames16(const float* gates_ws, const void*
     return replay_chain(ctx.s, key, "nbasr_lstm_recurrence_frames16", [](void* p) {
         const Ctx& c = *static_cast<const Ctx*>(p);
         unsigned* const range = reinterpret_cast<unsigned*>(c.tiles) - (LX_HEADER_WORDS - LX_W_RANGE);
-        (void)hipMemsetAsync(range, 0, (LX_HEADER_WORDS - LX_W_RANGE) * sizeof(unsigned) + c.tiles_bytes, c.s);      // the range words + the images
+        zero_async(range, (LX_HEADER_WORDS - LX_W_RANGE) * sizeof(unsigned) + c.tiles_bytes, c.s);                     // the range words + the images
         hipLaunchKernelGGL(lx_gate_range_kernel, dim3((c.frames + 7) / 8, c.batch), dim3(256), 0, c.s, c.gates, range, c.batch, c.frames, 4 * c.hidden);
         const int row_tiles = (c.hidden + 3) / 4;
         const int n_tiles = (c.batch + 15) / 16;
@@ -697,8 +696,8 @@ extern "C" int nbasr_lstm_recurrence_xcd(const float* gates_ws, const void* pack
         if (done == nullptr) e = hipEventCreateWithFlags(&done, hipEventDisableTiming);
         else e = hipStreamWaitEvent(as_stream(stream), done, 0);
     }
-    if (e == hipSuccess) e = hipMemsetAsync(xcd_ws, 0, ws_bytes, as_stream(stream));
     if (e != hipSuccess) { set_error("nbasr_lstm_recurrence_xcd: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    zero_async(xcd_ws, ws_bytes, as_stream(stream));
     const int n_tiles = (batch + 15) / 16;
     hipLaunchKernelGGL(lx_gate_range_kernel, dim3((frames + 7) / 8, batch), dim3(256), 0, as_stream(stream), gates_ws,
                        static_cast<unsigned*>(xcd_ws) + LX_W_RANGE, batch, frames, 4 * hidden);

@@ -255,6 +255,7 @@ class ForwardPlan:
         self.tail_mode = os.environ.get('NBASR_TAIL', 'auto')
         if self.tail_mode not in ('auto', 'side', 'main'):
             raise ValueError(f"NBASR_TAIL={self.tail_mode!r}: expected 'auto', 'side' or 'main'")
+        self._released_on, self._released_event = None, None   # PlanPool: the stream the last forward was enqueued on, an event behind it
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
         self._seq_outcome = {}       # ring slot -> whether that launch failed, once its word has been read (check_seq_slot)
@@ -1401,14 +1402,38 @@ class PlanPool:
         return (PlanPool, ())            # copies / pickles of a model start with an empty pool
 
     def acquire(self, device):
+        """An idle plan for a forward on ``device``'s CURRENT stream.  A plan is handed back (``release``) as soon as its forward has been
+        ENQUEUED: its workspaces are still being read and written by that stream.  The same stream takes it again for free (stream
+        order); another stream (two threads running forwards on two streams of one device: round 6, `bench.py --in-flight`) gets a plan
+        of its own if it can -- the launch tapes of a plan are per stream as well -- and otherwise the least recently released one,
+        behind the event ``release`` recorded and behind that plan's pipelined tails (round 6: before, such a plan was re-used at once
+        and the two streams raced on its workspaces)."""
         device = torch.device(device)
+        stream = torch.cuda.current_stream(device) if device.type == 'cuda' and torch.cuda.is_available() else None
+        sid = stream.cuda_stream if stream is not None else None
         with self._lock:
             idle = self._idle.get(device.index)
             if idle:
-                return idle.pop()
+                for i in range(len(idle) - 1, -1, -1):                  # most recently released first
+                    if idle[i]._released_on == sid or idle[i]._released_on is None:
+                        return idle.pop(i)
+                if len(idle) >= self.MAX_IDLE_PER_DEVICE:               # bounded: a caller that makes a fresh stream per forward must not grow the pool for ever
+                    plan = idle.pop(0)
+                    if plan._released_event is not None:
+                        stream.wait_event(plan._released_event)
+                    plan.wait_tails()
+                    return plan
         return ForwardPlan(device)
 
+    MAX_IDLE_PER_DEVICE = 6
+
     def release(self, plan):
+        if plan.device.type == 'cuda' and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            stream = torch.cuda.current_stream(plan.device)
+            if plan._released_event is None:
+                plan._released_event = torch.cuda.Event()
+            plan._released_event.record(stream)
+            plan._released_on = stream.cuda_stream
         with self._lock:
             self._idle.setdefault(plan.device.index, []).append(plan)
 

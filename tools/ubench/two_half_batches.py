@@ -20,12 +20,21 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--steps', type=int, default=20)
 ap.add_argument('--ways', type=int, default=2)
 ap.add_argument('--full', action='store_true', help='every way runs the WHOLE batch (two batches in flight on two streams) instead of a slice of it')
+ap.add_argument('--plain-first', type=int, default=0, help='that many plain model(x) calls (the resident recurrence) before everything else')
+ap.add_argument('--events', action='store_true', help='an event behind every result, waited for by the main thread (as bench.py does)')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 model = nb.get_model([[1, 0], [1, 0, 0], [1, 0, 0, 0]], use_rnn=True, dropout_rate=0.0)
 keyed_fill_(model, seed=1235, mode='lively')
 model = model.to(dev).eval()
 x = keyed_input(a.batch, 1000, seed=0).to(dev)
+
+
+if a.plain_first:
+    with torch.no_grad():
+        for _ in range(a.plain_first):
+            model(x)
+    torch.cuda.synchronize()
 
 
 def whole():
@@ -42,6 +51,15 @@ outs = [None] * a.ways
 def worker(i):
     with torch.no_grad(), torch.cuda.stream(streams[i]):
         hs = [model.forward_async(parts[i]) for _ in range(a.steps)]
+        if a.events:
+            evs = []
+            for h in hs:
+                o = h.result()
+                ev = torch.cuda.Event()
+                ev.record(streams[i])
+                evs.append((o, ev))
+            outs[i] = evs
+            return
         outs[i] = [h.result() for h in hs][-1]
         streams[i].synchronize()
 
@@ -52,6 +70,14 @@ def split():
         t.start()
     for t in ts:
         t.join()
+    if a.events:
+        here, last = torch.cuda.current_stream(dev), None
+        for evs in outs:
+            for o, ev in evs:
+                here.wait_event(ev)
+                o.record_stream(here)
+                last = o
+        return last
     return outs[0] if a.full else torch.cat(outs, 0)
 
 
