@@ -44,7 +44,6 @@ import json
 import os
 import statistics
 import sys
-import threading
 import time
 
 import torch
@@ -157,8 +156,6 @@ def main():
             out = step()
         return out
 
-    way_streams = [torch.cuda.Stream(device=device) for _ in range(max(args.in_flight, 1))] if args.in_flight > 1 else []
-
     def pipelined(ways=None):
         # back-to-back batches: the LSTM + head of step i run on a side stream while the main stream already runs the
         # encoder of step i+1 (model.forward_async); every step is a complete forward and all K finish before the
@@ -171,34 +168,13 @@ def main():
                 for h in handles:
                     out = runner.gather_logits(h.result())
             return out
-        # W chains in flight (round 6): thread i enqueues its share of the K steps on its own stream (its own plan, tapes and cached
-        # recurrence graphs: executor.PlanPool keeps a plan with the stream it was released on) and waits for that stream.  The
-        # all-gathers are issued afterwards by THIS thread in one fixed order (a collective must be enqueued in the same order on every
-        # rank).  (An event behind every step's logits for the issuing thread to wait on, instead of the stream synchronisation in the
-        # worker, halved the rate: tools/ubench/two_half_batches.py --events.)
-        counts = [args.steps // ways + (1 if i < args.steps % ways else 0) for i in range(ways)]
-        done, errors = [None] * ways, []
-
-        def worker(i):
-            try:
-                with torch.no_grad(), torch.cuda.stream(way_streams[i]):
-                    handles = [model.forward_async(cur['x']) for _ in range(counts[i])]
-                    done[i] = [h.result() for h in handles]
-                    way_streams[i].synchronize()
-            except BaseException as e:                    # noqa: BLE001 -- re-raised by the issuing thread below
-                errors.append(e)
-
-        threads = [threading.Thread(target=worker, args=(i,)) for i in range(ways)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if errors:
-            raise errors[0]
+        # W chains in flight (round 6, model.forward_many): thread i enqueues steps i, i + W, ... on its own stream (its own plan, tapes
+        # and cached recurrence graphs: executor.PlanPool keeps a plan with the stream it was released on) and waits for that stream.
+        # The all-gathers are issued afterwards by THIS thread in one fixed order (a collective must be enqueued in the same order
+        # on every rank).
         out = None
-        for outs in done:
-            for o in outs:
-                out = runner.gather_logits(o)
+        for o in model.forward_many([cur['x']] * args.steps, in_flight=ways):
+            out = runner.gather_logits(o)
         return out
 
     for _ in range(args.warmup):

@@ -97,3 +97,26 @@ def test_a_plan_changes_streams_only_behind_its_release_event():
             s.synchronize()
             assert torch.equal(o, want)
     assert len(model._plans) <= PlanPool.MAX_IDLE_PER_DEVICE
+
+
+@pytest.mark.parametrize('in_flight', [1, 2, 3])
+def test_forward_many_returns_every_batchs_own_logits_in_order(in_flight):
+    """`ASRModel.forward_many`: batches of different sizes and lengths, W chains in flight -- each result is that batch's lone forward."""
+    model = _model()
+    shapes = [(8, 1000), (3, 333), (8, 1000), (5, 64), (8, 1000), (1, 17), (8, 1000), (8, 999), (2, 500), (8, 1000), (8, 1000), (4, 250)]
+    xs = [keyed_input(b, t, seed=10 + i).to(DEV) for i, (b, t) in enumerate(shapes)]
+    with torch.no_grad():
+        want = [model(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    for _ in range(3):
+        got = model.forward_many(xs, in_flight=in_flight)
+        assert len(got) == len(xs)
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+    assert model.forward_many([], in_flight=in_flight) == []
+
+
+def test_forward_many_raises_in_the_callers_thread():
+    model = _model()
+    with pytest.raises(ValueError, match='expected a'):
+        model.forward_many([torch.zeros(2, 79, 50, device=DEV)] * 4, in_flight=2)
