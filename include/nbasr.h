@@ -63,6 +63,13 @@ int nbasr_pad_amounts(int kernel, int dilation, int stride, int* left, int* righ
  * convs, reference model.py:76): ceil(ceil(T/2)/2).  Host arithmetic. */
 int nbasr_output_frames(int frames);
 
+/* ABI 6 -- a non-blocking stream of the library's own on the current device (hipStreamCreateWithFlags, default priority), for the life
+ * of the process.  For a host whose framework hands out streams from a small recycled pool (PyTorch: 32 per priority): the streams a
+ * pipelined forward's tail and the chains of `forward_many` run on are chosen by probing which candidates execute beside the streams
+ * they must overlap with (a stream sits on one of a few hardware queues from its creation on; nb_asr_amd/streams.py), and a dozen
+ * probes into the pool a "new" stream is one that is already in use.  No reference counterpart (the reference runs on one stream). */
+int nbasr_stream_create(nbasr_stream_t* stream);
+
 /* One entry point per operation.  Tensors x / y / skips are `dtype` tensors (NBASR_F32 | NBASR_BF16) where an entry point takes a
  * `dtype`; weights, biases, gamma / beta and statistics are fp32 everywhere.  A pending LayerNorm travels as a nbasr_deferred_ln
  * ("normalise on load"; NULL = none). */

@@ -132,6 +132,16 @@ extern "C" int nbasr_pad_amounts(int kernel, int dilation, int stride, int* left
     return NBASR_OK;
 }
 
+extern "C" int nbasr_stream_create(nbasr_stream_t* stream) {
+    nbasr::clear_error();
+    NBASR_REQUIRE(stream, NBASR_ENULL, "nbasr_stream_create: NULL output pointer");
+    hipStream_t s = nullptr;
+    const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipGetLastError(); nbasr::set_error("nbasr_stream_create: %s", hipGetErrorString(e)); return static_cast<int>(e); }
+    *stream = s;
+    return NBASR_OK;
+}
+
 extern "C" int nbasr_output_frames(int frames) {
     if (frames <= 0) return 0;
     const int half = (frames + 1) / 2;

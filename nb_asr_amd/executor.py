@@ -438,6 +438,7 @@ class ForwardPlan:
         self._graphs.clear()
         self._tapes.clear()
         self._bufs.clear()
+        self.side_stream = None                     # (streams.py remembers it for the main stream: a plan built again gets the same one)
 
     def _set_shape(self, batch, frames, use_rnn):
         from .model import FILTERS, DOWN_STRIDES, LSTM_HIDDEN
@@ -748,13 +749,18 @@ class ForwardPlan:
     def _ensure_pipeline(self):
         if self.side_stream is not None:
             return
-        # high priority: its own hardware queue (an ordinary second stream can end up sharing the main stream's queue,
-        # e.g. once RCCL has created its streams, and the overlap silently disappears), and the short dependent LSTM
-        # steps get dispatched ahead of the encoder's bulk work.
+        # The tail's stream must sit on another hardware queue than the stream the encoder runs on -- and than every other stream this
+        # package runs chains or tails on (two chains in flight: ASRModel.forward_many) -- or the overlap silently disappears: streams.py
+        # probes pool streams for that.  Normal priority (round 6; rounds 1-5: high priority, "dispatched ahead of the encoder's bulk
+        # work"): measured no gain from the priority (10 528 vs 10 548 utterances/s at 64 x 1000), and a high-priority queue starves the
+        # normal-priority queue it shares a pipe with -- another chain's encoder, with two chains in flight.
         # (Measured and rejected: giving the tail 8-32 compute units of its own through CU-masked streams.  The 128
         # workgroups of a step then run in several rounds and the whole pipeline slows 2-3x; tools/ubench/cu_mask_map.hip
         # documents the mask layout.)
-        self.side_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        from . import streams
+        # (a chain stream of forward_many finds its tail stream chosen already; a lone caller's first pipelined forward probes here, waiting
+        # for its own stream only when it runs beside other threads of the process)
+        self.side_stream = streams.tail_stream_for(self.device, torch.cuda.current_stream(self.device), whole_device=threading.active_count() == 1)
         for t in self._bufs.values():                 # allocated on the main stream, from now on also read on the side stream
             t.record_stream(self.side_stream)
         for _, _, built in self._packed.values():     # derived weights (packed w_ih / w_hh, fp32 copies): read by the tails too

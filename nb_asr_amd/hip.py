@@ -35,6 +35,7 @@ SIGNATURES = {
     'nbasr_last_error': (ctypes.c_char_p, []),
     'nbasr_pad_amounts': (_c_int, [_c_int, _c_int, _c_int, ctypes.POINTER(_c_int), ctypes.POINTER(_c_int)]),
     'nbasr_output_frames': (_c_int, [_c_int]),
+    'nbasr_stream_create': (_c_int, [ctypes.POINTER(ctypes.c_void_p)]),
     # LayerNorm, statistics, node ops (storage-type generic: a trailing dtype code)
     'nbasr_layernorm_channels': (_c_int, [_c_float_p] * 5 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_int, _c_stream]),
     'nbasr_channel_stats': (_c_int, [_c_float_p] * 2 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_stream]),
@@ -120,7 +121,7 @@ SIGNATURES = {
 }
 
 # entry points that only answer on the host (never recorded on a launch tape); every other one enqueues work on a stream
-_HOST_ONLY = frozenset({'nbasr_version', 'nbasr_build_id', 'nbasr_last_error', 'nbasr_pad_amounts', 'nbasr_output_frames',
+_HOST_ONLY = frozenset({'nbasr_version', 'nbasr_build_id', 'nbasr_last_error', 'nbasr_pad_amounts', 'nbasr_output_frames', 'nbasr_stream_create',
                         'nbasr_grouped_cell_fits', 'nbasr_grouped_cell_mfma_fits'})
 _ENQUEUES = frozenset(name for name in SIGNATURES if name not in _HOST_ONLY and not name.endswith('_bytes')
                       and '_bytes_' not in name)

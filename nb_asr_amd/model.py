@@ -167,8 +167,9 @@ class ASRModel(nn.Module):
             return outs
         pool = self.__dict__.setdefault('_way_streams', {})
         streams = pool.setdefault(device.index, [])
-        while len(streams) < ways:
-            streams.append(torch.cuda.Stream(device=device))
+        if len(streams) < ways:
+            from . import streams as stream_picker          # pool streams on different hardware queues (probed: streams.py)
+            streams.extend(stream_picker.chain_streams(device, ways - len(streams), have=streams))
         caller = torch.cuda.current_stream(device)
         ready = torch.cuda.Event()
         ready.record(caller)                             # the inputs were produced on the caller's stream
