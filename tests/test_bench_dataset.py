@@ -129,11 +129,11 @@ def test_reference_loader_reads_the_file(tmp_path):
 
 
 def test_committed_full_sweep_covers_the_search_space():
-    """profiles/r05_sweep/nb-asr-bench-mi355x-fp32.pickle: BASELINE config 5's artefact, produced on one MI355X by
+    """profiles/r06_sweep/nb-asr-bench-mi355x-fp32.pickle: BASELINE config 5's artefact, produced on one MI355X by
     tools/latency_sweep.py (8 242 architectures, B=32, T=1000).  One row per unique model hash of the search space, positive
     finite latencies, the reference's header keys only."""
     import math
-    path = pathlib.Path(__file__).resolve().parent.parent / 'profiles' / 'r05_sweep' / bench_dataset.file_name('mi355x-fp32')
+    path = pathlib.Path(__file__).resolve().parent.parent / 'profiles' / 'r06_sweep' / bench_dataset.file_name('mi355x-fp32')
     header, device, db = bench_dataset.read_benchmarking_dataset(path)
     assert device == 'mi355x-fp32' and sorted(header) == ['columns', 'dataset_type', 'search_space', 'version']
     unique = search_space.get_unique_architectures()

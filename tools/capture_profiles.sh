@@ -1,7 +1,8 @@
 #!/bin/bash
 # Re-captures the judged evidence under gpurun_out/ (copy the summaries into profiles/ afterwards).
 # usage (on the GPU box, from the repo root):  bash tools/capture_profiles.sh r01
-# (the profiled runs keep ONE chain of steps in flight: a second chain's kernels would stretch the durations being recorded)
+# (the profiled runs keep ONE chain of steps in flight -- a second chain's kernels would stretch the durations being recorded -- and leave
+# the strong-scaling proxy out: its 8-utterance launches would be averaged into the per-kernel durations and counters)
 set -u
 TAG=${1:-rXX}
 REPO=$(pwd)
@@ -10,14 +11,14 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 python3 bench.py > "$OUT/${TAG}_bench_n1.json" 2> "$OUT/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" --in-flight 1 --steps 20 --warmup 5 --no-cpu-baseline --no-strict > "$OUT/stats.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$REPO/bench.py" --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-strict > "$OUT/fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$REPO/bench.py" --in-flight 1 --steps 2 --warmup 1 --no-cpu-baseline --no-strict > "$OUT/write.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/mfma" -- python3 "$REPO/bench.py" --in-flight 1 --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/mfma.log" 2>&1
-rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d "$OUT/valu" -- python3 "$REPO/bench.py" --in-flight 1 --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/valu.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --steps 20 --warmup 5 --no-cpu-baseline --no-strict > "$OUT/stats.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --steps 2 --warmup 1 --no-cpu-baseline --no-strict > "$OUT/fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --steps 2 --warmup 1 --no-cpu-baseline --no-strict > "$OUT/write.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/mfma" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/mfma.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace --output-format csv -d "$OUT/valu" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/valu.log" 2>&1
 # BASELINE configs[3] per GPU in bf16: bench line + kernel stats
 python3 "$REPO/bench.py" --arch dense-skip --batch 32 --frames 1600 --dtype bf16 > "$OUT/${TAG}_bench_cfg3_bf16.json" 2> "$OUT/bench_bf16.err"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_bf16" -- python3 "$REPO/bench.py" --in-flight 1 --arch dense-skip --batch 32 --frames 1600 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_bf16.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_bf16" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --arch dense-skip --batch 32 --frames 1600 --dtype bf16 --steps 20 --warmup 5 --no-cpu-baseline > "$OUT/stats_bf16.log" 2>&1
 cd "$REPO"
 F=$(find "$OUT/fetch" -name '*counter_collection.csv' | head -1)
 W=$(find "$OUT/write" -name '*counter_collection.csv' | head -1)

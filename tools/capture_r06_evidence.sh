@@ -10,11 +10,11 @@ bash tools/capture_profiles.sh r06 > $OUT/capture.log 2>&1
 cp -r $REPO/gpurun_out/profiles_r06/* $OUT/ 2>/dev/null
 BF16="--arch dense-skip --batch 32 --frames 1600 --dtype bf16"
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch16" -- python3 "$REPO/bench.py" --in-flight 1 $BF16 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/fetch16.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write16" -- python3 "$REPO/bench.py" --in-flight 1 $BF16 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/write16.log" 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/mfma16" -- python3 "$REPO/bench.py" --in-flight 1 $BF16 --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline > "$OUT/mfma16.log" 2>&1
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$OUT/lds16" -- python3 "$REPO/bench.py" --in-flight 1 $BF16 --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline > "$OUT/lds16.log" 2>&1
-rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$OUT/lds32" -- python3 "$REPO/bench.py" --in-flight 1 --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/lds32.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch16" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy $BF16 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/fetch16.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d "$OUT/write16" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy $BF16 --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/write16.log" 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT/mfma16" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy $BF16 --steps 3 --warmup 1 --no-pipeline --no-cpu-baseline > "$OUT/mfma16.log" 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$OUT/lds16" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy $BF16 --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline > "$OUT/lds16.log" 2>&1
+rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d "$OUT/lds32" -- python3 "$REPO/bench.py" --in-flight 1 --no-strong-proxy --steps 2 --warmup 1 --no-pipeline --no-cpu-baseline --no-strict > "$OUT/lds32.log" 2>&1
 cd $REPO
 F=$(find "$OUT/fetch16" -name '*counter_collection.csv' | head -1); W=$(find "$OUT/write16" -name '*counter_collection.csv' | head -1)
 python3 tools/summarize_pmc.py "$F" "$W" > "$OUT/r06_pmc_hbm_traffic_cfg3_bf16.csv"

@@ -44,7 +44,8 @@ def whole():
 
 
 parts = [x.clone() if a.full else x[i * a.batch // a.ways:(i + 1) * a.batch // a.ways].contiguous() for i in range(a.ways)]
-streams = [torch.cuda.Stream(device=dev) for _ in range(a.ways)]
+from nb_asr_amd import streams as stream_picker
+streams = stream_picker.chain_streams(dev, a.ways)          # streams on different hardware queues, their tail streams chosen too (streams.py)
 outs = [None] * a.ways
 
 
