@@ -96,6 +96,9 @@ def main():
                     help='chains of pipelined steps in flight at once: W streams (one host thread each) take the K steps in turn, so '
                          'that one step\'s kernels fill the compute units another step\'s leave idle (8 utterances occupy 200 of 256 '
                          'CUs with one wave per SIMD).  Every step is still a complete forward of the whole batch; 1 = one chain')
+    ap.add_argument('--tail-group', default='auto',
+                    help="consecutive steps of a chain share ONE LSTM recurrence + head over all their utterances (model.forward_many): "
+                         "'auto' = groups of up to 64 utterances (8 steps at 8 per GPU, none at 64), an integer = that many steps, 1 = off")
     ap.add_argument('--force-collective', action='store_true',
                     help='take the RCCL path with one rank too: a 1-rank nccl group on this GPU, every step ends with the all-gather of '
                          'the logits (parallel.ShardedForward(force_collective=True)); reports allgather_us')
@@ -156,6 +159,8 @@ def main():
             out = step()
         return out
 
+    tail_group = args.tail_group if args.tail_group == 'auto' else int(args.tail_group)
+
     def pipelined(ways=None):
         # back-to-back batches: the LSTM + head of step i run on a side stream while the main stream already runs the
         # encoder of step i+1 (model.forward_async); every step is a complete forward and all K finish before the
@@ -173,7 +178,7 @@ def main():
         # The all-gathers are issued afterwards by THIS thread in one fixed order (a collective must be enqueued in the same order
         # on every rank).
         out = None
-        for o in model.forward_many([cur['x']] * args.steps, in_flight=ways):
+        for o in model.forward_many([cur['x']] * args.steps, in_flight=ways, tail_group=tail_group):
             out = runner.gather_logits(o)
         return out
 
@@ -184,7 +189,9 @@ def main():
             model.forward_async(x).result()
     def warm_chains():
         if args.in_flight > 1 and not args.no_pipeline:
-            pipelined()                                   # every chain's plan, launch tapes and recurrence graphs exist before a timed region
+            for _ in range(3):                            # every chain's plan, launch tapes (recorded at a key's second sight) and recurrence
+                pipelined()                               # graphs (captured at the third) exist before a timed region: with tail groups a
+                                                          # (member, slot) key comes up only once or twice in a pass of K steps
 
     warm_chains()
     elapsed_seq, out = timed(sequential)
@@ -327,6 +334,7 @@ def main():
         'value_weak': weak_value if world > 1 and args.scaling == 'weak' else None,
         'ms_per_step_weak': weak_ms if world > 1 and args.scaling == 'weak' else None,
         'in_flight': max(args.in_flight, 1) if not args.no_pipeline else 1,
+        'tail_group': (args.tail_group if args.in_flight > 1 and not args.no_pipeline else 1),
         'value_one_in_flight': args.batch * world * args.steps / elapsed_one,
         'ms_per_step_one_in_flight': 1e3 * elapsed_one / args.steps,
         'strong_proxy': proxy,

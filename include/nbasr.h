@@ -405,6 +405,14 @@ int nbasr_linear_fused_packed(const float* x, void* ws, const void* packed_w, co
 int nbasr_lstm_input_projection_packed(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
                                        const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
                                        int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream);
+/* ABI 6 -- the same projection into the rows of a LARGER gate tensor: gates_ws is (frames, batch_total, 4 * hidden) and this call
+ * writes utterances batch_offset .. batch_offset + batch - 1 of it.  For a host that runs ONE recurrence over the gates of several
+ * forwards (nb_asr_amd: `ASRModel.forward_many(tail_group=...)` -- at 8 utterances a frame of the recurrence costs what it costs at 32,
+ * and no utterance's result depends on the batch it is computed in). */
+int nbasr_lstm_input_projection_packed_into(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                            const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                            int hidden, const nbasr_deferred_ln* ln, int batch_total, int batch_offset,
+                                            nbasr_stream_t stream);
 /* The same two maps for the bf16 storage path (reference ops.py:42-50 and model.py:100,118-121 under model.to(torch.bfloat16)) on the
  * bf16 matrix cores, ONE v_mfma_f32_16x16x32_bf16 per 32 products (round 4): x, y, skips are bf16 (batch, channels, ld) rows, ld % 8
  * == 0; the weights are the fp32 values of the bf16 parameter, packed once per version (nbasr_pointwise_bf16_weights_bytes /

@@ -472,11 +472,10 @@ extern "C" int nbasr_linear_fused_packed(const float* x, void* ws, const void* p
     return pw_launch<false, true>(a, s, "nbasr_linear_fused_packed");
 }
 
-extern "C" int nbasr_lstm_input_projection_packed(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
-                                                  const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
-                                                  int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+static int lstm_projection_packed_impl(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                       const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                       int hidden, const nbasr_deferred_ln* ln, int batch_total, int batch_offset, nbasr_stream_t stream)
 {
-    clear_error();
     const int rc0 = pw_common_checks("nbasr_lstm_input_projection_packed", x, ws, packed_w_ih, b_ih, gates_ws, batch, c_in, frames, ld, 4 * hidden);
     if (rc0 != NBASR_OK) return rc0 == 1 ? NBASR_OK : rc0;
     NBASR_REQUIRE(b_hh != nullptr, NBASR_ENULL, "nbasr_lstm_input_projection_packed: b_hh is NULL");
@@ -492,8 +491,28 @@ extern "C" int nbasr_lstm_input_projection_packed(const float* x, void* ws, cons
     a.wp = wp;
     a.n_mt = pw_n_mt(4 * hidden); a.n_ks = pw_n_ks(c_in); a.n_nt = pw_n_nt(ld);
     a.w_inv = reinterpret_cast<const float*>(wp + static_cast<size_t>(a.n_mt) * a.n_ks * PW_A_STEP) + static_cast<size_t>(a.n_mt) * PW_M;
-    a.bias = b_ih; a.bias2 = b_hh; a.y = gates_ws;
+    a.bias = b_ih; a.bias2 = b_hh; a.y = gates_ws + static_cast<size_t>(batch_offset) * 4 * hidden;
     a.c_out = 4 * hidden; a.frames = frames; a.ld_out = ld; a.batch = batch;
-    a.row_stride_t = batch; a.row_stride_b = 1;
+    a.row_stride_t = batch_total; a.row_stride_b = 1;        // gates_ws[(t * batch_total + batch_offset + b) * 4 hidden + j]
     return pw_launch<true, false>(a, s, "nbasr_lstm_input_projection_packed");
+}
+
+extern "C" int nbasr_lstm_input_projection_packed(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                                  const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                                  int hidden, const nbasr_deferred_ln* ln, nbasr_stream_t stream)
+{
+    clear_error();
+    return lstm_projection_packed_impl(x, ws, packed_w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, hidden, ln, batch, 0, stream);
+}
+
+extern "C" int nbasr_lstm_input_projection_packed_into(const float* x, void* ws, const void* packed_w_ih, const float* b_ih,
+                                                       const float* b_hh, float* gates_ws, int batch, int c_in, int frames, int ld,
+                                                       int hidden, const nbasr_deferred_ln* ln, int batch_total, int batch_offset,
+                                                       nbasr_stream_t stream)
+{
+    clear_error();
+    NBASR_REQUIRE(batch_offset >= 0 && batch >= 0 && batch_offset + batch <= batch_total, NBASR_EINVAL,
+                  "nbasr_lstm_input_projection_packed_into: utterances %d .. %d do not lie inside a gate tensor of %d", batch_offset,
+                  batch_offset + batch, batch_total);
+    return lstm_projection_packed_impl(x, ws, packed_w_ih, b_ih, b_hh, gates_ws, batch, c_in, frames, ld, hidden, ln, batch_total, batch_offset, stream);
 }

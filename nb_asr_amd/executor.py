@@ -89,6 +89,23 @@ class PendingLogits:
         return self._logits
 
 
+class GroupLogits(PendingLogits):
+    """Handle of a pipelined forward whose LSTM + head run together with those of the other forwards of its TAIL GROUP (round 6,
+    `ASRModel.forward_many(tail_group=...)`): the logits exist once the group's last forward has been enqueued."""
+
+    def __init__(self):
+        super().__init__(None, None)
+
+    def _set(self, logits, event):
+        self._logits, self._event = logits, event
+
+    def result(self):
+        if self._logits is None:
+            raise hip.HipError('this forward belongs to a tail group whose last forward has not been enqueued yet '
+                               '(forward_many enqueues a whole group before it reads a result)')
+        return super().result()
+
+
 def _load_gc_table():
     import json
     import pathlib
@@ -139,8 +156,8 @@ class LaunchTape:
     strong-scaling split of the benchmark batch) that host time, 2.4 ms, exceeds the device time.  A replay issues the same
     calls in ~0.4 ms (tools/ubench/host_issue.py)."""
 
-    def __init__(self, entries, x_ptr, pipelined, pipe):
-        self.entries, self.pipelined, self.pipe = entries, pipelined, pipe
+    def __init__(self, entries, x_ptr, pipelined, pipe, group=None):
+        self.entries, self.pipelined, self.pipe, self.group = entries, pipelined, pipe, group
         self.x_slots = []
         producers = [(i, e) for i, e in enumerate(entries) if e[0] is None and e[2] is not None]
         for i, e in enumerate(entries):
@@ -176,6 +193,8 @@ class LaunchTape:
                 if rc:
                     hip._check(rc, fn.__name__)
         logits, plan._tape_logits = plan._tape_logits, None
+        if self.group is not None:
+            return plan._group_member(self.group, logits)
         if self.pipelined:
             return PendingLogits(logits, plan.tail_done[plan._turn] if self.pipe else None)
         return logits
@@ -255,6 +274,7 @@ class ForwardPlan:
         self.tail_mode = os.environ.get('NBASR_TAIL', 'auto')
         if self.tail_mode not in ('auto', 'side', 'main'):
             raise ValueError(f"NBASR_TAIL={self.tail_mode!r}: expected 'auto', 'side' or 'main'")
+        self._group_handles = []      # handles of the tail group being enqueued (_group_member)
         self._released_on, self._released_event = None, None   # PlanPool: the stream the last forward was enqueued on, an event behind it
         self._seq_host, self._seq_pending = None, None      # pinned ring of status words / deque of (event behind the copy, slot) (check_seq)
         self._seq_slot, self._seq_failed = 0, False
@@ -767,7 +787,7 @@ class ForwardPlan:
             if isinstance(built, torch.Tensor):
                 built.record_stream(self.side_stream)
 
-    def _pipeline_buffers(self, channels, frames, need_enc=True):
+    def _pipeline_buffers(self, channels, frames, need_enc=True, group=None):
         """Double-buffered gate pre-activations of the pipelined tail (+ an fp32 hand-over copy of the encoder output where the
         storage types differ, bf16 path): (slot, encoder output view or None)."""
         from .model import LSTM_HIDDEN
@@ -775,6 +795,13 @@ class ForwardPlan:
         ld = hip.round_up4(frames)
         enc = [self._buf(f'enc_out{i}', self.batch * channels * ld) for i in range(2)] if need_enc else None
         self.gates_pipe = [self.gates_ws, self._buf('gates1', self.batch * self.out_frames * 4 * LSTM_HIDDEN)]
+        if group is not None:
+            # a tail group: the gates of its n forwards in ONE (frames, n * batch, 4 hidden) tensor per slot; the slot turns with the
+            # group's first forward, the others write into the slot that is current
+            n_floats = group[1] * self.batch * self.out_frames * 4 * LSTM_HIDDEN
+            self.gates_group = [self._buf('gates_group0', n_floats), self._buf('gates_group1', n_floats)]
+            if group[0] > 0:
+                return self._turn, None
 
         def rotate():
             self._turn ^= 1
@@ -823,7 +850,7 @@ class ForwardPlan:
 
     _TAPE_ENV = ('NBASR_GC_F32_VARIANT',)       # (NBASR_LSTM_SEQ and the other plan switches are read once, when the plan is built)
 
-    def _tape_key(self, model, x, pipelined):
+    def _tape_key(self, model, x, pipelined, group=None):
         """Everything the recorded launch sequence depends on; None: this call cannot use a tape."""
         if getattr(model, '_is_replica', False) or x.numel() == 0:    # DataParallel replica: its weights are fresh tensors every step
             return None
@@ -833,7 +860,8 @@ class ForwardPlan:
             slots = self._param_slots = (weakref.ref(model), found, epoch)
         params = tuple([(d[n].data_ptr(), d[n]._version) for d, n in slots[1]])
         pipe = bool(pipelined) and model.use_rnn and self._tail_on_side_stream(x.shape[0])
-        return (x.dtype, tuple(x.shape), x.data_ptr() % 16 == 0, bool(pipelined), (self._turn ^ 1) if pipe else -1,
+        slot = -1 if not pipe else (self._turn ^ 1) if (group is None or group[0] == 0) else self._turn      # (a group's first forward rotates the slot)
+        return (x.dtype, tuple(x.shape), x.data_ptr() % 16 == 0, bool(pipelined), slot, group,
                 torch.cuda.current_stream(self.device).cuda_stream, tuple(os.environ.get(k) for k in self._TAPE_ENV),
                 epoch, tuple(map(id, model.model)), params, self._structure_fingerprint(model))
 
@@ -857,15 +885,17 @@ class ForwardPlan:
                            getattr(layer, 'groups', 0), getattr(layer, 'p', None)))
         return tuple(fp)
 
-    def run(self, model, x, taps=None, pipelined=False, _capturing=False):
-        """``_enqueue`` + the hand-over of a one-launch recurrence's status slot to the handle a pipelined forward returns."""
+    def run(self, model, x, taps=None, pipelined=False, _capturing=False, group=None):
+        """``_enqueue`` + the hand-over of a one-launch recurrence's status slot to the handle a pipelined forward returns.
+        ``group`` = (g, n): this pipelined forward is the g-th of a TAIL GROUP of n forwards of the same shape enqueued back to back
+        through this plan -- their LSTM + head run as ONE recurrence over n x batch utterances behind the last of them."""
         self._seq_last = None
-        out = self._enqueue(model, x, taps, pipelined, _capturing)
+        out = self._enqueue(model, x, taps, pipelined, _capturing, group)
         if self._seq_last is not None and isinstance(out, PendingLogits):
             out._seq = (self,) + self._seq_last
         return out
 
-    def _enqueue(self, model, x, taps=None, pipelined=False, _capturing=False):
+    def _enqueue(self, model, x, taps=None, pipelined=False, _capturing=False, group=None):
         """Enqueue one forward of ``model`` (its parameters are read now, so a DataParallel replica runs with its own).
         ``taps`` (a dict) receives a copy of every layer's output, keyed by the layer's index in ``model.model``, in the
         oracle's layouts ((B,C,T) for encoder layers and the LSTM).  ``pipelined``: LSTM + head go to the side stream and
@@ -881,10 +911,14 @@ class ForwardPlan:
         if x.dtype not in (torch.float32, torch.bfloat16):
             raise hip.HipError(f'input must be float32 or bfloat16 (got {x.dtype})')
         x = x.detach().contiguous()
-        body = self._run_bf16 if x.dtype == torch.bfloat16 else self._run_f32
+        group = self._group_or_none(model, x, taps, pipelined, _capturing, group)
+        if group is not None:
+            body = lambda m, xx, tp, pl, cp: self._run_f32(m, xx, tp, pl, cp, group)          # noqa: E731
+        else:
+            body = self._run_bf16 if x.dtype == torch.bfloat16 else self._run_f32
         key = None
         if self.tape_mode and taps is None and not _capturing and self.timer is None:
-            key = self._tape_key(model, x, pipelined)
+            key = self._tape_key(model, x, pipelined, group)
         if key is None:
             return body(model, x, taps, pipelined, _capturing)
         tape = self._tapes.get(key)
@@ -906,14 +940,42 @@ class ForwardPlan:
             hip.stop_tape()
             self._recording = None
         if self._mutations == before:
-            if len(self._tapes) >= 16:
+            if len(self._tapes) >= 48:               # (a tail group of 8 on two slots: 16 tapes of one shape)
                 self._tapes.clear()
             self._tapes[key] = LaunchTape(entries, x.data_ptr(), bool(pipelined),
-                                          bool(pipelined) and model.use_rnn and self._tail_on_side_stream(x.shape[0]))
+                                          bool(pipelined) and model.use_rnn and self._tail_on_side_stream(x.shape[0]), group)
         self._tape_logits = None
         return out
 
-    def _run_f32(self, model, x, taps, pipelined, _capturing):
+    def _group_or_none(self, model, x, taps, pipelined, capturing, group):
+        """The tail group this forward can really run in: fp32, a pipelined tail on the side stream, the fp16-pair per-frame recurrence
+        and the packed input projection (the defaults), n x batch utterances within the recurrence's workspace form."""
+        if group is None or group[1] <= 1 or not pipelined or taps is not None or capturing or x.dtype != torch.float32:
+            return None
+        from .model import LSTM_HIDDEN
+        if not (model.use_rnn and self._tail_on_side_stream(x.shape[0]) and self.linear_mode == 'f16x2' and self.lstm_seq_mode in ('auto', 'frames')
+                and isinstance(model.model[-1], torch.nn.Linear) and isinstance(model.model[-2], torch.nn.LSTM)
+                and hip.lstm_xcd_workspace_bytes(group[1] * x.shape[0], LSTM_HIDDEN)):
+            return None
+        return (int(group[0]), int(group[1]))
+
+    def _group_member(self, group, logits_all):
+        """The handle of the forward just enqueued as member ``group`` = (g, n); the last member hands every handle its rows."""
+        g, n = group
+        if g == 0:
+            self._group_handles = []
+        handle = GroupLogits()
+        self._group_handles.append(handle)
+        if g == n - 1:
+            if len(self._group_handles) != n or logits_all is None:
+                raise hip.HipError(f'tail group of {n}: {len(self._group_handles)} forwards were enqueued through this plan before its last one')
+            rows, done = logits_all.shape[0] // n, self.tail_done[self._turn]
+            for j, h in enumerate(self._group_handles):
+                h._set(logits_all[j * rows:(j + 1) * rows], done)
+            self._group_handles = []
+        return handle
+
+    def _run_f32(self, model, x, taps, pipelined, _capturing, group=None):
         from .model import SearchCell
         from .ops import PadConvRelu
         import torch.nn as nn
@@ -1039,7 +1101,7 @@ class ForwardPlan:
                     outs.append(self._timed(kind, meta, lambda: node_into(node, outs, act_frames, view, ln0, st, lin_ctx, self._gc_variant(view, node, ln0, st, len(outs)))))
                 act, cur, pending = outs[-1], free[len(layer.nodes) - 1], None
                 if feeds_tail:
-                    pipe_k, _ = self._pipeline_buffers(layer.filters, act_frames, need_enc=False)
+                    pipe_k, _ = self._pipeline_buffers(layer.filters, act_frames, need_enc=False, group=group)
                 if epilogue_stats:
                     norm = layer.norm_layer
                     self._timed('stats_finalize', (blk, layer.filters, layer.filters, 0, act_frames, 0),
@@ -1063,6 +1125,35 @@ class ForwardPlan:
                 w_ih, w_hh = layer.weight_ih_l0.detach(), layer.weight_hh_l0.detach()
                 b_ih, b_hh = layer.bias_ih_l0.detach(), layer.bias_hh_l0.detach()
                 gates = self.gates_pipe[pipe_k] if pipe else self.gates_ws
+                if group is not None:
+                    # TAIL GROUP (round 6): this forward's gates become utterances g * batch .. of the group's (frames, n * batch, 4 hidden)
+                    # gate tensor; the last member runs ONE recurrence and ONE head over all of them -- a frame of the recurrence costs
+                    # at 32 utterances what it costs at 8, and no utterance's h depends on the batch it is computed in (bit-identical)
+                    g, n = group
+                    gb = n * self.batch
+                    gates_all = self.gates_group[pipe_k]
+                    packed_ih, ws = self._packed_linear(layer.weight_ih_l0), self._pointwise_ws(src.shape[1], src.shape[2])
+                    self._timed('lstm_projection', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_input_projection_packed(src, src_frames, packed_ih, b_ih, b_hh, gates_all, layer.hidden_size,
+                                                                         ws, ln, batch_total=gb, batch_offset=g * self.batch))
+                    if g < n - 1:
+                        return self._group_member(group, None)
+                    self._to_side_stream()
+                    tail_ctx = torch.cuda.stream(self.side_stream)
+                    tail_ctx.__enter__()
+                    hidden = layer.hidden_size
+                    xcd_ws = self._buf('lstm_xcd_group', hip.lstm_xcd_workspace_bytes(gb, hidden), torch.uint8)
+                    cell_all = self._buf('cell_group', gb * hidden)[: gb * hidden]
+                    h_all = self._buf('h_out_group', gb * act_frames * hidden)[: gb * act_frames * hidden].view(gb, act_frames, hidden)
+                    gview = gates_all[: act_frames * gb * 4 * hidden].view(act_frames, gb, 4 * hidden)
+                    self._timed('lstm', (blk, layer.input_size, layer.hidden_size, 0, act_frames, 0),
+                                lambda: hip.lstm_recurrence_frames16(gview, self._packed_whh16(layer.weight_hh_l0), cell_all, h_all, xcd_ws))
+                    head = model.model[idx + 1]
+                    logits = self._new_logits((gb, act_frames, head.out_features), torch.float32, True)
+                    hip.linear_head(h_all, head.weight.detach(), head.bias.detach(), logits)
+                    self._tail_enqueued(pipe_k)
+                    tail_ctx.__exit__(None, None, None)
+                    return self._group_member(group, logits)
                 # the input projection is one large GEMM: it stays with the encoder; only the recurrence moves over
                 if self.linear_mode == 'f16x2':
                     packed_ih, ws = self._packed_linear(layer.weight_ih_l0), self._pointwise_ws(src.shape[1], src.shape[2])

@@ -74,6 +74,7 @@ SIGNATURES = {
     # LSTM + head
     'nbasr_lstm_input_projection': (_c_int, [_c_float_p] * 5 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
     'nbasr_lstm_input_projection_packed': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_stream]),
+    'nbasr_lstm_input_projection_packed_into': (_c_int, [_c_float_p] * 6 + [_c_int] * 5 + [_c_ln_p, _c_int, _c_int, _c_stream]),
     'nbasr_pointwise_bf16_weights_bytes': (ctypes.c_size_t, [_c_int] * 2),
     'nbasr_pointwise_bf16_workspace_bytes': (ctypes.c_size_t, [_c_int] * 3),
     'nbasr_pack_pointwise_weights_bf16': (_c_int, [_c_float_p] * 2 + [_c_int] * 2 + [_c_stream]),
@@ -715,9 +716,18 @@ def linear_fused_packed(x, frames, packed, c_out, bias, skips, y, ws, ln=None, l
     return y
 
 
-def lstm_input_projection_packed(x, frames, packed_w_ih, b_ih, b_hh, gates_ws, hidden, ws, ln=None):
+def lstm_input_projection_packed(x, frames, packed_w_ih, b_ih, b_hh, gates_ws, hidden, ws, ln=None, batch_total=None, batch_offset=0):
+    """``batch_total``: gates_ws is the (frames, batch_total, 4 hidden) gate tensor of SEVERAL forwards and this call fills utterances
+    batch_offset .. batch_offset + batch - 1 of it (one recurrence over all of them follows: nbasr.h)."""
     b, c_in, ld = x.shape
     _check_pointwise(packed_w_ih, ws, 4 * hidden, c_in, b, ld)
+    if batch_total is not None:
+        if gates_ws.numel() < frames * batch_total * 4 * hidden:
+            raise HipError(f'lstm_input_projection_packed: gates_ws holds {gates_ws.numel()} floats, ({frames}, {batch_total}, {4 * hidden}) needs more')
+        _check(load_library().nbasr_lstm_input_projection_packed_into(
+            _dev(x, 'x'), ws.data_ptr(), packed_w_ih.data_ptr(), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
+            b, c_in, frames, ld, hidden, _ln(ln), batch_total, batch_offset, _stream(x)), 'nbasr_lstm_input_projection_packed_into')
+        return gates_ws
     _check(load_library().nbasr_lstm_input_projection_packed(
         _dev(x, 'x'), ws.data_ptr(), packed_w_ih.data_ptr(), _dev(b_ih, 'b_ih'), _dev(b_hh, 'b_hh'), _dev(gates_ws, 'gates_ws'),
         b, c_in, frames, ld, hidden, _ln(ln), _stream(x)), 'nbasr_lstm_input_projection_packed')

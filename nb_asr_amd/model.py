@@ -146,23 +146,45 @@ class ASRModel(nn.Module):
         handle; ``handle.result()`` makes the current stream wait for the logits and returns them."""
         return self.forward(input, _pipelined=True)
 
-    def forward_many(self, inputs, in_flight=2):
+    def forward_many(self, inputs, in_flight=2, tail_group='auto'):
         """Logits of a sequence of batches, ``in_flight`` chains of pipelined forwards at a time (round 6): chain i takes batches i,
         i + W, ... on a stream of its own from a host thread of its own (``forward_async``: its encoder on that stream, its LSTM + head
         on its plan's side stream), so that one batch's kernels fill the compute units another's leave idle -- 8 utterances occupy 200 of
         the 256 CUs with one wave per SIMD.  Measured on one MI355X (bench.py): 8 utterances per batch 5 350 -> 6 960 utterances/s, 16:
         7 460 -> 8 870, 32: 9 000 -> 10 040, 64: 10 220 -> 10 620; three chains (six streams: more than the four hardware queues) fall
         to half.  Every result is the lone forward's, bit for bit (tests/test_in_flight_gpu.py).  Returns the logits in input order,
-        complete (each chain's stream has been waited for); ``in_flight=1`` is a loop of ``forward_async``."""
+        complete (each chain's stream has been waited for); ``in_flight=1`` is a loop of ``forward_async``.
+
+        ``tail_group``: consecutive batches of ONE shape in a chain share their LSTM + head -- the gates of up to that many forwards form one
+        (frames, n x batch, 4 hidden) tensor and ONE recurrence runs behind the last of them (a frame of the recurrence costs at 64
+        utterances little more than at 8; an utterance's h does not depend on the batch it is computed in, so the logits are the lone
+        forward's bit for bit).  'auto': groups of up to 64 utterances; 1: every forward its own tail.  Measured (bench.py, two chains):
+        7 110 -> 7 360 utterances/s at 8 per batch, 9 140 -> 9 370 at 16, 10 360 -> 10 620 at 32 -- the two encoders, not the tails, are
+        what two chains are bound by."""
         import threading
         inputs = list(inputs)
         if not inputs:
             return []
         ways = max(1, min(int(in_flight), len(inputs)))
         device = inputs[0].device
+
+        def enqueue(mine):
+            """Pipelined forwards of inputs[k], k in ``mine``, on the current stream: (k, handle) pairs; runs of one shape as tail groups."""
+            handles, at = [], 0
+            while at < len(mine):
+                first = inputs[mine[at]]
+                limit = tail_group if tail_group != 'auto' else max(1, 64 // max(int(first.shape[0]), 1))
+                n = 1
+                while n < limit and at + n < len(mine) and inputs[mine[at + n]].shape == first.shape and inputs[mine[at + n]].dtype == first.dtype:
+                    n += 1
+                for g in range(n):
+                    handles.append((mine[at + g], self.forward(inputs[mine[at + g]], _pipelined=True, _group=(g, n) if n > 1 else None)))
+                at += n
+            return handles
+
         if ways == 1:
             with torch.no_grad():
-                outs = [h.result() for h in [self.forward_async(x) for x in inputs]]
+                outs = [h.result() for _, h in enqueue(list(range(len(inputs))))]
             torch.cuda.current_stream(device).synchronize()
             return outs
         pool = self.__dict__.setdefault('_way_streams', {})
@@ -179,7 +201,7 @@ class ASRModel(nn.Module):
             try:
                 with torch.no_grad(), torch.cuda.device(device), torch.cuda.stream(streams[i]):
                     streams[i].wait_event(ready)
-                    handles = [(k, self.forward_async(inputs[k])) for k in range(i, len(inputs), ways)]
+                    handles = enqueue(list(range(i, len(inputs), ways)))
                     for k, h in handles:
                         outs[k] = h.result()
                     streams[i].synchronize()
@@ -197,7 +219,7 @@ class ASRModel(nn.Module):
             o.record_stream(caller)                      # allocated on a chain's stream, used by the caller from here on
         return outs
 
-    def forward(self, input, _taps=None, _pipelined=False):
+    def forward(self, input, _taps=None, _pipelined=False, _group=None):
         """input (B, 80, T) float32 on a HIP device -> logits (B, T', num_classes + 1).
 
         Error reporting of the one-launch LSTM recurrence (a resident cooperative grid; it can time out when ANOTHER process or
@@ -245,7 +267,7 @@ class ASRModel(nn.Module):
             self._plans.poll(input.device)
         plan = self._plans.acquire(input.device)
         try:
-            return plan.run(self, input, _taps, _pipelined)
+            return plan.run(self, input, _taps, _pipelined, group=_group)
         finally:
             self._plans.release(plan)
 

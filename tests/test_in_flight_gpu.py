@@ -120,3 +120,33 @@ def test_forward_many_raises_in_the_callers_thread():
     model = _model()
     with pytest.raises(ValueError, match='expected a'):
         model.forward_many([torch.zeros(2, 79, 50, device=DEV)] * 4, in_flight=2)
+
+
+@pytest.mark.parametrize('in_flight,tail_group', [(1, 2), (1, 'auto'), (2, 'auto'), (2, 3), (2, 8), (2, 1)])
+def test_tail_groups_share_one_recurrence_and_change_no_bit(in_flight, tail_group):
+    """`forward_many(tail_group=...)`: consecutive batches of one shape in a chain run their LSTM + head as ONE recurrence over all
+    their utterances (the projection writes each forward's gates into its rows of the group's gate tensor); an utterance's result does
+    not depend on the batch it is computed in, so every forward's logits are the lone forward's.  Mixed shapes break the runs."""
+    model = _model()
+    shapes = [(8, 1000)] * 9 + [(3, 333)] * 4 + [(8, 1000)] * 5 + [(5, 64)] + [(8, 1000)] * 6 + [(4, 250)] * 7
+    xs = [keyed_input(b, t, seed=10 + i).to(DEV) for i, (b, t) in enumerate(shapes)]
+    with torch.no_grad():
+        want = [model(x).clone() for x in xs]
+    torch.cuda.synchronize()
+    for _ in range(3):                  # first pass records the launch tapes of every (member, slot), later passes replay them
+        got = model.forward_many(xs, in_flight=in_flight, tail_group=tail_group)
+        assert len(got) == len(xs)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert g.shape == w.shape and torch.equal(g, w), i
+
+
+def test_a_tail_group_members_result_needs_the_whole_group():
+    model = _model()
+    x = keyed_input(4, 200, seed=1).to(DEV)
+    with torch.no_grad():
+        first = model.forward(x, _pipelined=True, _group=(0, 2))
+        with pytest.raises(nb.hip.HipError, match='tail group'):
+            first.result()
+        second = model.forward(x, _pipelined=True, _group=(1, 2))
+        want = model(x)
+        assert torch.equal(first.result(), want) and torch.equal(second.result(), want)
