@@ -96,9 +96,11 @@ def main():
                     help='chains of pipelined steps in flight at once: W streams (one host thread each) take the K steps in turn, so '
                          'that one step\'s kernels fill the compute units another step\'s leave idle (8 utterances occupy 200 of 256 '
                          'CUs with one wave per SIMD).  Every step is still a complete forward of the whole batch; 1 = one chain')
-    ap.add_argument('--tail-group', default='auto',
+    ap.add_argument('--tail-group', default='1',
                     help="consecutive steps of a chain share ONE LSTM recurrence + head over all their utterances (model.forward_many): "
-                         "'auto' = groups of up to 64 utterances (8 steps at 8 per GPU, none at 64), an integer = that many steps, 1 = off")
+                         "1 = off (default: every timed step is a forward of its own from end to end), 'auto' = groups of up to 64 "
+                         "utterances (8 steps at 8 per GPU, none at 64), an integer = that many steps.  Bit-identical logits; measured "
+                         "+3.5 % at 8 utterances per GPU, +2.6 % at 16 / 32, +0.8 % at 64")
     ap.add_argument('--force-collective', action='store_true',
                     help='take the RCCL path with one rank too: a 1-rank nccl group on this GPU, every step ends with the all-gather of '
                          'the logits (parallel.ShardedForward(force_collective=True)); reports allgather_us')

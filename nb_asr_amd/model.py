@@ -146,7 +146,7 @@ class ASRModel(nn.Module):
         handle; ``handle.result()`` makes the current stream wait for the logits and returns them."""
         return self.forward(input, _pipelined=True)
 
-    def forward_many(self, inputs, in_flight=2, tail_group='auto'):
+    def forward_many(self, inputs, in_flight=2, tail_group=1):
         """Logits of a sequence of batches, ``in_flight`` chains of pipelined forwards at a time (round 6): chain i takes batches i,
         i + W, ... on a stream of its own from a host thread of its own (``forward_async``: its encoder on that stream, its LSTM + head
         on its plan's side stream), so that one batch's kernels fill the compute units another's leave idle -- 8 utterances occupy 200 of
@@ -158,7 +158,7 @@ class ASRModel(nn.Module):
         ``tail_group``: consecutive batches of ONE shape in a chain share their LSTM + head -- the gates of up to that many forwards form one
         (frames, n x batch, 4 hidden) tensor and ONE recurrence runs behind the last of them (a frame of the recurrence costs at 64
         utterances little more than at 8; an utterance's h does not depend on the batch it is computed in, so the logits are the lone
-        forward's bit for bit).  'auto': groups of up to 64 utterances; 1: every forward its own tail.  Measured (bench.py, two chains):
+        forward's bit for bit).  1 (default): every forward its own tail; 'auto': groups of up to 64 utterances.  Measured (bench.py, two chains):
         7 110 -> 7 360 utterances/s at 8 per batch, 9 140 -> 9 370 at 16, 10 360 -> 10 620 at 32 -- the two encoders, not the tails, are
         what two chains are bound by."""
         import threading
