@@ -150,3 +150,28 @@ def test_a_tail_group_members_result_needs_the_whole_group():
         second = model.forward(x, _pipelined=True, _group=(1, 2))
         want = model(x)
         assert torch.equal(first.result(), want) and torch.equal(second.result(), want)
+
+
+def test_chosen_streams_run_side_by_side_and_are_remembered():
+    """streams.py: the chain streams of forward_many are pairwise on different hardware queues, a main stream's tail stream overlaps
+    with it and is the same one at every request (a plan that is dropped and built again runs its tail where it ran before)."""
+    from nb_asr_amd import streams
+    chains = streams.chain_streams(DEV, 2)
+    assert len({s.cuda_stream for s in chains}) == 2
+    assert streams.overlaps(DEV, chains[0], chains[1])
+    for s in chains:
+        tail = streams.tail_stream_for(DEV, s)
+        assert tail.cuda_stream != s.cuda_stream and streams.overlaps(DEV, tail, s)
+        assert streams.tail_stream_for(DEV, s) is tail
+    assert not streams.overlaps(DEV, chains[0], chains[0])
+    default_tail = streams.tail_stream_for(DEV, torch.cuda.default_stream(DEV))
+    assert streams.overlaps(DEV, default_tail, torch.cuda.default_stream(DEV))
+    model = _model()
+    x = keyed_input(4, 200, seed=2).to(DEV)
+    with torch.no_grad():
+        want = model(x).clone()
+        assert torch.equal(model.forward_async(x).result(), want)
+        side = model._plans.values()[-1].side_stream
+        model._plans.clear()
+        assert torch.equal(model.forward_async(x).result(), want)
+        assert model._plans.values()[-1].side_stream is side
