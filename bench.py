@@ -101,6 +101,9 @@ def main():
                          "1 = off (default: every timed step is a forward of its own from end to end), 'auto' = groups of up to 64 "
                          "utterances (8 steps at 8 per GPU, none at 64), an integer = that many steps.  Bit-identical logits; measured "
                          "+3.5 % at 8 utterances per GPU, +2.6 % at 16 / 32, +0.8 % at 64")
+    ap.add_argument('--backend', choices=('nccl', 'gloo'), default='nccl',
+                    help='process-group backend with N > 1 (nccl = RCCL, the measured configuration).  gloo: a functional check of the N-rank '
+                         'control flow on a box with fewer GPUs than ranks -- ranks then share devices (local rank modulo the device count)')
     ap.add_argument('--force-collective', action='store_true',
                     help='take the RCCL path with one rank too: a 1-rank nccl group on this GPU, every step ends with the all-gather of '
                          'the logits (parallel.ShardedForward(force_collective=True)); reports allgather_us')
@@ -126,10 +129,11 @@ def main():
         global_batch, args.batch = args.batch, hi - lo
         if args.batch * world != global_batch:
             sys.exit(f'--scaling strong needs --batch divisible by the number of GPUs ({global_batch} over {world})')
-    device = torch.device('cuda', local_rank)
+    device = torch.device('cuda', local_rank if args.backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1))
     torch.cuda.set_device(device)
     # RCCL process group when world > 1 (or --force-collective: a 1-rank nccl group, so that the collective path runs on one GPU too)
-    runner = ShardedForward(world_size=world, rank=rank, device=device, force_collective=args.force_collective)
+    runner = ShardedForward(world_size=world, rank=rank, device=device, force_collective=args.force_collective,
+                            backend=args.backend if (world > 1 or args.force_collective) else None)
 
     arch = ARCHS[args.arch]
     model = nb.get_model(arch, use_rnn=True, dropout_rate=0.0)
