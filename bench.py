@@ -183,6 +183,8 @@ def main():
         # and cached recurrence graphs: executor.PlanPool keeps a plan with the stream it was released on) and waits for that stream.
         # The all-gathers are issued afterwards by THIS thread in one fixed order (a collective must be enqueued in the same order
         # on every rank).
+        if os.environ.get('NBASR_BENCH_FAIL_CHAINS') == '1':          # test hook: the one-GPU fall-back to one chain (in_flight_error)
+            raise RuntimeError('NBASR_BENCH_FAIL_CHAINS=1')
         out = None
         for o in model.forward_many([cur['x']] * args.steps, in_flight=ways, tail_group=tail_group):
             out = runner.gather_logits(o)
@@ -193,8 +195,21 @@ def main():
     with torch.no_grad():
         for _ in range(2):
             model.forward_async(x).result()
+    in_flight_error = []
+
     def warm_chains():
         if args.in_flight > 1 and not args.no_pipeline:
+            if world == 1 and not runner.collective and not in_flight_error:
+                # one GPU, no collective in the step: if the chains cannot run on this box (a stream that cannot be created, a capture the
+                # runtime refuses) the line says so and carries the one-chain number, instead of no line at all.  With N > 1 a rank must
+                # not change its sequence of collectives on its own: there the failure stays a failure.
+                try:
+                    pipelined()
+                except Exception as e:          # noqa: BLE001
+                    in_flight_error.append(f'{type(e).__name__}: {e}'[:400])
+                    args.in_flight = 1
+                    model._plans.clear()
+                    return
             for _ in range(3):                            # every chain's plan, launch tapes (recorded at a key's second sight) and recurrence
                 pipelined()                               # graphs (captured at the third) exist before a timed region: with tail groups a
                                                           # (member, slot) key comes up only once or twice in a pass of K steps
@@ -340,6 +355,7 @@ def main():
         'value_weak': weak_value if world > 1 and args.scaling == 'weak' else None,
         'ms_per_step_weak': weak_ms if world > 1 and args.scaling == 'weak' else None,
         'in_flight': max(args.in_flight, 1) if not args.no_pipeline else 1,
+        'in_flight_error': in_flight_error[0] if in_flight_error else None,
         'tail_group': (args.tail_group if args.in_flight > 1 and not args.no_pipeline else 1),
         'value_one_in_flight': args.batch * world * args.steps / elapsed_one,
         'ms_per_step_one_in_flight': 1e3 * elapsed_one / args.steps,
