@@ -23,6 +23,7 @@ import torch
 _lock = threading.RLock()
 _used = {}                   # device index -> [(kind, stream)]: 'chain' (forward_many's streams), 'chain_tail', 'tail'
 _tails = {}                  # (device index, main stream handle) -> its tail stream
+_spare = {}                  # device index -> candidates that were created, probed and not taken (tried first by the next choice)
 _verdicts = {}               # (device index, handle a, handle b) -> bool
 _single = {}                 # device index -> seconds of one spin kernel
 SPIN_CYCLES = 150_000
@@ -76,15 +77,25 @@ def overlaps(device, a, b, whole_device=True):
 
 
 def _pick(device, must, kind, whole_device=True):
-    """A normal-priority pool stream that overlaps with every stream in ``must`` and with as much of what is in use as possible (weighted:
-    a chain's stream is always busy while `forward_many` runs, its tail stream nearly so, a lone plan's tail stream only between
-    calls); registered as ``kind``.  Falls back to the least conflicting candidate (never fails)."""
+    """A normal-priority stream of our own that overlaps with every stream in ``must`` and with as much of what is in use as possible
+    (weighted: a chain's stream is always busy while `forward_many` runs, its tail stream nearly so, a lone plan's tail stream only
+    between calls); registered as ``kind``.  Candidates: the ones earlier choices created and did not take, then up to MAX_CANDIDATES new
+    ones.  Falls back to the least conflicting candidate (never fails)."""
     used = _used.setdefault(device.index, [])
-    best, best_score = None, None
+    spare = _spare.setdefault(device.index, [])
+    best, best_score, tried = None, None, []
     taken = {s.cuda_stream for _, s in used} | {m.cuda_stream for m in must}
-    for _ in range(MAX_CANDIDATES):
-        cand = _new_stream(device)
-        if cand.cuda_stream in taken:                     # (a pool stream that came round again)
+    created = 0
+    while True:
+        if len(tried) < len(spare):
+            cand = spare[len(tried)]
+        elif created < MAX_CANDIDATES:
+            cand, created = _new_stream(device), created + 1
+            spare.append(cand)
+        else:
+            break
+        tried.append(cand)
+        if cand.cuda_stream in taken:
             continue
         score = sum(1000 for s in must if not overlaps(device, cand, s, whole_device))
         for k, s in used:
@@ -101,6 +112,7 @@ def _pick(device, must, kind, whole_device=True):
             break
     if best is None:
         best = _new_stream(device)
+    spare[:] = [c for c in spare if c is not best]
     used.append((kind, best))
     return best
 
